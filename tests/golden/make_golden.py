@@ -1,0 +1,419 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference (/root/reference) on
+seeded synthetic inputs, and pin oracle/ against it.  Build-container only:
+
+    python -B tests/golden/make_golden.py            # all fixture sets
+    python -B tests/golden/make_golden.py gae act    # a subset
+
+Fixtures hold only inputs that cannot be regenerated from a seed, plus expected outputs —
+never reference source.  Weights/observations are regenerated from seeds by cadre_amd.synth.
+Every set is also compared with the oracle restatement here; a mismatch aborts generation.
+"""
+import os
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+
+import _ref_shim as shim
+from cadre_amd import synth
+from oracle import encoder_ref, ppo_ref
+
+torch.set_num_threads(8)
+TMP = tempfile.mkdtemp(prefix="cadre_golden_")
+shim.install(TMP)
+
+SEED_ENC = 7
+SEED_PPO = 11
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024.0))
+
+
+def close(a, b, tol, what):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    err = np.abs(a - b).max() / max(1e-30, np.abs(b).max())
+    print("  oracle vs reference  %-28s rel-max-err %.3e" % (what, err))
+    assert err <= tol, (what, err)
+
+
+# ----------------------------------------------------------------------------- reference builders
+def ref_danet(feat_h, feat_w, seed=SEED_ENC):
+    """Reference DANet with synthetic weights; module surgery for non-native map sizes
+    (InterTaskAtt hard-codes 5x8, intertask_att.py:17-18,31)."""
+    from carla_perception.Config.auto_danet import danet_config
+    from carla_perception.Networks.danet import DANet
+    cfg = danet_config()
+    net = DANet(cfg.networks["autoencoder"])
+    if (feat_h, feat_w) != (5, 8):
+        ita = net.inter_task_att
+        ita.input_h, ita.input_w = feat_h, feat_w
+        ita.input_dim = 512 * feat_h * feat_w
+        for br in ("visual", "bc"):
+            for role in ("query", "key", "value"):
+                seq = getattr(ita, "%s_%s_layer" % (br, role))
+                seq[1] = torch.nn.Linear(ita.input_dim, 512)
+    sd = net.state_dict()
+    mine = synth.encoder_state(feat_h, feat_w, seed)
+    for k, v in mine.items():
+        assert k in sd and tuple(sd[k].shape) == v.shape, (k, v.shape)
+        sd[k] = torch.from_numpy(v)
+    net.load_state_dict(sd)
+    net.eval()
+    return net, mine, sd
+
+
+def frames(n, H, W, seed):
+    r = np.random.RandomState(seed)
+    rgb = r.randint(0, 256, (n, H, W, 3)).astype(np.uint8)
+    route = ((r.rand(n, W, H) < 0.15) * 255).astype(np.uint8)
+    return rgb, route
+
+
+def model_cfg():
+    return shim.AD(use_lstm=True, vae_device=-1, device_num=-1, vae_params="CoPM", measurement_dim=18,
+                   num_output=shim.AD(steer=33, throttle=3), command_num=4)
+
+
+def ref_agent(seed=SEED_PPO):
+    """Reference CadreAgent on CPU with synthetic encoder checkpoint + synthetic PPO nets."""
+    ck = shim.encoder_ckpt_path(TMP)
+    if not os.path.exists(ck):
+        os.makedirs(os.path.dirname(ck), exist_ok=True)
+        _net, _mine, sd = ref_danet(5, 8)
+        torch.save({"autoencoder": sd}, ck)
+    from ppo_agent.agent import CadreAgent
+    steer = {i: (i - 16) / 16.0 for i in range(33)}
+    thr = {0: [0, 0], 1: [0, 1], 2: [0.6, 0]}
+    agent = CadreAgent(rank=0, model_cfg=model_cfg(), frame=8, STEER_CONTROL=steer, THROTTLE_CONTROL=thr,
+                       ent_coeff=0.01, value_coeff=0.1, clip_coeff=1.0, clip=0.1)
+    st = synth.ppo_state(seed)
+    for mn, d in st.items():
+        agent.model_dict[mn].load_state_dict({k: torch.from_numpy(v) for k, v in d.items()})
+    return agent, st
+
+
+# ----------------------------------------------------------------------------- fixture sets
+def gen_prep():
+    """F-prep: pre_process incl. the uint8 truncation quirk (agent.py:46-57)."""
+    agent, _ = ref_agent()
+    rgb, route = frames(4, 12, 20, 3)
+    route[0] = 0                      # max == 0 branch
+    route[1][route[1] > 0] = 255      # max == 255
+    route[2] = (route[2] // 255) * 7  # max == 7 (other)
+    route[3] = np.random.RandomState(5).randint(0, 200, route[3].shape).astype(np.uint8)
+    td = dict(rgb=rgb, route_fig=route.copy())
+    out = agent.pre_process(td)
+    o2, r2 = encoder_ref.pre_process(rgb, route)
+    assert np.array_equal(out, o2) and np.array_equal(td["route_fig"], r2)
+    save("prep", rgb=rgb, route=route, out=out, route_after=td["route_fig"])
+
+
+def gen_enc(tag, H, W, n=2):
+    fh, fw = synth.feat_hw(H, W)
+    net, mine, _ = ref_danet(fh, fw)
+    rgb, route = frames(n, H, W, 100 + H)
+    x, _ = encoder_ref.pre_process(rgb, route)
+    xt = torch.from_numpy(x)
+    with torch.no_grad():
+        l4 = net.backbone(xt)
+        da = net.da_head(l4)
+        lat = net.get_latent_feature(xt, "concate")
+    o_lat, taps = encoder_ref.latent(xt, mine, return_taps=True)
+    close(taps["layer4"], l4, 1e-6, tag + " layer4")
+    close(taps["da"], da, 1e-6, tag + " da_head")
+    close(o_lat, lat, 1e-6, tag + " latent")
+    save("enc_" + tag, H=H, W=W, n=n, frame_seed=100 + H, seed=SEED_ENC,
+         layer4=l4.numpy(), da=da.numpy(), latent=lat.numpy())
+
+
+def gen_gae():
+    from ppo_agent.storage import RolloutStorage
+    out = {}
+    for T in (32, 128, 200):
+        r = np.random.RandomState(T)
+        st = RolloutStorage(T, 2, 530, 8, 530, True, 0.99, 0.95)
+        st.rewards[:, 0] = torch.from_numpy(r.rand(T + 1).astype(np.float32))
+        st.value_preds[:, 0] = torch.from_numpy(r.standard_normal(T + 1).astype(np.float32))
+        st.masks[:, 0] = torch.from_numpy((r.rand(T + 1) >= 0.05).astype(np.float32))
+        nv = torch.tensor([[float(r.standard_normal())]])
+        rew, val, msk = (st.rewards[:, 0].numpy().copy(), st.value_preds[:, 0].numpy().copy(),
+                         st.masks[:, 0].numpy().copy())
+        st.compute_returns(nv)
+        ret = st.returns[:, 0].numpy().copy()
+        adv_raw = st.returns[:-1] - st.value_preds[:-1]
+        adv = (adv_raw - adv_raw.mean()) / (adv_raw.std() + 1e-8)
+        o_ret, o_V = ppo_ref.gae_returns(rew, val, msk, nv.item(), 0.99, 0.95)
+        assert np.array_equal(o_ret.view(np.uint32), ret.view(np.uint32)), "GAE not bit-exact T=%d" % T
+        o_adv = ppo_ref.advantages(o_ret, o_V)
+        assert np.array_equal(o_adv.numpy().view(np.uint32), adv[:, 0].numpy().view(np.uint32))
+        out.update({"T%d_rewards" % T: rew, "T%d_values" % T: val, "T%d_masks" % T: msk,
+                    "T%d_next" % T: np.float32(nv.item()), "T%d_returns" % T: ret,
+                    "T%d_adv_raw" % T: adv_raw[:, 0].numpy(), "T%d_adv" % T: adv[:, 0].numpy(),
+                    "T%d_argsort" % T: np.argsort(adv[:, 0].numpy(), kind="stable")})
+    print("  GAE + advantage normalisation: oracle bit-exact vs reference")
+    save("gae", **out)
+
+
+def gen_sampler():
+    from ppo_agent.storage import RolloutStorage
+    out = {}
+    for T, mbn in ((32, 2), (128, 2), (200, 2), (50, 3)):
+        st = RolloutStorage(T, mbn, 4, 8, 4, True, 0.99, 0.95)
+        th = RolloutStorage(T, mbn, 4, 8, 4, True, 0.99, 0.95)
+        st.command[:, 0] = torch.arange(T + 1, dtype=torch.int)      # command row == index -> recover indices
+        th.command[:, 0] = torch.arange(T + 1, dtype=torch.int)
+        adv = torch.zeros(T, 1)
+        torch.manual_seed(1000 + T)
+        got = []
+        for _ in range(4):                                            # train.py:93-96
+            g1, g2 = st.feed_forward_generator(adv), th.feed_forward_generator(adv)
+            for a, b in zip(g1, g2):
+                got.append(a[8][:, 0].numpy().copy())
+                got.append(b[8][:, 0].numpy().copy())
+        torch.manual_seed(1000 + T)
+        mine = []
+        for _ in range(4):
+            i1 = i2 = None
+            nb = -(-T // (T // mbn))
+            for b in range(nb):
+                if b == 0:
+                    i1 = ppo_ref.sampler_indices(T, mbn)
+                    i2 = ppo_ref.sampler_indices(T, mbn)
+                mine.append(np.array(i1[b])); mine.append(np.array(i2[b]))
+        assert len(got) == len(mine) and all(np.array_equal(a, b) for a, b in zip(got, mine))
+        out["T%d_m%d" % (T, mbn)] = np.concatenate(got)
+        out["T%d_m%d_lens" % (T, mbn)] = np.array([len(g) for g in got])
+    print("  sampler index streams: oracle identical to reference")
+    save("sampler", **out)
+
+
+def fill_storages(T, seed, with_hidden=True):
+    """Seeded storage contents shared by reference objects and tests (regenerable)."""
+    r = np.random.RandomState(seed)
+    d = {}
+    for hd, K in (("steer", 33), ("throttle", 3)):
+        d[hd] = dict(
+            obs=(r.standard_normal((T + 1, 8, 530)) * 0.5).astype(np.float32),
+            action=r.randint(0, K, (T + 1, 1)).astype(np.int64),
+            action_log_probs=(-np.log(K) + 0.1 * r.standard_normal((T + 1, 1))).astype(np.float32),
+            value_preds=(0.3 * r.standard_normal((T + 1, 1))).astype(np.float32),
+            rewards=r.rand(T + 1, 1).astype(np.float32),
+            masks=(r.rand(T + 1, 1) >= 0.05).astype(np.float32),
+            command=r.randint(0, 4, (T + 1, 1)).astype(np.int32),
+            hn=((r.standard_normal((T + 1, 530)) * 0.1) if with_hidden else np.zeros((T + 1, 530))).astype(np.float32),
+            cn=((r.standard_normal((T + 1, 530)) * 0.1) if with_hidden else np.zeros((T + 1, 530))).astype(np.float32),
+        )
+    return d
+
+
+def gen_update():
+    """F-update / F-chief: the learner section train.py:76-110 replayed against reference
+    CadreAgent + RolloutStorage objects, one worker, T=32, 2 epochs."""
+    from ppo_agent.storage import RolloutStorage
+    from ppo_agent.models import Shared_grad_buffers
+    T, mbn, epochs = 32, 2, 2
+    agent, st0 = ref_agent()
+    data = fill_storages(T, 77)
+    stor = {}
+    for hd in ("steer", "throttle"):
+        s = RolloutStorage(T, mbn, 530, 8, 530, True, 0.99, 0.95)
+        for k, v in data[hd].items():
+            getattr(s, k).copy_(torch.from_numpy(v))
+        stor[hd] = s
+    # learner section
+    nvs, nvt = agent.get_value(False, stor["steer"].get_last(), stor["throttle"].get_last())
+    adv = {}
+    for hd, nv in (("steer", nvs), ("throttle", nvt)):
+        stor[hd].compute_returns(nv.detach())
+        a = stor[hd].returns[:-1] - stor[hd].value_preds[:-1]
+        adv[hd] = (a - a.mean()) / (a.std() + 1e-8)
+    params = [p for m in agent.model_dict.values() for p in m.parameters()]
+    opt = torch.optim.Adam(params, lr=3e-4)
+    # oracle twin
+    o_params = ppo_ref.to_torch_params(st0, requires_grad=True)
+    o_adam = {m: {k: (torch.zeros_like(p), torch.zeros_like(p)) for k, p in d.items()} for m, d in o_params.items()}
+    o_stor = {hd: {k: torch.from_numpy(v).clone() for k, v in data[hd].items()} for hd in data}
+    o_adv = {}
+    for hd in ("steer", "throttle"):
+        cmd = int(o_stor[hd]["command"][-1].item())
+        with torch.no_grad():
+            x, _ = ppo_ref.lstm_forward(o_stor[hd]["obs"][-1], (torch.zeros(1, 530), torch.zeros(1, 530)),
+                                        o_params["%s_lstm_%d" % (hd, cmd)])
+            nv = ppo_ref.mlp3(x, o_params["%s_ppo_%d" % (hd, cmd)], "critic")
+        ret, V = ppo_ref.gae_returns(o_stor[hd]["rewards"][:, 0].numpy(), o_stor[hd]["value_preds"][:, 0].numpy(),
+                                     o_stor[hd]["masks"][:, 0].numpy(), nv.item(), 0.99, 0.95)
+        o_stor[hd]["returns"] = torch.from_numpy(ret).view(-1, 1)
+        o_stor[hd]["value_preds"] = torch.from_numpy(V).view(-1, 1)
+        o_adv[hd] = ppo_ref.advantages(ret, V).view(-1, 1)
+        assert np.array_equal(o_adv[hd].numpy().view(np.uint32), adv[hd].numpy().view(np.uint32)), hd
+    torch.manual_seed(4242)
+    losses, gnorms, gsums, psums = [], [], [], []
+    step = 0
+    names = sorted(agent.model_dict)
+    for _ in range(epochs):
+        g1 = stor["steer"].feed_forward_generator(adv["steer"])
+        g2 = stor["throttle"].feed_forward_generator(adv["throttle"])
+        for s_s, t_s in zip(g1, g2):
+            l3 = agent.update_policy(s_s, t_s)
+            # oracle on the same index sets (recovered from the gathered tuples is not possible in
+            # general -> rerun oracle gather with the same RNG stream below)
+            losses.append(l3)
+            gn = [float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in agent.model_dict[n].parameters())))
+                  for n in names]
+            gnorms.append(gn)
+            gsums.append([float(sum(p.grad.double().sum() for p in agent.model_dict[n].parameters())) for n in names])
+            # chief.py:13-21 with one worker: grads -> clip per model -> Adam
+            for n in names:
+                torch.nn.utils.clip_grad_norm_(agent.model_dict[n].parameters(), 250.0)
+            opt.step()
+            psums.append([float(sum(p.data.double().sum() for p in agent.model_dict[n].parameters())) for n in names])
+            # oracle replay of this very step
+            step += 1
+            o_l3 = ppo_ref.update_policy(o_params, _as_oracle(s_s), _as_oracle(t_s))
+            close(o_l3, l3, 2e-6, "update step %d losses" % step)
+            o_gn = [float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in o_params[n].values()))) for n in names]
+            close(o_gn, gn, 2e-5, "update step %d grad norms" % step)
+            grads = {m: {k: p.grad for k, p in d.items()} for m, d in o_params.items()}
+            ppo_ref.chief_step(o_params, grads, o_adam, step)
+            o_ps = [float(sum(p.data.double().sum() for p in o_params[n].values())) for n in names]
+            close(o_ps, psums[-1], 1e-6, "update step %d param sums" % step)
+    # reduced gradient max-norm case: force the clip to engage once (max_grad_norm tiny)
+    save("update", T=T, mbn=mbn, epochs=epochs, data_seed=77, ppo_seed=SEED_PPO, torch_seed=4242,
+         names=np.array(names), losses=np.array(losses, np.float64), grad_norms=np.array(gnorms),
+         grad_sums=np.array(gsums), param_sums=np.array(psums),
+         adv_steer=adv["steer"].numpy(), adv_throttle=adv["throttle"].numpy(),
+         next_value=np.array([nvs.item(), nvt.item()], np.float32))
+
+
+def _as_oracle(samples):
+    return tuple(x if not isinstance(x, list) else [y.clone() for y in x] for x in samples)
+
+
+def gen_clip():
+    """F-chief with the clip engaged: random grads with per-model norm > max_grad_norm."""
+    st0 = synth.ppo_state(SEED_PPO)
+    names = sorted(st0)
+    import torch.nn as nn
+    from ppo_agent.models import Model, LSTM
+    mods = {}
+    for n in names:
+        m = LSTM(530, hid_size=530) if "lstm" in n else Model(530, 33 if n.startswith("steer") else 3)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in st0[n].items()})
+        mods[n] = m
+    opt = torch.optim.Adam([p for n in mods for p in mods[n].parameters()], lr=3e-4)
+    o_params = ppo_ref.to_torch_params(st0)
+    o_adam = {m: {k: (torch.zeros_like(p), torch.zeros_like(p)) for k, p in d.items()} for m, d in o_params.items()}
+    psums, pabs = [], []
+    for step in (1, 2, 3):
+        grads = {}
+        for i, n in enumerate(names):
+            scale = 2.0 if i % 2 == 0 else 0.01          # half the models clip, half do not
+            grads[n] = {}
+            for k, p in mods[n].named_parameters():
+                g = synth.make_tensor("g%d.%s.%s" % (step, n, k), tuple(p.shape), "bias", 5) * scale * 10
+                p.grad = torch.from_numpy(g.copy())
+                grads[n][k] = torch.from_numpy(g.copy())
+        for n in names:
+            nn.utils.clip_grad_norm_(mods[n].parameters(), 250.0)
+        opt.step()
+        ppo_ref.chief_step(o_params, grads, o_adam, step)
+        ps = [float(sum(p.data.double().sum() for p in mods[n].parameters())) for n in names]
+        pa = [float(sum(p.data.double().abs().sum() for p in mods[n].parameters())) for n in names]
+        o_ps = [float(sum(p.data.double().sum() for p in o_params[n].values())) for n in names]
+        close(o_ps, ps, 1e-7, "clip+adam step %d" % step)
+        psums.append(ps); pabs.append(pa)
+    save("chief", names=np.array(names), param_sums=np.array(psums), param_abs=np.array(pabs),
+         ppo_seed=SEED_PPO, grad_seed=5)
+
+
+def gen_act():
+    """F-act: CadreAgent.act on native-size observations (agent.py:114-141) + sampling rule."""
+    agent, st0 = ref_agent()
+    steps = synth.synth_rollout(6, 144, 256, seed=4321)
+    mine = synth.encoder_state(5, 8, SEED_ENC)
+    o_params = ppo_ref.to_torch_params(st0)
+    feats, acts, lps, vals, qs, margins = [], [], [], [], [], []
+    torch.manual_seed(99)
+    for td in steps:
+        obs = dict(rgb=td["rgb"], route_fig=td["route_fig"].copy(), measurements=td["measurements"],
+                   command=td["command"])
+        state = torch.get_rng_state()
+        feat, a, lp, v, hid = agent.act(obs)
+        assert float(hid[0].abs().sum()) == 0.0          # a13 quirk: zeros returned
+        after = torch.get_rng_state()
+        # re-derive the sampler noise with identical generator consumption
+        torch.set_rng_state(state)
+        q_s = torch.empty(1, 33).exponential_(1)
+        q_t = torch.empty(1, 3).exponential_(1)
+        assert torch.equal(torch.get_rng_state(), after), "sampler RNG consumption differs"
+        # oracle
+        o_feat = encoder_ref.latent_feature(td["rgb"], td["route_fig"], td["measurements"], mine)
+        close(o_feat, feat, 1e-6, "act feature")
+        c = td["command"]
+        z = (torch.zeros(1, 530), torch.zeros(1, 530))
+        with torch.no_grad():
+            for hd, q, K, j in (("steer", q_s, 33, 0), ("throttle", q_t, 3, 1)):
+                x, _ = ppo_ref.lstm_forward(o_feat, z, o_params["%s_lstm_%d" % (hd, c)])
+                lg = ppo_ref.categorical_logits(x, o_params["%s_ppo_%d" % (hd, c)])
+                idx = ppo_ref.sample_from_logits(lg, q)
+                assert int(idx) == int(a[j]), ("sampling rule mismatch", hd)
+                p = torch.softmax(lg, -1)
+                ratio = (p / q)[0]
+                top2 = torch.topk(ratio, 2).values
+                margins.append(float((top2[0] - top2[1]) / top2[0]))
+        feats.append(feat.numpy()); acts.append([int(a[0]), int(a[1])])
+        lps.append([lp[0].item(), lp[1].item()]); vals.append([v[0].item(), v[1].item()])
+        qs.append(np.concatenate([q_s.numpy()[0], q_t.numpy()[0]]))
+    print("  act: sampling == argmax(p/q), identical RNG consumption; min margin %.3e" % min(margins))
+    save("act", rollout_seed=4321, torch_seed=99, feats=np.array(feats), actions=np.array(acts),
+         log_probs=np.array(lps), values=np.array(vals), q=np.array(qs), margins=np.array(margins))
+
+
+def gen_insert():
+    """F-insert: cursor modulo T+1 drift (storage.py:45-58) and F-snapshot keys (agent.py:245-260)."""
+    from ppo_agent.storage import RolloutStorage
+    T = 5
+    s = RolloutStorage(T, 1, 6, 2, 6, True, 0.99, 0.95)
+    r = np.random.RandomState(3)
+    seq = []
+    for i in range(T + 3):
+        obs = r.standard_normal((2, 6)).astype(np.float32)
+        hn = r.standard_normal((1, 6)).astype(np.float32)
+        cn = r.standard_normal((1, 6)).astype(np.float32)
+        a, lp, v, rew, m, c = i % 3, -0.1 * i, 0.5 * i, 0.25 * i, float(i % 2), i % 4
+        s.insert(torch.from_numpy(obs), torch.tensor(a), torch.tensor([[lp]]), torch.tensor([[v]]),
+                 torch.tensor(rew), torch.tensor([[m]]), (torch.from_numpy(hn), torch.from_numpy(cn)), c)
+        seq.append((obs, hn, cn))
+    agent, _ = ref_agent()
+    p = os.path.join(TMP, "snap.pt")
+    agent.save_snapshot(p)
+    keys = sorted(torch.load(p, weights_only=False).keys())
+    save("insert", T=T, step=s.step, obs=s.obs.numpy(), action=s.action.numpy(), alp=s.action_log_probs.numpy(),
+         values=s.value_preds.numpy(), rewards=s.rewards.numpy(), masks=s.masks.numpy(),
+         command=s.command.numpy(), hn=s.hn.numpy(), cn=s.cn.numpy(), snapshot_keys=np.array(keys))
+
+
+SETS = dict(prep=gen_prep, gae=gen_gae, sampler=gen_sampler, insert=gen_insert, act=gen_act,
+            update=gen_update, chief=gen_clip,
+            enc_native=lambda: gen_enc("native", 144, 256),
+            enc_84=lambda: gen_enc("84", 84, 84),
+            enc_288=lambda: gen_enc("288", 288, 288))
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or list(SETS)
+    for w in which:
+        print("== " + w)
+        SETS[w]()
+    print("done; reference tree untouched:", not os.path.exists("/root/reference/ppo_agent/__pycache__"))

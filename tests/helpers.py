@@ -1,0 +1,69 @@
+"""Shared test helpers: seeded storage contents and the oracle replay of the learner section
+(reference ppo_agent/train.py:76-110) used by both the CPU oracle-pinning test and the GPU
+parity tests."""
+import numpy as np
+import torch
+
+from cadre_amd import synth
+from oracle import ppo_ref
+
+
+def fill_storages(T, seed, with_hidden=True):
+    """Must stay identical to tests/golden/make_golden.py:fill_storages (regenerable inputs)."""
+    r = np.random.RandomState(seed)
+    d = {}
+    for hd, K in (("steer", 33), ("throttle", 3)):
+        d[hd] = dict(
+            obs=(r.standard_normal((T + 1, 8, 530)) * 0.5).astype(np.float32),
+            action=r.randint(0, K, (T + 1, 1)).astype(np.int64),
+            action_log_probs=(-np.log(K) + 0.1 * r.standard_normal((T + 1, 1))).astype(np.float32),
+            value_preds=(0.3 * r.standard_normal((T + 1, 1))).astype(np.float32),
+            rewards=r.rand(T + 1, 1).astype(np.float32),
+            masks=(r.rand(T + 1, 1) >= 0.05).astype(np.float32),
+            command=r.randint(0, 4, (T + 1, 1)).astype(np.int32),
+            hn=((r.standard_normal((T + 1, 530)) * 0.1) if with_hidden else np.zeros((T + 1, 530))).astype(np.float32),
+            cn=((r.standard_normal((T + 1, 530)) * 0.1) if with_hidden else np.zeros((T + 1, 530))).astype(np.float32),
+        )
+    return d
+
+
+def oracle_learner_replay(g, max_steps=None):
+    T, mbn, epochs = int(g["T"]), int(g["mbn"]), int(g["epochs"])
+    st0 = synth.ppo_state(int(g["ppo_seed"]))
+    names = [str(n) for n in g["names"]]
+    data = fill_storages(T, int(g["data_seed"]))
+    params = ppo_ref.to_torch_params(st0, requires_grad=True)
+    adam = {m: {k: (torch.zeros_like(p), torch.zeros_like(p)) for k, p in d.items()} for m, d in params.items()}
+    stor = {hd: {k: torch.from_numpy(v).clone() for k, v in data[hd].items()} for hd in data}
+    adv = {}
+    for hd in ("steer", "throttle"):
+        cmd = int(stor[hd]["command"][-1].item())
+        with torch.no_grad():
+            x, _ = ppo_ref.lstm_forward(stor[hd]["obs"][-1], (torch.zeros(1, 530), torch.zeros(1, 530)),
+                                        params["%s_lstm_%d" % (hd, cmd)])
+            nv = ppo_ref.mlp3(x, params["%s_ppo_%d" % (hd, cmd)], "critic")
+        ret, V = ppo_ref.gae_returns(stor[hd]["rewards"][:, 0].numpy(), stor[hd]["value_preds"][:, 0].numpy(),
+                                     stor[hd]["masks"][:, 0].numpy(), nv.item(), 0.99, 0.95)
+        stor[hd]["returns"] = torch.from_numpy(ret).view(-1, 1)
+        stor[hd]["value_preds"] = torch.from_numpy(V).view(-1, 1)
+        adv[hd] = ppo_ref.advantages(ret, V).view(-1, 1)
+    torch.manual_seed(int(g["torch_seed"]))
+    out = dict(losses=[], grad_norms=[], param_sums=[], adv_steer=adv["steer"].numpy(),
+               adv_throttle=adv["throttle"].numpy())
+    step = 0
+    for _ in range(epochs):
+        i_s = ppo_ref.sampler_indices(T, mbn)
+        i_t = ppo_ref.sampler_indices(T, mbn)
+        for a, b in zip(i_s, i_t):
+            if max_steps is not None and step >= max_steps:
+                break
+            step += 1
+            l3 = ppo_ref.update_policy(params, ppo_ref.gather_minibatch(stor["steer"], a, adv["steer"]),
+                                       ppo_ref.gather_minibatch(stor["throttle"], b, adv["throttle"]))
+            out["losses"].append(l3)
+            out["grad_norms"].append([float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params[n].values())))
+                                      for n in names])
+            grads = {m: {k: p.grad for k, p in d.items()} for m, d in params.items()}
+            ppo_ref.chief_step(params, grads, adam, step)
+            out["param_sums"].append([float(sum(p.data.double().sum() for p in params[n].values())) for n in names])
+    return out
