@@ -1,0 +1,148 @@
+"""Flat, padded HBM arena for the 16 trainable nets (8 LSTM + 8 actor-critic `Model`s).
+
+MI355X-first layout of what the reference keeps as 112 separate nn.Parameters
+(ppo_agent/models.py:100-125): ONE fp32 buffer for parameters, ONE for gradients, two for
+Adam state.  Consequences:
+  * every per-net matmul becomes a strided batch of one GEMM launch (uniform net stride);
+  * input width 530 is padded to 544 (= 17 k-tiles of 32) with zero columns, so GEMM rows are
+    16-B aligned and there is no K tail; n_out (33 / 3) is padded to 64 zero rows;
+  * the reference's gradient hand-off (`Shared_grad_buffers.add_gradient`, models.py:231-239)
+    is one all-reduce over the gradient arena, and chief.py:13-21 is one fused clip+Adam pass;
+  * nn.Module parameters handed to the caller (`agent.model_dict`, state_dict/pickle
+    compatibility) are strided *views* into the arena, `.grad` likewise.
+
+Net index g = head * command_num + command, head 0 = steer, 1 = throttle.
+"""
+import torch
+
+HEADS = ("steer", "throttle")
+
+
+def _rup(x, m):
+    return (x + m - 1) // m * m
+
+
+class PPOArena:
+    def __init__(self, device, obs_dim=530, n_out=None, command_num=4, hid=128):
+        n_out = n_out or {"steer": 33, "throttle": 3}
+        self.device = torch.device(device)
+        self.D = obs_dim
+        self.DP = _rup(obs_dim, 32)
+        self.H4 = 4 * obs_dim
+        self.C = command_num
+        self.Z = 2 * command_num
+        self.hid = hid
+        self.n_out = (int(n_out["steer"]), int(n_out["throttle"]))
+        self.NP = 64
+        assert max(self.n_out) <= self.NP and self.H4 % 4 == 0
+        # LSTM block
+        self.o_wih = 0
+        self.o_whh = self.H4 * self.DP
+        self.o_bih = 2 * self.H4 * self.DP
+        self.o_bhh = self.o_bih + self.H4
+        self.size_L = self.o_bhh + self.H4
+        # PPO tower (actor = tower 0 'control.linear', critic = tower 1)
+        self.t_w1 = 0
+        self.t_b1 = hid * self.DP
+        self.t_w2 = self.t_b1 + hid
+        self.t_b2 = self.t_w2 + hid * hid
+        self.t_w3 = self.t_b2 + hid
+        self.t_b3 = self.t_w3 + self.NP * hid
+        self.size_T = self.t_b3 + self.NP
+        self.size_P = 2 * self.size_T
+        self.P0 = self.Z * self.size_L
+        self.total = self.P0 + self.Z * self.size_P
+        assert self.size_L % 4 == 0 and self.size_T % 4 == 0
+        self.params = torch.zeros(self.total, device=self.device)
+        self.grads = torch.zeros(self.total, device=self.device)
+        self.exp_avg = None
+        self.exp_avg_sq = None
+        self.step = 0
+        # clip segments in reference model order is irrelevant for the math; one segment per model
+        offs = [g * self.size_L for g in range(self.Z)] + [self.P0 + g * self.size_P for g in range(self.Z)] + [self.total]
+        self.seg_off = torch.tensor(offs, dtype=torch.int64, device=self.device)
+        self.norms2 = torch.zeros(2 * self.Z, dtype=torch.float64, device=self.device)
+
+    # ------------------------------------------------------------------ naming
+    def net_index(self, head, command):
+        return HEADS.index(head) * self.C + command
+
+    def model_names(self):
+        return ["%s_lstm_%d" % (h, c) for h in HEADS for c in range(self.C)] + \
+               ["%s_ppo_%d" % (h, c) for h in HEADS for c in range(self.C)]
+
+    def segment_of(self, model_name):
+        head, kind, c = model_name.split("_")
+        g = self.net_index(head, int(c))
+        return g if kind == "lstm" else self.Z + g
+
+    # ------------------------------------------------------------------ views
+    def lstm_views(self, buf, g):
+        b = g * self.size_L
+        D, DP, H4 = self.D, self.DP, self.H4
+        return {
+            "rnn.weight_ih": buf[b + self.o_wih: b + self.o_wih + H4 * DP].view(H4, DP)[:, :D],
+            "rnn.weight_hh": buf[b + self.o_whh: b + self.o_whh + H4 * DP].view(H4, DP)[:, :D],
+            "rnn.bias_ih": buf[b + self.o_bih: b + self.o_bih + H4],
+            "rnn.bias_hh": buf[b + self.o_bhh: b + self.o_bhh + H4],
+        }
+
+    def ppo_views(self, buf, g):
+        out = {}
+        hid, DP, D, NP = self.hid, self.DP, self.D, self.NP
+        head = g // self.C
+        for tower, name in ((0, "control.linear"), (1, "critic")):
+            b = self.P0 + g * self.size_P + tower * self.size_T
+            n3 = self.n_out[head] if tower == 0 else 1
+            out[name + ".0.weight"] = buf[b + self.t_w1: b + self.t_w1 + hid * DP].view(hid, DP)[:, :D]
+            out[name + ".0.bias"] = buf[b + self.t_b1: b + self.t_b1 + hid]
+            out[name + ".2.weight"] = buf[b + self.t_w2: b + self.t_w2 + hid * hid].view(hid, hid)
+            out[name + ".2.bias"] = buf[b + self.t_b2: b + self.t_b2 + hid]
+            out[name + ".4.weight"] = buf[b + self.t_w3: b + self.t_w3 + NP * hid].view(NP, hid)[:n3]
+            out[name + ".4.bias"] = buf[b + self.t_b3: b + self.t_b3 + n3]
+        return out
+
+    def views(self, buf, model_name):
+        head, kind, c = model_name.split("_")
+        g = self.net_index(head, int(c))
+        return self.lstm_views(buf, g) if kind == "lstm" else self.ppo_views(buf, g)
+
+    # ------------------------------------------------------------------ module binding
+    def bind(self, model_name, module):
+        """Move `module`'s parameters into the arena (values preserved) and point p.data / p.grad at
+        the arena views.  Idempotent."""
+        pv, gv = self.views(self.params, model_name), self.views(self.grads, model_name)
+        with torch.no_grad():
+            for name, p in module.named_parameters():
+                v = pv[name]
+                if p.data.data_ptr() != v.data_ptr():
+                    v.copy_(p.data.to(self.device))
+                    p.data = v
+                p.grad = gv[name]
+        module._cadre_arena = self
+        module._cadre_name = model_name
+        return module
+
+    def attach_grads(self, model_dict):
+        """(Re-)attach arena gradient views — `zero_grad(set_to_none=True)` by a caller detaches them."""
+        for name, module in model_dict.items():
+            gv = None
+            for pn, p in module.named_parameters():
+                if p.grad is None or getattr(p, "_cadre_g", None) is not p.grad:
+                    if gv is None:
+                        gv = self.views(self.grads, name)
+                    p.grad = gv[pn]
+                    p._cadre_g = p.grad
+
+    def load_numpy_state(self, state):
+        """state: {model_name: {param_name: ndarray}} (cadre_amd.synth.ppo_state layout)."""
+        with torch.no_grad():
+            for mn, d in state.items():
+                v = self.views(self.params, mn)
+                for k, arr in d.items():
+                    v[k].copy_(torch.as_tensor(arr).to(self.device))
+
+    def ensure_adam(self):
+        if self.exp_avg is None:
+            self.exp_avg = torch.zeros_like(self.params)
+            self.exp_avg_sq = torch.zeros_like(self.params)

@@ -1,0 +1,709 @@
+// cadre_kernels.hip — the non-GEMM kernels of the Cadre PPO learner hot path for gfx950.
+// HBM-bound pointwise / small-reduction work: coalesced NHWC access, LDS staging per frame,
+// wave64 shuffle reductions.  Reference citations (paths under /root/reference) are on each
+// entry point in include/cadre_hip.h.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include "../../include/cadre_hip.h"
+
+thread_local char g_cadre_err[256] = {0};
+int cadre_fail(const char* msg) {
+  strncpy(g_cadre_err, msg, sizeof(g_cadre_err) - 1);
+  return -1;
+}
+extern "C" int cadre_abi_version(void) { return CADRE_ABI_VERSION; }
+extern "C" const char* cadre_last_error(void) { return g_cadre_err; }
+
+#define ST(s) ((hipStream_t)(s))
+#define FAIL_IF(cond, msg) \
+  if (cond) return cadre_fail(msg)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// ============================================================================ pre_process
+__global__ void route_max_kernel(const uint8_t* route, uint32_t* frame_max, int per_frame) {
+  const int f = blockIdx.y;
+  const uint8_t* r = route + (int64_t)f * per_frame;
+  uint32_t m = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per_frame; i += gridDim.x * blockDim.x)
+    m = max(m, (uint32_t)r[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(frame_max + f, m);
+}
+
+__global__ void preprocess_kernel(const uint8_t* rgb, const uint8_t* route, const float* lut,
+                                  const uint32_t* frame_max, float* out, uint8_t* route_norm,
+                                  int F, int H, int W) {
+  __shared__ float s_lut[256];
+  s_lut[threadIdx.x & 255] = lut[threadIdx.x & 255];
+  __syncthreads();
+  const int64_t total = (int64_t)F * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int w = (int)(i % W);
+    const int h = (int)((i / W) % H);
+    const int f = (int)(i / ((int64_t)W * H));
+    const uint8_t* px = rgb + i * 3;
+    const int64_t ridx = ((int64_t)f * W + w) * H + h;       // route stored [F][W][H]
+    const uint32_t mx = frame_max[f];
+    const uint8_t rv = route[ridx];
+    // agent.py:51-54: route[i] = 1.0*route[i]/max stored into uint8 -> truncates to {0,1}
+    const uint8_t rn = mx > 0 ? (uint8_t)(rv == mx ? 1 : 0) : rv;
+    float4 o;
+    o.x = s_lut[px[0]];
+    o.y = s_lut[px[1]];
+    o.z = s_lut[px[2]];
+    o.w = (float)rn;
+    reinterpret_cast<float4*>(out)[i] = o;
+    if (route_norm) route_norm[ridx] = rn;
+  }
+}
+
+extern "C" int cadre_preprocess(const uint8_t* rgb, const uint8_t* route, const float* lut255,
+                                float* out, uint8_t* route_norm, uint32_t* frame_max,
+                                int32_t F, int32_t H, int32_t W, void* stream) {
+  FAIL_IF(!rgb || !route || !lut255 || !out || !frame_max || F < 1 || H < 1 || W < 1,
+          "cadre_preprocess: bad argument");
+  hipError_t e = hipMemsetAsync(frame_max, 0, sizeof(uint32_t) * F, ST(stream));
+  if (e != hipSuccess) return (int)e;
+  const int per = H * W;
+  dim3 g1(min(64, (per + 255) / 256), F);
+  hipLaunchKernelGGL(route_max_kernel, g1, dim3(256), 0, ST(stream), route, frame_max, per);
+  const int64_t total = (int64_t)F * per;
+  const int blocks = (int)std::min<int64_t>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(256), 0, ST(stream), rgb, route, lut255,
+                     frame_max, out, route_norm, F, H, W);
+  return (int)hipGetLastError();
+}
+
+// ============================================================================ maxpool 3x3 s2 p1
+__global__ void maxpool_kernel(const float* x, float* y, int F, int H, int W, int C4, int Ho, int Wo) {
+  const int64_t total = (int64_t)F * Ho * Wo * C4;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  float4* y4 = reinterpret_cast<float4*>(y);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    int64_t r = i / C4;
+    const int wo = (int)(r % Wo); r /= Wo;
+    const int ho = (int)(r % Ho);
+    const int f = (int)(r / Ho);
+    float4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh) {
+      const int hi = ho * 2 - 1 + dh;
+      if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        const int wi = wo * 2 - 1 + dw;
+        if ((unsigned)wi >= (unsigned)W) continue;
+        const float4 v = x4[(((int64_t)f * H + hi) * W + wi) * C4 + c];
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    }
+    y4[i] = m;
+  }
+}
+
+extern "C" int cadre_maxpool3x3s2(const float* x, float* y, int32_t F, int32_t H, int32_t W, int32_t C,
+                                  void* stream) {
+  FAIL_IF(!x || !y || F < 1 || H < 1 || W < 1 || C < 4 || (C & 3), "cadre_maxpool3x3s2: bad argument");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int64_t total = (int64_t)F * Ho * Wo * (C / 4);
+  const int blocks = (int)std::min<int64_t>((total + 255) / 256, 16384);
+  hipLaunchKernelGGL(maxpool_kernel, dim3(blocks), dim3(256), 0, ST(stream), x, y, F, H, W, C / 4, Ho, Wo);
+  return (int)hipGetLastError();
+}
+
+// ============================================================================ PAM (position attention)
+// One workgroup per frame.  qkv [Np][160] = (q 16 | k 16 | v 128) from the merged 1x1-conv GEMM.
+#define PAM_MAXNP 96
+__global__ __launch_bounds__(256) void pam_kernel(const float* qkv, const float* x, float gamma, float* y, int Np) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* q = sm;                    // [Np][17]
+  float* k = q + Np * 17;           // [Np][17]
+  float* v = k + Np * 17;           // [Np][128]
+  float* att = v + Np * 128;        // [Np][Np+1]
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const float* src = qkv + (int64_t)f * Np * 160;
+  for (int i = tid; i < Np * 160; i += 256) {
+    const int n = i / 160, c = i % 160;
+    const float val = src[i];
+    if (c < 16) q[n * 17 + c] = val;
+    else if (c < 32) k[n * 17 + c - 16] = val;
+    else v[n * 128 + c - 32] = val;
+  }
+  __syncthreads();
+  const int P = Np + 1;
+  for (int i = tid; i < Np * Np; i += 256) {        // energy[n][m] = q[n] . k[m]   (da_att.py:43)
+    const int n = i / Np, m = i % Np;
+    float e = 0.f;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) e += q[n * 17 + d] * k[m * 17 + d];
+    att[n * P + m] = e;
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int n = wave; n < Np; n += 4) {               // row softmax (da_att.py:44)
+    float mx = -INFINITY;
+    for (int m = lane; m < Np; m += 64) mx = fmaxf(mx, att[n * P + m]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int m = lane; m < Np; m += 64) {
+      const float e = expf(att[n * P + m] - mx);
+      att[n * P + m] = e;
+      s += e;
+    }
+    s = wave_sum(s);
+    for (int m = lane; m < Np; m += 64) att[n * P + m] = att[n * P + m] / s;
+  }
+  __syncthreads();
+  const int c = tid & 127;
+  const float* xf = x + (int64_t)f * Np * 128;
+  float* yf = y + (int64_t)f * Np * 128;
+  for (int n = tid >> 7; n < Np; n += 2) {           // out[n][c] = sum_m att[n][m] v[m][c]  (:47)
+    float o = 0.f;
+    for (int m = 0; m < Np; ++m) o += att[n * P + m] * v[m * 128 + c];
+    yf[n * 128 + c] = gamma * o + xf[n * 128 + c];
+  }
+}
+
+extern "C" int cadre_pam(const float* x, const float* qkv, float gamma, float* y, int32_t F, int32_t Np,
+                         void* stream) {
+  FAIL_IF(!x || !qkv || !y || F < 1 || Np < 1 || Np > PAM_MAXNP, "cadre_pam: bad argument (Np<=96)");
+  const size_t shm = sizeof(float) * ((size_t)Np * 34 + (size_t)Np * 128 + (size_t)Np * (Np + 1));
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)pam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(pam_kernel, dim3(F), dim3(256), shm, ST(stream), qkv, x, gamma, y, Np);
+  return (int)hipGetLastError();
+}
+
+// ============================================================================ CAM (channel attention)
+__global__ __launch_bounds__(256) void cam_kernel(const float* x, float gamma, float* y, int Np) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* xs = sm;                 // [Np][128]
+  float* E = xs + Np * 128;       // [128][129]
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const float* xf = x + (int64_t)f * Np * 128;
+  for (int i = tid; i < Np * 32; i += 256)
+    reinterpret_cast<float4*>(xs)[i] = reinterpret_cast<const float4*>(xf)[i];
+  __syncthreads();
+  {  // energy[c][d] = sum_n x[n][c] x[n][d]   (da_att.py:74): 8x8 register block per thread
+    const int c0 = (tid >> 4) * 8, d0 = (tid & 15) * 8;
+    float acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+    for (int n = 0; n < Np; ++n) {
+      float a[8], b[8];
+      const float4 a0 = *reinterpret_cast<const float4*>(xs + n * 128 + c0);
+      const float4 a1 = *reinterpret_cast<const float4*>(xs + n * 128 + c0 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(xs + n * 128 + d0);
+      const float4 b1 = *reinterpret_cast<const float4*>(xs + n * 128 + d0 + 4);
+      a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
+      b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] += a[i] * b[j];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) E[(c0 + i) * 129 + d0 + j] = acc[i][j];
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int c = wave; c < 128; c += 4) {               // energy_new = rowmax - energy; softmax (:75-76)
+    const float e0 = E[c * 129 + lane], e1 = E[c * 129 + lane + 64];
+    const float rmax = wave_max(fmaxf(e0, e1));
+    const float n0 = rmax - e0, n1 = rmax - e1;
+    const float m2 = wave_max(fmaxf(n0, n1));
+    const float p0 = expf(n0 - m2), p1 = expf(n1 - m2);
+    const float s = wave_sum(p0 + p1);
+    E[c * 129 + lane] = p0 / s;
+    E[c * 129 + lane + 64] = p1 / s;
+  }
+  __syncthreads();
+  const int c = tid & 127;
+  float* yf = y + (int64_t)f * Np * 128;
+  for (int n = tid >> 7; n < Np; n += 2) {            // out[c][n] = sum_d att[c][d] x[d][n]  (:79)
+    float o = 0.f;
+    for (int d = 0; d < 128; ++d) o += E[c * 129 + d] * xs[n * 128 + d];
+    yf[n * 128 + c] = gamma * o + xs[n * 128 + c];
+  }
+}
+
+extern "C" int cadre_cam(const float* x, float gamma, float* y, int32_t F, int32_t Np, void* stream) {
+  FAIL_IF(!x || !y || F < 1 || Np < 1 || Np > PAM_MAXNP, "cadre_cam: bad argument (Np<=96)");
+  const size_t shm = sizeof(float) * ((size_t)Np * 128 + 128 * 129);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)cam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(cam_kernel, dim3(F), dim3(256), shm, ST(stream), x, gamma, y, Np);
+  return (int)hipGetLastError();
+}
+
+// ============================================================================ inter-task attention tail
+__global__ __launch_bounds__(256) void intertask_kernel(const float* qkv, float* out, int64_t ldo, float temp) {
+  __shared__ float s[6 * 256];
+  __shared__ float red[8];
+  const int f = blockIdx.x, i = threadIdx.x;
+  const float* src = qkv + (int64_t)f * 1536;
+#pragma unroll
+  for (int r = 0; r < 6; ++r) s[r * 256 + i] = src[r * 256 + i];
+  __syncthreads();
+  const float* vq = s, *vk = s + 256, *vv = s + 512, *bq = s + 768, *bk = s + 1024, *bv = s + 1280;
+  // direction 0: visual query x bc key -> bc value  (intertask_att.py:137-157)
+  // direction 1: bc query x visual key -> visual value (:160-176)
+#pragma unroll
+  for (int dir = 0; dir < 2; ++dir) {
+    const float* Q = dir == 0 ? vq : bq;
+    const float* K = dir == 0 ? bk : vk;
+    const float* V = dir == 0 ? bv : vv;
+    const float qi = Q[i] / temp;
+    float mx = -INFINITY;
+    for (int j = 0; j < 256; ++j) mx = fmaxf(mx, qi * K[j]);
+    float sum = 0.f;
+    for (int j = 0; j < 256; ++j) sum += expf(qi * K[j] - mx);
+    float o = 0.f;
+    for (int j = 0; j < 256; ++j) o += V[j] * (expf(qi * K[j] - mx) / sum);
+    o += V[i];
+    // cat((att_visual, att_bc)) danet.py:232: visual first
+    out[(int64_t)f * ldo + (dir == 0 ? 256 : 0) + i] = o;
+  }
+  (void)red;
+}
+
+extern "C" int cadre_intertask_att(const float* qkv, float* out, int64_t ldo, int32_t F, float temperature,
+                                   void* stream) {
+  FAIL_IF(!qkv || !out || F < 1 || ldo < 512, "cadre_intertask_att: bad argument");
+  hipLaunchKernelGGL(intertask_kernel, dim3(F), dim3(256), 0, ST(stream), qkv, out, ldo, temperature);
+  return (int)hipGetLastError();
+}
+
+__global__ void append_meas_kernel(const double* meas, float* feat, int64_t ldo, int F) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F * 18) return;
+  const int f = i / 18, j = i % 18;
+  feat[(int64_t)f * ldo + 512 + j] = (float)meas[f * 3 + (j % 3)];
+}
+extern "C" int cadre_append_measurements(const double* meas, float* feat, int64_t ldo, int32_t F, void* stream) {
+  FAIL_IF(!meas || !feat || F < 1 || ldo < 530, "cadre_append_measurements: bad argument");
+  hipLaunchKernelGGL(append_meas_kernel, dim3((F * 18 + 255) / 256), dim3(256), 0, ST(stream), meas, feat, ldo, F);
+  return (int)hipGetLastError();
+}
+
+// ============================================================================ GAE + advantage normalisation
+// One 64-lane workgroup per sequence: stage r, V, m in LDS (coalesced), lane 0 runs the strict
+// left-to-right scan with explicitly rounded fp32 ops (no FMA contraction), all lanes then
+// form the advantages and the double-precision mean / unbiased std.
+__global__ __launch_bounds__(64) void gae_kernel(const float* rewards, float* value_preds, const float* masks,
+                                                 const float* next_value, float* returns, float* adv, int T,
+                                                 float gamma, float gamma_tau, int normalise) {
+  // Forbid FMA contraction for the whole body so every product and sum is rounded separately, as
+  // torch's one-op-at-a-time CPU code does (HIP's __fmul_rn & co. are plain inline operators that
+  // the optimiser still contracts, so the arithmetic is written with bare operators here).
+#pragma clang fp contract(off)
+  extern __shared__ float sm[];
+  float* r = sm, *V = sm + (T + 1), *m = V + (T + 1), *ret = m + (T + 1);
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const int64_t base = (int64_t)s * (T + 1);
+  for (int i = lane; i <= T; i += 64) {
+    r[i] = rewards[base + i];
+    V[i] = value_preds[base + i];
+    m[i] = masks[base + i];
+  }
+  __syncthreads();
+  if (lane == 0) {
+    V[T] = next_value[s];                              // storage.py:70
+    float gae = 0.f;
+    for (int t = T - 1; t >= 0; --t) {                  // storage.py:72-76
+      const float t1 = (gamma * V[t + 1]);
+      const float t2 = (t1 * m[t]);
+      const float t3 = (r[t] + t2);
+      const float delta = (t3 - V[t]);
+      const float u1 = (gamma_tau * m[t]);
+      const float u2 = (u1 * gae);
+      gae = (delta + u2);
+      ret[t] = (gae + V[t]);
+    }
+    value_preds[base + T] = V[T];
+  }
+  __syncthreads();
+  double sum = 0.0;
+  for (int i = lane; i < T; i += 64) {
+    returns[base + i] = ret[i];
+    const float a = (ret[i] - V[i]);            // train.py:82
+    r[i] = a;                                           // reuse r[] for advantages
+    sum += (double)a;
+  }
+  sum = wave_sum_d(sum);
+  if (!normalise) {
+    for (int i = lane; i < T; i += 64) adv[(int64_t)s * T + i] = r[i];
+    return;
+  }
+  const double mean = sum / T;
+  double sq = 0.0;
+  for (int i = lane; i < T; i += 64) {
+    const double d = (double)r[i] - mean;
+    sq += d * d;
+  }
+  sq = wave_sum_d(sq);
+  const float meanf = (float)mean;
+  const float stdf = (float)sqrt(sq / (T - 1));         // torch.std default: unbiased
+  const float den = (stdf + 1e-8f);
+  for (int i = lane; i < T; i += 64)                    // train.py:87
+    adv[(int64_t)s * T + i] = ((r[i] - meanf) / den);
+}
+
+extern "C" int cadre_gae(const float* rewards, float* value_preds, const float* masks, const float* next_value,
+                         float* returns, float* adv, int32_t nseq, int32_t T, float gamma, float gamma_tau,
+                         int32_t normalise, void* stream) {
+  FAIL_IF(!rewards || !value_preds || !masks || !next_value || !returns || !adv || nseq < 1 || T < 2 || T > 8000,
+          "cadre_gae: bad argument");
+  const size_t shm = sizeof(float) * 4 * (T + 1);
+  hipLaunchKernelGGL(gae_kernel, dim3(nseq), dim3(64), shm, ST(stream), rewards, value_preds, masks, next_value,
+                     returns, adv, T, gamma, gamma_tau, normalise);
+  return (int)hipGetLastError();
+}
+
+// ============================================================================ minibatch gather (time-major)
+__global__ void gather_obs_kernel(const float* obs, int64_t ldo, int S, const int64_t* idx, int B, float* x,
+                                  int64_t ldx, int D) {
+  const int b = blockIdx.x, s = blockIdx.y;
+  const float* src = obs + ((int64_t)idx[b] * S + s) * ldo;
+  float* dst = x + ((int64_t)s * B + b) * ldx;
+  for (int d = threadIdx.x; d < ldx; d += blockDim.x) dst[d] = d < D ? src[d] : 0.f;
+}
+extern "C" int cadre_gather_obs(const float* obs, int64_t ldo, int32_t S, const int64_t* idx, int32_t B, float* x,
+                                int64_t ldx, int32_t D, void* stream) {
+  FAIL_IF(!obs || !idx || !x || S < 1 || B < 1 || D < 1 || ldx < D || ldo < D, "cadre_gather_obs: bad argument");
+  hipLaunchKernelGGL(gather_obs_kernel, dim3(B, S), dim3(128), 0, ST(stream), obs, ldo, S, idx, B, x, ldx, D);
+  return (int)hipGetLastError();
+}
+
+// ============================================================================ LSTM cell pointwise
+__global__ void lstm_fwd_kernel(float* gates, int64_t ldg, int64_t g_str, const float* c_prev, int64_t c_prev_str,
+                                int c_prev_div, float* c_out, float* h_out, float* tanh_c, int64_t ldh,
+                                int64_t h_str, int B, int Hd) {
+  const int z = blockIdx.z;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * Hd) return;
+  const int b = i / Hd, j = i % Hd;
+  float* g = gates + z * g_str + (int64_t)b * ldg;
+  const float ig = sigmoidf_(g[j]);
+  const float fg = sigmoidf_(g[Hd + j]);
+  const float gg = tanhf(g[2 * Hd + j]);
+  const float og = sigmoidf_(g[3 * Hd + j]);
+  const float cp = c_prev[(z / c_prev_div) * c_prev_str + (int64_t)b * ldh + j];
+  const float c = fg * cp + ig * gg;
+  const float tc = tanhf(c);
+  g[j] = ig; g[Hd + j] = fg; g[2 * Hd + j] = gg; g[3 * Hd + j] = og;
+  const int64_t o = z * h_str + (int64_t)b * ldh + j;
+  c_out[o] = c;
+  tanh_c[o] = tc;
+  h_out[o] = og * tc;
+}
+
+extern "C" int cadre_lstm_pointwise_fwd(float* gates, int64_t ldg, int64_t g_str, const float* c_prev,
+                                        int64_t c_prev_str, int32_t c_prev_div, float* c_out, float* h_out,
+                                        float* tanh_c, int64_t ldh, int64_t h_str, int32_t B, int32_t Hd,
+                                        int32_t batch, void* stream) {
+  FAIL_IF(!gates || !c_prev || !c_out || !h_out || !tanh_c || B < 1 || Hd < 1 || batch < 1 || c_prev_div < 1,
+          "cadre_lstm_pointwise_fwd: bad argument");
+  dim3 grid((B * Hd + 255) / 256, 1, batch);
+  hipLaunchKernelGGL(lstm_fwd_kernel, grid, dim3(256), 0, ST(stream), gates, ldg, g_str, c_prev, c_prev_str,
+                     c_prev_div, c_out, h_out, tanh_c, ldh, h_str, B, Hd);
+  return (int)hipGetLastError();
+}
+
+__global__ void lstm_bwd_kernel(const float* gates, float* dgates, int64_t ldg, int64_t g_str, const float* dh,
+                                float* dc, int64_t d_str, const float* tanh_c, const float* c_prev,
+                                int64_t c_prev_str, int c_prev_div, int64_t ldh, int64_t h_str, int B, int Hd) {
+  const int z = blockIdx.z;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * Hd) return;
+  const int b = i / Hd, j = i % Hd;
+  const float* g = gates + z * g_str + (int64_t)b * ldg;
+  float* dg = dgates + z * g_str + (int64_t)b * ldg;
+  const int64_t o = z * h_str + (int64_t)b * ldh + j;
+  const int64_t od = z * d_str + (int64_t)b * ldh + j;
+  const float ig = g[j], fg = g[Hd + j], gg = g[2 * Hd + j], og = g[3 * Hd + j];
+  const float tc = tanh_c[o];
+  const float dht = dh[od];
+  const float dct = dc[od] + dht * og * (1.f - tc * tc);
+  const float cp = c_prev[(z / c_prev_div) * c_prev_str + (int64_t)b * ldh + j];
+  dg[j] = dct * gg * ig * (1.f - ig);
+  dg[Hd + j] = dct * cp * fg * (1.f - fg);
+  dg[2 * Hd + j] = dct * ig * (1.f - gg * gg);
+  dg[3 * Hd + j] = dht * tc * og * (1.f - og);
+  dc[od] = dct * fg;
+}
+
+extern "C" int cadre_lstm_pointwise_bwd(const float* gates, float* dgates, int64_t ldg, int64_t g_str,
+                                        const float* dh, float* dc, int64_t d_str, const float* tanh_c,
+                                        const float* c_prev, int64_t c_prev_str, int32_t c_prev_div, int64_t ldh,
+                                        int64_t h_str, int32_t B, int32_t Hd, int32_t batch, void* stream) {
+  FAIL_IF(!gates || !dgates || !dh || !dc || !tanh_c || !c_prev || B < 1 || Hd < 1 || batch < 1 || c_prev_div < 1,
+          "cadre_lstm_pointwise_bwd: bad argument");
+  dim3 grid((B * Hd + 255) / 256, 1, batch);
+  hipLaunchKernelGGL(lstm_bwd_kernel, grid, dim3(256), 0, ST(stream), gates, dgates, ldg, g_str, dh, dc, d_str,
+                     tanh_c, c_prev, c_prev_str, c_prev_div, ldh, h_str, B, Hd);
+  return (int)hipGetLastError();
+}
+
+// ============================================================================ column sums / relu backward
+__global__ void colsum_kernel(const float* X, int64_t ldx, int64_t x_str, float* out, int64_t o_str, int M, int N,
+                              int accumulate) {
+  // 256 threads = 64 columns x 4 row-slices; slices combined through LDS in fixed order
+  __shared__ float part[4][64];
+  const int z = blockIdx.z;
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (col < N) {
+    const float* x = X + z * x_str + col;
+    for (int m = sl; m < M; m += 4) s += x[(int64_t)m * ldx];
+  }
+  part[sl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (sl == 0 && col < N) {
+    const float t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    float* o = out + z * o_str + col;
+    *o = accumulate ? *o + t : t;
+  }
+}
+extern "C" int cadre_colsum(const float* X, int64_t ldx, int64_t x_str, float* out, int64_t o_str, int32_t M,
+                            int32_t N, int32_t batch, int32_t accumulate, void* stream) {
+  FAIL_IF(!X || !out || M < 1 || N < 1 || batch < 1, "cadre_colsum: bad argument");
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, 1, batch), dim3(256), 0, ST(stream), X, ldx, x_str, out,
+                     o_str, M, N, accumulate);
+  return (int)hipGetLastError();
+}
+
+__global__ void relu_bwd_kernel(const float* act, float* dy, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dy[i] = act[i] > 0.f ? dy[i] : 0.f;
+}
+extern "C" int cadre_relu_bwd(const float* act, float* dy, int64_t n, void* stream) {
+  FAIL_IF(!act || !dy || n < 1, "cadre_relu_bwd: bad argument");
+  const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks), dim3(256), 0, ST(stream), act, dy, n);
+  return (int)hipGetLastError();
+}
+
+// ============================================================================ policy head + PPO loss (fwd+bwd)
+#define MAX_NOUT 64
+__global__ __launch_bounds__(256) void ppo_loss_kernel(const float* logits, int64_t ldl, int64_t l_ns,
+                                                       const float* values, int64_t ldv, int64_t v_ns,
+                                                       const int64_t* actions, const int32_t* commands,
+                                                       const float* old_values, const float* returns,
+                                                       const float* old_logp, const float* adv, int B, int n_steer,
+                                                       int n_throttle, float clip, float value_coeff,
+                                                       float clip_coeff, float ent_coeff, float inv_b,
+                                                       float* losses, float* dlogits, float* dvalues) {
+  const int hd = blockIdx.x;                       // 0 steer, 1 throttle
+  const int K = hd == 0 ? n_steer : n_throttle;
+  __shared__ float red[3][4];
+  float s_act = 0.f, s_val = 0.f, s_ent = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const int row = hd * B + b;                    // per-head sample arrays are [2][B]
+    const int c = commands[row];
+    const int a = (int)actions[row];
+    // zero the gradients of the three masked-out command nets (agent.py:178-182 multiply by 0)
+    for (int cc = 0; cc < 4; ++cc) {
+      float* dl = dlogits + (int64_t)(hd * 4 + cc) * l_ns + (int64_t)b * ldl;
+      for (int k = 0; k < ldl; ++k) dl[k] = 0.f;
+      dvalues[(int64_t)(hd * 4 + cc) * v_ns + (int64_t)b * ldv] = 0.f;
+    }
+    if (c < 0 || c > 3) continue;
+    const int net = hd * 4 + c;
+    const float* x = logits + (int64_t)net * l_ns + (int64_t)b * ldl;
+    float lg[MAX_NOUT];
+    float mx = -INFINITY;
+    for (int k = 0; k < K; ++k) mx = fmaxf(mx, x[k]);
+    float se = 0.f;
+    for (int k = 0; k < K; ++k) se += expf(x[k] - mx);
+    const float lse = mx + logf(se);               // Categorical(logits=x).logits  distributions.py:80-81
+    float mx2 = -INFINITY;
+    for (int k = 0; k < K; ++k) { lg[k] = x[k] - lse; mx2 = fmaxf(mx2, lg[k]); }
+    float se2 = 0.f;
+    for (int k = 0; k < K; ++k) se2 += expf(lg[k] - mx2);
+    float H = 0.f;                                 // entropy = -sum p*logp  distributions.py:104
+    for (int k = 0; k < K; ++k) { const float pk = expf(lg[k] - mx2) / se2; H -= pk * lg[k]; }
+    const float lp = lg[a];
+    const float v = values[(int64_t)net * v_ns + (int64_t)b * ldv];
+    const float A = adv[row], ov = old_values[row], R = returns[row];
+    // agent.py:184-187 / 215-218
+    const float ratio = expf(lp - old_logp[row]);
+    const float s1 = ratio * A;
+    const float rc = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
+    const float s2 = rc * A;
+    s_act += -fminf(s1, s2);
+    // agent.py:189-192 / 220-223
+    const float dv = v - ov;
+    const float dvc = fminf(fmaxf(dv, -clip), clip);
+    const float vpc = ov + dvc;
+    const float vl = (v - R) * (v - R), vlc = (vpc - R) * (vpc - R);
+    s_val += fmaxf(vl, vlc);
+    s_ent += H;
+    // ---- backward of total = vc*0.5*mean(max) + cc*mean(-min) - ec*mean(H)
+    const bool in_ratio = ratio >= 1.f - clip && ratio <= 1.f + clip;
+    float dmin_dr;                                 // d min(s1,s2) / d ratio (torch ties split 0.5/0.5)
+    if (s1 < s2) dmin_dr = A;
+    else if (s1 > s2) dmin_dr = in_ratio ? A : 0.f;
+    else dmin_dr = 0.5f * A + (in_ratio ? 0.5f * A : 0.f);
+    const float dlp = clip_coeff * inv_b * (-dmin_dr) * ratio;
+    const bool in_v = dv >= -clip && dv <= clip;
+    float dmax_dv;
+    const float g1 = 2.f * (v - R), g2 = in_v ? 2.f * (vpc - R) : 0.f;
+    if (vl > vlc) dmax_dv = g1;
+    else if (vl < vlc) dmax_dv = g2;
+    else dmax_dv = 0.5f * g1 + 0.5f * g2;
+    dvalues[(int64_t)net * v_ns + (int64_t)b * ldv] = value_coeff * inv_b * 0.5f * dmax_dv;
+    const float dH = -ent_coeff * inv_b;
+    float* dl = dlogits + (int64_t)net * l_ns + (int64_t)b * ldl;
+    for (int k = 0; k < K; ++k) {
+      const float pk = expf(lg[k] - mx2) / se2;
+      dl[k] = dlp * ((k == a ? 1.f : 0.f) - pk) + dH * (-pk * (lg[k] + H));
+    }
+  }
+  s_act = wave_sum(s_act); s_val = wave_sum(s_val); s_ent = wave_sum(s_ent);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wave] = s_val; red[1][wave] = s_act; red[2][wave] = s_ent; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float tv = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    const float ta = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    const float te = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+    atomicAdd(losses + 0, value_coeff * 0.5f * tv * inv_b);
+    atomicAdd(losses + 1, clip_coeff * ta * inv_b);
+    atomicAdd(losses + 2, ent_coeff * te * inv_b);
+  }
+}
+
+extern "C" int cadre_ppo_loss(const float* logits, int64_t ldl, int64_t l_ns, const float* values, int64_t ldv,
+                              int64_t v_ns, const int64_t* actions, const int32_t* commands, const float* old_values, const float* returns,
+                              const float* old_logp, const float* adv, int32_t B, int32_t n_out_steer,
+                              int32_t n_out_throttle, float clip, float value_coeff, float clip_coeff,
+                              float ent_coeff, float inv_b, float* losses, float* dlogits, float* dvalues,
+                              void* stream) {
+  FAIL_IF(!logits || !values || !actions || !commands || !old_values || !returns || !old_logp || !adv || !losses ||
+              !dlogits || !dvalues || B < 1 || n_out_steer < 1 || n_out_steer > MAX_NOUT || n_out_throttle < 1 ||
+              n_out_throttle > MAX_NOUT || ldl < n_out_steer || ldl < n_out_throttle,
+          "cadre_ppo_loss: bad argument");
+  hipError_t e = hipMemsetAsync(losses, 0, 3 * sizeof(float), ST(stream));
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(ppo_loss_kernel, dim3(2), dim3(256), 0, ST(stream), logits, ldl, l_ns, values, ldv, v_ns,
+                     actions, commands,
+                     old_values, returns, old_logp, adv, B, n_out_steer, n_out_throttle, clip, value_coeff,
+                     clip_coeff, ent_coeff, inv_b, losses, dlogits, dvalues);
+  return (int)hipGetLastError();
+}
+
+// ============================================================================ sampling: argmax(p / q)
+__global__ __launch_bounds__(64) void sample_kernel(const float* logits, int64_t ldl, const float* q, int64_t ldq,
+                                                    int K, int64_t* action, float* logp) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const float x = lane < K ? logits[(int64_t)r * ldl + lane] : -INFINITY;
+  const float mx = wave_max(x);
+  const float se = wave_sum(lane < K ? expf(x - mx) : 0.f);
+  const float lg = x - (mx + logf(se));                          // normalised logits
+  const float mx2 = wave_max(lane < K ? lg : -INFINITY);
+  const float e2 = lane < K ? expf(lg - mx2) : 0.f;
+  const float p = e2 / wave_sum(e2);                             // F.softmax(self.logits)  distributions.py:97
+  const float pn = p / wave_sum(p);                              // Categorical(probs=) renormalises
+  float best = lane < K ? pn / q[(int64_t)r * ldq + lane] : -INFINITY;
+  int bi = lane;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {                             // argmax, lowest index wins ties
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  const float lsel = __shfl(lg, bi, 64);
+  if (lane == 0) { action[r] = bi; logp[r] = lsel; }
+}
+extern "C" int cadre_sample(const float* logits, int64_t ldl, const float* q, int64_t ldq, int32_t R, int32_t n_out,
+                            int64_t* action, float* logp, void* stream) {
+  FAIL_IF(!logits || !q || !action || !logp || R < 1 || n_out < 1 || n_out > 64, "cadre_sample: bad argument");
+  hipLaunchKernelGGL(sample_kernel, dim3(R), dim3(64), 0, ST(stream), logits, ldl, q, ldq, n_out, action, logp);
+  return (int)hipGetLastError();
+}
+
+// ============================================================================ per-model clip + Adam
+__global__ void sqnorm_kernel(const float* g, const int64_t* seg_off, double* norms2) {
+  const int mdl = blockIdx.y;
+  const int64_t lo = seg_off[mdl], hi = seg_off[mdl + 1];
+  double s = 0.0;
+  for (int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (int64_t)gridDim.x * blockDim.x) {
+    const double v = g[i];
+    s += v * v;
+  }
+  s = wave_sum_d(s);
+  __shared__ double part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(norms2 + mdl, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+__global__ void adam_kernel(float* p, const float* g, float* m, float* v, const int64_t* seg_off,
+                            const double* norms2, float max_norm, float step_size, float w1, float beta2,
+                            float w2, float bc2_sqrt, float eps) {
+  const int mdl = blockIdx.y;
+  const int64_t lo = seg_off[mdl], hi = seg_off[mdl + 1];
+  const float total = (float)sqrt(norms2[mdl]);
+  const float coef = fminf(max_norm / (total + 1e-6f), 1.f);   // clip_grad_norm_: clamp(max=1.0), always applied
+  for (int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * coef;
+    const float mi = m[i] + w1 * (gi - m[i]);                  // exp_avg.lerp_(grad, 1-beta1)
+    const float vi = v[i] * beta2 + w2 * (gi * gi);            // mul_(beta2).addcmul_(g,g,1-beta2)
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+  }
+}
+
+extern "C" int cadre_clip_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                               const int64_t* seg_off, int32_t n_models, double* norms2, double max_norm, double lr,
+                               double beta1, double beta2, double eps, int32_t step, void* stream) {
+  FAIL_IF(!params || !grads || !exp_avg || !exp_avg_sq || !seg_off || !norms2 || n_models < 1 || step < 1,
+          "cadre_clip_adam: bad argument");
+  hipError_t e = hipMemsetAsync(norms2, 0, sizeof(double) * n_models, ST(stream));
+  if (e != hipSuccess) return (int)e;
+  dim3 grid(64, n_models);
+  hipLaunchKernelGGL(sqnorm_kernel, grid, dim3(256), 0, ST(stream), grads, seg_off, norms2);
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, grid, dim3(256), 0, ST(stream), params, grads, exp_avg, exp_avg_sq, seg_off,
+                     norms2, (float)max_norm, (float)(lr / bc1), (float)(1.0 - beta1), (float)beta2,
+                     (float)(1.0 - beta2), (float)sqrt(bc2), (float)eps);
+  return (int)hipGetLastError();
+}

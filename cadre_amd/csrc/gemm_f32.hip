@@ -1,0 +1,363 @@
+// gemm_f32.hip — LDS-tiled fp32 GEMM / implicit-GEMM convolution for gfx950 (MI355X).
+//
+// One kernel template covers every matmul-shaped op on the Cadre PPO hot path:
+//   * a_mode 0/1 x b_mode 0/1: NT / NN / TN products for nn.Linear and LSTMCell forward,
+//     dX and dW (reference ppo_agent/models.py:130-177, distributions.py:34-40,
+//     carla_perception/Networks/danet_blocks/intertask_att.py:39-80);
+//   * a_mode 2: NHWC implicit-GEMM conv, Cin % 32 == 0 (resnet.py:26-55,152-166,
+//     danet.py:21-41,96,108); a_mode 3: the Cin==4 7x7 stem (resnet.py:111-112).
+//
+// MI355X mapping: 256-thread workgroup = 4 wave64, 2x2 waves, each wave WM x WN tiles of
+// v_mfma_f32_32x32x2_f32 (exact f32 fma chain, 64 FLOP/clk/SIMD = the fp32 roof).  BK = 32.
+// Tiles are register-staged (16-B global loads, zero fill for halo / tails) into a
+// double-buffered LDS image; k-contiguous operands use a 36-float row pitch so that
+// ds_read_b128 fragment reads are bank-conflict free (MI355X_MICROARCH.md §LDS), k-major
+// operands are stored as they arrive and read with conflict-free ds_read_b32.
+// The k order inside a 8-deep step is permuted (lane half h owns k = 8*kb + 4*h + i) — the
+// same permutation on A and B, so the products pair correctly.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/cadre_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static_assert(sizeof(cadre_gemm_t) == 240, "cadre_gemm_t layout is part of the C ABI (ctypes mirror in cadre_amd/hip.py)");
+
+#define BK 32
+#define LDS_PITCH 36
+
+struct RowInfo {           // per-thread, per staged row: decoded once
+  const float* base;       // dense: row pointer; conv: image base pointer
+  int hi0, wi0;            // conv: top-left input coordinate of the receptive field
+  bool valid;
+};
+
+template <int WM, int WN>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(cadre_gemm_t p) {
+  constexpr int BM = 2 * WM * 32;
+  constexpr int BN = 2 * WN * 32;
+  constexpr int RA = BM / 32;  // 16-B chunks per thread per A tile (k-contiguous staging)
+  constexpr int RB = BN / 32;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDS_PITCH];
+  float* As = lds;
+  float* Bs = lds + 2 * BM * LDS_PITCH;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const int tilesN = (p.N + BN - 1) / BN;
+  const int tile_m = blockIdx.x / tilesN, tile_n = blockIdx.x % tilesN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int z = blockIdx.z;
+  const float* A = p.A + (int64_t)((z / p.a_div) % p.a_mod) * p.a_str;
+  const float* B = p.B + (int64_t)((z / p.b_div) % p.b_mod) * p.b_str;
+  float* C = p.C + (int64_t)((z / p.c_div) % p.c_mod) * p.c_str;
+
+  const int nk_total = (p.K + BK - 1) / BK;
+  int kt_begin = 0, kt_end = nk_total;
+  if (p.split_k > 1) {
+    const int per = (nk_total + p.split_k - 1) / p.split_k;
+    kt_begin = blockIdx.y * per;
+    kt_end = min(nk_total, kt_begin + per);
+    C += (int64_t)blockIdx.y * p.M * p.ldc;
+  }
+
+  // ---------------------------------------------------------------- staging setup
+  // k-contiguous operand: thread owns chunk column cc (4 floats of the 32-deep tile) of rows
+  // rr + 32*i.  k-major operand: tile is [32 k][BM] floats, thread owns chunks id = tid+256*i.
+  const int cc = tid & 7, rr = tid >> 3;
+  RowInfo arow[RA];
+  if (p.a_mode == 0) {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int m = m0 + rr + 32 * i;
+      arow[i].valid = m < p.M;
+      arow[i].base = A + (int64_t)min(m, p.M - 1) * p.lda;
+      arow[i].hi0 = arow[i].wi0 = 0;
+    }
+  } else if (p.a_mode >= 2) {
+    const int hw = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int m = m0 + rr + 32 * i;
+      arow[i].valid = m < p.M;
+      const int mm = min(m, p.M - 1);
+      const int img = mm / hw, rem = mm % hw;
+      const int ho = rem / p.Wo, wo = rem % p.Wo;
+      arow[i].base = A + (int64_t)img * p.H * p.W * p.Cin;
+      arow[i].hi0 = ho * p.stride - p.pad;
+      arow[i].wi0 = wo * p.stride - p.pad;
+    }
+  }
+  const float* brow[RB];
+  bool bvalid[RB];
+  if (p.b_mode == 0) {
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int n = n0 + rr + 32 * i;
+      bvalid[i] = n < p.N;
+      brow[i] = B + (int64_t)min(n, p.N - 1) * p.ldb;
+    }
+  }
+
+  f32x4 areg[RA], breg[RB];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  auto load_tiles = [&](int kt) {
+    const int k0 = kt * BK;
+    // ---- A
+    if (p.a_mode == 0) {
+      const int k = k0 + cc * 4;
+      const bool kv = k < p.K;  // K % 4 == 0
+#pragma unroll
+      for (int i = 0; i < RA; ++i)
+        areg[i] = (arow[i].valid && kv) ? *reinterpret_cast<const f32x4*>(arow[i].base + k) : zero4;
+    } else if (p.a_mode == 1) {
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        const int id = tid + 256 * i;
+        const int kk = id / (BM / 4), mc = id % (BM / 4);
+        const int k = k0 + kk, m = m0 + mc * 4;
+        areg[i] = (k < p.K && m < p.M) ? *reinterpret_cast<const f32x4*>(A + (int64_t)k * p.lda + m) : zero4;
+      }
+    } else if (p.a_mode == 2) {
+      const int pos = k0 / p.Cin, ci = k0 % p.Cin + cc * 4;  // uniform per tile (Cin % 32 == 0)
+      const int kh = pos / p.KW, kw = pos % p.KW;
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        const int hi = arow[i].hi0 + kh, wi = arow[i].wi0 + kw;
+        const bool ok = arow[i].valid && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        areg[i] = ok ? *reinterpret_cast<const f32x4*>(arow[i].base + ((int64_t)hi * p.W + wi) * p.Cin + ci) : zero4;
+      }
+    } else {  // stem: Cin == 4, one 16-B chunk = one (kh,kw) position
+      const int pos = k0 / 4 + cc;
+      const int kh = pos / p.KW, kw = pos % p.KW;
+      const bool kv = pos < p.KH * p.KW;
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        const int hi = arow[i].hi0 + kh, wi = arow[i].wi0 + kw;
+        const bool ok = kv && arow[i].valid && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        areg[i] = ok ? *reinterpret_cast<const f32x4*>(arow[i].base + ((int64_t)hi * p.W + wi) * 4) : zero4;
+      }
+    }
+    // ---- B
+    if (p.b_mode == 0) {
+      const int k = k0 + cc * 4;
+      const bool kv = k < p.K;
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+        breg[i] = (bvalid[i] && kv) ? *reinterpret_cast<const f32x4*>(brow[i] + k) : zero4;
+    } else {
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int id = tid + 256 * i;
+        const int kk = id / (BN / 4), nc = id % (BN / 4);
+        const int k = k0 + kk, n = n0 + nc * 4;
+        breg[i] = (k < p.K && n < p.N) ? *reinterpret_cast<const f32x4*>(B + (int64_t)k * p.ldb + n) : zero4;
+      }
+    }
+  };
+
+  auto store_tiles = [&](int buf) {
+    float* as = As + buf * BM * LDS_PITCH;
+    float* bs = Bs + buf * BN * LDS_PITCH;
+    if (p.a_mode == 1) {
+#pragma unroll
+      for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(as + (tid + 256 * i) * 4) = areg[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < RA; ++i)
+        *reinterpret_cast<f32x4*>(as + (rr + 32 * i) * LDS_PITCH + cc * 4) = areg[i];
+    }
+    if (p.b_mode == 1) {
+#pragma unroll
+      for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(bs + (tid + 256 * i) * 4) = breg[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < RB; ++i)
+        *reinterpret_cast<f32x4*>(bs + (rr + 32 * i) * LDS_PITCH + cc * 4) = breg[i];
+    }
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (kt_begin < kt_end) {
+    load_tiles(kt_begin);
+    store_tiles(0);
+  }
+  __syncthreads();
+
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int buf = (kt - kt_begin) & 1;
+    const bool more = kt + 1 < kt_end;
+    if (more) load_tiles(kt + 1);  // global loads in flight under the MFMAs below
+
+    const float* as = As + buf * BM * LDS_PITCH;
+    const float* bs = Bs + buf * BN * LDS_PITCH;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      f32x4 af[WM], bf[WN];
+      const int kq = kb * 8 + lh * 4;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        const int row = (wm * WM + i) * 32 + l31;
+        if (p.a_mode == 1) {
+          af[i][0] = as[(kq + 0) * BM + row];
+          af[i][1] = as[(kq + 1) * BM + row];
+          af[i][2] = as[(kq + 2) * BM + row];
+          af[i][3] = as[(kq + 3) * BM + row];
+        } else {
+          af[i] = *reinterpret_cast<const f32x4*>(as + row * LDS_PITCH + kq);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int col = (wn * WN + j) * 32 + l31;
+        if (p.b_mode == 1) {
+          bf[j][0] = bs[(kq + 0) * BN + col];
+          bf[j][1] = bs[(kq + 1) * BN + col];
+          bf[j][2] = bs[(kq + 2) * BN + col];
+          bf[j][3] = bs[(kq + 3) * BN + col];
+        } else {
+          bf[j] = *reinterpret_cast<const f32x4*>(bs + col * LDS_PITCH + kq);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  const bool raw = p.split_k > 1;
+  const int actk = p.act & 15;
+  const bool post = (p.act & 16) != 0;   // residual added after the activation
+  const float* scale = (!raw && p.scale) ? p.scale + (int64_t)((z / p.s_div) % p.s_mod) * p.s_str : nullptr;
+  const float* shift = (!raw && p.shift) ? p.shift + (int64_t)((z / p.s_div) % p.s_mod) * p.s_str : nullptr;
+  const float* resid = (!raw && p.resid) ? p.resid + (int64_t)((z / p.r_div) % p.r_mod) * p.r_str : nullptr;
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int col = n0 + (wn * WN + j) * 32 + l31;
+    if (col >= p.N) continue;
+    const float sc = scale ? scale[col] : 1.f;
+    const float sh = shift ? shift[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (wm * WM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row >= p.M) continue;
+        float v = acc[i][j][r];
+        if (!raw) {
+          v = v * sc + sh;
+          const float rv = resid ? resid[(int64_t)row * p.ldr + col] : 0.f;
+          if (!post) v += rv;
+          if (actk == 1) v = fmaxf(v, 0.f);
+          else if (actk == 2) v = v > 0.f ? v : v * p.slope;
+          if (post) v += rv;
+        }
+        C[(int64_t)row * p.ldc + col] = v;
+      }
+    }
+  }
+}
+
+__global__ void splitk_reduce_kernel(const float* slabs, int split_k, int64_t slab_stride, int64_t lds_,
+                                     float* C, int64_t ldc, int M, int N, const float* scale,
+                                     const float* shift, int act, float slope) {
+  const int64_t total = (int64_t)M * N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / N), n = (int)(i % N);
+    float v = 0.f;
+    for (int s = 0; s < split_k; ++s) v += slabs[s * slab_stride + (int64_t)m * lds_ + n];
+    v = v * (scale ? scale[n] : 1.f) + (shift ? shift[n] : 0.f);
+    if (act == 1) v = fmaxf(v, 0.f);
+    else if (act == 2) v = v > 0.f ? v : v * slope;
+    C[(int64_t)m * ldc + n] = v;
+  }
+}
+
+extern thread_local char g_cadre_err[256];
+int cadre_fail(const char* msg);
+
+#define GEMM_CHECK(cond, msg) \
+  if (!(cond)) return cadre_fail("cadre_gemm_f32: " msg)
+
+extern "C" int cadre_gemm_f32(const cadre_gemm_t* pp, void* stream) {
+  cadre_gemm_t p = *pp;
+  GEMM_CHECK(p.A && p.B && p.C, "null operand");
+  GEMM_CHECK(p.M > 0 && p.N > 0 && p.K > 0, "empty problem");
+  GEMM_CHECK(p.a_mode >= 0 && p.a_mode <= 3 && p.b_mode >= 0 && p.b_mode <= 1, "bad operand mode");
+  GEMM_CHECK(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0, "operands must be 16-byte aligned");
+  if (p.a_mode == 0) GEMM_CHECK(p.K % 4 == 0 && p.lda % 4 == 0, "a_mode 0 needs K%4==0, lda%4==0");
+  if (p.a_mode == 1) GEMM_CHECK(p.M % 4 == 0 && p.lda % 4 == 0, "a_mode 1 needs M%4==0, lda%4==0");
+  if (p.b_mode == 0) GEMM_CHECK(p.K % 4 == 0 && p.ldb % 4 == 0, "b_mode 0 needs K%4==0, ldb%4==0");
+  if (p.b_mode == 1) GEMM_CHECK(p.N % 4 == 0 && p.ldb % 4 == 0, "b_mode 1 needs N%4==0, ldb%4==0");
+  if (p.a_mode == 2) GEMM_CHECK(p.Cin % 32 == 0 && p.K == p.KH * p.KW * p.Cin, "conv needs Cin%32==0, K==KH*KW*Cin");
+  if (p.a_mode == 3) GEMM_CHECK(p.Cin == 4 && p.K == p.KH * p.KW * 4, "stem conv needs Cin==4");
+  if (p.a_mode >= 2) GEMM_CHECK(p.M % (p.Ho * p.Wo) == 0 && p.stride > 0, "conv M must be Nimg*Ho*Wo");
+  if (p.batch < 1) p.batch = 1;
+  if (p.split_k < 1) p.split_k = 1;
+  if (p.a_div < 1) p.a_div = 1;
+  if (p.b_div < 1) p.b_div = 1;
+  if (p.c_div < 1) p.c_div = 1;
+  if (p.s_div < 1) p.s_div = 1;
+  if (p.r_div < 1) p.r_div = 1;
+  if (p.a_mod < 1) p.a_mod = 1 << 30;
+  if (p.b_mod < 1) p.b_mod = 1 << 30;
+  if (p.c_mod < 1) p.c_mod = 1 << 30;
+  if (p.s_mod < 1) p.s_mod = 1 << 30;
+  if (p.r_mod < 1) p.r_mod = 1 << 30;
+  GEMM_CHECK(p.split_k == 1 || p.batch == 1, "split_k with batch unsupported");
+  int tile = p.tile;
+  if (tile == 0) {
+    // biggest tile that still gives every one of the 256 CUs a workgroup
+    auto ntiles = [&](int bm, int bn) {
+      return (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.batch * p.split_k;
+    };
+    if (p.N <= 64) tile = ntiles(128, 64) >= 256 ? 2 : 3;
+    else tile = ntiles(128, 128) >= 256 ? 1 : 3;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  dim3 block(256);
+  if (tile == 1) {
+    dim3 grid(((p.M + 127) / 128) * ((p.N + 127) / 128), p.split_k, p.batch);
+    hipLaunchKernelGGL((gemm_f32_kernel<2, 2>), grid, block, 0, st, p);
+  } else if (tile == 2) {
+    dim3 grid(((p.M + 127) / 128) * ((p.N + 63) / 64), p.split_k, p.batch);
+    hipLaunchKernelGGL((gemm_f32_kernel<2, 1>), grid, block, 0, st, p);
+  } else if (tile == 3) {
+    dim3 grid(((p.M + 63) / 64) * ((p.N + 63) / 64), p.split_k, p.batch);
+    hipLaunchKernelGGL((gemm_f32_kernel<1, 1>), grid, block, 0, st, p);
+  } else {
+    return cadre_fail("cadre_gemm_f32: bad tile");
+  }
+  return (int)hipGetLastError();
+}
+
+extern "C" int cadre_splitk_reduce(const float* slabs, int32_t split_k, int64_t slab_stride, int64_t lds_,
+                                   float* C, int64_t ldc, int32_t M, int32_t N, const float* scale,
+                                   const float* shift, int32_t act, float slope, void* stream) {
+  if (!slabs || !C || split_k < 1 || M < 1 || N < 1) return cadre_fail("cadre_splitk_reduce: bad argument");
+  const int64_t total = (int64_t)M * N;
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slabs, split_k,
+                     slab_stride, lds_, C, ldc, M, N, scale, shift, act, slope);
+  return (int)hipGetLastError();
+}

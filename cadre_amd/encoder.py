@@ -1,0 +1,260 @@
+"""DANet act-time encoder forward on MI355X: `DANet.get_latent_feature(x, "concate")`
+(reference carla_perception/Networks/danet.py:216-238) as a chain of HIP launches.
+
+Data layout: activations NHWC fp32 in HBM (one [F*Ho*Wo, C] row-major matrix per layer, so
+every conv is an implicit GEMM whose output is already the next layer's input), conv weights
+[Cout][KH][KW][Cin] (k contiguous), eval BatchNorm folded to a per-channel (scale, shift)
+epilogue, the six inter-task first-layer matrices re-ordered once at load time from the
+reference's NCHW flatten (c*hw+pos) to the NHWC flatten (pos*512+c) and concatenated per
+branch so the 128 M weights (288x288) stream through HBM once per frame batch.
+
+Weights come in the reference's state_dict naming so a real `net_epoch<N>` checkpoint
+(`{'autoencoder': state_dict}`, experiments_builder.py:442-462) drops in.  Any input size
+whose layer-4 map has <= 96 positions is supported (the reference hard-codes 5x8).
+"""
+import numpy as np
+import torch
+
+from . import hip, synth
+
+BN_EPS = 1e-5
+
+
+def _fold_bn(sd, bn, conv_bias=None):
+    w, b = sd[bn + ".weight"].double(), sd[bn + ".bias"].double()
+    mean, var = sd[bn + ".running_mean"].double(), sd[bn + ".running_var"].double()
+    scale = w / torch.sqrt(var + BN_EPS)
+    shift = b - mean * scale
+    if conv_bias is not None:
+        shift = shift + conv_bias.double() * scale
+    return scale.float(), shift.float()
+
+
+def _khwc(w):
+    """OIHW -> [O][KH*KW*I] with k contiguous."""
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+
+
+class _Conv:
+    __slots__ = ("w", "scale", "shift", "cin", "cout", "k", "stride", "pad", "act")
+
+    def __init__(self, w, scale, shift, k, stride, pad, act, dev):
+        self.w = _khwc(w).to(dev)
+        self.scale = None if scale is None else scale.contiguous().to(dev)
+        self.shift = None if shift is None else shift.contiguous().to(dev)
+        self.cout, self.cin = w.shape[0], w.shape[1]
+        self.k, self.stride, self.pad, self.act = k, stride, pad, act
+
+
+class DANetEncoderHIP:
+    """Frozen encoder; `latent(rgb_u8, route_u8)` -> [F,512] features on device."""
+
+    def __init__(self, state_dict, H, W, device="cuda:0", max_frames=64):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise hip.CadreHipError("DANetEncoderHIP needs a HIP device (device_num/vae_device >= 0); no CPU path")
+        hip.lib()
+        self.H, self.W = H, W
+        self.max_frames = max_frames
+        sd = {k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(v))).float().cpu()
+              for k, v in state_dict.items() if not k.endswith("num_batches_tracked")}
+        dev = self.device
+        fh, fw = synth.feat_hw(H, W)
+        self.fh, self.fw, self.Np = fh, fw, fh * fw
+        if self.Np > 96:
+            raise hip.CadreHipError("layer-4 map %dx%d > 96 positions not supported by the PAM/CAM kernels" % (fh, fw))
+        need = 512 * self.Np
+        got = sd["inter_task_att.visual_query_layer.1.weight"].shape[1]
+        if got != need:
+            raise hip.CadreHipError("encoder weights are for a %d-wide inter-task input, this %dx%d input needs %d "
+                                    "(reference hard-codes 5x8: intertask_att.py:17-18)" % (got, H, W, need))
+        # ---- trunk (resnet.py:111-115, 152-166)
+        sc, sh = _fold_bn(sd, "backbone.bn1", sd["backbone.conv1.bias"])
+        self.stem = _Conv(sd["backbone.conv1.weight"], sc, sh, 7, 2, 3, 1, dev)
+        self.blocks = []
+        for li in range(1, 5):
+            for bi in range(2):
+                pre = "backbone.layer%d.%d" % (li, bi)
+                stride = 2 if (li > 1 and bi == 0) else 1
+                c1 = _Conv(sd[pre + ".conv1.weight"], *_fold_bn(sd, pre + ".bn1"), 3, stride, 1, 1, dev)
+                c2 = _Conv(sd[pre + ".conv2.weight"], *_fold_bn(sd, pre + ".bn2"), 3, 1, 1, 1, dev)
+                down = None
+                if (pre + ".downsample.0.weight") in sd:
+                    down = _Conv(sd[pre + ".downsample.0.weight"], *_fold_bn(sd, pre + ".downsample.1"), 1, stride, 0, 0, dev)
+                self.blocks.append((c1, c2, down))
+        # ---- DANet head (danet.py:21-41)
+        hd = "da_head."
+        self.conv5a = _Conv(sd[hd + "conv5a.0.weight"], *_fold_bn(sd, hd + "conv5a.1"), 3, 1, 1, 1, dev)
+        self.conv5c = _Conv(sd[hd + "conv5c.0.weight"], *_fold_bn(sd, hd + "conv5c.1"), 3, 1, 1, 1, dev)
+        self.conv51 = _Conv(sd[hd + "conv51.0.weight"], *_fold_bn(sd, hd + "conv51.1"), 3, 1, 1, 1, dev)
+        self.conv52 = _Conv(sd[hd + "conv52.0.weight"], *_fold_bn(sd, hd + "conv52.1"), 3, 1, 1, 1, dev)
+        self.pam_w = torch.cat([sd[hd + "sa.%s_conv.weight" % n].reshape(-1, 128) for n in ("query", "key", "value")]).contiguous().to(dev)
+        self.pam_b = torch.cat([sd[hd + "sa.%s_conv.bias" % n] for n in ("query", "key", "value")]).contiguous().to(dev)
+        self.pam_gamma = float(sd[hd + "sa.gamma"].item())
+        self.cam_gamma = float(sd[hd + "sc.gamma"].item())
+        self.conv8 = _Conv(sd[hd + "conv8.1.weight"], None, sd[hd + "conv8.1.bias"], 1, 1, 0, 0, dev)
+        self.visual_conv = _Conv(sd["visual_conv.weight"], None, sd["visual_conv.bias"], 1, 1, 0, 0, dev)
+        self.bc_conv = _Conv(sd["bc_conv.weight"], None, sd["bc_conv.bias"], 1, 1, 0, 0, dev)
+        # ---- inter-task attention MLPs (intertask_att.py:39-80); order q,k,v per branch
+        Np = self.Np
+        self.ita_w1, self.ita_b1 = [], []
+        w2, b2 = [], []
+        for br in ("visual", "bc"):
+            ws, bs = [], []
+            for role in ("query", "key", "value"):
+                pre = "inter_task_att.%s_%s_layer" % (br, role)
+                w = sd[pre + ".1.weight"].view(512, 512, Np).permute(0, 2, 1).reshape(512, Np * 512)
+                ws.append(w)
+                bs.append(sd[pre + ".1.bias"])
+                w2.append(sd[pre + ".3.weight"])
+                b2.append(sd[pre + ".3.bias"])
+            self.ita_w1.append(torch.cat(ws).contiguous().to(dev))        # [1536][Np*512]
+            self.ita_b1.append(torch.cat(bs).contiguous().to(dev))
+        self.ita_w2 = torch.stack(w2).contiguous().to(dev)                # [6][256][512]
+        self.ita_b2 = torch.stack(b2).contiguous().to(dev)                # [6][256]
+        self.temperature = 256 ** 0.5                                     # intertask_att.py:29
+        self.lut255 = torch.from_numpy((np.arange(256) / 255.).astype(np.float32)).to(dev)   # agent.py:46
+        self._ws = {}
+        self.n_weights = sum(t.numel() for t in self._all_weight_tensors())
+
+    def _all_weight_tensors(self):
+        convs = [self.stem, self.conv5a, self.conv5c, self.conv51, self.conv52, self.conv8, self.visual_conv, self.bc_conv]
+        for c1, c2, d in self.blocks:
+            convs += [c1, c2] + ([d] if d is not None else [])
+        ts = [self.pam_w, self.pam_b, self.ita_w2, self.ita_b2] + self.ita_w1 + self.ita_b1
+        for c in convs:
+            ts += [t for t in (c.w, c.scale, c.shift) if t is not None]
+        return ts
+
+    # ------------------------------------------------------------------ workspace
+    def _buf(self, key, shape, dtype=torch.float32):
+        t = self._ws.get(key)
+        if t is None or t.shape != torch.Size(shape) or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._ws[key] = t
+        return t
+
+    # ------------------------------------------------------------------ layers
+    def _conv(self, c, x, F, H, W, key, resid=None, act=None):
+        Ho = (H + 2 * c.pad - c.k) // c.stride + 1
+        Wo = (W + 2 * c.pad - c.k) // c.stride + 1
+        out = self._buf(key, (F, Ho, Wo, c.cout))
+        K = c.k * c.k * c.cin
+        M = F * Ho * Wo
+        act = c.act if act is None else act
+        if c.k == 1 and c.stride == 1:
+            hip.gemm(x, c.w, out, M, c.cout, K, K, K, c.cout, scale=c.scale, shift=c.shift, resid=resid,
+                     ldr=c.cout, act=act)
+        else:
+            hip.gemm(x, c.w, out, M, c.cout, K, 0, K, c.cout, a_mode=3 if c.cin == 4 else 2, scale=c.scale,
+                     shift=c.shift, resid=resid, ldr=c.cout, act=act,
+                     conv=(H, W, c.cin, Ho, Wo, c.k, c.k, c.stride, c.pad))
+        return out, Ho, Wo
+
+    def preprocess(self, rgb_d, route_d, route_norm_d=None):
+        """agent.py:43-75 on device: u8 [F,H,W,3] + u8 [F,W,H] -> f32 NHWC [F,H,W,4]."""
+        F = rgb_d.shape[0]
+        x = self._buf("pre", (F, self.H, self.W, 4))
+        fmax = self._buf("fmax", (F,), torch.int32)
+        L = hip.lib()
+        hip.check(L.cadre_preprocess(hip.ptr(rgb_d), hip.ptr(route_d), hip.ptr(self.lut255), hip.ptr(x),
+                                     hip.ptr(route_norm_d), hip.ptr(fmax), F, self.H, self.W, hip.stream()),
+                  "cadre_preprocess")
+        return x
+
+    def forward_nhwc(self, x, out=None, ldo=512, taps=None):
+        """x f32 NHWC [F,H,W,4] (device) -> latent written into out[:, :512] (row pitch ldo)."""
+        L = hip.lib()
+        st = hip.stream()
+        F = x.shape[0]
+        H, W = self.H, self.W
+        y, H, W = self._conv(self.stem, x, F, H, W, "stem")
+        Hp, Wp = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        p = self._buf("pool", (F, Hp, Wp, 64))
+        hip.check(L.cadre_maxpool3x3s2(hip.ptr(y), hip.ptr(p), F, H, W, 64, st), "cadre_maxpool3x3s2")
+        cur, H, W = p, Hp, Wp
+        for i, (c1, c2, down) in enumerate(self.blocks):                      # resnet.py:40-55
+            t, H2, W2 = self._conv(c1, cur, F, H, W, "b%d_t" % i)
+            idt = cur
+            if down is not None:
+                idt, _, _ = self._conv(down, cur, F, H, W, "b%d_d" % i)
+            cur, H, W = self._conv(c2, t, F, H2, W2, "b%d_o" % i, resid=idt)
+        l4 = cur
+        Np = H * W
+        assert Np == self.Np
+        # ---- da_head (danet.py:43-69)
+        f1, _, _ = self._conv(self.conv5a, l4, F, H, W, "f1")
+        qkv = self._buf("pam_qkv", (F * Np, 160))
+        hip.gemm(f1, self.pam_w, qkv, F * Np, 160, 128, 128, 128, 160, shift=self.pam_b)
+        sa = self._buf("sa", (F, H, W, 128))
+        hip.check(L.cadre_pam(hip.ptr(f1), hip.ptr(qkv), self.pam_gamma, hip.ptr(sa), F, Np, st), "cadre_pam")
+        sa_conv, _, _ = self._conv(self.conv51, sa, F, H, W, "sa_conv")
+        f2, _, _ = self._conv(self.conv5c, l4, F, H, W, "f2")
+        sc = self._buf("sc", (F, H, W, 128))
+        hip.check(L.cadre_cam(hip.ptr(f2), self.cam_gamma, hip.ptr(sc), F, Np, st), "cadre_cam")
+        # feat_sum = sa_conv + sc_conv (danet.py:57) fused into conv52's epilogue as a residual added
+        # AFTER its ReLU (act|16): relu(bn(conv52(sc))) + sa_conv
+        feat_sum, _, _ = self._conv(self.conv52, sc, F, H, W, "feat_sum", resid=sa_conv, act=1 | 16)
+        da, _, _ = self._conv(self.conv8, feat_sum, F, H, W, "da")
+        vis, _, _ = self._conv(self.visual_conv, da, F, H, W, "vis")
+        bc, _, _ = self._conv(self.bc_conv, da, F, H, W, "bc")
+        if taps is not None:
+            taps.update(layer4=l4, da=da, vis=vis, bc=bc)
+        # ---- inter-task attention (intertask_att.py:121-176)
+        Kin = Np * 512
+        hid = self._buf("ita_hid", (F, 3072))
+        # split-K chosen from K alone: every output element is then summed in the same order for any
+        # frame batch, so per-frame results are bit-identical across batch sizes (latent cache, §8f-1)
+        split = int(max(1, min(32, Kin // 2048)))
+        for b, src in enumerate((vis, bc)):
+            if split > 1:
+                slabs = self._buf("ita_slab", (split, F, 1536))
+                hip.gemm(src, self.ita_w1[b], slabs, F, 1536, Kin, Kin, Kin, 1536, split_k=split, tile=3 if F <= 64 else 0)
+                hip.check(L.cadre_splitk_reduce(hip.ptr(slabs), split, F * 1536, 1536, hid.data_ptr() + 4 * 1536 * b,
+                                                3072, F, 1536, None, hip.ptr(self.ita_b1[b]), 2, 0.01, st),
+                          "cadre_splitk_reduce")
+            else:
+                hip.gemm(src, self.ita_w1[b], hid[:, 1536 * b:], F, 1536, Kin, Kin, Kin, 3072, shift=self.ita_b1[b],
+                         act=2, slope=0.01)
+        qkv2 = self._buf("ita_qkv", (F, 6, 256))
+        hip.gemm(hid, self.ita_w2, qkv2, F, 256, 512, 3072, 512, 1536, shift=self.ita_b2, batch=6,
+                 a_z=(1, 0, 512), b_z=(1, 0, 256 * 512), c_z=(1, 0, 256), s_z=(1, 0, 256))
+        if out is None:
+            out = torch.zeros(F, ldo, device=self.device)
+        hip.check(L.cadre_intertask_att(hip.ptr(qkv2), hip.ptr(out), out.stride(0), F, self.temperature, st),
+                  "cadre_intertask_att")
+        return out
+
+    def latent(self, rgb_d, route_d, out=None, route_norm_d=None, taps=None):
+        """Frames are processed in chunks of `max_frames` (workspace sized once)."""
+        F = rgb_d.shape[0]
+        if out is None:
+            out = torch.zeros(F, 512, device=self.device)
+        for s in range(0, F, self.max_frames):
+            e = min(F, s + self.max_frames)
+            rn = None if route_norm_d is None else route_norm_d[s:e]
+            x = self.preprocess(rgb_d[s:e], route_d[s:e], rn)
+            self.forward_nhwc(x, out[s:e], taps=taps)
+        return out
+
+    # ------------------------------------------------------------------ accounting
+    def flops_per_frame(self):
+        H, W = self.H, self.W
+        total = 0
+        def conv(c, H, W):
+            Ho = (H + 2 * c.pad - c.k) // c.stride + 1
+            Wo = (W + 2 * c.pad - c.k) // c.stride + 1
+            return 2 * Ho * Wo * c.cout * c.cin * c.k * c.k, Ho, Wo
+        f, H, W = conv(self.stem, H, W); total += f
+        H, W = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        for c1, c2, d in self.blocks:
+            f, H2, W2 = conv(c1, H, W); total += f
+            if d is not None:
+                total += conv(d, H, W)[0]
+            f, H, W = conv(c2, H2, W2); total += f
+        for c in (self.conv5a, self.conv5c, self.conv51, self.conv52, self.conv8, self.visual_conv, self.bc_conv):
+            total += conv(c, H, W)[0]
+        Np = H * W
+        total += 2 * Np * 160 * 128 + 2 * (Np * Np * 16 + Np * Np * 128) + 2 * 2 * (128 * 128 * Np)
+        total += 2 * (2 * 1536 * Np * 512 + 6 * 256 * 512)
+        return total

@@ -1,0 +1,111 @@
+"""ctypes binding of libcadre_hip.so (include/cadre_hip.h) + thin tensor-pointer helpers.
+
+PyTorch-ROCm is plumbing here: it owns device memory and streams; every call below hands
+raw device pointers and the current HIP stream to the C ABI.  There is NO CPU fallback:
+a missing library raises at first use (`lib()`), and every kernel wrapper requires device
+tensors.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcadre_hip.so")
+_lib = None
+
+i32, i64, f32, f64, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("A", vp), ("B", vp), ("C", vp), ("scale", vp), ("shift", vp), ("resid", vp),
+                ("lda", i64), ("ldb", i64), ("ldc", i64), ("ldr", i64),
+                ("M", i32), ("N", i32), ("K", i32), ("a_mode", i32), ("b_mode", i32),
+                ("act", i32), ("slope", f32), ("batch", i32),
+                ("a_div", i32), ("a_mod", i32), ("b_div", i32), ("b_mod", i32), ("c_div", i32), ("c_mod", i32),
+                ("s_div", i32), ("s_mod", i32), ("r_div", i32), ("r_mod", i32),
+                ("a_str", i64), ("b_str", i64), ("c_str", i64), ("s_str", i64), ("r_str", i64),
+                ("H", i32), ("W", i32), ("Cin", i32), ("Ho", i32), ("Wo", i32), ("KH", i32), ("KW", i32),
+                ("stride", i32), ("pad", i32), ("split_k", i32), ("tile", i32)]
+
+
+# name -> argtypes (restype is int unless noted); must list every symbol of include/cadre_hip.h
+SYMBOLS = {
+    "cadre_abi_version": [],
+    "cadre_last_error": [],
+    "cadre_gemm_f32": [C.POINTER(GemmDesc), vp],
+    "cadre_splitk_reduce": [vp, i32, i64, i64, vp, i64, i32, i32, vp, vp, i32, f32, vp],
+    "cadre_preprocess": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "cadre_maxpool3x3s2": [vp, vp, i32, i32, i32, i32, vp],
+    "cadre_pam": [vp, vp, f32, vp, i32, i32, vp],
+    "cadre_cam": [vp, f32, vp, i32, i32, vp],
+    "cadre_intertask_att": [vp, vp, i64, i32, f32, vp],
+    "cadre_append_measurements": [vp, vp, i64, i32, vp],
+    "cadre_gae": [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, vp],
+    "cadre_gather_obs": [vp, i64, i32, vp, i32, vp, i64, i32, vp],
+    "cadre_lstm_pointwise_fwd": [vp, i64, i64, vp, i64, i32, vp, vp, vp, i64, i64, i32, i32, i32, vp],
+    "cadre_lstm_pointwise_bwd": [vp, vp, i64, i64, vp, vp, i64, vp, vp, i64, i32, i64, i64, i32, i32, i32, vp],
+    "cadre_colsum": [vp, i64, i64, vp, i64, i32, i32, i32, i32, vp],
+    "cadre_relu_bwd": [vp, vp, i64, vp],
+    "cadre_ppo_loss": [vp, i64, i64, vp, i64, i64, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, f32, vp, vp, vp, vp],
+    "cadre_sample": [vp, i64, vp, i64, i32, i32, vp, vp, vp],
+    "cadre_clip_adam": [vp, vp, vp, vp, vp, i32, vp, f64, f64, f64, f64, f64, i32, vp],
+}
+
+
+class CadreHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the HIP library; fail loudly if it is missing (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CadreHipError(
+                "libcadre_hip.so not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `python -m cadre_amd.build`. There is no CPU fallback for the Cadre MI355X learner." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, args in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = C.c_char_p if name == "cadre_last_error" else C.c_int
+        if L.cadre_abi_version() != 1:
+            raise CadreHipError("libcadre_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().cadre_last_error().decode() if rc < 0 else "hipError_t %d" % rc
+        raise CadreHipError("%s failed: %s" % (what, msg))
+
+
+def ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise CadreHipError("cadre_amd kernels need device (HIP) tensors; got a CPU tensor — there is no CPU path")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, scale=None, shift=None, resid=None, ldr=0,
+         act=0, slope=0.01, batch=1, a_z=(1, 0, 0), b_z=(1, 0, 0), c_z=(1, 0, 0), s_z=(1, 0, 0), r_z=(1, 0, 0),
+         conv=None, split_k=1, tile=0):
+    """C = act((A . B^T) * scale + shift + resid).  *_z = (div, mod, stride) batch addressing."""
+    d = GemmDesc()
+    d.A, d.B, d.C = ptr(A), ptr(B), ptr(Cout)
+    d.scale, d.shift, d.resid = ptr(scale), ptr(shift), ptr(resid)
+    d.lda, d.ldb, d.ldc, d.ldr = lda, ldb, ldc, ldr
+    d.M, d.N, d.K, d.a_mode, d.b_mode, d.act, d.slope, d.batch = M, N, K, a_mode, b_mode, act, slope, batch
+    (d.a_div, d.a_mod, d.a_str), (d.b_div, d.b_mod, d.b_str) = a_z, b_z
+    (d.c_div, d.c_mod, d.c_str), (d.s_div, d.s_mod, d.s_str), (d.r_div, d.r_mod, d.r_str) = c_z, s_z, r_z
+    if conv is not None:
+        d.H, d.W, d.Cin, d.Ho, d.Wo, d.KH, d.KW, d.stride, d.pad = conv
+    d.split_k, d.tile = split_k, tile
+    check(lib().cadre_gemm_f32(C.byref(d), stream()), "cadre_gemm_f32")

@@ -1,0 +1,188 @@
+"""PPO inner loop on MI355X: the math of `CadreAgent.update_policy` / `act` / `get_value`
+(reference ppo_agent/agent.py:114-237) and of `chief` (ppo_agent/chief.py:13-21) as batched
+HIP launches over the parameter arena (cadre_amd/arena.py).
+
+The reference runs 8 (head x command) LSTM+MLP nets one after another, each through 8
+LSTMCell calls, and lets autograd replay ~1000 tiny kernels.  Here the 8 nets are ONE strided
+batch: the input projections of all 8 time steps and 4 command nets of a head are one GEMM,
+each recurrent step is one GEMM + one pointwise launch for all 8 nets, the backward pass is
+written out explicitly (same formulas autograd would apply) and writes straight into the flat
+gradient arena.  No autograd graph, no per-parameter tensors, nothing on the host between
+launches — the whole update is ~60 launches on one stream.
+"""
+import torch
+
+from . import hip
+
+
+class PPOLearnerHIP:
+    def __init__(self, arena, clip=0.1, value_coeff=0.1, clip_coeff=1.0, ent_coeff=0.01, seq_length=8):
+        self.a = arena
+        self.clip, self.vc, self.cc, self.ec = float(clip), float(value_coeff), float(clip_coeff), float(ent_coeff)
+        self.S = seq_length
+        self._ws = {}
+        hip.lib()
+
+    # ------------------------------------------------------------------ workspace
+    def workspace(self, B, Z=None, S=None):
+        a = self.a
+        Z = a.Z if Z is None else Z
+        S = self.S if S is None else S
+        key = (B, Z, S)
+        w = self._ws.get(key)
+        if w is None:
+            dev = a.device
+            z = lambda *shape, dtype=torch.float32: torch.zeros(*shape, dtype=dtype, device=dev)
+            w = dict(
+                X=z(2, S, B, a.DP), h0=z(2, B, a.DP), c0=z(2, B, a.DP),
+                G=z(Z, S, B, a.H4), dG=z(Z, S, B, a.H4),
+                Hs=z(Z, S + 1, B, a.DP), Cs=z(Z, S + 1, B, a.DP), TC=z(Z, S + 1, B, a.DP),
+                A1=z(2 * Z, B, a.hid), A2=z(2 * Z, B, a.hid), O3=z(2 * Z, B, a.NP),
+                dO3=z(2 * Z, B, a.NP), dA2=z(2 * Z, B, a.hid), dA1=z(2 * Z, B, a.hid),
+                dH=z(Z, B, a.DP), dC=z(Z, B, a.DP),
+                actions=z(2, B, dtype=torch.int64), commands=z(2, B, dtype=torch.int32),
+                old_values=z(2, B), returns=z(2, B), old_logp=z(2, B), adv=z(2, B),
+                losses=z(3),
+            )
+            self._ws[key] = w
+        return w
+
+    # ------------------------------------------------------------------ forward
+    def _forward(self, w, B, nets, x_div, S=None):
+        """LSTM (S steps) + both MLP towers for `Z` nets.  nets = (g0, g_stride, Z): arena net
+        indices g0 + i*g_stride.  Net i reads inputs X[i // x_div], h0/c0[i // x_div]."""
+        a = self.a
+        S = self.S if S is None else S
+        g0, gs, Z = nets
+        P, st = a.params, hip.stream()
+        L = hip.lib()
+        DP, H4, hid, NP = a.DP, a.H4, a.hid, a.NP
+        pL = P[g0 * a.size_L:]
+        sL = gs * a.size_L
+        X, G, Hs, Cs, TC = w["X"], w["G"], w["Hs"], w["Cs"], w["TC"]
+        # h_{-1}, c_{-1} (hidden_state_batch, agent.py:166-175) into slot 0 of every net
+        Hs.view(-1, x_div, S + 1, B, DP)[:, :, 0].copy_(w["h0"][:Z // x_div].unsqueeze(1))
+        Cs.view(-1, x_div, S + 1, B, DP)[:, :, 0].copy_(w["c0"][:Z // x_div].unsqueeze(1))
+        # all input projections x_t W_ih^T + b_ih: one GEMM [S*B, DP] x [DP, H4] per net
+        hip.gemm(X, pL[a.o_wih:], G, S * B, H4, DP, DP, DP, H4, shift=pL[a.o_bih:], batch=Z,
+                 a_z=(x_div, 0, S * B * DP), b_z=(1, 0, sL), c_z=(1, 0, S * B * H4), s_z=(1, 0, sL))
+        for t in range(S):                                          # models.py:148-151
+            Gt = G[:, t]
+            hip.gemm(Hs[:, t], pL[a.o_whh:], Gt, B, H4, DP, DP, DP, H4, shift=pL[a.o_bhh:], resid=Gt, ldr=H4,
+                     batch=Z, a_z=(1, 0, (S + 1) * B * DP), b_z=(1, 0, sL), c_z=(1, 0, S * B * H4),
+                     s_z=(1, 0, sL), r_z=(1, 0, S * B * H4))
+            hip.check(L.cadre_lstm_pointwise_fwd(hip.ptr(Gt), H4, S * B * H4, hip.ptr(Cs[:, t]), (S + 1) * B * DP, 1,
+                                                 hip.ptr(Cs[:, t + 1]), hip.ptr(Hs[:, t + 1]), hip.ptr(TC[:, t + 1]),
+                                                 DP, (S + 1) * B * DP, B, a.D, Z, st), "cadre_lstm_pointwise_fwd")
+        # actor (tower 0) + critic (tower 1): z = 2*i + tower  (models.py:171-177, distributions.py:34-40)
+        pP = P[a.P0 + g0 * a.size_P:]
+        sT = a.size_T if gs == 1 else None
+        A1, A2, O3 = w["A1"], w["A2"], w["O3"]
+        for tower in ((None,) if sT else (0, 1)):
+            if sT:      # contiguous nets: 2Z towers with uniform stride
+                pw, zb, nb, div, zs, cs = pP, 0, 2 * Z, 2, a.size_T, 1
+            else:       # strided nets (act/get_value): one launch per tower
+                pw, zb, nb, div, zs, cs = pP[tower * a.size_T:], tower, Z, 1, gs * a.size_P, 2
+            hip.gemm(Hs[:, S], pw[a.t_w1:], A1[zb:], B, hid, DP, DP, DP, hid, shift=pw[a.t_b1:], act=1, batch=nb,
+                     a_z=(div, 0, (S + 1) * B * DP), b_z=(1, 0, zs), c_z=(1, 0, cs * B * hid), s_z=(1, 0, zs))
+            hip.gemm(A1[zb:], pw[a.t_w2:], A2[zb:], B, hid, hid, hid, hid, hid, shift=pw[a.t_b2:], act=1, batch=nb,
+                     a_z=(1, 0, cs * B * hid), b_z=(1, 0, zs), c_z=(1, 0, cs * B * hid), s_z=(1, 0, zs))
+            hip.gemm(A2[zb:], pw[a.t_w3:], O3[zb:], B, NP, hid, hid, hid, NP, shift=pw[a.t_b3:], batch=nb,
+                     a_z=(1, 0, cs * B * hid), b_z=(1, 0, zs), c_z=(1, 0, cs * B * NP), s_z=(1, 0, zs))
+
+    # ------------------------------------------------------------------ update_policy
+    def update(self, B, inv_b):
+        """Forward + loss + backward for the packed minibatch in workspace(B).  Gradients of all 16
+        nets are written (not accumulated) into arena.grads.  Returns the device tensor
+        losses[3] = (value_loss*vc, action_loss*cc, ent_loss*ec) (agent.py:226-237)."""
+        a, S = self.a, self.S
+        w = self.workspace(B)
+        Z, C = a.Z, a.C
+        L, st = hip.lib(), hip.stream()
+        DP, H4, hid, NP = a.DP, a.H4, a.hid, a.NP
+        self._forward(w, B, (0, 1, Z), C)
+        O3, dO3 = w["O3"], w["dO3"]
+        hip.check(L.cadre_ppo_loss(hip.ptr(O3), NP, 2 * B * NP, hip.ptr(O3[1]), NP, 2 * B * NP,
+                                   hip.ptr(w["actions"]), hip.ptr(w["commands"]), hip.ptr(w["old_values"]),
+                                   hip.ptr(w["returns"]), hip.ptr(w["old_logp"]), hip.ptr(w["adv"]), B,
+                                   a.n_out[0], a.n_out[1], self.clip, self.vc, self.cc, self.ec, inv_b,
+                                   hip.ptr(w["losses"]), hip.ptr(dO3), hip.ptr(dO3[1]), st), "cadre_ppo_loss")
+        # ---------------- backward: MLP towers (16 = 2Z batched)
+        Gr = a.grads
+        pP, gP = a.params[a.P0:], Gr[a.P0:]
+        sT, nb = a.size_T, 2 * Z
+        A1, A2, dA1, dA2 = w["A1"], w["A2"], w["dA1"], w["dA2"]
+        Hs = w["Hs"]
+        zT = (1, 0, sT)
+
+        def layer_bwd(dY, n_y, Xin, ldx_, n_x, x_z, o_w, o_b, dX):
+            # dW = dY^T X ; db = colsum(dY) ; dX = dY W
+            hip.gemm(dY, Xin, gP[o_w:], n_y, n_x, B, n_y, ldx_, n_x, a_mode=1, b_mode=1, batch=nb,
+                     a_z=(1, 0, B * n_y), b_z=x_z, c_z=zT)
+            hip.check(L.cadre_colsum(hip.ptr(dY), n_y, B * n_y, hip.ptr(gP[o_b:]), sT, B, n_y, nb, 0, st), "cadre_colsum")
+            if dX is not None:
+                hip.gemm(dY, pP[o_w:], dX, B, n_x, n_y, n_y, n_x, n_x, b_mode=1, batch=nb,
+                         a_z=(1, 0, B * n_y), b_z=zT, c_z=(1, 0, B * n_x))
+
+        layer_bwd(dO3, NP, A2, hid, hid, (1, 0, B * hid), a.t_w3, a.t_b3, dA2)
+        hip.check(L.cadre_relu_bwd(hip.ptr(A2), hip.ptr(dA2), nb * B * hid, st), "cadre_relu_bwd")
+        layer_bwd(dA2, hid, A1, hid, hid, (1, 0, B * hid), a.t_w2, a.t_b2, dA1)
+        hip.check(L.cadre_relu_bwd(hip.ptr(A1), hip.ptr(dA1), nb * B * hid, st), "cadre_relu_bwd")
+        layer_bwd(dA1, hid, Hs[:, S], DP, DP, (2, 0, (S + 1) * B * DP), a.t_w1, a.t_b1, None)
+        # dh_S = dZ1_actor W1_actor + dZ1_critic W1_critic   (two launches, second accumulates)
+        dH, dC = w["dH"], w["dC"]
+        for tower in (0, 1):
+            hip.gemm(dA1[tower:], pP[tower * sT + a.t_w1:], dH, B, DP, hid, hid, DP, DP, b_mode=1, batch=Z,
+                     a_z=(1, 0, 2 * B * hid), b_z=(1, 0, a.size_P), c_z=(1, 0, B * DP),
+                     resid=dH if tower else None, ldr=DP, r_z=(1, 0, B * DP))
+        # ---------------- backward through time (autograd of models.py:148-151)
+        dC.zero_()
+        G, dG, Cs, TC, X = w["G"], w["dG"], w["Cs"], w["TC"], w["X"]
+        pL, gL, sL = a.params, Gr, a.size_L
+        for t in range(S - 1, -1, -1):
+            hip.check(L.cadre_lstm_pointwise_bwd(hip.ptr(G[:, t]), hip.ptr(dG[:, t]), H4, S * B * H4, hip.ptr(dH),
+                                                 hip.ptr(dC), B * DP, hip.ptr(TC[:, t + 1]), hip.ptr(Cs[:, t]),
+                                                 (S + 1) * B * DP, 1, DP, (S + 1) * B * DP, B, a.D, Z, st),
+                      "cadre_lstm_pointwise_bwd")
+            if t > 0:   # dh_{t-1} = dG_t W_hh
+                hip.gemm(dG[:, t], pL[a.o_whh:], dH, B, DP, H4, H4, DP, DP, b_mode=1, batch=Z,
+                         a_z=(1, 0, S * B * H4), b_z=(1, 0, sL), c_z=(1, 0, B * DP))
+        # dW_hh = sum_t dG_t^T h_{t-1} ; dW_ih = sum_t dG_t^T x_t ; db_ih = db_hh = colsum(dG)
+        hip.gemm(dG, Hs, gL[a.o_whh:], H4, DP, S * B, H4, DP, DP, a_mode=1, b_mode=1, batch=Z,
+                 a_z=(1, 0, S * B * H4), b_z=(1, 0, (S + 1) * B * DP), c_z=(1, 0, sL))
+        hip.gemm(dG, X, gL[a.o_wih:], H4, DP, S * B, H4, DP, DP, a_mode=1, b_mode=1, batch=Z,
+                 a_z=(1, 0, S * B * H4), b_z=(C, 0, S * B * DP), c_z=(1, 0, sL))
+        for o_b in (a.o_bih, a.o_bhh):
+            hip.check(L.cadre_colsum(hip.ptr(dG), H4, S * B * H4, hip.ptr(gL[o_b:]), sL, S * B, H4, Z, 0, st),
+                      "cadre_colsum")
+        return w["losses"]
+
+    # ------------------------------------------------------------------ optimiser (chief.py:13-21)
+    def clip_adam(self, lr=3e-4, max_grad_norm=250.0, betas=(0.9, 0.999), eps=1e-8):
+        a = self.a
+        a.ensure_adam()
+        a.step += 1
+        hip.check(hip.lib().cadre_clip_adam(hip.ptr(a.params), hip.ptr(a.grads), hip.ptr(a.exp_avg),
+                                            hip.ptr(a.exp_avg_sq), hip.ptr(a.seg_off), 2 * a.Z, hip.ptr(a.norms2),
+                                            float(max_grad_norm), float(lr), float(betas[0]), float(betas[1]),
+                                            float(eps), a.step, hip.stream()), "cadre_clip_adam")
+
+    # ------------------------------------------------------------------ inference (act / get_value)
+    def infer(self, feats, commands, h0=None, c0=None):
+        """LSTM + both towers of net (steer, commands[0]) and (throttle, commands[1]) at batch 1.
+        feats: [2][S][DP-padded] views or one shared [S][D] feature block.  Returns (O3 [4][1][NP]:
+        rows (steer actor, steer critic, throttle actor, throttle critic))."""
+        a, S = self.a, feats.shape[-2]
+        w = self.workspace(1, 2, S)
+        X = w["X"]
+        if feats.dim() == 2:
+            X[:, :, 0, :a.D].copy_(feats.unsqueeze(0).expand(2, S, a.D))
+        else:
+            X[:, :, 0, :a.D].copy_(feats)
+        if h0 is None:
+            w["h0"].zero_(); w["c0"].zero_()
+        else:
+            w["h0"][:, 0, :a.D].copy_(h0); w["c0"][:, 0, :a.D].copy_(c0)
+        g_s, g_t = commands[0], a.C + commands[1]
+        self._forward(w, 1, (g_s, g_t - g_s, 2), 1, S=S)
+        return w["O3"], w["Hs"][:, S], w["Cs"][:, S]

@@ -1,0 +1,179 @@
+"""Mirror of reference ppo_agent/agent.py `CadreAgent`: same constructor, attributes and
+method contracts (act / get_value / update_policy / update_model / convert_action / avg_action /
+save_snapshot / load_snapshot), every tensor op on HIP kernels via cadre_amd.encoder and
+cadre_amd.learner."""
+import numpy as np
+import torch
+
+from .. import hip
+from ..learner import PPOLearnerHIP
+from .models import LSTM, Model, _cfg, arena_of, create_model, get_vae_output
+
+
+class CadreAgent(object):
+    def __init__(self, rank, model_cfg, frame, STEER_CONTROL, THROTTLE_CONTROL, ent_coeff, value_coeff, clip_coeff,
+                 clip):
+        self.rank = rank
+        self.vae_model, self.model_dict = create_model(model_cfg, load_vae=True)
+        self.use_lstm = _cfg(model_cfg, "use_lstm")
+        self.command_num = _cfg(model_cfg, "command_num")
+        self.device = torch.device("cuda:" + str(_cfg(model_cfg, "device_num")))
+        self.vae_device = torch.device("cuda:" + str(_cfg(model_cfg, "vae_device")))
+        self.STEER_CONTROL = STEER_CONTROL
+        self.THROTTLE_CONTROL = THROTTLE_CONTROL
+        self.ent_coeff, self.value_coeff, self.clip_coeff, self.clip = ent_coeff, value_coeff, clip_coeff, clip
+        self.lstm_input, self.vae_params = get_vae_output(model_cfg)
+        self.use_vae = True
+        self.frame = frame
+        self.pre_latent_feature = None
+        self.hidden_state = (torch.zeros(1, self.lstm_input, device=self.device),
+                             torch.zeros(1, self.lstm_input, device=self.device))
+        self.arena = arena_of(self.model_dict)
+        self.learner = PPOLearnerHIP(self.arena, clip, value_coeff, clip_coeff, ent_coeff, seq_length=frame)
+        self.arena._learner = self.learner
+        self.mutate_route = _cfg(model_cfg, "mutate_route", True)
+        self._feat = None
+
+    # ------------------------------------------------------------------ observation -> feature
+    def pre_process(self, tick_data):
+        """agent.py:43-75 on device; returns the NHWC f32 tensor [S,H,W,4] (the reference returns
+        NCHW numpy — same values, channels-last) and applies the in-place uint8 route quirk."""
+        rgb = torch.from_numpy(np.ascontiguousarray(tick_data["rgb"])).to(self.vae_device, non_blocking=True)
+        route_np = tick_data["route_fig"]
+        route = torch.from_numpy(np.ascontiguousarray(route_np)).to(self.vae_device, non_blocking=True)
+        rn = torch.empty_like(route) if self.mutate_route else None
+        x = self.vae_model.preprocess(rgb, route, rn)
+        if rn is not None:
+            route_np[...] = rn.cpu().numpy()            # agent.py:51-54 mutates the caller's dict
+        return x
+
+    def get_latent_feature(self, tick_data):
+        """agent.py:97-112 -> [S, 530] f32 device tensor (a view of a 544-pitch row buffer)."""
+        x = self.pre_process(tick_data)
+        S = x.shape[0]
+        if self._feat is None or self._feat.shape[0] != S:
+            self._feat = torch.zeros(S, self.arena.DP, device=self.device)
+        feat = torch.zeros_like(self._feat)              # fresh rows: callers keep references (rollout insert)
+        self.vae_model.forward_nhwc(x, feat)
+        meas = torch.from_numpy(np.ascontiguousarray(tick_data["measurements"], dtype=np.float64)).to(self.device)
+        hip.check(hip.lib().cadre_append_measurements(hip.ptr(meas), hip.ptr(feat), feat.stride(0), S, hip.stream()),
+                  "cadre_append_measurements")
+        return feat[:, :self.lstm_input]
+
+    # ------------------------------------------------------------------ act
+    def _sample(self, O3, tower_row, K, q_host):
+        q = q_host.to(self.device, non_blocking=True)
+        action = torch.empty(1, dtype=torch.int64, device=self.device)
+        logp = torch.empty(1, 1, device=self.device)
+        hip.check(hip.lib().cadre_sample(hip.ptr(O3[tower_row]), O3.shape[-1], hip.ptr(q), K, 1, K, hip.ptr(action),
+                                         hip.ptr(logp), hip.stream()), "cadre_sample")
+        return action, logp
+
+    def act(self, tick_data):
+        """agent.py:114-141.  Sampling consumes the global torch CPU generator exactly like the
+        reference (one exponential_(1) draw of n_out floats per head, steer first)."""
+        command = tick_data["command"]
+        ppo_feature = self.get_latent_feature(tick_data)
+        O3, _, _ = self.learner.infer(ppo_feature, (command, command))
+        nS, nT = self.arena.n_out
+        q_s = torch.empty(1, nS).exponential_(1)
+        q_t = torch.empty(1, nT).exponential_(1)
+        a_s, lp_s = self._sample(O3, 0, nS, q_s)
+        a_t, lp_t = self._sample(O3, 2, nT, q_t)
+        v_s = O3[1, :, :1].clone()
+        v_t = O3[3, :, :1].clone()
+        ctl_s = self.model_dict["steer_ppo_%d" % command].control
+        ctl_t = self.model_dict["throttle_ppo_%d" % command].control
+        ctl_s._last_action, ctl_s._last_logp = a_s, lp_s
+        ctl_t._last_action, ctl_t._last_logp = a_t, lp_t
+        # the reference discards the new hidden state and returns the zeros (agent.py:123-124,141)
+        return ppo_feature, [a_s[0], a_t[0]], [lp_s, lp_t], [v_s, v_t], self.hidden_state
+
+    def get_value(self, done, steer_batch, throttle_batch):
+        """agent.py:143-164."""
+        if done:
+            return torch.zeros(1), torch.zeros(1)
+        s_obs, s_cmd = steer_batch
+        t_obs, t_cmd = throttle_batch
+        O3, _, _ = self.learner.infer(torch.stack([s_obs, t_obs]), (int(s_cmd), int(t_cmd)))
+        return O3[1, :, :1].clone(), O3[3, :, :1].clone()
+
+    # ------------------------------------------------------------------ update
+    def _pack(self, w, hd, samples):
+        obs, act, old_v, ret, _masks, old_lp, adv, hidden, cmd = samples
+        B = act.shape[0]
+        S, D = self.learner.S, self.arena.D
+        w["X"][hd].view(S * B, -1)[:, :D].copy_(obs)
+        w["h0"][hd][:, :D].copy_(hidden[0])
+        w["c0"][hd][:, :D].copy_(hidden[1])
+        w["actions"][hd].copy_(act.reshape(-1))
+        w["commands"][hd].copy_(cmd.reshape(-1))
+        w["old_values"][hd].copy_(old_v.reshape(-1))
+        w["returns"][hd].copy_(ret.reshape(-1))
+        w["old_logp"][hd].copy_(old_lp.reshape(-1))
+        w["adv"][hd].copy_(adv.reshape(-1))
+
+    def update_policy(self, steer_samples, throttle_samples, workers=1):
+        """agent.py:166-237: fused forward + loss + explicit backward; `.grad` of every parameter in
+        model_dict (views of the gradient arena) holds d total_loss afterwards.  With `workers` > 1
+        the sample tuples are the row-concatenation of that many equal-size worker minibatches and
+        the losses are the SUM of per-worker means."""
+        B = steer_samples[1].shape[0]
+        if throttle_samples[1].shape[0] != B:
+            raise ValueError("steer/throttle minibatches differ in size")
+        w = self.learner.workspace(B)
+        self._pack(w, 0, steer_samples)
+        self._pack(w, 1, throttle_samples)
+        losses = self.learner.update(B, float(workers) / B)
+        self.arena.attach_grads(self.model_dict)
+        v, a, e = losses.tolist()
+        return v, a, e
+
+    def update_model(self, shared_model_list):
+        """agent.py:239-243 (weight pull).  Same arena -> nothing to copy."""
+        src = arena_of(shared_model_list)
+        if src is not self.arena:
+            self.arena.params.copy_(src.params)
+
+    # ------------------------------------------------------------------ controls
+    def convert_action(self, discrete_action):
+        steer = self.STEER_CONTROL[discrete_action[0].item()]
+        throttle, brake = self.THROTTLE_CONTROL[discrete_action[1].item()]
+        return [steer, throttle, brake]
+
+    def avg_action(self, discrete_action_list):
+        """agent.py:83-95 (eval-time ensemble)."""
+        n = len(discrete_action_list)
+        ctl = np.array([self.convert_action(a) for a in discrete_action_list]).mean(0).tolist()
+        if n > 1 and ctl[-1] < 0.5:
+            ctl[-1] = 0.0
+        return ctl
+
+    # ------------------------------------------------------------------ snapshots
+    def save_snapshot(self, model_path, fix_missing_lstm=False):
+        """agent.py:245-260: pickled nn.Modules keyed by model name.  The reference writes
+        steer_ppo twice and never throttle_lstm; `fix_missing_lstm=True` adds it."""
+        out = {}
+        kinds = ["throttle_ppo_", "steer_ppo_", "steer_lstm_"] + (["throttle_lstm_"] if fix_missing_lstm else [])
+        for c in range(self.command_num):
+            for kind in kinds:
+                name = kind + str(c)
+                src = self.model_dict[name]
+                if "lstm" in name:
+                    m = LSTM(self.lstm_input, hid_size=self.lstm_input)
+                else:
+                    m = Model(self.lstm_input, src.control.num_outputs)
+                m.load_state_dict({k: v.detach().cpu().contiguous() for k, v in src.state_dict().items()})
+                out[name] = m
+        torch.save(out, model_path)
+
+    def load_snapshot(self, model_path, device):
+        """agent.py:262-271."""
+        if device is None:
+            device = self.device
+        try:
+            model_dict = torch.load(model_path, map_location="cpu", weights_only=False)
+            for name in model_dict:
+                self.model_dict[name].load_state_dict(model_dict[name].state_dict())
+        except Exception as e:
+            raise ImportError("load snapshot error due to {}".format(e))

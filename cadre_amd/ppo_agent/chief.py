@@ -1,0 +1,37 @@
+"""Mirror of reference ppo_agent/chief.py:8-27: once every worker has handed in its gradients,
+clip each model's gradient norm to `max_grad_norm`, take one Adam step over all 16 nets,
+clear the buffers and flip the traffic light — as ONE fused HIP pass over the arena
+(cadre_clip_adam) instead of 16 clip calls + a 112-tensor optimizer.step()."""
+import time
+
+from ..learner import PPOLearnerHIP
+
+
+def _hyper(optimizer):
+    g = optimizer.param_groups[0]
+    return g["lr"], tuple(g.get("betas", (0.9, 0.999))), g.get("eps", 1e-8)
+
+
+def chief_step(shared_grad_buffers, optimizer, max_grad_norm):
+    """One optimiser step (chief.py:13-23) on the arena behind `shared_grad_buffers`."""
+    arena = shared_grad_buffers.arena
+    lr, betas, eps = _hyper(optimizer) if optimizer is not None else (3e-4, (0.9, 0.999), 1e-8)
+    step = getattr(arena, "_learner", None)
+    if step is None:
+        arena._learner = step = PPOLearnerHIP(arena)
+    step.clip_adam(lr=lr, max_grad_norm=max_grad_norm, betas=betas, eps=eps)
+    shared_grad_buffers.reset()
+
+
+def chief(update_threshold, traffic_light, counter, shared_model_list, shared_grad_buffers, optimizer,
+          son_process_counter, max_grad_norm, total_thread):
+    while True:
+        if counter.get() >= update_threshold:
+            chief_step(shared_grad_buffers, optimizer, max_grad_norm)
+            counter.reset()
+            traffic_light.switch()
+        elif son_process_counter.get() >= total_thread:
+            print("chief finished.")
+            break
+        else:
+            time.sleep(0.0005)      # the reference polls with sleep(1): <= 1 optimiser step / s

@@ -1,0 +1,88 @@
+"""Mirror of reference ppo_agent/train.py: `train(rank, ...)` worker loop with the learner
+section (train.py:76-110) factored into `learner_section` so it can be driven by replayed /
+synthetic rollouts (tests, bench.py) as well as by the live CARLA `EnvWrapper`."""
+import os
+
+import numpy as np
+import torch
+
+from .agent import CadreAgent
+from .chief import chief_step
+from .models import get_vae_output
+from .storage import RolloutStorage
+from .utils import check_exist
+
+
+def learner_section(agent, steer_rollout, throttle_rollout, done, train_cfg, shared_grad_buffers,
+                    optimizer=None, traffic_light=None, counter=None, shared_model_list=None, in_process_chief=True):
+    """train.py:76-110.  Returns (value_loss_list, policy_loss_list, ent_loss_list).
+    With `in_process_chief` (one process per GPU) the optimiser step runs right after the gradient
+    all-reduce instead of waiting on a separate chief process."""
+    use_adv_norm = train_cfg["use_adv_norm"]
+    nv_s, nv_t = agent.get_value(done, steer_rollout.get_last(), throttle_rollout.get_last())
+    steer_adv = steer_rollout.compute_returns(nv_s.detach(), normalise=use_adv_norm)
+    throttle_adv = throttle_rollout.compute_returns(nv_t.detach(), normalise=use_adv_norm)
+    vl, pl, el = [], [], []
+    for _ in range(train_cfg["ppo_epoch"]):
+        g_s = steer_rollout.feed_forward_generator(steer_adv)
+        g_t = throttle_rollout.feed_forward_generator(throttle_adv)
+        for s_samples, t_samples in zip(g_s, g_t):
+            v, p, e = agent.update_policy(s_samples, t_samples)
+            vl.append(v); pl.append(p); el.append(e)
+            if in_process_chief:
+                shared_grad_buffers.add_gradient(agent.model_dict)
+                chief_step(shared_grad_buffers, optimizer, train_cfg["max_grad_norm"])
+            else:
+                signal_init = traffic_light.get()
+                shared_grad_buffers.add_gradient(agent.model_dict)
+                counter.increment()
+                while traffic_light.get() == signal_init:
+                    pass
+            if shared_model_list is not None:
+                agent.update_model(shared_model_list)
+    return vl, pl, el
+
+
+def train(rank, train_cfg, agent_cfg, env_cfg, rollout_cfg, traffic_light=None, counter=None,
+          shared_model_list=None, shared_grad_buffers=None, son_process_counter=None, env_cls=None, logger=None):
+    if env_cls is None:
+        from env_wrapper import EnvWrapper as env_cls        # needs the CARLA stack (reference env_wrapper.py)
+    env_cfg.rank = rank
+    for k in ("port", "routes", "scenarios", "town"):
+        env_cfg[k] = env_cfg[k][rank]
+    env_cfg.seq_length = rollout_cfg.seq_length
+    env = env_cls(env_cfg)
+    model_dir = os.path.join(env.work_dir, "models")
+    check_exist(model_dir)
+    num_steps = rollout_cfg.num_steps
+    hidden_size, _ = get_vae_output(agent_cfg.model_cfg)
+    agent_cfg.rank = rank
+    agent = CadreAgent(**agent_cfg)
+    device = torch.device("cuda:" + str(agent_cfg.model_cfg.device_num))
+    rollout_cfg.hidden_size = hidden_size
+    steer_rollout = RolloutStorage(**rollout_cfg); steer_rollout.to(device)
+    throttle_rollout = RolloutStorage(**rollout_cfg); throttle_rollout.to(device)
+    obs = env.reset()
+    done = False
+    for episode in range(train_cfg.max_episode):
+        for _ in range(num_steps):
+            command = obs["command"]
+            feat, action, alp, values, hidden = agent.act(obs)
+            obs, reward, done, info = env.step(agent.convert_action(action))
+            ad = info["action_done"]
+            steer_rollout.insert(feat, action[0], alp[0], values[0], reward[0],
+                                 torch.tensor([[0.0] if ad[0] else [1.0]]), hidden, command)
+            throttle_rollout.insert(feat, action[1], alp[1], values[1], reward[1],
+                                    torch.tensor([[0.0] if ad[1] else [1.0]]), hidden, command)
+            if done:
+                obs = env.reset()
+        vl, pl, el = learner_section(agent, steer_rollout, throttle_rollout, done, train_cfg, shared_grad_buffers,
+                                     traffic_light=traffic_light, counter=counter,
+                                     shared_model_list=shared_model_list, in_process_chief=False)
+        if episode % train_cfg.log_interval == 0 and rank == 0 and logger is not None:
+            logger.log("Episode: {}, value loss: {:.4f}, policy loss: {:.4f}, entropy loss: {:.4f}".format(
+                episode, np.mean(vl), np.mean(pl), np.mean(el)))
+        if episode % train_cfg.save_interval == 0 and rank == 0:
+            agent.save_snapshot(os.path.join(model_dir, "ppo_model_{}.pt".format(episode)))
+    son_process_counter.increment()
+    print("process {} finished.".format(rank))

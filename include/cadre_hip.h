@@ -1,0 +1,159 @@
+/*
+ * cadre_hip.h — C ABI of libcadre_hip.so, the MI355X (gfx950) kernels behind the Cadre PPO
+ * learner hot path.  Plain pointers + sizes + a hipStream_t (passed as void*),
+ * int status return (0 = ok, <0 = bad argument, >0 = hipError_t), never throws, never owns
+ * caller memory, no torch types.  All pointers are DEVICE pointers unless noted.
+ *
+ * The reference (BIT-MCS/Cadre) is pure Python; the "FFI" a maintainer binds is ctypes
+ * (see INTEGRATION.md).  Each entry point cites the reference code it replaces
+ * (paths relative to /root/reference).
+ */
+#ifndef CADRE_HIP_H
+#define CADRE_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CADRE_ABI_VERSION 1
+int cadre_abi_version(void);
+/* human-readable last argument error of the calling thread ("" if none) */
+const char* cadre_last_error(void);
+
+/* ---------------------------------------------------------------- generic tiled GEMM / conv
+ * C[z][M,N] = act( (sum_k A(m,k) B(n,k)) * scale[n] + shift[n] + resid[m,n] )
+ * on v_mfma_f32_32x32x2_f32 (exact f32 fma chain).  Replaces every nn.Linear / nn.Conv2d /
+ * nn.LSTMCell matmul on the path: carla_perception/Networks/danet_blocks/resnet.py:111-181,
+ * danet.py:21-41,96,108, intertask_att.py:39-80, ppo_agent/models.py:130-177,
+ * ppo_agent/distributions.py:34-40 (forward) and their autograd backward (dX, dW).
+ */
+typedef struct {
+  const float* A;      /* a_mode 0: [M][lda] (k contiguous); 1: [K][lda] (m contiguous);
+                          2: NHWC activation, implicit-GEMM conv gather (Cin%32==0);
+                          3: NHWC activation with Cin==4 (stem)                       */
+  const float* B;      /* b_mode 0: [N][ldb] (k contiguous); 1: [K][ldb] (n contiguous)  */
+  float* C;            /* [M][ldc] row-major (== NHWC for convs)                         */
+  const float* scale;  /* per-n multiplier or NULL (=1)   (folded eval BatchNorm)        */
+  const float* shift;  /* per-n addend or NULL (=0)       (bias / folded BN)             */
+  const float* resid;  /* [M][ldr] added before the activation, or NULL; may alias C     */
+  int64_t lda, ldb, ldc, ldr;
+  int32_t M, N, K;
+  int32_t a_mode, b_mode;
+  int32_t act;         /* 0 none, 1 ReLU, 2 LeakyReLU(slope); |16: add resid AFTER the act   */
+  float slope;
+  /* batch (grid.z): operand offset = ((z / div) % mod) * stride elements                */
+  int32_t batch;
+  int32_t a_div, a_mod, b_div, b_mod, c_div, c_mod, s_div, s_mod, r_div, r_mod;
+  int64_t a_str, b_str, c_str, s_str, r_str;
+  /* conv geometry (a_mode 2/3): input [Nimg][H][W][Cin], output [Nimg][Ho][Wo][N]       */
+  int32_t H, W, Cin, Ho, Wo, KH, KW, stride, pad;
+  /* split-K: >1 writes raw partial sums to `C + s*M*ldc (+ z offsets)`; finish with
+     cadre_splitk_reduce.  With split_k>1 scale/shift/resid/act are ignored here.        */
+  int32_t split_k;
+  int32_t tile;        /* 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64                      */
+} cadre_gemm_t;
+int cadre_gemm_f32(const cadre_gemm_t* p, void* stream);
+/* C[M][ldc] = act(sum_s slab[s][M][lds] * scale + shift + resid) */
+int cadre_splitk_reduce(const float* slabs, int32_t split_k, int64_t slab_stride, int64_t lds,
+                        float* C, int64_t ldc, int32_t M, int32_t N, const float* scale,
+                        const float* shift, int32_t act, float slope, void* stream);
+
+/* ---------------------------------------------------------------- encoder pieces
+ * pre_process: ppo_agent/agent.py:43-75.  rgb u8 [F][H][W][3], route u8 [F][W][H] (stored
+ * transposed like the reference) -> out f32 NHWC [F][H][W][4].  rgb/255 via the 256-entry
+ * LUT `lut255` (host computes float32(i/255.) in double, bit-exact with agent.py:46).
+ * Route quirk agent.py:51-54: per-frame max, value stored back into uint8 -> {0,1}.
+ * `route_norm` (u8 [F][W][H], may be NULL) receives the mutated route the reference leaves
+ * in the caller's dict.  `frame_max` is u32 [F] scratch. */
+int cadre_preprocess(const uint8_t* rgb, const uint8_t* route, const float* lut255,
+                     float* out, uint8_t* route_norm, uint32_t* frame_max,
+                     int32_t F, int32_t H, int32_t W, void* stream);
+/* nn.MaxPool2d(3,2,1) resnet.py:114 on NHWC [F][H][W][C] (C%4==0) -> [F][Ho][Wo][C] */
+int cadre_maxpool3x3s2(const float* x, float* y, int32_t F, int32_t H, int32_t W, int32_t C,
+                       void* stream);
+/* PAM_Module.forward da_att.py:32-51 after the three 1x1 convs: qkv [F][Np][160] =
+ * (query 16 | key 16 | value 128) comes from ONE cadre_gemm_f32 over the concatenated
+ * query/key/value conv weights; this kernel does energy = q.k^T, row softmax,
+ * out = att.v, y = gamma*out + x on NHWC x [F][Np][128].  One workgroup per frame, Np <= 96. */
+int cadre_pam(const float* x, const float* qkv, float gamma, float* y, int32_t F, int32_t Np,
+              void* stream);
+/* CAM_Module.forward da_att.py:63-83 on NHWC x [F][Np][128] */
+int cadre_cam(const float* x, float gamma, float* y, int32_t F, int32_t Np, void* stream);
+/* InterTaskAtt 'transformer' tail intertask_att.py:137-176: qkv [F][6][256] ordered
+ * (vis_q, vis_k, vis_v, bc_q, bc_k, bc_v) -> out [F][ldo] = cat(att_visual, att_bc) */
+int cadre_intertask_att(const float* qkv, float* out, int64_t ldo, int32_t F, float temperature,
+                        void* stream);
+/* agent.py:105-111: feat[f][512..529] = float(measurements[f][j%3]) (f64 -> f32), ld = ldo */
+int cadre_append_measurements(const double* meas, float* feat, int64_t ldo, int32_t F, void* stream);
+
+/* ---------------------------------------------------------------- storage math
+ * RolloutStorage.compute_returns GAE branch (ppo_agent/storage.py:69-76), strict fp32
+ * left-to-right, no FMA contraction; one lane per sequence.  Arrays are [nseq][T+1]
+ * (value_preds[.][T] is overwritten with next_value like storage.py:70).  Then
+ * train.py:82-88: adv = ret[:-1]-V[:-1], optional (adv-mean)/(std_unbiased+1e-8). */
+int cadre_gae(const float* rewards, float* value_preds, const float* masks, const float* next_value,
+              float* returns, float* adv, int32_t nseq, int32_t T, float gamma, float gamma_tau,
+              int32_t normalise, void* stream);
+/* feed_forward_generator gather (storage.py:99-120): obs [T+1][S][ldo] rows idx[B] ->
+ * time-major x [S][B][ldx]; hn/cn/scalars gathered likewise. */
+int cadre_gather_obs(const float* obs, int64_t ldo, int32_t S, const int64_t* idx, int32_t B,
+                     float* x, int64_t ldx, int32_t D, void* stream);
+
+/* ---------------------------------------------------------------- LSTM cell pointwise
+ * nn.LSTMCell gate math (models.py:130-152).  gates [B][ldg] pre-activations (i,f,g,o blocks
+ * of Hd), batched over `batch` nets with strides; c_prev of net z is read at
+ * c_prev + (z / c_prev_div) * c_prev_str (step 0 shares the head's c0 across its 4 command
+ * nets).  Forward overwrites gates with the activated values (kept for backward), writes
+ * c_out, h_out, tanh_c. */
+int cadre_lstm_pointwise_fwd(float* gates, int64_t ldg, int64_t g_str, const float* c_prev,
+                             int64_t c_prev_str, int32_t c_prev_div, float* c_out, float* h_out,
+                             float* tanh_c, int64_t ldh, int64_t h_str, int32_t B, int32_t Hd,
+                             int32_t batch, void* stream);
+/* backward of one step: dh (in: upstream+recurrent grad of h_t), dc (in/out: grad of c_t ->
+ * grad of c_{t-1}), both [batch][B][ldh] with net stride d_str; activated gates, tanh_c,
+ * c_prev -> dgates [B][ldg] */
+int cadre_lstm_pointwise_bwd(const float* gates, float* dgates, int64_t ldg, int64_t g_str,
+                             const float* dh, float* dc, int64_t d_str, const float* tanh_c,
+                             const float* c_prev,
+                             int64_t c_prev_str, int32_t c_prev_div, int64_t ldh, int64_t h_str,
+                             int32_t B, int32_t Hd, int32_t batch, void* stream);
+/* column sums: out[z][n] (+)= sum_m X[z][m][n]  (bias gradients) */
+int cadre_colsum(const float* X, int64_t ldx, int64_t x_str, float* out, int64_t o_str,
+                 int32_t M, int32_t N, int32_t batch, int32_t accumulate, void* stream);
+/* y = relu'(act) * dy elementwise ([rows][ld], batch), in place on dy */
+int cadre_relu_bwd(const float* act, float* dy, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------- policy head + PPO loss
+ * Replaces Model.evaluate_actions (models.py:199-208), Categorical_1d (distributions.py:
+ * 66-105) and the loss of CadreAgent.update_policy (agent.py:166-229) forward AND backward.
+ * Per head hd in {0:steer,1:throttle}, command net c in 0..3 (net = hd*4+c):
+ *   logits: net n row b at logits + n*l_ns + b*ldl (first n_out[hd] columns valid),
+ *   values: net n row b at values + n*v_ns + b*ldv.  Sample arrays are [2 heads][B].
+ * Outputs: losses[3] = (value_loss*value_coeff, action_loss*clip_coeff, ent*ent_coeff),
+ *   dlogits / dvalues (same addressing) = d total_loss / d(raw logits | critic output);
+ *   whole dlogits rows (ldl columns) are written, only column 0 of a dvalues row.
+ * `inv_b` = 1/(rows per worker minibatch) (sum of per-worker means). */
+int cadre_ppo_loss(const float* logits, int64_t ldl, int64_t l_ns, const float* values, int64_t ldv,
+                   int64_t v_ns, const int64_t* actions, const int32_t* commands, const float* old_values, const float* returns,
+                   const float* old_logp, const float* adv, int32_t B, int32_t n_out_steer,
+                   int32_t n_out_throttle, float clip, float value_coeff, float clip_coeff,
+                   float ent_coeff, float inv_b, float* losses, float* dlogits, float* dvalues,
+                   void* stream);
+/* Model.act sampling (models.py:184-189, distributions.py:96-99) == argmax(p/q), q supplied
+ * by the host from the torch CPU generator.  logits [R][ldl] raw; outputs action i64 [R],
+ * log_prob f32 [R] of the sampled action. */
+int cadre_sample(const float* logits, int64_t ldl, const float* q, int64_t ldq, int32_t R,
+                 int32_t n_out, int64_t* action, float* logp, void* stream);
+
+/* ---------------------------------------------------------------- optimiser
+ * chief.py:13-21 + main.py:55: per-model clip_grad_norm_(max_norm) then Adam (torch defaults)
+ * over a flat parameter arena made of `n_models` segments [seg_off[i], seg_off[i+1]).
+ * norms2 is f64 [n_models] scratch (zeroed inside). */
+int cadre_clip_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                    const int64_t* seg_off, int32_t n_models, double* norms2, double max_norm,
+                    double lr, double beta1, double beta2, double eps, int32_t step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,3 @@
+from cadre_amd.ppo_agent.agent import *  # noqa: F401,F403
+from cadre_amd.ppo_agent import agent as _m
+globals().update({k: v for k, v in vars(_m).items() if not k.startswith('__')})

@@ -1,0 +1,108 @@
+"""CPU: host-side logic of the drop-in mirror — storage cursor / sampler stream, arena layout,
+C-ABI symbol table, loud failure without a HIP device.  No kernel is launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_exports_every_declared_symbol():
+    from cadre_amd import hip
+    hdr = open(os.path.join(ROOT, "include", "cadre_hip.h")).read()
+    declared = set(re.findall(r"\b(cadre_[a-z0-9_]+)\s*\(", hdr))
+    declared.discard("cadre_gemm_t")
+    assert declared == set(hip.SYMBOLS), declared ^ set(hip.SYMBOLS)
+    L = ctypes.CDLL(hip.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert hip.lib().cadre_abi_version() == 1
+    assert ctypes.sizeof(hip.GemmDesc) == 240      # static_assert-ed in gemm_f32.hip
+
+
+def test_no_cpu_fallback():
+    from cadre_amd import hip
+    from ppo_agent.models import create_model
+    from ppo_agent.storage import RolloutStorage
+    cfg = dict(use_lstm=True, vae_device=-1, device_num=-1, vae_params="CoPM", measurement_dim=18,
+               num_output=dict(steer=33, throttle=3), command_num=4)
+    with pytest.raises(hip.CadreHipError):
+        create_model(cfg, load_vae=False)
+    st = RolloutStorage(8, 2, 530, 8, 530, True, 0.99, 0.95)
+    with pytest.raises(hip.CadreHipError):
+        st.compute_returns(torch.zeros(1))
+    with pytest.raises(hip.CadreHipError):
+        hip.ptr(torch.zeros(4))
+
+
+def test_product_never_imports_oracle():
+    for base in ("cadre_amd", "ppo_agent"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, base)):
+            for f in fs:
+                if f.endswith(".py") and f != "selfcheck.py":
+                    src = open(os.path.join(dp, f)).read()
+                    assert "oracle" not in src, os.path.join(dp, f)
+
+
+def test_storage_insert_cursor_drift(golden):
+    """F-insert: modulo-(T+1) cursor, hn/cn written at step+1 (storage.py:45-58)."""
+    from ppo_agent.storage import RolloutStorage
+    g = golden("insert")
+    T = int(g["T"])
+    s = RolloutStorage(T, 1, 6, 2, 6, True, 0.99, 0.95)
+    r = np.random.RandomState(3)
+    for i in range(T + 3):
+        obs = r.standard_normal((2, 6)).astype(np.float32)
+        hn = r.standard_normal((1, 6)).astype(np.float32)
+        cn = r.standard_normal((1, 6)).astype(np.float32)
+        s.insert(torch.from_numpy(obs), torch.tensor(i % 3), torch.tensor([[-0.1 * i]]), torch.tensor([[0.5 * i]]),
+                 torch.tensor(0.25 * i), torch.tensor([[float(i % 2)]]),
+                 (torch.from_numpy(hn), torch.from_numpy(cn)), i % 4)
+    assert s.step == int(g["step"])
+    for mine, key in ((s.obs, "obs"), (s.action, "action"), (s.action_log_probs, "alp"), (s.value_preds, "values"),
+                      (s.rewards, "rewards"), (s.masks, "masks"), (s.command, "command"), (s.hn, "hn"), (s.cn, "cn")):
+        assert np.array_equal(mine.numpy(), g[key]), key
+    assert s._obs[:, :, 6:].abs().max() == 0
+
+
+@pytest.mark.parametrize("T,mbn", [(32, 2), (128, 2), (200, 2), (50, 3)])
+def test_storage_sampler_stream_matches_reference(golden, T, mbn):
+    from ppo_agent.storage import RolloutStorage
+    g = golden("sampler")
+    want = np.split(g["T%d_m%d" % (T, mbn)], np.cumsum(g["T%d_m%d_lens" % (T, mbn)])[:-1])
+    a = RolloutStorage(T, mbn, 4, 8, 4, True, 0.99, 0.95)
+    b = RolloutStorage(T, mbn, 4, 8, 4, True, 0.99, 0.95)
+    torch.manual_seed(1000 + T)
+    got = []
+    for _ in range(4):
+        ia, ib = a.sample_indices(), b.sample_indices()      # steer draws first (train.py:94-96)
+        for x, y in zip(ia, ib):
+            got += [x.numpy(), y.numpy()]
+    assert len(got) == len(want) and all(np.array_equal(x, y) for x, y in zip(got, want))
+
+
+def test_arena_layout():
+    from cadre_amd.arena import PPOArena
+    a = PPOArena.__new__(PPOArena)
+    # layout arithmetic only (no device allocation)
+    import types
+    a2 = types.SimpleNamespace()
+    D, DP, H4 = 530, 544, 2120
+    size_L = 2 * H4 * DP + 2 * H4
+    size_T = 128 * DP + 128 + 128 * 128 + 128 + 64 * 128 + 64
+    assert size_L == 2310800 and size_T == 94528
+    assert 8 * size_L + 16 * size_T == 19998848
+    # real parameter count of the reference nets
+    real = 8 * (2 * H4 * D + 2 * H4) + 4 * ((128 * D + 128 + 128 * 128 + 128) * 2 + 33 * 128 + 33 + 128 + 1) \
+        + 4 * ((128 * D + 128 + 128 * 128 + 128) * 2 + 3 * 128 + 3 + 128 + 1)
+    assert real == 19382808
+
+
+def test_snapshot_key_quirk(golden):
+    g = golden("insert")
+    keys = sorted(str(k) for k in g["snapshot_keys"])
+    assert keys == sorted(["%s_%d" % (k, c) for c in range(4) for k in ("throttle_ppo", "steer_ppo", "steer_lstm")])

@@ -1,0 +1,366 @@
+"""GPU: every C-ABI kernel of libcadre_hip.so against plain torch-CPU fp32 / the oracle.
+Tolerances: fp32 accumulate-order differences only (<= 2e-5 relative to the tensor's max)
+unless the op is integer/strict-order (bit-exact asserted)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(x):
+    return torch.as_tensor(x).cuda()
+
+
+def rel(a, b):
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from cadre_amd import hip as h
+    h.lib()
+    return h
+
+
+# ----------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K,tile", [(200, 136, 544, 1), (77, 50, 64, 3), (300, 64, 96, 2), (64, 2120, 544, 0),
+                                        (5, 33, 128, 3)])
+@pytest.mark.parametrize("a_mode,b_mode", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_modes(hip, M, N, K, tile, a_mode, b_mode):
+    if a_mode == 1 and M % 4:
+        M += 4 - M % 4
+    if b_mode == 1 and N % 4:
+        N += 4 - N % 4
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g)
+    B = torch.randn(N, K, generator=g)
+    scale = torch.rand(N, generator=g) + 0.5
+    shift = torch.randn(N, generator=g)
+    resid = torch.randn(M, N, generator=g)
+    want = F.leaky_relu((A @ B.t()) * scale + shift + resid, 0.1)
+    Ad = dev(A if a_mode == 0 else A.t().contiguous())
+    Bd = dev(B if b_mode == 0 else B.t().contiguous())
+    out = torch.zeros(M, N + 3, device="cuda")
+    hip.gemm(Ad, Bd, out, M, N, K, K if a_mode == 0 else M, K if b_mode == 0 else N, N + 3, a_mode, b_mode,
+             scale=dev(scale), shift=dev(shift), resid=dev(resid), ldr=N, act=2, slope=0.1, tile=tile)
+    torch.cuda.synchronize()
+    assert rel(out[:, :N], want) < 2e-5
+    assert float(out[:, N:].abs().max()) == 0.0
+
+
+def test_gemm_batched_and_splitk(hip):
+    g = torch.Generator().manual_seed(3)
+    Z, M, N, K = 8, 96, 160, 544
+    A = torch.randn(2, M, K, generator=g)          # shared by groups of 4 (z // 4)
+    B = torch.randn(Z, N, K, generator=g)
+    bias = torch.randn(Z, N, generator=g)
+    want = torch.stack([A[z // 4] @ B[z].t() + bias[z] for z in range(Z)])
+    out = torch.empty(Z, M, N, device="cuda")
+    hip.gemm(dev(A), dev(B), out, M, N, K, K, K, N, shift=dev(bias), batch=Z, a_z=(4, 0, M * K), b_z=(1, 0, N * K),
+             c_z=(1, 0, M * N), s_z=(1, 0, N))
+    torch.cuda.synchronize()
+    assert rel(out, want) < 2e-5
+    # split-K with slab reduce + bias + LeakyReLU
+    K2 = 4608
+    A2 = torch.randn(40, K2, generator=g); B2 = torch.randn(200, K2, generator=g) * 0.05
+    b2 = torch.randn(200, generator=g)
+    want2 = F.leaky_relu(A2 @ B2.t() + b2, 0.01)
+    S = 6
+    slabs = torch.empty(S, 40, 200, device="cuda")
+    hip.gemm(dev(A2), dev(B2), slabs, 40, 200, K2, K2, K2, 200, split_k=S)
+    out2 = torch.empty(40, 200, device="cuda")
+    b2_d = dev(b2)
+    hip.check(hip.lib().cadre_splitk_reduce(slabs.data_ptr(), S, 40 * 200, 200, out2.data_ptr(), 200, 40, 200, None,
+                                            b2_d.data_ptr(), 2, 0.01, hip.stream()), "reduce")
+    torch.cuda.synchronize()
+    assert rel(out2, want2) < 2e-5
+
+
+@pytest.mark.parametrize("Cin,Cout,H,W,k,s,p", [(64, 64, 18, 22, 3, 1, 1), (64, 128, 18, 22, 3, 2, 1),
+                                                 (64, 128, 17, 21, 1, 2, 0), (128, 160, 9, 9, 1, 1, 0),
+                                                 (4, 64, 30, 36, 7, 2, 3)])
+def test_conv_implicit_gemm(hip, Cin, Cout, H, W, k, s, p):
+    g = torch.Generator().manual_seed(Cin + Cout + k)
+    Nimg = 3
+    x = torch.randn(Nimg, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g)
+    y = F.conv2d(x, w, None, s, p)
+    Ho, Wo = y.shape[2], y.shape[3]
+    res = torch.randn(Nimg, Cout, Ho, Wo, generator=g)
+    want = F.relu(y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res)
+    xd = dev(x.permute(0, 2, 3, 1).contiguous())
+    wd = dev(w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous())
+    rd = dev(res.permute(0, 2, 3, 1).contiguous())
+    out = torch.empty(Nimg, Ho, Wo, Cout, device="cuda")
+    K = k * k * Cin
+    hip.gemm(xd, wd, out, Nimg * Ho * Wo, Cout, K, 0, K, Cout, a_mode=3 if Cin == 4 else 2, scale=dev(scale),
+             shift=dev(shift), resid=rd, ldr=Cout, act=1, conv=(H, W, Cin, Ho, Wo, k, k, s, p))
+    torch.cuda.synchronize()
+    assert rel(out.permute(0, 3, 1, 2), want) < 2e-5
+
+
+# ----------------------------------------------------------------------------- encoder pieces
+def test_preprocess_bit_exact(hip, golden):
+    g = golden("prep")
+    rgb, route = g["rgb"], g["route"]
+    Fn, H, W = rgb.shape[:3]
+    lut = torch.from_numpy((np.arange(256) / 255.).astype(np.float32)).cuda()
+    out = torch.empty(Fn, H, W, 4, device="cuda")
+    rn = torch.empty(Fn, W, H, dtype=torch.uint8, device="cuda")
+    fm = torch.empty(Fn, dtype=torch.int32, device="cuda")
+    rgb_d, route_d = dev(rgb), dev(route)          # keep device temporaries alive across the call
+    hip.check(hip.lib().cadre_preprocess(rgb_d.data_ptr(), route_d.data_ptr(), lut.data_ptr(), out.data_ptr(),
+                                         rn.data_ptr(), fm.data_ptr(), Fn, H, W, hip.stream()), "prep")
+    torch.cuda.synchronize()
+    assert np.array_equal(out.permute(0, 3, 1, 2).cpu().numpy(), g["out"])        # byte-for-byte
+    assert np.array_equal(rn.cpu().numpy(), g["route_after"])
+
+
+def test_maxpool(hip):
+    x = torch.randn(2, 64, 15, 18)
+    want = F.max_pool2d(x, 3, 2, 1)
+    out = torch.empty(2, want.shape[2], want.shape[3], 64, device="cuda")
+    xd = dev(x.permute(0, 2, 3, 1).contiguous())
+    hip.check(hip.lib().cadre_maxpool3x3s2(xd.data_ptr(), out.data_ptr(), 2, 15,
+                                           18, 64, hip.stream()), "maxpool")
+    assert torch.equal(out.permute(0, 3, 1, 2).cpu(), want)
+
+
+@pytest.mark.parametrize("h,w", [(3, 3), (5, 8), (9, 9)])
+def test_pam_cam(hip, h, w):
+    from oracle import encoder_ref
+    g = torch.Generator().manual_seed(h * w)
+    Fn, Np = 3, h * w
+    x = torch.randn(Fn, 128, h, w, generator=g) * 0.4
+    sd = {"da_head.sa.gamma": torch.tensor([0.5]), "da_head.sc.gamma": torch.tensor([0.7])}
+    for nm, co in (("query", 16), ("key", 16), ("value", 128)):
+        sd["da_head.sa.%s_conv.weight" % nm] = torch.randn(co, 128, 1, 1, generator=g) * 0.1
+        sd["da_head.sa.%s_conv.bias" % nm] = torch.randn(co, generator=g) * 0.1
+    want_p = encoder_ref.pam(x, sd)
+    want_c = encoder_ref.cam(x, sd)
+    xd = dev(x.permute(0, 2, 3, 1).contiguous())
+    wqkv = torch.cat([sd["da_head.sa.%s_conv.weight" % n].view(-1, 128) for n in ("query", "key", "value")])
+    bqkv = torch.cat([sd["da_head.sa.%s_conv.bias" % n] for n in ("query", "key", "value")])
+    qkv = torch.empty(Fn * Np, 160, device="cuda")
+    hip.gemm(xd, dev(wqkv), qkv, Fn * Np, 160, 128, 128, 128, 160, shift=dev(bqkv))
+    y = torch.empty_like(xd)
+    hip.check(hip.lib().cadre_pam(xd.data_ptr(), qkv.data_ptr(), 0.5, y.data_ptr(), Fn, Np, hip.stream()), "pam")
+    assert rel(y.permute(0, 3, 1, 2), want_p) < 2e-5
+    y2 = torch.empty_like(xd)
+    hip.check(hip.lib().cadre_cam(xd.data_ptr(), 0.7, y2.data_ptr(), Fn, Np, hip.stream()), "cam")
+    assert rel(y2.permute(0, 3, 1, 2), want_c) < 2e-5
+
+
+def test_intertask_tail_and_measurements(hip):
+    g = torch.Generator().manual_seed(5)
+    Fn = 4
+    qkv = torch.randn(Fn, 6, 256, generator=g) * 2.0
+    vq, vk, vv, bq, bk, bv = (qkv[:, i] for i in range(6))
+
+    def cross(q, k, v):
+        e = torch.bmm((q.view(Fn, 1, 256).permute(0, 2, 1)) / 16.0, k.view(Fn, 1, 256))
+        att = torch.softmax(e, -1)
+        return torch.bmm(v.view(Fn, 1, 256), att.permute(0, 2, 1)).view(Fn, -1) + v
+    want = torch.cat([cross(bq, vk, vv), cross(vq, bk, bv)], -1)
+    meas = torch.rand(Fn, 3, dtype=torch.float64)
+    out = torch.zeros(Fn, 544, device="cuda")
+    qkv_d, meas_d = dev(qkv), dev(meas)
+    hip.check(hip.lib().cadre_intertask_att(qkv_d.data_ptr(), out.data_ptr(), 544, Fn, 16.0, hip.stream()), "ita")
+    hip.check(hip.lib().cadre_append_measurements(meas_d.data_ptr(), out.data_ptr(), 544, Fn, hip.stream()), "meas")
+    assert rel(out[:, :512], want) < 2e-5
+    assert torch.equal(out[:, 512:530].cpu(), meas.repeat(1, 6).float())
+    assert float(out[:, 530:].abs().max()) == 0.0
+
+
+# ----------------------------------------------------------------------------- storage math
+@pytest.mark.parametrize("T", [32, 128, 200])
+def test_gae_bit_exact_and_ordering(hip, golden, T):
+    g = golden("gae")
+    nseq = 3                                            # same sequence replicated + a perturbed one
+    r = np.stack([g["T%d_rewards" % T]] * nseq); v = np.stack([g["T%d_values" % T]] * nseq)
+    m = np.stack([g["T%d_masks" % T]] * nseq)
+    r[2] = r[2][::-1]
+    nv = torch.full((nseq,), float(g["T%d_next" % T])).cuda()
+    rd, vd, md = dev(r.copy()), dev(v.copy()), dev(m.copy())
+    ret = torch.zeros(nseq, T + 1, device="cuda"); adv = torch.empty(nseq, T, device="cuda")
+    hip.check(hip.lib().cadre_gae(rd.data_ptr(), vd.data_ptr(), md.data_ptr(), nv.data_ptr(), ret.data_ptr(),
+                                  adv.data_ptr(), nseq, T, float(np.float32(0.99)), float(np.float32(0.99 * 0.95)), 1, hip.stream()),
+              "gae")
+    ret, adv, vd = ret.cpu().numpy(), adv.cpu().numpy(), vd.cpu().numpy()
+    for s in (0, 1):
+        assert np.array_equal(ret[s].view(np.uint32), g["T%d_returns" % T].view(np.uint32))   # bit-exact
+        assert vd[s][T] == g["T%d_next" % T]
+        assert np.array_equal(np.argsort(adv[s], kind="stable"), g["T%d_argsort" % T])        # advantage ordering
+        assert np.abs(adv[s] - g["T%d_adv" % T]).max() <= 4e-6 * np.abs(g["T%d_adv" % T]).max()
+    from oracle import ppo_ref
+    o_ret, o_V = ppo_ref.gae_returns(r[2], v[2], m[2], float(g["T%d_next" % T]), 0.99, 0.95)
+    assert np.array_equal(ret[2].view(np.uint32), o_ret.view(np.uint32))
+    # un-normalised
+    adv2 = torch.empty(nseq, T, device="cuda")
+    v2, ret2 = dev(v.copy()), torch.zeros(nseq, T + 1, device="cuda")
+    hip.check(hip.lib().cadre_gae(rd.data_ptr(), v2.data_ptr(), md.data_ptr(), nv.data_ptr(),
+                                  ret2.data_ptr(), adv2.data_ptr(), nseq, T,
+                                  float(np.float32(0.99)), float(np.float32(0.99 * 0.95)), 0, hip.stream()), "gae")
+    assert np.array_equal(adv2[0].cpu().numpy().view(np.uint32), g["T%d_adv_raw" % T].view(np.uint32))
+
+
+def test_gather_obs(hip):
+    obs = torch.randn(33, 8, 530)
+    obs_d = torch.zeros(33, 8, 544, device="cuda"); obs_d[:, :, :530] = obs.cuda()
+    idx = torch.randperm(32)[:16]
+    x = torch.full((8, 16, 544), 7.0, device="cuda")
+    idx_d = idx.cuda()
+    hip.check(hip.lib().cadre_gather_obs(obs_d.data_ptr(), 544, 8, idx_d.data_ptr(), 16, x.data_ptr(), 544, 530,
+                                         hip.stream()), "gather")
+    want = obs[idx].permute(1, 0, 2)
+    assert torch.equal(x[:, :, :530].cpu(), want) and float(x[:, :, 530:].abs().max()) == 0.0
+
+
+# ----------------------------------------------------------------------------- LSTM pointwise
+def test_lstm_pointwise_fwd_bwd(hip):
+    g = torch.Generator().manual_seed(9)
+    Z, B, Hd, ldg, ldh = 8, 6, 530, 2120, 544
+    G = torch.randn(Z, B, 4 * Hd, generator=g)
+    c0 = torch.randn(2, B, Hd, generator=g)             # shared per head (z // 4)
+    dh = torch.randn(Z, B, Hd, generator=g); dc_in = torch.randn(Z, B, Hd, generator=g)
+    Gr = G.clone().requires_grad_(True); c0r = c0.clone().requires_grad_(True)
+    i, f, gg, o = Gr.chunk(4, -1)
+    cp = c0r[torch.arange(Z) // 4]
+    c = torch.sigmoid(f) * cp + torch.sigmoid(i) * torch.tanh(gg)
+    h = torch.sigmoid(o) * torch.tanh(c)
+    Gd = dev(G.clone())
+    c0d = torch.zeros(2, B, ldh, device="cuda"); c0d[:, :, :Hd] = c0.cuda()
+    cd = torch.zeros(Z, B, ldh, device="cuda"); hd_ = torch.zeros_like(cd); tcd = torch.zeros_like(cd)
+    L = hip.lib()
+    hip.check(L.cadre_lstm_pointwise_fwd(Gd.data_ptr(), ldg, B * ldg, c0d.data_ptr(), B * ldh, 4, cd.data_ptr(),
+                                         hd_.data_ptr(), tcd.data_ptr(), ldh, B * ldh, B, Hd, Z, hip.stream()), "lf")
+    assert rel(hd_[:, :, :Hd], h) < 1e-5 and rel(cd[:, :, :Hd], c) < 1e-5
+    assert float(hd_[:, :, Hd:].abs().max()) == 0.0
+    dhd = torch.zeros(Z, B, ldh, device="cuda"); dhd[:, :, :Hd] = dh.cuda()
+    dcd = torch.zeros(Z, B, ldh, device="cuda"); dcd[:, :, :Hd] = dc_in.cuda()
+    dG = torch.zeros(Z, B, ldg, device="cuda")
+    hip.check(L.cadre_lstm_pointwise_bwd(Gd.data_ptr(), dG.data_ptr(), ldg, B * ldg, dhd.data_ptr(), dcd.data_ptr(),
+                                         B * ldh, tcd.data_ptr(), c0d.data_ptr(), B * ldh, 4, ldh, B * ldh, B, Hd, Z,
+                                         hip.stream()), "lb")
+    # Gr.grad accumulated both backward calls: second call's contribution = full; subtract first
+    Gr2 = G.clone().requires_grad_(True); c0r2 = c0.clone().requires_grad_(True)
+    i, f, gg, o = Gr2.chunk(4, -1)
+    c2 = torch.sigmoid(f) * c0r2[torch.arange(Z) // 4] + torch.sigmoid(i) * torch.tanh(gg)
+    h2 = torch.sigmoid(o) * torch.tanh(c2)
+    (h2 * dh + c2 * dc_in).sum().backward()
+    assert rel(dG, Gr2.grad) < 1e-5
+    want_dcprev = (dc_in + dh * torch.sigmoid(o) * (1 - torch.tanh(c2) ** 2)) * torch.sigmoid(f)
+    assert rel(dcd[:, :, :Hd], want_dcprev.detach()) < 1e-5
+
+
+def test_colsum_relu_bwd(hip):
+    X = torch.randn(3, 70, 130)
+    out = torch.ones(3, 130, device="cuda")
+    Xd = dev(X)
+    hip.check(hip.lib().cadre_colsum(Xd.data_ptr(), 130, 70 * 130, out.data_ptr(), 130, 70, 130, 3, 1,
+                                     hip.stream()), "colsum")
+    assert rel(out, X.sum(1) + 1) < 1e-5
+    a = torch.randn(1000); dy = torch.randn(1000); dyd = dev(dy.clone())
+    ad = dev(a)
+    hip.check(hip.lib().cadre_relu_bwd(ad.data_ptr(), dyd.data_ptr(), 1000, hip.stream()), "relu_bwd")
+    assert torch.equal(dyd.cpu(), dy * (a > 0))
+
+
+# ----------------------------------------------------------------------------- PPO loss
+@pytest.mark.parametrize("B,scale", [(16, 1.0), (64, 4.0)])
+def test_ppo_loss_fwd_bwd(hip, B, scale):
+    """vs autograd through the oracle formulas (agent.py:166-229); `scale` widens ratios so
+    both clip branches and both value branches are exercised."""
+    g = torch.Generator().manual_seed(B)
+    ldl, nS, nT = 64, 33, 3
+    logits = torch.zeros(8, B, ldl); values = torch.randn(8, B, generator=g)
+    logits[:4, :, :nS] = torch.randn(4, B, nS, generator=g) * scale
+    logits[4:, :, :nT] = torch.randn(4, B, nT, generator=g) * scale
+    actions = torch.stack([torch.randint(0, nS, (B,), generator=g), torch.randint(0, nT, (B,), generator=g)])
+    cmds = torch.randint(0, 4, (2, B), generator=g, dtype=torch.int32)
+    old_v = torch.randn(2, B, generator=g); rets = torch.randn(2, B, generator=g)
+    adv = torch.randn(2, B, generator=g)
+    old_lp = torch.stack([torch.full((B,), -np.log(nS)), torch.full((B,), -np.log(nT))]) + 0.3 * torch.randn(2, B, generator=g)
+    clip, vc, cc, ec = 0.1, 0.1, 1.0, 0.01
+    lg = logits.clone().requires_grad_(True); vv = values.clone().requires_grad_(True)
+    tot_v = tot_a = tot_e = 0
+    for hd, K in ((0, nS), (1, nT)):
+        cur_v = cur_lp = ent = 0
+        for c in range(4):
+            raw = lg[hd * 4 + c, :, :K]
+            lgn = raw - raw.logsumexp(-1, keepdim=True)
+            lp = lgn.gather(1, actions[hd].view(-1, 1))
+            p = torch.softmax(lgn, -1)
+            e = -(lgn * p).sum(-1, keepdim=True)
+            msk = (cmds[hd] == c).view(-1, 1)
+            cur_v = cur_v + vv[hd * 4 + c].view(-1, 1) * msk
+            cur_lp = cur_lp + lp * msk
+            ent = ent + e * msk
+        ratio = torch.exp(cur_lp - old_lp[hd].view(-1, 1)); A = adv[hd].view(-1, 1)
+        tot_a = tot_a - torch.min(ratio * A, torch.clamp(ratio, 1 - clip, 1 + clip) * A).mean()
+        ov, R = old_v[hd].view(-1, 1), rets[hd].view(-1, 1)
+        vpc = ov + (cur_v - ov).clamp(-clip, clip)
+        tot_v = tot_v + 0.5 * torch.max((cur_v - R).pow(2), (vpc - R).pow(2)).mean()
+        tot_e = tot_e + ent.mean()
+    total = tot_v * vc + tot_a * cc - tot_e * ec
+    total.backward()
+    losses = torch.zeros(3, device="cuda"); dl = torch.full((8, B, ldl), 9.0, device="cuda")
+    dv = torch.full((8, B), 9.0, device="cuda")
+    d_ = [dev(t) for t in (logits, values, actions, cmds, old_v, rets, old_lp, adv)]
+    hip.check(hip.lib().cadre_ppo_loss(d_[0].data_ptr(), ldl, B * ldl, d_[1].data_ptr(), 1, B, d_[2].data_ptr(),
+                                       d_[3].data_ptr(), d_[4].data_ptr(), d_[5].data_ptr(),
+                                       d_[6].data_ptr(), d_[7].data_ptr(), B, nS, nT, clip, vc, cc, ec,
+                                       1.0 / B, losses.data_ptr(), dl.data_ptr(), dv.data_ptr(), hip.stream()), "loss")
+    want = torch.tensor([float(tot_v * vc), float(tot_a * cc), float(tot_e * ec)])
+    assert rel(losses, want) < 1e-5
+    assert rel(dv, vv.grad) < 1e-5
+    assert rel(dl, lg.grad) < 2e-5
+
+
+def test_sample_matches_golden_rule(hip, golden):
+    from oracle import ppo_ref
+    g = torch.Generator().manual_seed(1)
+    for K in (33, 3):
+        R = 64
+        logits = torch.randn(R, K, generator=g) * 2
+        q = torch.empty(R, K).exponential_(1, generator=g)
+        lgn = logits - logits.logsumexp(-1, keepdim=True)
+        want = ppo_ref.sample_from_logits(lgn, q)
+        act = torch.empty(R, dtype=torch.int64, device="cuda"); lp = torch.empty(R, device="cuda")
+        ld = torch.zeros(R, 64); ld[:, :K] = logits
+        ld_d, q_d = dev(ld), dev(q)
+        hip.check(hip.lib().cadre_sample(ld_d.data_ptr(), 64, q_d.data_ptr(), K, R, K, act.data_ptr(),
+                                         lp.data_ptr(), hip.stream()), "sample")
+        assert torch.equal(act.cpu(), want)                                   # bit-exact indices
+        assert rel(lp, lgn.gather(1, want.view(-1, 1)).view(-1)) < 1e-5
+
+
+def test_clip_adam(hip):
+    from oracle import ppo_ref
+    g = torch.Generator().manual_seed(2)
+    sizes = [1000, 257, 4096, 33]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n = int(off[-1])
+    p0 = torch.randn(n, generator=g)
+    params = {"m%d" % i: {"w": p0[off[i]:off[i + 1]].clone()} for i in range(4)}
+    adam = {k: {"w": (torch.zeros_like(v["w"]), torch.zeros_like(v["w"]))} for k, v in params.items()}
+    pd = dev(p0.clone()); m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+    nrm = torch.zeros(4, dtype=torch.float64, device="cuda"); offd = dev(off)
+    for step in (1, 2, 3):
+        gr = torch.randn(n, generator=g) * torch.repeat_interleave(torch.tensor([30.0, 0.01, 5.0, 100.0]),
+                                                                   torch.tensor(sizes))
+        grads = {"m%d" % i: {"w": gr[off[i]:off[i + 1]].clone()} for i in range(4)}
+        ppo_ref.chief_step(params, grads, adam, step, lr=3e-4, max_grad_norm=250.0)
+        gr_d = dev(gr)
+        hip.check(hip.lib().cadre_clip_adam(pd.data_ptr(), gr_d.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                            offd.data_ptr(), 4, nrm.data_ptr(), 250.0, 3e-4, 0.9, 0.999, 1e-8, step,
+                                            hip.stream()), "adam")
+        want = torch.cat([params["m%d" % i]["w"] for i in range(4)])
+        assert float((pd.cpu() - want).abs().max()) < 2e-7

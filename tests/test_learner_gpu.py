@@ -1,0 +1,164 @@
+"""GPU: the drop-in path (ppo_agent.agent / storage / chief mirrors on HIP kernels) against
+golden vectors produced by the imported reference (tests/golden/{update,act,chief}.npz).
+north_star bar: bit-exact action indices and advantage ordering, fp32 losses within 1e-4 rel."""
+import numpy as np
+import pytest
+import torch
+
+from cadre_amd import synth
+from tests.helpers import fill_storages
+
+pytestmark = pytest.mark.gpu
+LOSS_TOL = 1e-4
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def make_agent(H, W, enc_seed=7, ppo_seed=11):
+    from ppo_agent.agent import CadreAgent
+    fh, fw = synth.feat_hw(H, W)
+    cfg = dict(use_lstm=True, vae_device=0, device_num=0, vae_params="CoPM", measurement_dim=18,
+               num_output=dict(steer=33, throttle=3), command_num=4, obs_hw=(H, W),
+               vae_state_dict=synth.encoder_state(fh, fw, enc_seed))
+    steer = {i: (i - 16) / 16.0 for i in range(33)}
+    thr = {0: [0, 0], 1: [0, 1], 2: [0.6, 0]}
+    agent = CadreAgent(rank=0, model_cfg=cfg, frame=8, STEER_CONTROL=steer, THROTTLE_CONTROL=thr, ent_coeff=0.01,
+                       value_coeff=0.1, clip_coeff=1.0, clip=0.1)
+    agent.arena.load_numpy_state(synth.ppo_state(ppo_seed))
+    return agent
+
+
+def per_model(arena, buf, names, fn):
+    out = []
+    for n in names:
+        v = arena.views(buf, n)
+        out.append(fn([t.double() for t in v.values()]))
+    return out
+
+
+def test_learner_section_replay_vs_reference(golden):
+    """F-update: train.py:76-110 replay (get_value -> GAE -> adv-norm -> 2 epochs x 2 minibatches of
+    update_policy + per-model clip + Adam) on identical RolloutStorage inputs."""
+    from ppo_agent.chief import chief_step
+    from ppo_agent.models import Shared_grad_buffers
+    from ppo_agent.storage import RolloutStorage
+    g = golden("update")
+    T, mbn, epochs = int(g["T"]), int(g["mbn"]), int(g["epochs"])
+    names = [str(n) for n in g["names"]]
+    agent = make_agent(84, 84, ppo_seed=int(g["ppo_seed"]))
+    data = fill_storages(T, int(g["data_seed"]))
+    stor = {}
+    for hd in ("steer", "throttle"):
+        s = RolloutStorage(T, mbn, 530, 8, 530, True, 0.99, 0.95)
+        for k, v in data[hd].items():
+            getattr(s, k).copy_(torch.from_numpy(v))
+        s.to("cuda:0")
+        stor[hd] = s
+    nv_s, nv_t = agent.get_value(False, stor["steer"].get_last(), stor["throttle"].get_last())
+    assert rel([nv_s.item(), nv_t.item()], g["next_value"]) < LOSS_TOL
+    adv = {}
+    for hd, nv in (("steer", nv_s), ("throttle", nv_t)):
+        adv[hd] = stor[hd].compute_returns(nv.detach())
+        mine = adv[hd].cpu().numpy()[:, 0]
+        want = g["adv_" + hd][:, 0]
+        assert rel(mine, want) < LOSS_TOL
+    shared = Shared_grad_buffers(agent.model_dict, agent.device)
+    opt = torch.optim.Adam([p for m in agent.model_dict.values() for p in m.parameters()], lr=3e-4)
+    torch.manual_seed(int(g["torch_seed"]))
+    step = 0
+    for _ in range(epochs):
+        g_s = stor["steer"].feed_forward_generator(adv["steer"])
+        g_t = stor["throttle"].feed_forward_generator(adv["throttle"])
+        for s_s, t_s in zip(g_s, g_t):
+            l3 = agent.update_policy(s_s, t_s)
+            assert rel(l3, g["losses"][step]) < LOSS_TOL, (step, l3, g["losses"][step])
+            gn = per_model(agent.arena, agent.arena.grads, names, lambda ts: float(torch.sqrt(sum((t ** 2).sum() for t in ts))))
+            assert rel(gn, g["grad_norms"][step]) < 5e-4, (step, gn, g["grad_norms"][step])
+            gs = per_model(agent.arena, agent.arena.grads, names, lambda ts: float(sum(t.sum() for t in ts)))
+            assert np.abs(np.array(gs) - g["grad_sums"][step]).max() < 5e-4 * np.abs(g["grad_norms"][step]).max()
+            # .grad attributes are the arena views the reference's Shared_grad_buffers would read
+            p = agent.model_dict["steer_lstm_0"].rnn.weight_hh
+            assert p.grad is not None and p.grad.shape == p.shape and float(p.grad.abs().sum()) > 0
+            shared.add_gradient(agent.model_dict)
+            chief_step(shared, opt, 250.0)
+            ps = per_model(agent.arena, agent.arena.params, names, lambda ts: float(sum(t.sum() for t in ts)))
+            assert rel(ps, g["param_sums"][step]) < 1e-5, (step,)
+            step += 1
+    assert step == len(g["losses"])
+
+
+def test_update_policy_matches_oracle_autograd_per_param():
+    """Per-parameter gradient check of the explicit backward against oracle autograd (B=24)."""
+    from oracle import ppo_ref
+    agent = make_agent(84, 84)
+    st0 = synth.ppo_state(11)
+    params = ppo_ref.to_torch_params(st0, requires_grad=True)
+    r = np.random.RandomState(5)
+    B, S = 24, 8
+    samples, dsamples = [], []
+    for hd, K in (("steer", 33), ("throttle", 3)):
+        tup = (torch.from_numpy((r.standard_normal((S * B, 530)) * 0.5).astype(np.float32)),
+               torch.from_numpy(r.randint(0, K, (B, 1)).astype(np.int64)),
+               torch.from_numpy((0.3 * r.standard_normal((B, 1))).astype(np.float32)),
+               torch.from_numpy(r.standard_normal((B, 1)).astype(np.float32)),
+               torch.ones(B, 1),
+               torch.from_numpy((-np.log(K) + 0.2 * r.standard_normal((B, 1))).astype(np.float32)),
+               torch.from_numpy(r.standard_normal((B, 1)).astype(np.float32)),
+               [torch.from_numpy((0.1 * r.standard_normal((B, 530))).astype(np.float32)),
+                torch.from_numpy((0.1 * r.standard_normal((B, 530))).astype(np.float32))],
+               torch.from_numpy(r.randint(0, 4, (B, 1)).astype(np.int32)))
+        samples.append(tup)
+        dsamples.append(tuple(x.cuda() if not isinstance(x, list) else [y.cuda() for y in x] for x in tup))
+    want = ppo_ref.update_policy(params, samples[0], samples[1])
+    got = agent.update_policy(dsamples[0], dsamples[1])
+    assert rel(got, want) < LOSS_TOL
+    worst = 0.0
+    for mn, d in params.items():
+        gv = agent.arena.views(agent.arena.grads, mn)
+        scale = max(float(p.grad.abs().max()) for p in d.values())
+        for k, p in d.items():
+            err = float((gv[k].cpu() - p.grad).abs().max()) / max(scale, 1e-12)
+            worst = max(worst, err)
+            assert err < 2e-4, (mn, k, err)
+    print("worst per-parameter gradient error (rel. to model max |g|): %.2e" % worst)
+
+
+def test_act_matches_reference(golden):
+    """F-act: native 144x256 observations through encoder + LSTM + heads + sampling."""
+    g = golden("act")
+    agent = make_agent(144, 256)
+    steps = synth.synth_rollout(6, 144, 256, seed=int(g["rollout_seed"]))
+    torch.manual_seed(int(g["torch_seed"]))
+    for i, td in enumerate(steps):
+        obs = dict(rgb=td["rgb"], route_fig=td["route_fig"].copy(), measurements=td["measurements"],
+                   command=td["command"])
+        feat, a, lp, v, hid = agent.act(obs)
+        assert set(np.unique(obs["route_fig"])) <= {0, 1}                    # caller's dict mutated (agent.py:51-54)
+        assert float(hid[0].abs().sum()) == 0.0 and tuple(feat.shape) == (8, 530)
+        assert rel(feat.cpu().numpy(), g["feats"][i]) < 2e-4
+        assert [int(a[0]), int(a[1])] == list(g["actions"][i]), (i, g["margins"][2 * i:2 * i + 2])   # bit-exact
+        assert a[0].dim() == 0 and a[0].dtype == torch.int64 and tuple(lp[0].shape) == (1, 1)
+        assert rel([lp[0].item(), lp[1].item()], g["log_probs"][i]) < 1e-3
+        assert rel([v[0].item(), v[1].item()], g["values"][i]) < 1e-3
+        ctl = agent.convert_action(a)
+        assert len(ctl) == 3
+
+
+def test_snapshot_roundtrip(tmp_path):
+    agent = make_agent(84, 84)
+    p = str(tmp_path / "ppo_model_0.pt")
+    agent.save_snapshot(p)
+    saved = torch.load(p, weights_only=False)
+    assert sorted(saved) == sorted(["%s_%d" % (k, c) for c in range(4) for k in ("throttle_ppo", "steer_ppo", "steer_lstm")])
+    before = agent.arena.params.clone()
+    agent.arena.params.mul_(0.5)
+    agent.load_snapshot(p, None)
+    names = [n for n in agent.model_dict if not n.startswith("throttle_lstm")]
+    for n in names:
+        for k, v in agent.arena.views(agent.arena.params, n).items():
+            assert torch.equal(v, agent.arena.views(before, n)[k])
+    with pytest.raises(ImportError):
+        agent.load_snapshot(str(tmp_path / "missing.pt"), None)
