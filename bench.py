@@ -1,0 +1,307 @@
+#!/usr/bin/env python3
+"""bench.py — PPO-update throughput of the MI355X-native Cadre learner (BASELINE.json metric).
+
+One "step" = one learner ROUND over one batch of synthetic rollouts:
+  encode every window of W*T transitions (8 frames each, reference convention — the
+  reference re-encodes all 8 frames of the sliding window at every env step) -> fill the
+  rollout storages -> get_value -> GAE + advantage normalisation -> ppo_epoch(4) x
+  mini_batch_num(2) x (update_policy + gradient all-reduce(SUM) + per-model clip + Adam).
+value = (n_gpus * W * T) / t_round  [samples/s], inputs resident in HBM before timing.
+
+    python bench.py                       # N=1, config C2: 1 worker x 128 steps, 288x288, fp32
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+T_START = time.perf_counter()
+CONFIGS = {
+    "C1": dict(workers=1, T=32, H=84, W=84),
+    "C2": dict(workers=1, T=128, H=288, W=288),
+    "C3": dict(workers=4, T=128, H=288, W=288),
+}
+PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PPO_EPOCH, MINI_BATCH_NUM, SEQ = 4, 2, 8
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+class Worker:
+    """One logical CARLA worker: synthetic sliding-window observations resident in HBM + its two storages."""
+
+    def __init__(self, cfg, seed, device):
+        from ppo_agent.storage import RolloutStorage
+        T, H, W = cfg["T"], cfg["H"], cfg["W"]
+        rng = np.random.RandomState(seed)
+        nf = T + SEQ - 1
+        self.rgb = torch.from_numpy(rng.randint(0, 256, (nf, H, W, 3)).astype(np.uint8)).to(device)
+        self.route = torch.from_numpy(((rng.rand(nf, W, H) < 0.15) * 255).astype(np.uint8)).to(device)
+        meas = rng.rand(nf, 3)
+        self.win = (torch.arange(T).view(T, 1) + torch.arange(SEQ).view(1, SEQ)).reshape(-1).to(device)   # frame ids
+        self.meas = torch.from_numpy(meas).to(device)[self.win].contiguous()                             # [T*S,3] f64
+        self.stor = []
+        for K in (33, 3):
+            s = RolloutStorage(T, MINI_BATCH_NUM, 530, SEQ, 530, True, 0.99, 0.95)
+            s.action.copy_(torch.from_numpy(rng.randint(0, K, (T + 1, 1))))
+            s.action_log_probs.copy_(torch.from_numpy((-np.log(K) + 0.1 * rng.standard_normal((T + 1, 1))).astype(np.float32)))
+            s.value_preds.copy_(torch.from_numpy((0.3 * rng.standard_normal((T + 1, 1))).astype(np.float32)))
+            s.rewards.copy_(torch.from_numpy(rng.rand(T + 1, 1).astype(np.float32)))
+            s.masks.copy_(torch.from_numpy((rng.rand(T + 1, 1) >= 0.02).astype(np.float32)))
+            s.command.copy_(torch.from_numpy(rng.randint(0, 4, (T + 1, 1)).astype(np.int32)))
+            s.to(device)
+            self.stor.append(s)
+
+
+def encode_worker(agent, wk, cfg, chunk_windows):
+    """a2/a3: all T windows x 8 frames through the HIP encoder, latent rows written straight into
+    the steer storage's 544-pitch feature buffer, measurements appended, copied to throttle."""
+    from cadre_amd import hip
+    T = cfg["T"]
+    enc = agent.vae_model
+    obs_rows = wk.stor[0]._obs.view(-1, wk.stor[0]._ldo)          # [(T+1)*S, 544]
+    L = hip.lib()
+    for t0 in range(0, T, chunk_windows):
+        t1 = min(T, t0 + chunk_windows)
+        ids = wk.win[t0 * SEQ:t1 * SEQ]
+        x = enc.preprocess(wk.rgb.index_select(0, ids), wk.route.index_select(0, ids))
+        rows = obs_rows[t0 * SEQ:t1 * SEQ]
+        enc.forward_nhwc(x, rows)
+        hip.check(L.cadre_append_measurements(hip.ptr(wk.meas[t0 * SEQ:t1 * SEQ]), hip.ptr(rows), rows.stride(0),
+                                              (t1 - t0) * SEQ, hip.stream()), "cadre_append_measurements")
+    obs_rows[T * SEQ:].copy_(obs_rows[(T - 1) * SEQ:T * SEQ])      # row T (bootstrap obs) = last window
+    wk.stor[1]._obs.copy_(wk.stor[0]._obs)
+
+
+def learner_round(agent, workers, cfg, shared, timers=None):
+    from ppo_agent.chief import chief_step
+    t0 = time.perf_counter()
+    for wk in workers:
+        encode_worker(agent, wk, cfg, cfg["chunk_windows"])
+    if timers is not None:
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+    advs = []
+    for wk in workers:
+        nv_s, nv_t = agent.get_value(False, wk.stor[0].get_last(), wk.stor[1].get_last())
+        advs.append((wk.stor[0].compute_returns(nv_s), wk.stor[1].compute_returns(nv_t)))
+    nW = len(workers)
+    losses = []
+    for _ in range(PPO_EPOCH):
+        idx = [(wk.stor[0].sample_indices(), wk.stor[1].sample_indices()) for wk in workers]
+        for b in range(len(idx[0][0])):
+            per = [(wk.stor[0].gather(idx[i][0][b], advs[i][0]), wk.stor[1].gather(idx[i][1][b], advs[i][1]))
+                   for i, wk in enumerate(workers)]
+            if nW == 1:
+                s_s, t_s = per[0]
+            else:
+                s_s = _cat([p[0] for p in per]); t_s = _cat([p[1] for p in per])
+            losses.append(agent.update_policy(s_s, t_s, workers=nW))
+            shared.add_gradient(agent.model_dict)                 # RCCL all-reduce(SUM) when world_size > 1
+            chief_step(shared, None, 250.0)
+    if timers is not None:
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        timers.append((t1 - t0, t2 - t1))
+    return losses
+
+
+def _cat(tuples):
+    """Row-concatenate W workers' 9-tuples; obs is time-major [S*B, D] -> interleave per time step."""
+    nW = len(tuples)
+    B = tuples[0][1].shape[0]
+    obs = torch.stack([t[0].view(SEQ, B, -1) for t in tuples], 1).reshape(SEQ * nW * B, -1)
+    out = [obs]
+    for k in (1, 2, 3, 4, 5, 6):
+        out.append(torch.cat([t[k] for t in tuples], 0))
+    out.append([torch.cat([t[7][0] for t in tuples], 0), torch.cat([t[7][1] for t in tuples], 0)])
+    out.append(torch.cat([t[8] for t in tuples], 0))
+    return tuple(out)
+
+
+def host_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota
+    (os.cpu_count() reports the whole machine inside a container and oversubscribes OpenMP)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q[0] != "max":
+            n = min(n, max(1, int(int(q[0]) / int(q[1]))))
+    except (OSError, ValueError, IndexError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(cfg, enc_state, ppo_state):
+    """Oracle (kind 'port') on the host cores, bounded sample, extrapolated to one round."""
+    from oracle import encoder_ref, ppo_ref
+    from cadre_amd import synth
+    ncores = host_cores()
+    torch.set_num_threads(ncores)
+    log("[bench] cpu_baseline on %d host threads (os.cpu_count()=%s)" % (ncores, os.cpu_count()))
+    T, H, W, nW = cfg["T"], cfg["H"], cfg["W"], cfg["workers"]
+    td = synth.synth_rollout(2, H, W, seed=1)
+    t0 = time.perf_counter()
+    nwin = 0
+    while nwin < 1 or (time.perf_counter() - t0 < 6.0 and nwin < 16):
+        encoder_ref.latent_feature(td[nwin % 2]["rgb"], td[nwin % 2]["route_fig"], td[nwin % 2]["measurements"], enc_state)
+        nwin += 1
+    t_win = (time.perf_counter() - t0) / nwin
+    params = ppo_ref.to_torch_params(ppo_state, requires_grad=True)
+    adam = {m: {k: (torch.zeros_like(p), torch.zeros_like(p)) for k, p in d.items()} for m, d in params.items()}
+    r = np.random.RandomState(0)
+    B = T // MINI_BATCH_NUM
+    samp = []
+    for K in (33, 3):
+        samp.append((torch.from_numpy((r.standard_normal((SEQ * B, 530)) * 0.5).astype(np.float32)),
+                     torch.from_numpy(r.randint(0, K, (B, 1)).astype(np.int64)),
+                     torch.from_numpy((0.3 * r.standard_normal((B, 1))).astype(np.float32)),
+                     torch.from_numpy(r.standard_normal((B, 1)).astype(np.float32)), torch.ones(B, 1),
+                     torch.from_numpy((-np.log(K) + 0.1 * r.standard_normal((B, 1))).astype(np.float32)),
+                     torch.from_numpy(r.standard_normal((B, 1)).astype(np.float32)),
+                     [torch.zeros(B, 530), torch.zeros(B, 530)], torch.from_numpy(r.randint(0, 4, (B, 1)).astype(np.int32))))
+    t0 = time.perf_counter()
+    nup = 0
+    while nup < 1 or (time.perf_counter() - t0 < 6.0 and nup < 16):
+        ppo_ref.update_policy(params, samp[0], samp[1])
+        grads = {m: {k: p.grad for k, p in d.items()} for m, d in params.items()}
+        ppo_ref.chief_step(params, grads, adam, nup + 1)
+        nup += 1
+    t_up = (time.perf_counter() - t0) / nup
+    t_round = nW * T * t_win + nW * PPO_EPOCH * MINI_BATCH_NUM * t_up
+    return dict(value=nW * T / t_round, unit="samples/s", cores=ncores, kind="port",
+                sample="oracle (torch-CPU restatement, %d threads): %d encoder windows of 8 frames at %dx%d (%.3f s each) + "
+                       "%d update_policy+clip+Adam steps at minibatch %d (%.3f s each), extrapolated to one round of "
+                       "%d windows + %d updates" % (ncores, nwin, H, W, t_win, nup, B, t_up, nW * T,
+                                                   nW * PPO_EPOCH * MINI_BATCH_NUM))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
+    ap.add_argument("--chunk-windows", type=int, default=16, help="windows (x8 frames) per encoder launch chain")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from cadre_amd import hip, synth
+    from ppo_agent.agent import CadreAgent
+    from ppo_agent.models import Shared_grad_buffers
+    cfg = dict(CONFIGS[args.config]); cfg["chunk_windows"] = args.chunk_windows
+    H, W, T, nW = cfg["H"], cfg["W"], cfg["T"], cfg["workers"]
+    fh, fw = synth.feat_hw(H, W)
+    enc_state = synth.encoder_state(fh, fw, 7)
+    ppo_state = synth.ppo_state(11)
+    mcfg = dict(use_lstm=True, vae_device=local_rank, device_num=local_rank, vae_params="CoPM", measurement_dim=18,
+                num_output=dict(steer=33, throttle=3), command_num=4, obs_hw=(H, W), vae_state_dict=enc_state,
+                encoder_max_frames=args.chunk_windows * SEQ)
+    agent = CadreAgent(rank=rank, model_cfg=mcfg, frame=SEQ, STEER_CONTROL={i: (i - 16) / 16.0 for i in range(33)},
+                       THROTTLE_CONTROL={0: [0, 0], 1: [0, 1], 2: [0.6, 0]}, ent_coeff=0.01, value_coeff=0.1,
+                       clip_coeff=1.0, clip=0.1)
+    agent.arena.load_numpy_state(ppo_state)                      # identical start on every rank (startup broadcast)
+    if world > 1:
+        dist.broadcast(agent.arena.params, 0)
+    dev = agent.device
+    workers = [Worker(cfg, 1234 + 1000 * rank + w, dev) for w in range(nW)]
+    shared = Shared_grad_buffers(agent.model_dict, dev)
+    torch.manual_seed(100 + rank)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    log("[bench] setup done, %d worker(s), %.1f s since start" % (nW, time.perf_counter() - T_START))
+    for _ in range(args.warmup):
+        learner_round(agent, workers, cfg, shared)
+    sync()
+    log("[bench] warmup done %.1f s" % (time.perf_counter() - T_START))
+    hip.PROFILE = prof = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = learner_round(agent, workers, cfg, shared)
+    sync()
+    elapsed = time.perf_counter() - t0
+    hip.PROFILE = None
+    log("[bench] timed region %.3f s for %d steps" % (elapsed, args.steps))
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    # ---- per-kernel roofline from the HIP events recorded inside the timed region
+    by = {}
+    for tile, kind, flops, e0, e1 in prof:
+        d = by.setdefault(tile, [0.0, 0.0, 0])
+        d[0] += flops; d[1] += e0.elapsed_time(e1) * 1e-3; d[2] += 1
+    dom = max(by, key=lambda k: by[k][1])
+    names = {1: "gemm_f32_kernel<2,2,*,*> (128x128 tile)", 2: "gemm_f32_kernel<2,1,*,*> (128x64 tile)", 3: "gemm_f32_kernel<1,1,*,*> (64x64 tile)"}
+    ach = by[dom][0] / by[dom][1] / 1e12
+    # untimed split pass for t_encode / t_update
+    timers = []
+    learner_round(agent, workers, cfg, shared, timers)
+    t_enc, t_upd = timers[0]
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * nW * T / (elapsed / args.steps)
+        flops_frame = agent.vae_model.flops_per_frame()
+        out = {
+            "metric": "ppo_update_samples_per_sec", "value": round(value, 2), "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %d worker(s) x %d-step rollout, %dx%dx3 synthetic obs (+route), DANet encoder "
+                                   "(8 frames/transition, reference convention) + PPO update (4 epochs x 2 minibatches), fp32"
+                                   % (args.config, nW, T, H, W),
+                       "workers_per_gpu": nW, "num_steps": T, "obs": [H, W], "minibatch_per_gpu": nW * T // MINI_BATCH_NUM,
+                       "parallelism": "dp%d" % world, "frames_per_round_per_gpu": nW * T * SEQ},
+            "t_encode_ms": round(t_enc * 1e3, 3), "t_update_ms": round(t_upd * 1e3, 3),
+            "encoder_frames_per_sec": round(nW * T * SEQ / t_enc, 1),
+            "encoder_tflops": round(nW * T * SEQ * flops_frame / t_enc / 1e12, 2),
+            "update_only_samples_per_sec": round(nW * T * PPO_EPOCH / t_upd, 1),
+            "roofline": {"kernel": names[dom], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "launches": by[dom][2], "avg_launch_us": round(by[dom][1] / by[dom][2] * 1e6, 2),
+                         "per_tile": {names[k]: {"tflops": round(v[0] / v[1] / 1e12, 2), "time_ms_per_step": round(v[1] / args.steps * 1e3, 3),
+                                                 "launches_per_step": v[2] // args.steps} for k, v in by.items()}},
+            "last_losses": [round(x, 6) for x in losses[-1]],
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, enc_state, ppo_state)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -33,7 +33,7 @@ struct RowInfo {           // per-thread, per staged row: decoded once
   bool valid;
 };
 
-template <int WM, int WN>
+template <int WM, int WN, int AMODE, int BMODE>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(cadre_gemm_t p) {
   constexpr int BM = 2 * WM * 32;
   constexpr int BN = 2 * WN * 32;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(cadre_gemm_t p) {
   // rr + 32*i.  k-major operand: tile is [32 k][BM] floats, thread owns chunks id = tid+256*i.
   const int cc = tid & 7, rr = tid >> 3;
   RowInfo arow[RA];
-  if (p.a_mode == 0) {
+  if constexpr (AMODE == 0) {
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       const int m = m0 + rr + 32 * i;
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(cadre_gemm_t p) {
       arow[i].base = A + (int64_t)min(m, p.M - 1) * p.lda;
       arow[i].hi0 = arow[i].wi0 = 0;
     }
-  } else if (p.a_mode >= 2) {
+  } else if constexpr (AMODE >= 2) {
     const int hw = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(cadre_gemm_t p) {
   }
   const float* brow[RB];
   bool bvalid[RB];
-  if (p.b_mode == 0) {
+  if constexpr (BMODE == 0) {
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       const int n = n0 + rr + 32 * i;
@@ -109,13 +109,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(cadre_gemm_t p) {
   auto load_tiles = [&](int kt) {
     const int k0 = kt * BK;
     // ---- A
-    if (p.a_mode == 0) {
+    if constexpr (AMODE == 0) {
       const int k = k0 + cc * 4;
       const bool kv = k < p.K;  // K % 4 == 0
 #pragma unroll
       for (int i = 0; i < RA; ++i)
         areg[i] = (arow[i].valid && kv) ? *reinterpret_cast<const f32x4*>(arow[i].base + k) : zero4;
-    } else if (p.a_mode == 1) {
+    } else if constexpr (AMODE == 1) {
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
         const int id = tid + 256 * i;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(cadre_gemm_t p) {
         const int k = k0 + kk, m = m0 + mc * 4;
         areg[i] = (k < p.K && m < p.M) ? *reinterpret_cast<const f32x4*>(A + (int64_t)k * p.lda + m) : zero4;
       }
-    } else if (p.a_mode == 2) {
+    } else if constexpr (AMODE == 2) {
       const int pos = k0 / p.Cin, ci = k0 % p.Cin + cc * 4;  // uniform per tile (Cin % 32 == 0)
       const int kh = pos / p.KW, kw = pos % p.KW;
 #pragma unroll
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(cadre_gemm_t p) {
       }
     }
     // ---- B
-    if (p.b_mode == 0) {
+    if constexpr (BMODE == 0) {
       const int k = k0 + cc * 4;
       const bool kv = k < p.K;
 #pragma unroll
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(cadre_gemm_t p) {
   auto store_tiles = [&](int buf) {
     float* as = As + buf * BM * LDS_PITCH;
     float* bs = Bs + buf * BN * LDS_PITCH;
-    if (p.a_mode == 1) {
+    if constexpr (AMODE == 1) {
 #pragma unroll
       for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(as + (tid + 256 * i) * 4) = areg[i];
     } else {
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(cadre_gemm_t p) {
       for (int i = 0; i < RA; ++i)
         *reinterpret_cast<f32x4*>(as + (rr + 32 * i) * LDS_PITCH + cc * 4) = areg[i];
     }
-    if (p.b_mode == 1) {
+    if constexpr (BMODE == 1) {
 #pragma unroll
       for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(bs + (tid + 256 * i) * 4) = breg[i];
     } else {
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(cadre_gemm_t p) {
 #pragma unroll
       for (int i = 0; i < WM; ++i) {
         const int row = (wm * WM + i) * 32 + l31;
-        if (p.a_mode == 1) {
+        if constexpr (AMODE == 1) {
           af[i][0] = as[(kq + 0) * BM + row];
           af[i][1] = as[(kq + 1) * BM + row];
           af[i][2] = as[(kq + 2) * BM + row];
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(cadre_gemm_t p) {
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
         const int col = (wn * WN + j) * 32 + l31;
-        if (p.b_mode == 1) {
+        if constexpr (BMODE == 1) {
           bf[j][0] = bs[(kq + 0) * BN + col];
           bf[j][1] = bs[(kq + 1) * BN + col];
           bf[j][2] = bs[(kq + 2) * BN + col];
@@ -250,6 +250,57 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(cadre_gemm_t p) {
   const float* scale = (!raw && p.scale) ? p.scale + (int64_t)((z / p.s_div) % p.s_mod) * p.s_str : nullptr;
   const float* shift = (!raw && p.shift) ? p.shift + (int64_t)((z / p.s_div) % p.s_mod) * p.s_str : nullptr;
   const float* resid = (!raw && p.resid) ? p.resid + (int64_t)((z / p.r_div) % p.r_mod) * p.r_str : nullptr;
+  const bool vec_ok = ((p.N | p.ldc | (resid ? p.ldr : 0)) & 3) == 0 && (((uintptr_t)C | (uintptr_t)resid) & 15) == 0;
+  if (vec_ok) {
+    // Stage each wave's accumulator tile through its own LDS slice so that global traffic is whole
+    // 16-B-per-lane row segments: residual read and output write are each R/rows_per_instr wide
+    // instructions per lane instead of 16*WM*WN scalar ones.  (The k-loop's last barrier has passed,
+    // so the staging buffers are free.)
+    constexpr int CW = WN * 32, RW = WM * 32, P = CW + 4;
+    constexpr int LPR = CW / 4;          // lanes per row
+    constexpr int RPI = 64 / LPR;        // rows per wave-instruction
+    float* cs = lds + wave * (RW * P);
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          cs[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * P + j * 32 + l31] = acc[i][j][r];
+    // same-wave producer/consumer: LDS ops of one wave complete in order, no barrier needed
+    const int c4 = (lane % LPR) * 4;
+    const int col = n0 + wn * CW + c4;
+    const bool cvalid = col < p.N;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (cvalid && scale) sc = *reinterpret_cast<const f32x4*>(scale + col);
+    if (cvalid && shift) sh = *reinterpret_cast<const f32x4*>(shift + col);
+    constexpr int NIT = RW / RPI;
+    f32x4 rv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = m0 + wm * RW + it * RPI + lane / LPR;
+      rv[it] = (resid && cvalid && row < p.M) ? *reinterpret_cast<const f32x4*>(resid + (int64_t)row * p.ldr + col)
+                                               : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int rloc = it * RPI + lane / LPR;
+      const int row = m0 + wm * RW + rloc;
+      f32x4 v = *reinterpret_cast<const f32x4*>(cs + rloc * P + c4);
+      if (!raw) {
+        v = v * sc + sh;
+        if (!post) v += rv[it];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (actk == 1) v[e] = fmaxf(v[e], 0.f);
+          else if (actk == 2) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
+        }
+        if (post) v += rv[it];
+      }
+      if (cvalid && row < p.M) *reinterpret_cast<f32x4*>(C + (int64_t)row * p.ldc + col) = v;
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
     const int col = n0 + (wn * WN + j) * 32 + l31;
@@ -336,18 +387,28 @@ extern "C" int cadre_gemm_f32(const cadre_gemm_t* pp, void* stream) {
   }
   hipStream_t st = (hipStream_t)stream;
   dim3 block(256);
-  if (tile == 1) {
-    dim3 grid(((p.M + 127) / 128) * ((p.N + 127) / 128), p.split_k, p.batch);
-    hipLaunchKernelGGL((gemm_f32_kernel<2, 2>), grid, block, 0, st, p);
-  } else if (tile == 2) {
-    dim3 grid(((p.M + 127) / 128) * ((p.N + 63) / 64), p.split_k, p.batch);
-    hipLaunchKernelGGL((gemm_f32_kernel<2, 1>), grid, block, 0, st, p);
-  } else if (tile == 3) {
-    dim3 grid(((p.M + 63) / 64) * ((p.N + 63) / 64), p.split_k, p.batch);
-    hipLaunchKernelGGL((gemm_f32_kernel<1, 1>), grid, block, 0, st, p);
-  } else {
-    return cadre_fail("cadre_gemm_f32: bad tile");
+  const int bm = tile == 3 ? 64 : 128, bn = tile == 1 ? 128 : 64;
+  if (tile < 1 || tile > 3) return cadre_fail("cadre_gemm_f32: bad tile");
+  if (p.a_mode >= 2 && p.b_mode != 0) return cadre_fail("cadre_gemm_f32: conv needs b_mode 0");
+  dim3 grid(((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn), p.split_k, p.batch);
+#define LAUNCH(WM_, WN_, AM_, BM_) hipLaunchKernelGGL((gemm_f32_kernel<WM_, WN_, AM_, BM_>), grid, block, 0, st, p)
+#define LAUNCH_TILE(AM_, BM_)                 \
+  do {                                        \
+    if (tile == 1) LAUNCH(2, 2, AM_, BM_);    \
+    else if (tile == 2) LAUNCH(2, 1, AM_, BM_); \
+    else LAUNCH(1, 1, AM_, BM_);              \
+  } while (0)
+  switch (p.a_mode * 2 + p.b_mode) {
+    case 0: LAUNCH_TILE(0, 0); break;
+    case 1: LAUNCH_TILE(0, 1); break;
+    case 2: LAUNCH_TILE(1, 0); break;
+    case 3: LAUNCH_TILE(1, 1); break;
+    case 4: LAUNCH_TILE(2, 0); break;
+    case 6: LAUNCH_TILE(3, 0); break;
+    default: return cadre_fail("cadre_gemm_f32: bad operand mode");
   }
+#undef LAUNCH_TILE
+#undef LAUNCH
   return (int)hipGetLastError();
 }
 

@@ -94,6 +94,22 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Optional launch profiler (bench.py): when PROFILE is a list, every gemm launch is bracketed by
+# HIP events recorded on the launch stream and appended as (tile_tag, flops, start_evt, end_evt).
+PROFILE = None
+
+
+def _tile_of(M, N, batch, split_k, tile):
+    if tile:
+        return tile
+
+    def nt(bm, bn):
+        return ((M + bm - 1) // bm) * ((N + bn - 1) // bn) * batch * split_k
+    if N <= 64:
+        return 2 if nt(128, 64) >= 256 else 3
+    return 1 if nt(128, 128) >= 256 else 3
+
+
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, scale=None, shift=None, resid=None, ldr=0,
          act=0, slope=0.01, batch=1, a_z=(1, 0, 0), b_z=(1, 0, 0), c_z=(1, 0, 0), s_z=(1, 0, 0), r_z=(1, 0, 0),
          conv=None, split_k=1, tile=0):
@@ -108,4 +124,12 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, scale=None, shi
     if conv is not None:
         d.H, d.W, d.Cin, d.Ho, d.Wo, d.KH, d.KW, d.stride, d.pad = conv
     d.split_k, d.tile = split_k, tile
+    if PROFILE is None:
+        check(lib().cadre_gemm_f32(C.byref(d), stream()), "cadre_gemm_f32")
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     check(lib().cadre_gemm_f32(C.byref(d), stream()), "cadre_gemm_f32")
+    e1.record()
+    kind = "conv" if a_mode >= 2 else "gemm"
+    PROFILE.append((_tile_of(M, N, max(1, batch), max(1, split_k), tile), kind, 2.0 * M * N * K * max(1, batch), e0, e1))
