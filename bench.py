@@ -72,7 +72,21 @@ def encode_worker(agent, wk, cfg, chunk_windows):
     enc = agent.vae_model
     obs_rows = wk.stor[0]._obs.view(-1, wk.stor[0]._ldo)          # [(T+1)*S, 544]
     L = hip.lib()
-    for t0 in range(0, T, chunk_windows):
+    if cfg.get("dedup"):
+        # sliding-window latent cache: each of the T+S-1 distinct frames is encoded
+        # once (bit-identical per-frame results), windows are assembled by a row gather
+        nf = wk.rgb.shape[0]
+        if getattr(wk, "lat", None) is None:
+            wk.lat = torch.zeros(nf, 512, device=wk.rgb.device)
+        step = chunk_windows * SEQ
+        for f0 in range(0, nf, step):
+            f1 = min(nf, f0 + step)
+            enc.forward_nhwc(enc.preprocess(wk.rgb[f0:f1], wk.route[f0:f1]), wk.lat[f0:f1])
+        obs_rows[:T * SEQ, :512].copy_(wk.lat.index_select(0, wk.win))
+        hip.check(L.cadre_append_measurements(hip.ptr(wk.meas), hip.ptr(obs_rows), obs_rows.stride(0), T * SEQ,
+                                              hip.stream()), "cadre_append_measurements")
+        chunk_windows = T + 1                                     # skip the per-window loop below
+    for t0 in range(0, T if not cfg.get("dedup") else 0, chunk_windows):
         t1 = min(T, t0 + chunk_windows)
         ids = wk.win[t0 * SEQ:t1 * SEQ]
         x = enc.preprocess(wk.rgb.index_select(0, ids), wk.route.index_select(0, ids))
@@ -96,36 +110,20 @@ def learner_round(agent, workers, cfg, shared, timers=None):
         nv_s, nv_t = agent.get_value(False, wk.stor[0].get_last(), wk.stor[1].get_last())
         advs.append((wk.stor[0].compute_returns(nv_s), wk.stor[1].compute_returns(nv_t)))
     nW = len(workers)
-    losses = []
+    dev_losses = []
     for _ in range(PPO_EPOCH):
         idx = [(wk.stor[0].sample_indices(), wk.stor[1].sample_indices()) for wk in workers]
         for b in range(len(idx[0][0])):
-            per = [(wk.stor[0].gather(idx[i][0][b], advs[i][0]), wk.stor[1].gather(idx[i][1][b], advs[i][1]))
-                   for i, wk in enumerate(workers)]
-            if nW == 1:
-                s_s, t_s = per[0]
-            else:
-                s_s = _cat([p[0] for p in per]); t_s = _cat([p[1] for p in per])
-            losses.append(agent.update_policy(s_s, t_s, workers=nW))
+            batches = [(wk.stor[0], idx[i][0][b], advs[i][0], wk.stor[1], idx[i][1][b], advs[i][1])
+                       for i, wk in enumerate(workers)]
+            dev_losses.append(agent.update_policy_from_storages(batches, sync=False))
             shared.add_gradient(agent.model_dict)                 # RCCL all-reduce(SUM) when world_size > 1
             chief_step(shared, None, 250.0)
+    losses = torch.stack(dev_losses).tolist()                     # the round's single host sync
     if timers is not None:
         torch.cuda.synchronize(); t2 = time.perf_counter()
         timers.append((t1 - t0, t2 - t1))
     return losses
-
-
-def _cat(tuples):
-    """Row-concatenate W workers' 9-tuples; obs is time-major [S*B, D] -> interleave per time step."""
-    nW = len(tuples)
-    B = tuples[0][1].shape[0]
-    obs = torch.stack([t[0].view(SEQ, B, -1) for t in tuples], 1).reshape(SEQ * nW * B, -1)
-    out = [obs]
-    for k in (1, 2, 3, 4, 5, 6):
-        out.append(torch.cat([t[k] for t in tuples], 0))
-    out.append([torch.cat([t[7][0] for t in tuples], 0), torch.cat([t[7][1] for t in tuples], 0)])
-    out.append(torch.cat([t[8] for t in tuples], 0))
-    return tuple(out)
 
 
 def host_cores():
@@ -197,8 +195,11 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
-    ap.add_argument("--chunk-windows", type=int, default=16, help="windows (x8 frames) per encoder launch chain")
+    ap.add_argument("--chunk-windows", type=int, default=64, help="windows (x8 frames) per encoder launch chain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dedup", action="store_true",
+                    help="encode each distinct frame once (sliding-window latent cache) instead of the "
+                         "reference's 8 frames per transition; NOT the default metric convention")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -216,7 +217,7 @@ def main():
     from cadre_amd import hip, synth
     from ppo_agent.agent import CadreAgent
     from ppo_agent.models import Shared_grad_buffers
-    cfg = dict(CONFIGS[args.config]); cfg["chunk_windows"] = args.chunk_windows
+    cfg = dict(CONFIGS[args.config]); cfg["chunk_windows"] = args.chunk_windows; cfg["dedup"] = args.dedup
     H, W, T, nW = cfg["H"], cfg["W"], cfg["T"], cfg["workers"]
     fh, fw = synth.feat_hw(H, W)
     enc_state = synth.encoder_state(fh, fw, 7)
@@ -280,13 +281,15 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %d worker(s) x %d-step rollout, %dx%dx3 synthetic obs (+route), DANet encoder "
-                                   "(8 frames/transition, reference convention) + PPO update (4 epochs x 2 minibatches), fp32"
-                                   % (args.config, nW, T, H, W),
+                                   "(%s) + PPO update (4 epochs x 2 minibatches), fp32"
+                                   % (args.config, nW, T, H, W,
+                                      "latent cache: each distinct frame encoded once" if args.dedup
+                                      else "8 frames/transition, reference convention"),
                        "workers_per_gpu": nW, "num_steps": T, "obs": [H, W], "minibatch_per_gpu": nW * T // MINI_BATCH_NUM,
-                       "parallelism": "dp%d" % world, "frames_per_round_per_gpu": nW * T * SEQ},
+                       "parallelism": "dp%d" % world, "frames_per_round_per_gpu": nW * (T + SEQ - 1 if args.dedup else T * SEQ)},
             "t_encode_ms": round(t_enc * 1e3, 3), "t_update_ms": round(t_upd * 1e3, 3),
-            "encoder_frames_per_sec": round(nW * T * SEQ / t_enc, 1),
-            "encoder_tflops": round(nW * T * SEQ * flops_frame / t_enc / 1e12, 2),
+            "encoder_frames_per_sec": round(nW * (T + SEQ - 1 if args.dedup else T * SEQ) / t_enc, 1),
+            "encoder_tflops": round(nW * (T + SEQ - 1 if args.dedup else T * SEQ) * flops_frame / t_enc / 1e12, 2),
             "update_only_samples_per_sec": round(nW * T * PPO_EPOCH / t_upd, 1),
             "roofline": {"kernel": names[dom], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,

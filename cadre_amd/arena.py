@@ -57,11 +57,13 @@ class PPOArena:
         self.grads = torch.zeros(self.total, device=self.device)
         self.exp_avg = None
         self.exp_avg_sq = None
+        self._bound = []
         self.step = 0
         # clip segments in reference model order is irrelevant for the math; one segment per model
         offs = [g * self.size_L for g in range(self.Z)] + [self.P0 + g * self.size_P for g in range(self.Z)] + [self.total]
         self.seg_off = torch.tensor(offs, dtype=torch.int64, device=self.device)
-        self.norms2 = torch.zeros(2 * self.Z, dtype=torch.float64, device=self.device)
+        self.norms2 = torch.zeros(2 * self.Z + 2, dtype=torch.float64, device=self.device)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.device)   # Adam step count (graph replay)
 
     # ------------------------------------------------------------------ naming
     def net_index(self, head, command):
@@ -119,20 +121,16 @@ class PPOArena:
                     v.copy_(p.data.to(self.device))
                     p.data = v
                 p.grad = gv[name]
+                self._bound.append((p, gv[name]))
         module._cadre_arena = self
         module._cadre_name = model_name
         return module
 
-    def attach_grads(self, model_dict):
+    def attach_grads(self, model_dict=None):
         """(Re-)attach arena gradient views — `zero_grad(set_to_none=True)` by a caller detaches them."""
-        for name, module in model_dict.items():
-            gv = None
-            for pn, p in module.named_parameters():
-                if p.grad is None or getattr(p, "_cadre_g", None) is not p.grad:
-                    if gv is None:
-                        gv = self.views(self.grads, name)
-                    p.grad = gv[pn]
-                    p._cadre_g = p.grad
+        for p, g in self._bound:
+            if p.grad is not g:
+                p.grad = g
 
     def load_numpy_state(self, state):
         """state: {model_name: {param_name: ndarray}} (cadre_amd.synth.ppo_state layout)."""

@@ -44,38 +44,69 @@ __global__ void route_max_kernel(const uint8_t* route, uint32_t* frame_max, int 
   const int f = blockIdx.y;
   const uint8_t* r = route + (int64_t)f * per_frame;
   uint32_t m = 0;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per_frame; i += gridDim.x * blockDim.x)
-    m = max(m, (uint32_t)r[i]);
+  const int stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
+  if ((((uintptr_t)r) & 15) == 0) {                       // 16 bytes per lane
+    const uint4* r4 = reinterpret_cast<const uint4*>(r);
+    const int n4 = per_frame >> 4;
+    for (int i = t0; i < n4; i += stride) {
+      const uint4 v = r4[i];
+      uint32_t w = v.x | v.y | v.z | v.w;                 // cheap pre-test: all-zero words skip the byte max
+      if (w) {
+        const uint32_t ws[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) m = max(m, (ws[k] >> (8 * b)) & 0xffu);
+      }
+    }
+    for (int i = (n4 << 4) + t0; i < per_frame; i += stride) m = max(m, (uint32_t)r[i]);
+  } else {
+    for (int i = t0; i < per_frame; i += stride) m = max(m, (uint32_t)r[i]);
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
   if ((threadIdx.x & 63) == 0 && m) atomicMax(frame_max + f, m);
 }
 
-__global__ void preprocess_kernel(const uint8_t* rgb, const uint8_t* route, const float* lut,
-                                  const uint32_t* frame_max, float* out, uint8_t* route_norm,
-                                  int F, int H, int W) {
+// One workgroup = a 32(h) x 32(w) pixel tile of one frame.  The route plane is stored [W][H] (h
+// fastest), the output NHWC (w fastest): the tile is read coalesced along h, transposed through LDS,
+// and written coalesced along w together with the LUT-converted RGB.
+__global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* rgb, const uint8_t* route, const float* lut,
+                                                         const uint32_t* frame_max, float* out, uint8_t* route_norm,
+                                                         int F, int H, int W) {
   __shared__ float s_lut[256];
-  s_lut[threadIdx.x & 255] = lut[threadIdx.x & 255];
+  __shared__ uint8_t s_r[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+  s_lut[threadIdx.x] = lut[threadIdx.x];
+  const int f = blockIdx.z, h0 = blockIdx.y * 32, w0 = blockIdx.x * 32;
+  const uint32_t mx = frame_max[f];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {                                // read route[f][w0+wl][h0+tx], wl = ty + 8j
+    const int wl = ty + 8 * j, w = w0 + wl, h = h0 + tx;
+    uint8_t rn = 0;
+    if (w < W && h < H) {
+      const int64_t ridx = ((int64_t)f * W + w) * H + h;
+      const uint8_t rv = route[ridx];
+      // agent.py:51-54: route[i] = 1.0*route[i]/max stored into uint8 -> truncates to {0,1}
+      rn = mx > 0 ? (uint8_t)(rv == mx ? 1 : 0) : rv;
+      if (route_norm) route_norm[ridx] = rn;
+    }
+    s_r[wl][tx] = rn;
+  }
   __syncthreads();
-  const int64_t total = (int64_t)F * H * W;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int w = (int)(i % W);
-    const int h = (int)((i / W) % H);
-    const int f = (int)(i / ((int64_t)W * H));
-    const uint8_t* px = rgb + i * 3;
-    const int64_t ridx = ((int64_t)f * W + w) * H + h;       // route stored [F][W][H]
-    const uint32_t mx = frame_max[f];
-    const uint8_t rv = route[ridx];
-    // agent.py:51-54: route[i] = 1.0*route[i]/max stored into uint8 -> truncates to {0,1}
-    const uint8_t rn = mx > 0 ? (uint8_t)(rv == mx ? 1 : 0) : rv;
-    float4 o;
-    o.x = s_lut[px[0]];
-    o.y = s_lut[px[1]];
-    o.z = s_lut[px[2]];
-    o.w = (float)rn;
-    reinterpret_cast<float4*>(out)[i] = o;
-    if (route_norm) route_norm[ridx] = rn;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {                                // write out[f][h0+hl][w0+tx][0..3], hl = ty + 8j
+    const int hl = ty + 8 * j, h = h0 + hl, w = w0 + tx;
+    if (h < H && w < W) {
+      const int64_t i = ((int64_t)f * H + h) * W + w;
+      const uint8_t* px = rgb + i * 3;
+      float4 o;
+      o.x = s_lut[px[0]];
+      o.y = s_lut[px[1]];
+      o.z = s_lut[px[2]];
+      o.w = (float)s_r[tx][hl];
+      reinterpret_cast<float4*>(out)[i] = o;
+    }
   }
 }
 
@@ -89,10 +120,8 @@ extern "C" int cadre_preprocess(const uint8_t* rgb, const uint8_t* route, const 
   const int per = H * W;
   dim3 g1(min(64, (per + 255) / 256), F);
   hipLaunchKernelGGL(route_max_kernel, g1, dim3(256), 0, ST(stream), route, frame_max, per);
-  const int64_t total = (int64_t)F * per;
-  const int blocks = (int)std::min<int64_t>((total + 255) / 256, 8192);
-  hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(256), 0, ST(stream), rgb, route, lut255,
-                     frame_max, out, route_norm, F, H, W);
+  hipLaunchKernelGGL(preprocess_kernel, dim3((W + 31) / 32, (H + 31) / 32, F), dim3(256), 0, ST(stream), rgb, route,
+                     lut255, frame_max, out, route_norm, F, H, W);
   return (int)hipGetLastError();
 }
 
@@ -409,6 +438,57 @@ extern "C" int cadre_gather_obs(const float* obs, int64_t ldo, int32_t S, const 
   return (int)hipGetLastError();
 }
 
+// Fused feed_forward_generator gather + update_policy input packing: one launch moves every field
+// of a head's minibatch from the rollout storage into the learner workspace (rows b0..b0+B of a
+// Bt-row packed batch, so several workers concatenate without extra copies).
+__global__ void gather_minibatch_kernel(const float* obs, int64_t ldo, int S, const float* hn, const float* cn,
+                                        int64_t ldh, const int64_t* action, const float* value_preds,
+                                        const float* returns, const float* logp, const int32_t* command,
+                                        const float* adv, const int64_t* idx, int B, int D, int Hd, int Bt, int b0,
+                                        float* X, int64_t ldx, float* h0, float* c0, int64_t ldho, int64_t* actions_o,
+                                        int32_t* commands_o, float* old_values_o, float* returns_o, float* old_logp_o,
+                                        float* adv_o) {
+  const int b = blockIdx.x, s = blockIdx.y;
+  const int64_t t = idx[b];
+  const int ob = b0 + b;
+  if (s < S) {
+    const float* src = obs + (t * S + s) * ldo;
+    float* dst = X + ((int64_t)s * Bt + ob) * ldx;
+    for (int d = threadIdx.x; d < ldx; d += blockDim.x) dst[d] = d < D ? src[d] : 0.f;
+    return;
+  }
+  const float* hs = hn + t * ldh;
+  const float* cs = cn + t * ldh;
+  for (int d = threadIdx.x; d < ldho; d += blockDim.x) {
+    h0[(int64_t)ob * ldho + d] = d < Hd ? hs[d] : 0.f;
+    c0[(int64_t)ob * ldho + d] = d < Hd ? cs[d] : 0.f;
+  }
+  if (threadIdx.x == 0) {
+    actions_o[ob] = action[t];
+    commands_o[ob] = command[t];
+    old_values_o[ob] = value_preds[t];
+    returns_o[ob] = returns[t];
+    old_logp_o[ob] = logp[t];
+    adv_o[ob] = adv[t];
+  }
+}
+extern "C" int cadre_gather_minibatch(const float* obs, int64_t ldo, int32_t S, const float* hn, const float* cn,
+                                      int64_t ldh, const int64_t* action, const float* value_preds,
+                                      const float* returns, const float* logp, const int32_t* command,
+                                      const float* adv, const int64_t* idx, int32_t B, int32_t D, int32_t Hd,
+                                      int32_t Bt, int32_t b0, float* X, int64_t ldx, float* h0, float* c0,
+                                      int64_t ldho, int64_t* actions_o, int32_t* commands_o, float* old_values_o,
+                                      float* returns_o, float* old_logp_o, float* adv_o, void* stream) {
+  FAIL_IF(!obs || !hn || !cn || !action || !value_preds || !returns || !logp || !command || !adv || !idx || !X ||
+              !h0 || !c0 || !actions_o || !commands_o || !old_values_o || !returns_o || !old_logp_o || !adv_o ||
+              S < 1 || B < 1 || D < 1 || Hd < 1 || b0 < 0 || b0 + B > Bt || ldx < D || ldho < Hd,
+          "cadre_gather_minibatch: bad argument");
+  hipLaunchKernelGGL(gather_minibatch_kernel, dim3(B, S + 1), dim3(128), 0, ST(stream), obs, ldo, S, hn, cn, ldh,
+                     action, value_preds, returns, logp, command, adv, idx, B, D, Hd, Bt, b0, X, ldx, h0, c0, ldho,
+                     actions_o, commands_o, old_values_o, returns_o, old_logp_o, adv_o);
+  return (int)hipGetLastError();
+}
+
 // ============================================================================ LSTM cell pointwise
 __global__ void lstm_fwd_kernel(float* gates, int64_t ldg, int64_t g_str, const float* c_prev, int64_t c_prev_str,
                                 int c_prev_div, float* c_out, float* h_out, float* tanh_c, int64_t ldh,
@@ -680,15 +760,102 @@ __global__ void adam_kernel(float* p, const float* g, float* m, float* v, const 
   const int64_t lo = seg_off[mdl], hi = seg_off[mdl + 1];
   const float total = (float)sqrt(norms2[mdl]);
   const float coef = fminf(max_norm / (total + 1e-6f), 1.f);   // clip_grad_norm_: clamp(max=1.0), always applied
-  for (int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (int64_t)gridDim.x * blockDim.x) {
+  // segment bounds are multiples of 4 floats (arena layout): 16 B per lane
+  const int64_t n4 = (hi - lo) >> 2;
+  float4* p4 = reinterpret_cast<float4*>(p + lo);
+  const float4* g4 = reinterpret_cast<const float4*>(g + lo);
+  float4* m4 = reinterpret_cast<float4*>(m + lo);
+  float4* v4 = reinterpret_cast<float4*>(v + lo);
+  const bool vec = (lo & 3) == 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; vec && i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+    float* pe = &pp.x; float* ge = &gg.x; float* me = &mm.x; float* ve = &vv.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gi = ge[e] * coef;
+      me[e] = me[e] + w1 * (gi - me[e]);                    // exp_avg.lerp_(grad, 1-beta1)
+      ve[e] = ve[e] * beta2 + w2 * (gi * gi);               // mul_(beta2).addcmul_(g,g,1-beta2)
+      pe[e] = pe[e] - step_size * (me[e] / (sqrtf(ve[e]) / bc2_sqrt + eps));
+    }
+    p4[i] = pp; m4[i] = mm; v4[i] = vv;
+  }
+  for (int64_t i = lo + (vec ? (n4 << 2) : 0) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi;
+       i += (int64_t)gridDim.x * blockDim.x) {
     const float gi = g[i] * coef;
-    const float mi = m[i] + w1 * (gi - m[i]);                  // exp_avg.lerp_(grad, 1-beta1)
-    const float vi = v[i] * beta2 + w2 * (gi * gi);            // mul_(beta2).addcmul_(g,g,1-beta2)
+    const float mi = m[i] + w1 * (gi - m[i]);
+    const float vi = v[i] * beta2 + w2 * (gi * gi);
     m[i] = mi;
     v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = p[i] - step_size * (mi / denom);
+    p[i] = p[i] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
   }
+}
+
+// Graph-capturable variant: the step count lives in device memory so a captured launch sequence
+// replays with fresh bias corrections.  scal = norms2 + n_models: {step_size, bc2_sqrt} as doubles.
+__global__ void adam_prep_kernel(double* norms2, int n_models, int32_t* step_dev, double lr, double beta1, double beta2) {
+  const int i = threadIdx.x;
+  if (i < n_models) norms2[i] = 0.0;
+  if (i == 0) {
+    const int step = ++(*step_dev);
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    norms2[n_models] = lr / bc1;
+    norms2[n_models + 1] = sqrt(bc2);
+  }
+}
+
+__global__ void adam_dev_kernel(float* p, const float* g, float* m, float* v, const int64_t* seg_off,
+                                const double* norms2, int n_models, float max_norm, float w1, float beta2, float w2,
+                                float eps) {
+  const int mdl = blockIdx.y;
+  const int64_t lo = seg_off[mdl], hi = seg_off[mdl + 1];
+  const float total = (float)sqrt(norms2[mdl]);
+  const float coef = fminf(max_norm / (total + 1e-6f), 1.f);
+  const float step_size = (float)norms2[n_models], bc2_sqrt = (float)norms2[n_models + 1];
+  // segment bounds are multiples of 4 floats (arena layout): 16 B per lane
+  const int64_t n4 = (hi - lo) >> 2;
+  float4* p4 = reinterpret_cast<float4*>(p + lo);
+  const float4* g4 = reinterpret_cast<const float4*>(g + lo);
+  float4* m4 = reinterpret_cast<float4*>(m + lo);
+  float4* v4 = reinterpret_cast<float4*>(v + lo);
+  const bool vec = (lo & 3) == 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; vec && i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+    float* pe = &pp.x; float* ge = &gg.x; float* me = &mm.x; float* ve = &vv.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gi = ge[e] * coef;
+      me[e] = me[e] + w1 * (gi - me[e]);                    // exp_avg.lerp_(grad, 1-beta1)
+      ve[e] = ve[e] * beta2 + w2 * (gi * gi);               // mul_(beta2).addcmul_(g,g,1-beta2)
+      pe[e] = pe[e] - step_size * (me[e] / (sqrtf(ve[e]) / bc2_sqrt + eps));
+    }
+    p4[i] = pp; m4[i] = mm; v4[i] = vv;
+  }
+  for (int64_t i = lo + (vec ? (n4 << 2) : 0) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * coef;
+    const float mi = m[i] + w1 * (gi - m[i]);
+    const float vi = v[i] * beta2 + w2 * (gi * gi);
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+  }
+}
+
+extern "C" int cadre_clip_adam_graph(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                                     const int64_t* seg_off, int32_t n_models, double* norms2, double max_norm,
+                                     double lr, double beta1, double beta2, double eps, int32_t* step_dev,
+                                     void* stream) {
+  FAIL_IF(!params || !grads || !exp_avg || !exp_avg_sq || !seg_off || !norms2 || !step_dev || n_models < 1 ||
+              n_models > 254,
+          "cadre_clip_adam_graph: bad argument");
+  hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(256), 0, ST(stream), norms2, n_models, step_dev, lr, beta1, beta2);
+  dim3 grid(64, n_models), grid2(256, n_models);
+  hipLaunchKernelGGL(sqnorm_kernel, grid, dim3(256), 0, ST(stream), grads, seg_off, norms2);
+  hipLaunchKernelGGL(adam_dev_kernel, grid2, dim3(256), 0, ST(stream), params, grads, exp_avg, exp_avg_sq, seg_off,
+                     norms2, n_models, (float)max_norm, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
+                     (float)eps);
+  return (int)hipGetLastError();
 }
 
 extern "C" int cadre_clip_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,

@@ -34,7 +34,7 @@ struct RowInfo {           // per-thread, per staged row: decoded once
 };
 
 template <int WM, int WN, int AMODE, int BMODE>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(cadre_gemm_t p) {
+__global__ __launch_bounds__(256, ((WM + WN) * 2 * 64 * 36 * 4 > 80 * 1024 ? 1 : 2)) void gemm_f32_kernel(cadre_gemm_t p) {
   constexpr int BM = 2 * WM * 32;
   constexpr int BN = 2 * WN * 32;
   constexpr int RA = BM / 32;  // 16-B chunks per thread per A tile (k-contiguous staging)
@@ -48,8 +48,17 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(cadre_gemm_t p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, lh = lane >> 5;
 
+  // XCD-aware tile order (cdna_hip_programming.md T1, bijective form): workgroups are dealt
+  // round-robin over the 8 XCDs, so give each XCD a CONTIGUOUS run of tiles — neighbouring M-tiles
+  // share conv halo rows and the N-tiles of one M-tile share the A panel, which then hit that
+  // XCD's private L2 instead of being re-fetched by up to 8 L2s.  Placement only affects speed.
   const int tilesN = (p.N + BN - 1) / BN;
-  const int tile_m = blockIdx.x / tilesN, tile_n = blockIdx.x % tilesN;
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tile_m = bid / tilesN, tile_n = bid % tilesN;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int z = blockIdx.z;
   const float* A = p.A + (int64_t)((z / p.a_div) % p.a_mod) * p.a_str;
@@ -78,7 +87,31 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(cadre_gemm_t p) {
       arow[i].base = A + (int64_t)min(m, p.M - 1) * p.lda;
       arow[i].hi0 = arow[i].wi0 = 0;
     }
-  } else if constexpr (AMODE >= 2) {
+  } else if constexpr (AMODE == 2) {
+    // implicit-GEMM gather, decoded once per staged row: 32-bit element offset of the receptive
+    // field's top-left tap (may be negative in the halo) + a bit mask of in-bounds taps, so the
+    // per-k-tile work is one scalar delta, one add and one bit test per row.
+    const int hw = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int m = m0 + rr + 32 * i;
+      const int mm = min(m, p.M - 1);
+      const int img = mm / hw, rem = mm % hw;
+      const int ho = rem / p.Wo, wo = rem % p.Wo;
+      const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+      arow[i].base = A;
+      arow[i].hi0 = ((img * p.H + hi0) * p.W + wi0) * p.Cin + cc * 4;   // element offset
+      unsigned mask = 0;
+      if (m < p.M) {
+        for (int kh = 0; kh < p.KH; ++kh)
+          for (int kw = 0; kw < p.KW; ++kw)
+            if ((unsigned)(hi0 + kh) < (unsigned)p.H && (unsigned)(wi0 + kw) < (unsigned)p.W)
+              mask |= 1u << (kh * p.KW + kw);
+      }
+      arow[i].wi0 = (int)mask;
+      arow[i].valid = m < p.M;
+    }
+  } else if constexpr (AMODE == 3) {
     const int hw = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
@@ -124,13 +157,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(cadre_gemm_t p) {
         areg[i] = (k < p.K && m < p.M) ? *reinterpret_cast<const f32x4*>(A + (int64_t)k * p.lda + m) : zero4;
       }
     } else if constexpr (AMODE == 2) {
-      const int pos = k0 / p.Cin, ci = k0 % p.Cin + cc * 4;  // uniform per tile (Cin % 32 == 0)
-      const int kh = pos / p.KW, kw = pos % p.KW;
+      const int pos = k0 / p.Cin, ci = k0 % p.Cin;             // uniform per tile (Cin % 32 == 0)
+      const int delta = ((pos / p.KW) * p.W + (pos % p.KW)) * p.Cin + ci;
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
-        const int hi = arow[i].hi0 + kh, wi = arow[i].wi0 + kw;
-        const bool ok = arow[i].valid && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-        areg[i] = ok ? *reinterpret_cast<const f32x4*>(arow[i].base + ((int64_t)hi * p.W + wi) * p.Cin + ci) : zero4;
+        const bool ok = ((unsigned)arow[i].wi0 >> pos) & 1u;
+        areg[i] = ok ? *reinterpret_cast<const f32x4*>(A + (int64_t)(arow[i].hi0 + delta)) : zero4;
       }
     } else {  // stem: Cin == 4, one 16-B chunk = one (kh,kw) position
       const int pos = k0 / 4 + cc;
@@ -256,48 +288,50 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(cadre_gemm_t p) {
     // 16-B-per-lane row segments: residual read and output write are each R/rows_per_instr wide
     // instructions per lane instead of 16*WM*WN scalar ones.  (The k-loop's last barrier has passed,
     // so the staging buffers are free.)
-    constexpr int CW = WN * 32, RW = WM * 32, P = CW + 4;
+    constexpr int CW = WN * 32, P = CW + 4;
     constexpr int LPR = CW / 4;          // lanes per row
     constexpr int RPI = 64 / LPR;        // rows per wave-instruction
-    float* cs = lds + wave * (RW * P);
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-      for (int j = 0; j < WN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          cs[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * P + j * 32 + l31] = acc[i][j][r];
-    // same-wave producer/consumer: LDS ops of one wave complete in order, no barrier needed
+    constexpr int NIT = 32 / RPI;        // instructions per 32-row slab
+    float* cs = lds + wave * (32 * P);
     const int c4 = (lane % LPR) * 4;
     const int col = n0 + wn * CW + c4;
     const bool cvalid = col < p.N;
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (cvalid && scale) sc = *reinterpret_cast<const f32x4*>(scale + col);
     if (cvalid && shift) sh = *reinterpret_cast<const f32x4*>(shift + col);
-    constexpr int NIT = RW / RPI;
-    f32x4 rv[NIT];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int row = m0 + wm * RW + it * RPI + lane / LPR;
-      rv[it] = (resid && cvalid && row < p.M) ? *reinterpret_cast<const f32x4*>(resid + (int64_t)row * p.ldr + col)
-                                               : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int i = 0; i < WM; ++i) {          // one 32-row slab of the wave tile at a time
+      const int rbase = m0 + (wm * WM + i) * 32;
+      f32x4 rv[NIT];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int rloc = it * RPI + lane / LPR;
-      const int row = m0 + wm * RW + rloc;
-      f32x4 v = *reinterpret_cast<const f32x4*>(cs + rloc * P + c4);
-      if (!raw) {
-        v = v * sc + sh;
-        if (!post) v += rv[it];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (actk == 1) v[e] = fmaxf(v[e], 0.f);
-          else if (actk == 2) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
-        }
-        if (post) v += rv[it];
+      for (int it = 0; it < NIT; ++it) {
+        const int row = rbase + it * RPI + lane / LPR;
+        rv[it] = (resid && cvalid && row < p.M) ? *reinterpret_cast<const f32x4*>(resid + (int64_t)row * p.ldr + col)
+                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      if (cvalid && row < p.M) *reinterpret_cast<f32x4*>(C + (int64_t)row * p.ldc + col) = v;
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          cs[((r & 3) + 8 * (r >> 2) + 4 * lh) * P + j * 32 + l31] = acc[i][j][r];
+      // same-wave producer/consumer: LDS ops of one wave execute in order, no barrier needed
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int rloc = it * RPI + lane / LPR;
+        const int row = rbase + rloc;
+        f32x4 v = *reinterpret_cast<const f32x4*>(cs + rloc * P + c4);
+        if (!raw) {
+          v = v * sc + sh;
+          if (!post) v += rv[it];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (actk == 1) v[e] = fmaxf(v[e], 0.f);
+            else if (actk == 2) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
+          }
+          if (post) v += rv[it];
+        }
+        if (cvalid && row < p.M) *reinterpret_cast<f32x4*>(C + (int64_t)row * p.ldc + col) = v;
+      }
     }
     return;
   }
@@ -350,6 +384,34 @@ int cadre_fail(const char* msg);
 #define GEMM_CHECK(cond, msg) \
   if (!(cond)) return cadre_fail("cadre_gemm_f32: " msg)
 
+// Auto tile: estimated efficiency = (measured steady-state factor of the tile shape) x (wave
+// quantisation over 256 CUs x resident workgroups per CU).  Factors from tools/gemm_bench.py on
+// MI355X (profiles/r01_gemm_tile_sweep.txt).
+static int pick_tile(const cadre_gemm_t& p) {
+  const int batch = p.batch < 1 ? 1 : p.batch, sk = p.split_k < 1 ? 1 : p.split_k;
+  struct Cand { int id, bm, bn, per_cu; double base; };
+  static const Cand big[2] = {{1, 128, 128, 2, 1.00}, {3, 64, 64, 4, 0.93}};
+  static const Cand narrow[2] = {{2, 128, 64, 2, 0.95}, {3, 64, 64, 4, 0.97}};
+  const Cand* c = p.N <= 64 ? narrow : big;
+  int best = c[0].id;
+  double best_e = -1.0;
+  for (int i = 0; i < 2; ++i) {
+    const double tiles = (double)((p.M + c[i].bm - 1) / c[i].bm) * ((p.N + c[i].bn - 1) / c[i].bn) * batch * sk;
+    const double slots = 256.0 * c[i].per_cu;
+    const double waves = tiles <= slots ? 1.0 : (double)(int64_t)((tiles + slots - 1) / slots);
+    // useful fraction of the padded tile grid (edge tiles) x quantisation x shape factor
+    const double useful = ((double)p.M * p.N * batch * sk) / (tiles * c[i].bm * c[i].bn);
+    const double e = c[i].base * useful * (tiles / (waves * slots));
+    if (e > best_e) { best_e = e; best = c[i].id; }
+  }
+  return best;
+}
+
+extern "C" int cadre_gemm_pick_tile(const cadre_gemm_t* pp) {
+  cadre_gemm_t p = *pp;
+  return p.tile ? p.tile : pick_tile(p);
+}
+
 extern "C" int cadre_gemm_f32(const cadre_gemm_t* pp, void* stream) {
   cadre_gemm_t p = *pp;
   GEMM_CHECK(p.A && p.B && p.C, "null operand");
@@ -361,6 +423,9 @@ extern "C" int cadre_gemm_f32(const cadre_gemm_t* pp, void* stream) {
   if (p.b_mode == 0) GEMM_CHECK(p.K % 4 == 0 && p.ldb % 4 == 0, "b_mode 0 needs K%4==0, ldb%4==0");
   if (p.b_mode == 1) GEMM_CHECK(p.N % 4 == 0 && p.ldb % 4 == 0, "b_mode 1 needs N%4==0, ldb%4==0");
   if (p.a_mode == 2) GEMM_CHECK(p.Cin % 32 == 0 && p.K == p.KH * p.KW * p.Cin, "conv needs Cin%32==0, K==KH*KW*Cin");
+  if (p.a_mode == 2) GEMM_CHECK(p.KH * p.KW <= 32, "conv window larger than 32 taps");
+  if (p.a_mode == 2)
+    GEMM_CHECK((int64_t)(p.M / (p.Ho * p.Wo)) * p.H * p.W * p.Cin < (1ll << 31), "conv input >= 2^31 elements: chunk the frame batch");
   if (p.a_mode == 3) GEMM_CHECK(p.Cin == 4 && p.K == p.KH * p.KW * 4, "stem conv needs Cin==4");
   if (p.a_mode >= 2) GEMM_CHECK(p.M % (p.Ho * p.Wo) == 0 && p.stride > 0, "conv M must be Nimg*Ho*Wo");
   if (p.batch < 1) p.batch = 1;
@@ -376,19 +441,12 @@ extern "C" int cadre_gemm_f32(const cadre_gemm_t* pp, void* stream) {
   if (p.s_mod < 1) p.s_mod = 1 << 30;
   if (p.r_mod < 1) p.r_mod = 1 << 30;
   GEMM_CHECK(p.split_k == 1 || p.batch == 1, "split_k with batch unsupported");
-  int tile = p.tile;
-  if (tile == 0) {
-    // biggest tile that still gives every one of the 256 CUs a workgroup
-    auto ntiles = [&](int bm, int bn) {
-      return (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.batch * p.split_k;
-    };
-    if (p.N <= 64) tile = ntiles(128, 64) >= 256 ? 2 : 3;
-    else tile = ntiles(128, 128) >= 256 ? 1 : 3;
-  }
+  const int tile = p.tile ? p.tile : pick_tile(p);
   hipStream_t st = (hipStream_t)stream;
   dim3 block(256);
-  const int bm = tile == 3 ? 64 : 128, bn = tile == 1 ? 128 : 64;
-  if (tile < 1 || tile > 3) return cadre_fail("cadre_gemm_f32: bad tile");
+  if (tile < 1 || tile > 6) return cadre_fail("cadre_gemm_f32: bad tile");
+  static const int BMS[7] = {0, 128, 128, 64, 256, 128, 256}, BNS[7] = {0, 128, 64, 64, 128, 256, 64};
+  const int bm = BMS[tile], bn = BNS[tile];
   if (p.a_mode >= 2 && p.b_mode != 0) return cadre_fail("cadre_gemm_f32: conv needs b_mode 0");
   dim3 grid(((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn), p.split_k, p.batch);
 #define LAUNCH(WM_, WN_, AM_, BM_) hipLaunchKernelGGL((gemm_f32_kernel<WM_, WN_, AM_, BM_>), grid, block, 0, st, p)
@@ -396,7 +454,10 @@ extern "C" int cadre_gemm_f32(const cadre_gemm_t* pp, void* stream) {
   do {                                        \
     if (tile == 1) LAUNCH(2, 2, AM_, BM_);    \
     else if (tile == 2) LAUNCH(2, 1, AM_, BM_); \
-    else LAUNCH(1, 1, AM_, BM_);              \
+    else if (tile == 3) LAUNCH(1, 1, AM_, BM_); \
+    else if (tile == 4) LAUNCH(4, 2, AM_, BM_); \
+    else if (tile == 5) LAUNCH(2, 4, AM_, BM_); \
+    else LAUNCH(4, 1, AM_, BM_);              \
   } while (0)
   switch (p.a_mode * 2 + p.b_mode) {
     case 0: LAUNCH_TILE(0, 0); break;

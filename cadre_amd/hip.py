@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libcadre_hip.so")
+LIB_PATH = os.environ.get("CADRE_HIP_LIB") or os.path.join(_HERE, "csrc", "libcadre_hip.so")
 _lib = None
 
 i32, i64, f32, f64, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
@@ -26,7 +26,7 @@ class GemmDesc(C.Structure):
                 ("s_div", i32), ("s_mod", i32), ("r_div", i32), ("r_mod", i32),
                 ("a_str", i64), ("b_str", i64), ("c_str", i64), ("s_str", i64), ("r_str", i64),
                 ("H", i32), ("W", i32), ("Cin", i32), ("Ho", i32), ("Wo", i32), ("KH", i32), ("KW", i32),
-                ("stride", i32), ("pad", i32), ("split_k", i32), ("tile", i32)]
+                ("stride", i32), ("pad", i32), ("split_k", i32), ("tile", i32), ("flags", i32)]
 
 
 # name -> argtypes (restype is int unless noted); must list every symbol of include/cadre_hip.h
@@ -34,6 +34,7 @@ SYMBOLS = {
     "cadre_abi_version": [],
     "cadre_last_error": [],
     "cadre_gemm_f32": [C.POINTER(GemmDesc), vp],
+    "cadre_gemm_pick_tile": [C.POINTER(GemmDesc)],
     "cadre_splitk_reduce": [vp, i32, i64, i64, vp, i64, i32, i32, vp, vp, i32, f32, vp],
     "cadre_preprocess": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "cadre_maxpool3x3s2": [vp, vp, i32, i32, i32, i32, vp],
@@ -43,6 +44,8 @@ SYMBOLS = {
     "cadre_append_measurements": [vp, vp, i64, i32, vp],
     "cadre_gae": [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, i32, vp],
     "cadre_gather_obs": [vp, i64, i32, vp, i32, vp, i64, i32, vp],
+    "cadre_gather_minibatch": [vp, i64, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32,
+                               vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp],
     "cadre_lstm_pointwise_fwd": [vp, i64, i64, vp, i64, i32, vp, vp, vp, i64, i64, i32, i32, i32, vp],
     "cadre_lstm_pointwise_bwd": [vp, vp, i64, i64, vp, vp, i64, vp, vp, i64, i32, i64, i64, i32, i32, i32, vp],
     "cadre_colsum": [vp, i64, i64, vp, i64, i32, i32, i32, i32, vp],
@@ -50,6 +53,7 @@ SYMBOLS = {
     "cadre_ppo_loss": [vp, i64, i64, vp, i64, i64, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, f32, vp, vp, vp, vp],
     "cadre_sample": [vp, i64, vp, i64, i32, i32, vp, vp, vp],
     "cadre_clip_adam": [vp, vp, vp, vp, vp, i32, vp, f64, f64, f64, f64, f64, i32, vp],
+    "cadre_clip_adam_graph": [vp, vp, vp, vp, vp, i32, vp, f64, f64, f64, f64, f64, vp, vp],
 }
 
 
@@ -99,17 +103,6 @@ def stream():
 PROFILE = None
 
 
-def _tile_of(M, N, batch, split_k, tile):
-    if tile:
-        return tile
-
-    def nt(bm, bn):
-        return ((M + bm - 1) // bm) * ((N + bn - 1) // bn) * batch * split_k
-    if N <= 64:
-        return 2 if nt(128, 64) >= 256 else 3
-    return 1 if nt(128, 128) >= 256 else 3
-
-
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, scale=None, shift=None, resid=None, ldr=0,
          act=0, slope=0.01, batch=1, a_z=(1, 0, 0), b_z=(1, 0, 0), c_z=(1, 0, 0), s_z=(1, 0, 0), r_z=(1, 0, 0),
          conv=None, split_k=1, tile=0):
@@ -124,6 +117,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, scale=None, shi
     if conv is not None:
         d.H, d.W, d.Cin, d.Ho, d.Wo, d.KH, d.KW, d.stride, d.pad = conv
     d.split_k, d.tile = split_k, tile
+    d.flags = 0
     if PROFILE is None:
         check(lib().cadre_gemm_f32(C.byref(d), stream()), "cadre_gemm_f32")
         return
@@ -132,4 +126,4 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, scale=None, shi
     check(lib().cadre_gemm_f32(C.byref(d), stream()), "cadre_gemm_f32")
     e1.record()
     kind = "conv" if a_mode >= 2 else "gemm"
-    PROFILE.append((_tile_of(M, N, max(1, batch), max(1, split_k), tile), kind, 2.0 * M * N * K * max(1, batch), e0, e1))
+    PROFILE.append((lib().cadre_gemm_pick_tile(C.byref(d)), kind, 2.0 * M * N * K * max(1, batch), e0, e1))

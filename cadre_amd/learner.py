@@ -10,6 +10,8 @@ written out explicitly (same formulas autograd would apply) and writes straight 
 gradient arena.  No autograd graph, no per-parameter tensors, nothing on the host between
 launches — the whole update is ~60 launches on one stream.
 """
+import os
+
 import torch
 
 from . import hip
@@ -21,6 +23,8 @@ class PPOLearnerHIP:
         self.clip, self.vc, self.cc, self.ec = float(clip), float(value_coeff), float(clip_coeff), float(ent_coeff)
         self.S = seq_length
         self._ws = {}
+        self._graphs = {}
+        self.use_graphs = os.environ.get("CADRE_HIP_GRAPHS", "1") != "0"
         hip.lib()
 
     # ------------------------------------------------------------------ workspace
@@ -94,7 +98,28 @@ class PPOLearnerHIP:
     def update(self, B, inv_b):
         """Forward + loss + backward for the packed minibatch in workspace(B).  Gradients of all 16
         nets are written (not accumulated) into arena.grads.  Returns the device tensor
-        losses[3] = (value_loss*vc, action_loss*cc, ent_loss*ec) (agent.py:226-237)."""
+        losses[3] = (value_loss*vc, action_loss*cc, ent_loss*ec) (agent.py:226-237).
+        The ~60-launch sequence has fixed shapes and pointers, so after one eager run it is captured
+        into a hipGraph per (B, inv_b) and replayed (launch-bound otherwise: ~2 ms of host time)."""
+        if not self.use_graphs:
+            return self._update_body(B, inv_b)
+        key = (B, inv_b)
+        g = self._graphs.get(key)
+        if g is None:
+            out = self._update_body(B, inv_b)              # eager warm-up (func attributes, lazy init)
+            if self._graphs.get(("warm",) + key):
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._update_body(B, inv_b)
+                self._graphs[key] = g
+            else:
+                self._graphs[("warm",) + key] = True
+            return out
+        g.replay()
+        return self.workspace(B)["losses"]
+
+    def _update_body(self, B, inv_b):
         a, S = self.a, self.S
         w = self.workspace(B)
         Z, C = a.Z, a.C
@@ -159,13 +184,33 @@ class PPOLearnerHIP:
 
     # ------------------------------------------------------------------ optimiser (chief.py:13-21)
     def clip_adam(self, lr=3e-4, max_grad_norm=250.0, betas=(0.9, 0.999), eps=1e-8):
+        """Three launches (prep, per-model square norms, Adam) with the step count in device memory,
+        captured into a hipGraph per hyper-parameter set."""
         a = self.a
         a.ensure_adam()
         a.step += 1
-        hip.check(hip.lib().cadre_clip_adam(hip.ptr(a.params), hip.ptr(a.grads), hip.ptr(a.exp_avg),
-                                            hip.ptr(a.exp_avg_sq), hip.ptr(a.seg_off), 2 * a.Z, hip.ptr(a.norms2),
-                                            float(max_grad_norm), float(lr), float(betas[0]), float(betas[1]),
-                                            float(eps), a.step, hip.stream()), "cadre_clip_adam")
+        key = ("adam", float(lr), float(max_grad_norm), float(betas[0]), float(betas[1]), float(eps))
+
+        def body():
+            hip.check(hip.lib().cadre_clip_adam_graph(
+                hip.ptr(a.params), hip.ptr(a.grads), hip.ptr(a.exp_avg), hip.ptr(a.exp_avg_sq), hip.ptr(a.seg_off),
+                2 * a.Z, hip.ptr(a.norms2), key[2], key[1], key[3], key[4], key[5], hip.ptr(a.step_dev),
+                hip.stream()), "cadre_clip_adam_graph")
+        if not self.use_graphs:
+            return body()
+        g = self._graphs.get(key)
+        if g is None:
+            if self._graphs.get(("warm",) + key):
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    body()
+                self._graphs[key] = g
+                g.replay()
+                return
+            self._graphs[("warm",) + key] = True
+            return body()
+        g.replay()
 
     # ------------------------------------------------------------------ inference (act / get_value)
     def infer(self, feats, commands, h0=None, c0=None):

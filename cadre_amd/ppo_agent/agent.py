@@ -32,29 +32,58 @@ class CadreAgent(object):
         self.learner = PPOLearnerHIP(self.arena, clip, value_coeff, clip_coeff, ent_coeff, seq_length=frame)
         self.arena._learner = self.learner
         self.mutate_route = _cfg(model_cfg, "mutate_route", True)
-        self._feat = None
+        self.latent_cache = _cfg(model_cfg, "latent_cache", True)
+        self._cache = None
 
     # ------------------------------------------------------------------ observation -> feature
-    def pre_process(self, tick_data):
-        """agent.py:43-75 on device; returns the NHWC f32 tensor [S,H,W,4] (the reference returns
+    def pre_process(self, tick_data, first=0):
+        """agent.py:43-75 on device; returns the NHWC f32 tensor [S-first,H,W,4] (the reference returns
         NCHW numpy — same values, channels-last) and applies the in-place uint8 route quirk."""
-        rgb = torch.from_numpy(np.ascontiguousarray(tick_data["rgb"])).to(self.vae_device, non_blocking=True)
+        rgb = torch.from_numpy(np.ascontiguousarray(tick_data["rgb"][first:])).to(self.vae_device, non_blocking=True)
         route_np = tick_data["route_fig"]
-        route = torch.from_numpy(np.ascontiguousarray(route_np)).to(self.vae_device, non_blocking=True)
+        route = torch.from_numpy(np.ascontiguousarray(route_np[first:])).to(self.vae_device, non_blocking=True)
         rn = torch.empty_like(route) if self.mutate_route else None
         x = self.vae_model.preprocess(rgb, route, rn)
         if rn is not None:
-            route_np[...] = rn.cpu().numpy()            # agent.py:51-54 mutates the caller's dict
+            route_np[first:] = rn.cpu().numpy()         # agent.py:51-54 mutates the caller's dict
         return x
 
+    def _window_shifted(self, tick_data):
+        """True when frames 0..S-2 of this observation are frames 1..S-1 of the previous one (the env's
+        sliding window, env_wrapper.py:899-904) — then only the newest frame needs encoding."""
+        c = self._cache
+        if c is None or not self.latent_cache:
+            return False
+        rgb, route = tick_data["rgb"], tick_data["route_fig"]
+        if rgb.shape != c["rgb"].shape or route.shape != c["route_raw"].shape:
+            return False
+        if not np.array_equal(rgb[:-1], c["rgb"][1:]):
+            return False
+        return np.array_equal(route[:-1], c["route_raw"][1:]) or np.array_equal(route[:-1], c["route_norm"][1:])
+
     def get_latent_feature(self, tick_data):
-        """agent.py:97-112 -> [S, 530] f32 device tensor (a view of a 544-pitch row buffer)."""
-        x = self.pre_process(tick_data)
-        S = x.shape[0]
-        if self._feat is None or self._feat.shape[0] != S:
-            self._feat = torch.zeros(S, self.arena.DP, device=self.device)
-        feat = torch.zeros_like(self._feat)              # fresh rows: callers keep references (rollout insert)
-        self.vae_model.forward_nhwc(x, feat)
+        """agent.py:97-112 -> [S, 530] f32 device tensor (a view of a 544-pitch row buffer).
+        Sliding-window latent cache: the encoder is per-frame in eval mode and the
+        HIP kernels are batch-invariant bit for bit (tests/test_encoder_gpu.py), so re-using the 7
+        latents already computed for the previous step changes no output bit and saves 7/8 of the
+        encoder work the reference repeats."""
+        S = tick_data["rgb"].shape[0]
+        feat = torch.zeros(S, self.arena.DP, device=self.device)   # fresh rows: callers keep references
+        shifted = self._window_shifted(tick_data)
+        raw_rgb = tick_data["rgb"].copy() if self.latent_cache else None
+        raw_route = tick_data["route_fig"].copy() if self.latent_cache else None
+        if shifted:
+            x = self.pre_process(tick_data, first=S - 1)
+            if self.mutate_route:
+                tick_data["route_fig"][:-1] = self._cache["route_norm"][1:]
+            feat[:-1, :512].copy_(self._cache["latent"][1:])
+            self.vae_model.forward_nhwc(x, feat[S - 1:])
+        else:
+            x = self.pre_process(tick_data)
+            self.vae_model.forward_nhwc(x, feat)
+        if self.latent_cache:
+            self._cache = dict(rgb=raw_rgb, route_raw=raw_route, route_norm=tick_data["route_fig"].copy(),
+                               latent=feat[:, :512].clone())
         meas = torch.from_numpy(np.ascontiguousarray(tick_data["measurements"], dtype=np.float64)).to(self.device)
         hip.check(hip.lib().cadre_append_measurements(hip.ptr(meas), hip.ptr(feat), feat.stride(0), S, hip.stream()),
                   "cadre_append_measurements")
@@ -128,6 +157,35 @@ class CadreAgent(object):
         self.arena.attach_grads(self.model_dict)
         v, a, e = losses.tolist()
         return v, a, e
+
+    def update_policy_from_storages(self, batches, sync=True):
+        """Fast path of the learner section: `batches` = [(steer_storage, steer_idx, steer_adv,
+        throttle_storage, throttle_idx, throttle_adv), ...] one entry per worker (equal sizes).
+        Same math as feed_forward_generator -> update_policy, but the minibatch gather writes
+        straight into the update workspace (cadre_gather_minibatch) and the losses stay on the device
+        unless `sync` (one host sync per round instead of one per minibatch)."""
+        nW = len(batches)
+        Bw = batches[0][1].numel()
+        B = nW * Bw
+        w = self.learner.workspace(B)
+        L, st = hip.lib(), hip.stream()
+        a = self.arena
+        for wi, (ss, si, sa, ts, ti, ta) in enumerate(batches):
+            for hd, (stor, idx, adv) in enumerate(((ss, si, sa), (ts, ti, ta))):
+                idx_d = idx.to(self.device, non_blocking=True)
+                hip.check(L.cadre_gather_minibatch(
+                    hip.ptr(stor._obs), stor._ldo, stor.seq_length, hip.ptr(stor._hn), hip.ptr(stor._cn), stor._ldh,
+                    hip.ptr(stor.action), hip.ptr(stor.value_preds), hip.ptr(stor.returns),
+                    hip.ptr(stor.action_log_probs), hip.ptr(stor.command), hip.ptr(adv), hip.ptr(idx_d), Bw, a.D, a.D,
+                    B, wi * Bw, hip.ptr(w["X"][hd]), a.DP, hip.ptr(w["h0"][hd]), hip.ptr(w["c0"][hd]), a.DP,
+                    hip.ptr(w["actions"][hd]), hip.ptr(w["commands"][hd]), hip.ptr(w["old_values"][hd]),
+                    hip.ptr(w["returns"][hd]), hip.ptr(w["old_logp"][hd]), hip.ptr(w["adv"][hd]), st),
+                    "cadre_gather_minibatch")
+        losses = self.learner.update(B, float(nW) / B)
+        self.arena.attach_grads(self.model_dict)
+        if sync:
+            return tuple(losses.tolist())
+        return losses.clone()
 
     def update_model(self, shared_model_list):
         """agent.py:239-243 (weight pull).  Same arena -> nothing to copy."""

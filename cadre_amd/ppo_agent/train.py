@@ -14,21 +14,33 @@ from .utils import check_exist
 
 
 def learner_section(agent, steer_rollout, throttle_rollout, done, train_cfg, shared_grad_buffers,
-                    optimizer=None, traffic_light=None, counter=None, shared_model_list=None, in_process_chief=True):
+                    optimizer=None, traffic_light=None, counter=None, shared_model_list=None, in_process_chief=True,
+                    fused_gather=True):
     """train.py:76-110.  Returns (value_loss_list, policy_loss_list, ent_loss_list).
     With `in_process_chief` (one process per GPU) the optimiser step runs right after the gradient
-    all-reduce instead of waiting on a separate chief process."""
+    all-reduce instead of waiting on a separate chief process.  `fused_gather` uses the storage ->
+    workspace gather kernel and keeps the per-minibatch losses on the device until the end of the
+    section (same numbers as the generator/tuple path, one host sync instead of eight)."""
     use_adv_norm = train_cfg["use_adv_norm"]
     nv_s, nv_t = agent.get_value(done, steer_rollout.get_last(), throttle_rollout.get_last())
     steer_adv = steer_rollout.compute_returns(nv_s.detach(), normalise=use_adv_norm)
     throttle_adv = throttle_rollout.compute_returns(nv_t.detach(), normalise=use_adv_norm)
+    dev_losses = []
     vl, pl, el = [], [], []
     for _ in range(train_cfg["ppo_epoch"]):
-        g_s = steer_rollout.feed_forward_generator(steer_adv)
-        g_t = throttle_rollout.feed_forward_generator(throttle_adv)
-        for s_samples, t_samples in zip(g_s, g_t):
-            v, p, e = agent.update_policy(s_samples, t_samples)
-            vl.append(v); pl.append(p); el.append(e)
+        if fused_gather:
+            idx_s, idx_t = steer_rollout.sample_indices(), throttle_rollout.sample_indices()   # steer draws first
+            steps = [("idx", a, b) for a, b in zip(idx_s, idx_t)]
+        else:
+            steps = [("tup", a, b) for a, b in zip(steer_rollout.feed_forward_generator(steer_adv),
+                                                     throttle_rollout.feed_forward_generator(throttle_adv))]
+        for kind, a, b in steps:
+            if kind == "idx":
+                dev_losses.append(agent.update_policy_from_storages(
+                    [(steer_rollout, a, steer_adv, throttle_rollout, b, throttle_adv)], sync=False))
+            else:
+                v, p, e = agent.update_policy(a, b)
+                vl.append(v); pl.append(p); el.append(e)
             if in_process_chief:
                 shared_grad_buffers.add_gradient(agent.model_dict)
                 chief_step(shared_grad_buffers, optimizer, train_cfg["max_grad_norm"])
@@ -40,6 +52,9 @@ def learner_section(agent, steer_rollout, throttle_rollout, done, train_cfg, sha
                     pass
             if shared_model_list is not None:
                 agent.update_model(shared_model_list)
+    if dev_losses:
+        for v, p, e in torch.stack(dev_losses).tolist():
+            vl.append(v); pl.append(p); el.append(e)
     return vl, pl, el
 
 

@@ -50,9 +50,13 @@ typedef struct {
   /* split-K: >1 writes raw partial sums to `C + s*M*ldc (+ z offsets)`; finish with
      cadre_splitk_reduce.  With split_k>1 scale/shift/resid/act are ignored here.        */
   int32_t split_k;
-  int32_t tile;        /* 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64                      */
+  int32_t tile;        /* 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128,
+                          5 = 128x256, 6 = 256x64 (4-6: one workgroup per CU)           */
+  int32_t flags;       /* reserved, must be 0 (keeps sizeof == 240)                          */
 } cadre_gemm_t;
 int cadre_gemm_f32(const cadre_gemm_t* p, void* stream);
+/* the tile id cadre_gemm_f32 would use for this descriptor (p->tile, or the auto choice) */
+int cadre_gemm_pick_tile(const cadre_gemm_t* p);
 /* C[M][ldc] = act(sum_s slab[s][M][lds] * scale + shift + resid) */
 int cadre_splitk_reduce(const float* slabs, int32_t split_k, int64_t slab_stride, int64_t lds,
                         float* C, int64_t ldc, int32_t M, int32_t N, const float* scale,
@@ -98,6 +102,17 @@ int cadre_gae(const float* rewards, float* value_preds, const float* masks, cons
  * time-major x [S][B][ldx]; hn/cn/scalars gathered likewise. */
 int cadre_gather_obs(const float* obs, int64_t ldo, int32_t S, const int64_t* idx, int32_t B,
                      float* x, int64_t ldx, int32_t D, void* stream);
+
+/* storage.py:99-120 + the unpacking at agent.py:167-168 in one launch: every field of one head's
+ * minibatch (rows idx[0..B) of the storage) is written into rows b0..b0+B of the Bt-row packed
+ * update workspace: X [S][Bt][ldx] time-major, h0/c0 [Bt][ldho], scalars [Bt]. */
+int cadre_gather_minibatch(const float* obs, int64_t ldo, int32_t S, const float* hn, const float* cn,
+                           int64_t ldh, const int64_t* action, const float* value_preds,
+                           const float* returns, const float* logp, const int32_t* command,
+                           const float* adv, const int64_t* idx, int32_t B, int32_t D, int32_t Hd,
+                           int32_t Bt, int32_t b0, float* X, int64_t ldx, float* h0, float* c0,
+                           int64_t ldho, int64_t* actions_o, int32_t* commands_o, float* old_values_o,
+                           float* returns_o, float* old_logp_o, float* adv_o, void* stream);
 
 /* ---------------------------------------------------------------- LSTM cell pointwise
  * nn.LSTMCell gate math (models.py:130-152).  gates [B][ldg] pre-activations (i,f,g,o blocks
@@ -152,6 +167,13 @@ int cadre_sample(const float* logits, int64_t ldl, const float* q, int64_t ldq, 
 int cadre_clip_adam(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                     const int64_t* seg_off, int32_t n_models, double* norms2, double max_norm,
                     double lr, double beta1, double beta2, double eps, int32_t step, void* stream);
+
+/* Same math, hipGraph-capturable: the 1-based step counter is *step_dev (device int32,
+ * incremented by the call); norms2 must hold n_models + 2 doubles. */
+int cadre_clip_adam_graph(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                          const int64_t* seg_off, int32_t n_models, double* norms2, double max_norm,
+                          double lr, double beta1, double beta2, double eps, int32_t* step_dev,
+                          void* stream);
 
 #ifdef __cplusplus
 }

@@ -162,3 +162,59 @@ def test_snapshot_roundtrip(tmp_path):
             assert torch.equal(v, agent.arena.views(before, n)[k])
     with pytest.raises(ImportError):
         agent.load_snapshot(str(tmp_path / "missing.pt"), None)
+
+
+def test_fused_gather_path_equals_tuple_path():
+    """update_policy_from_storages (gather kernel + hipGraph replay, 2 workers concatenated) gives the
+    same losses and gradients as feed_forward_generator tuples -> update_policy(workers=2)."""
+    from ppo_agent.storage import RolloutStorage
+    agent = make_agent(84, 84)
+    T = 16
+    stor = []
+    for w in range(2):
+        data = fill_storages(T, 300 + w)
+        pair = []
+        for hd in ("steer", "throttle"):
+            s = RolloutStorage(T, 2, 530, 8, 530, True, 0.99, 0.95)
+            for k, v in data[hd].items():
+                getattr(s, k).copy_(torch.from_numpy(v))
+            s.to("cuda:0")
+            s.compute_returns(torch.tensor([0.1 * (w + 1)]))
+            pair.append(s)
+        stor.append(pair)
+    idx = [torch.randperm(T)[:8] for _ in range(4)]
+    for rep in range(3):                                   # eager, eager+capture, graph replay
+        tup_s = [stor[w][0].gather(idx[2 * w], stor[w][0].advantages) for w in range(2)]
+        tup_t = [stor[w][1].gather(idx[2 * w + 1], stor[w][1].advantages) for w in range(2)]
+
+        def cat(ts):
+            B = ts[0][1].shape[0]
+            out = [torch.stack([t[0].reshape(8, B, -1) for t in ts], 1).reshape(8 * 2 * B, -1)]
+            out += [torch.cat([t[k] for t in ts], 0) for k in (1, 2, 3, 4, 5, 6)]
+            out.append([torch.cat([t[7][0] for t in ts], 0), torch.cat([t[7][1] for t in ts], 0)])
+            out.append(torch.cat([t[8] for t in ts], 0))
+            return tuple(out)
+        l_a = agent.update_policy(cat(tup_s), cat(tup_t), workers=2)
+        g_a = agent.arena.grads.clone()
+        l_b = agent.update_policy_from_storages(
+            [(stor[w][0], idx[2 * w], stor[w][0].advantages, stor[w][1], idx[2 * w + 1], stor[w][1].advantages)
+             for w in range(2)])
+        assert l_a == l_b and torch.equal(g_a, agent.arena.grads), rep
+
+
+def test_latent_cache_is_bit_identical():
+    """Sliding-window latent cache on vs off: identical features, actions, log-probs over a rollout
+    whose windows really slide (and one reset in the middle that must miss the cache)."""
+    a_on, a_off = make_agent(84, 84), make_agent(84, 84)
+    a_off.latent_cache = False
+    steps = synth.synth_rollout(5, 84, 84, seed=9) + synth.synth_rollout(3, 84, 84, seed=10)
+    for ag in (a_on, a_off):
+        torch.manual_seed(3)
+        ag._out = []
+        for td in steps:
+            obs = dict(rgb=td["rgb"], route_fig=td["route_fig"].copy(), measurements=td["measurements"],
+                       command=td["command"])
+            feat, a, lp, v, _ = ag.act(obs)
+            ag._out.append((feat.clone(), int(a[0]), int(a[1]), lp[0].item(), lp[1].item(), obs["route_fig"].copy()))
+    for x, y in zip(a_on._out, a_off._out):
+        assert torch.equal(x[0], y[0]) and x[1:5] == y[1:5] and np.array_equal(x[5], y[5])

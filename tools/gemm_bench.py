@@ -46,6 +46,7 @@ def conv_case(F, H, W, Cin, Cout, k, s, p, resid, tile=0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=128)
+    ap.add_argument("--tiles", default="0")
     args = ap.parse_args()
     F = args.frames
     hip.lib()
@@ -57,10 +58,21 @@ def main():
              ("layer3 3x3 256->256 @18 +res", 18, 18, 256, 256, 3, 1, 1, True),
              ("layer4 3x3 512->512 @9 +res", 9, 9, 512, 512, 3, 1, 1, True),
              ("conv5a 3x3 512->128 @9", 9, 9, 512, 128, 3, 1, 1, False)]
-    tot_f = tot_t = 0.0
+    tiles = [int(x) for x in args.tiles.split(",")]
     for name, H, W, ci, co, k, s, p, res in cases:
-        tf, t = conv_case(F, H, W, ci, co, k, s, p, res)
-        print("%-34s F=%d  %7.2f TFLOP/s  %8.1f us" % (name, F, tf, t * 1e6), flush=True)
+        row = []
+        for tl in tiles:
+            if tl in (1, 4, 5) and co <= 64:
+                row.append("   --  ")
+                continue
+            tf, t = conv_case(F, H, W, ci, co, k, s, p, res, tile=tl)
+            row.append("%6.1f " % tf)
+        print("%-34s F=%d  TFLOP/s by tile %s: %s" % (name, F, tiles, " ".join(row)), flush=True)
+    for tl in tiles:
+        M = N = K = 4096
+        A = torch.randn(M, K, device="cuda"); B = torch.randn(N, K, device="cuda"); Cc = torch.empty(M, N, device="cuda")
+        t = timeit(lambda: hip.gemm(A, B, Cc, M, N, K, K, K, N, tile=tl))
+        print("dense 4096^3 NT tile %d: %7.2f TFLOP/s" % (tl, 2.0 * M * N * K / t / 1e12), flush=True)
     # dense GEMMs of the PPO update (batched over 8 nets)
     for name, M, N, K, Z in (("lstm x-proj [512,544]x[544,2120] x8", 512, 2120, 544, 8),
                              ("lstm step  [64,544]x[544,2120] x8", 64, 2120, 544, 8),

@@ -17,7 +17,7 @@ def short(n):
 for f in sorted(glob.glob(os.path.join(root, "**", "*kernel_stats.csv"), recursive=True)):
     print("== kernel stats:", f)
     rows = list(csv.DictReader(open(f)))
-    for r in rows[:14]:
+    for r in rows[:40]:
         print("  %-72s calls %6s  total %10.3f ms  avg %9.1f us  %5s%%" % (
             short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, r["Percentage"]))
 for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
@@ -28,7 +28,7 @@ for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), r
         k = short(r["Kernel_Name"])
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[(k, r["Counter_Name"])] += 1
-    for k in sorted(acc, key=lambda k: -sum(acc[k].values()))[:10]:
+    for k in sorted(acc, key=lambda k: -sum(acc[k].values()))[:14]:
         n = max(cnt[(k, c)] for c in acc[k])
         print("  %-72s dispatches %d" % (k, n))
         for c, v in sorted(acc[k].items()):
