@@ -27,12 +27,6 @@ static_assert(sizeof(cadre_gemm_t) == 240, "cadre_gemm_t layout is part of the C
 #define BK 32
 #define LDS_PITCH 36
 
-struct RowInfo {           // per-thread, per staged row: decoded once
-  const float* base;       // dense: row pointer; conv: image base pointer
-  int hi0, wi0;            // conv: top-left input coordinate of the receptive field
-  bool valid;
-};
-
 template <int WM, int WN, int AMODE, int BMODE>
 __global__ __launch_bounds__(256, ((WM + WN) * 2 * 64 * 36 * 4 > 80 * 1024 ? 1 : 2)) void gemm_f32_kernel(cadre_gemm_t p) {
   constexpr int BM = 2 * WM * 32;
@@ -75,22 +69,28 @@ __global__ __launch_bounds__(256, ((WM + WN) * 2 * 64 * 36 * 4 > 80 * 1024 ? 1 :
   }
 
   // ---------------------------------------------------------------- staging setup
+  // All global->register staging goes through raw buffer loads (SRSRC form): the byte offset is a
+  // 32-bit VGPR, and any offset >= num_records (2 GiB window) returns zeros in hardware.  Halo taps,
+  // M/N tails and the K tail are therefore "loads from OOB" — no branches, no exec masking, no
+  // 64-bit address arithmetic in the k-loop, so the compiler can interleave the loads with MFMAs.
   // k-contiguous operand: thread owns chunk column cc (4 floats of the 32-deep tile) of rows
   // rr + 32*i.  k-major operand: tile is [32 k][BM] floats, thread owns chunks id = tid+256*i.
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)OOB, 0x00020000);
   const int cc = tid & 7, rr = tid >> 3;
-  RowInfo arow[RA];
+  unsigned aoff[RA];            // byte offset of the row's first staged chunk (or OOB)
+  unsigned amask[RA];           // conv: bit t set = tap t of the receptive field is inside the image
   if constexpr (AMODE == 0) {
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       const int m = m0 + rr + 32 * i;
-      arow[i].valid = m < p.M;
-      arow[i].base = A + (int64_t)min(m, p.M - 1) * p.lda;
-      arow[i].hi0 = arow[i].wi0 = 0;
+      aoff[i] = m < p.M ? (unsigned)(((int64_t)m * p.lda + cc * 4) * 4) : OOB;
+      amask[i] = 0;
     }
   } else if constexpr (AMODE == 2) {
-    // implicit-GEMM gather, decoded once per staged row: 32-bit element offset of the receptive
-    // field's top-left tap (may be negative in the halo) + a bit mask of in-bounds taps, so the
-    // per-k-tile work is one scalar delta, one add and one bit test per row.
+    // implicit-GEMM gather, decoded once per staged row: byte offset of the receptive field's
+    // top-left tap (negative in the top halo -> wraps to OOB, masked anyway) + in-bounds tap mask.
     const int hw = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
@@ -99,8 +99,7 @@ __global__ __launch_bounds__(256, ((WM + WN) * 2 * 64 * 36 * 4 > 80 * 1024 ? 1 :
       const int img = mm / hw, rem = mm % hw;
       const int ho = rem / p.Wo, wo = rem % p.Wo;
       const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-      arow[i].base = A;
-      arow[i].hi0 = ((img * p.H + hi0) * p.W + wi0) * p.Cin + cc * 4;   // element offset
+      aoff[i] = (unsigned)((((img * p.H + hi0) * p.W + wi0) * p.Cin + cc * 4) * 4);
       unsigned mask = 0;
       if (m < p.M) {
         for (int kh = 0; kh < p.KH; ++kh)
@@ -108,87 +107,78 @@ __global__ __launch_bounds__(256, ((WM + WN) * 2 * 64 * 36 * 4 > 80 * 1024 ? 1 :
             if ((unsigned)(hi0 + kh) < (unsigned)p.H && (unsigned)(wi0 + kw) < (unsigned)p.W)
               mask |= 1u << (kh * p.KW + kw);
       }
-      arow[i].wi0 = (int)mask;
-      arow[i].valid = m < p.M;
+      amask[i] = mask;
     }
   } else if constexpr (AMODE == 3) {
     const int hw = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       const int m = m0 + rr + 32 * i;
-      arow[i].valid = m < p.M;
       const int mm = min(m, p.M - 1);
       const int img = mm / hw, rem = mm % hw;
       const int ho = rem / p.Wo, wo = rem % p.Wo;
-      arow[i].base = A + (int64_t)img * p.H * p.W * p.Cin;
-      arow[i].hi0 = ho * p.stride - p.pad;
-      arow[i].wi0 = wo * p.stride - p.pad;
+      // pack (hi0, wi0) relative coordinates; offsets are formed per tile (one tap per 16-B chunk)
+      aoff[i] = (unsigned)(img * p.H * p.W * 16);
+      amask[i] = m < p.M ? (((unsigned)(ho * p.stride - p.pad + 0x4000) << 16) | (unsigned)(wo * p.stride - p.pad + 0x4000)) : 0u;
     }
   }
-  const float* brow[RB];
-  bool bvalid[RB];
+  unsigned boff[RB];
   if constexpr (BMODE == 0) {
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       const int n = n0 + rr + 32 * i;
-      bvalid[i] = n < p.N;
-      brow[i] = B + (int64_t)min(n, p.N - 1) * p.ldb;
+      boff[i] = n < p.N ? (unsigned)(((int64_t)n * p.ldb + cc * 4) * 4) : OOB;
     }
   }
 
   f32x4 areg[RA], breg[RB];
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto ldg = [](const __amdgpu_buffer_rsrc_t& rs, unsigned off) -> f32x4 {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+  };
 
   auto load_tiles = [&](int kt) {
     const int k0 = kt * BK;
     // ---- A
     if constexpr (AMODE == 0) {
-      const int k = k0 + cc * 4;
-      const bool kv = k < p.K;  // K % 4 == 0
+      const unsigned kb_ = (k0 + cc * 4 < p.K) ? (unsigned)k0 * 4u : OOB;   // K % 4 == 0
 #pragma unroll
-      for (int i = 0; i < RA; ++i)
-        areg[i] = (arow[i].valid && kv) ? *reinterpret_cast<const f32x4*>(arow[i].base + k) : zero4;
+      for (int i = 0; i < RA; ++i) areg[i] = ldg(rsA, aoff[i] + kb_);
     } else if constexpr (AMODE == 1) {
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
         const int id = tid + 256 * i;
         const int kk = id / (BM / 4), mc = id % (BM / 4);
         const int k = k0 + kk, m = m0 + mc * 4;
-        areg[i] = (k < p.K && m < p.M) ? *reinterpret_cast<const f32x4*>(A + (int64_t)k * p.lda + m) : zero4;
+        areg[i] = ldg(rsA, (k < p.K && m < p.M) ? (unsigned)(((int64_t)k * p.lda + m) * 4) : OOB);
       }
     } else if constexpr (AMODE == 2) {
       const int pos = k0 / p.Cin, ci = k0 % p.Cin;             // uniform per tile (Cin % 32 == 0)
-      const int delta = ((pos / p.KW) * p.W + (pos % p.KW)) * p.Cin + ci;
+      const unsigned delta = (unsigned)((((pos / p.KW) * p.W + (pos % p.KW)) * p.Cin + ci) * 4);
 #pragma unroll
-      for (int i = 0; i < RA; ++i) {
-        const bool ok = ((unsigned)arow[i].wi0 >> pos) & 1u;
-        areg[i] = ok ? *reinterpret_cast<const f32x4*>(A + (int64_t)(arow[i].hi0 + delta)) : zero4;
-      }
-    } else {  // stem: Cin == 4, one 16-B chunk = one (kh,kw) position
+      for (int i = 0; i < RA; ++i) areg[i] = ldg(rsA, ((amask[i] >> pos) & 1u) ? aoff[i] + delta : OOB);
+    } else {  // stem: Cin == 4, one 16-B chunk = one (kh,kw) tap
       const int pos = k0 / 4 + cc;
       const int kh = pos / p.KW, kw = pos % p.KW;
       const bool kv = pos < p.KH * p.KW;
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
-        const int hi = arow[i].hi0 + kh, wi = arow[i].wi0 + kw;
-        const bool ok = kv && arow[i].valid && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-        areg[i] = ok ? *reinterpret_cast<const f32x4*>(arow[i].base + ((int64_t)hi * p.W + wi) * 4) : zero4;
+        const int hi = (int)(amask[i] >> 16) - 0x4000 + kh, wi = (int)(amask[i] & 0xffffu) - 0x4000 + kw;
+        const bool ok = kv && amask[i] != 0u && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        areg[i] = ldg(rsA, ok ? aoff[i] + (unsigned)((hi * p.W + wi) * 16) : OOB);
       }
     }
     // ---- B
     if constexpr (BMODE == 0) {
-      const int k = k0 + cc * 4;
-      const bool kv = k < p.K;
+      const unsigned kb_ = (k0 + cc * 4 < p.K) ? (unsigned)k0 * 4u : OOB;
 #pragma unroll
-      for (int i = 0; i < RB; ++i)
-        breg[i] = (bvalid[i] && kv) ? *reinterpret_cast<const f32x4*>(brow[i] + k) : zero4;
+      for (int i = 0; i < RB; ++i) breg[i] = ldg(rsB, boff[i] + kb_);
     } else {
 #pragma unroll
       for (int i = 0; i < RB; ++i) {
         const int id = tid + 256 * i;
         const int kk = id / (BN / 4), nc = id % (BN / 4);
         const int k = k0 + kk, n = n0 + nc * 4;
-        breg[i] = (k < p.K && n < p.N) ? *reinterpret_cast<const f32x4*>(B + (int64_t)k * p.ldb + n) : zero4;
+        breg[i] = ldg(rsB, (k < p.K && n < p.N) ? (unsigned)(((int64_t)k * p.ldb + n) * 4) : OOB);
       }
     }
   };
@@ -390,9 +380,12 @@ int cadre_fail(const char* msg);
 static int pick_tile(const cadre_gemm_t& p) {
   const int batch = p.batch < 1 ? 1 : p.batch, sk = p.split_k < 1 ? 1 : p.split_k;
   struct Cand { int id, bm, bn, per_cu; double base; };
-  static const Cand big[2] = {{1, 128, 128, 2, 1.00}, {3, 64, 64, 4, 0.93}};
-  static const Cand narrow[2] = {{2, 128, 64, 2, 0.95}, {3, 64, 64, 4, 0.97}};
-  const Cand* c = p.N <= 64 ? narrow : big;
+  // dense: the 128x128 tile's operand reuse wins (131 vs 124 TFLOP/s at 4096^3); implicit-GEMM conv:
+  // four 64x64 workgroups per CU (4 waves/SIMD) hide the gather latency better (119-123 vs 112-117)
+  static const Cand big[2] = {{1, 128, 128, 2, 1.00}, {3, 64, 64, 4, 0.94}};
+  static const Cand big_conv[2] = {{1, 128, 128, 2, 0.96}, {3, 64, 64, 4, 1.00}};
+  static const Cand narrow[2] = {{2, 128, 64, 2, 0.88}, {3, 64, 64, 4, 1.00}};
+  const Cand* c = p.N <= 64 ? narrow : (p.a_mode >= 2 ? big_conv : big);
   int best = c[0].id;
   double best_e = -1.0;
   for (int i = 0; i < 2; ++i) {
@@ -424,8 +417,16 @@ extern "C" int cadre_gemm_f32(const cadre_gemm_t* pp, void* stream) {
   if (p.b_mode == 1) GEMM_CHECK(p.N % 4 == 0 && p.ldb % 4 == 0, "b_mode 1 needs N%4==0, ldb%4==0");
   if (p.a_mode == 2) GEMM_CHECK(p.Cin % 32 == 0 && p.K == p.KH * p.KW * p.Cin, "conv needs Cin%32==0, K==KH*KW*Cin");
   if (p.a_mode == 2) GEMM_CHECK(p.KH * p.KW <= 32, "conv window larger than 32 taps");
-  if (p.a_mode == 2)
-    GEMM_CHECK((int64_t)(p.M / (p.Ho * p.Wo)) * p.H * p.W * p.Cin < (1ll << 31), "conv input >= 2^31 elements: chunk the frame batch");
+  {  // every staged byte offset must fit the 2 GiB buffer window of the raw-buffer loads
+    const int64_t lim = 1ll << 31;
+    int64_t a_bytes, b_bytes;
+    if (p.a_mode >= 2) a_bytes = (int64_t)(p.M / (p.Ho * p.Wo)) * p.H * p.W * p.Cin * 4;
+    else a_bytes = (int64_t)(p.a_mode == 0 ? p.M : p.K) * p.lda * 4;
+    b_bytes = (int64_t)(p.b_mode == 0 ? p.N : p.K) * p.ldb * 4;
+    GEMM_CHECK(a_bytes < lim, "A operand spans >= 2 GiB: chunk the batch");
+    GEMM_CHECK(b_bytes < lim, "B operand spans >= 2 GiB");
+    if (p.a_mode == 3) GEMM_CHECK(p.H < 0x3000 && p.W < 0x3000, "stem image too large");
+  }
   if (p.a_mode == 3) GEMM_CHECK(p.Cin == 4 && p.K == p.KH * p.KW * 4, "stem conv needs Cin==4");
   if (p.a_mode >= 2) GEMM_CHECK(p.M % (p.Ho * p.Wo) == 0 && p.stride > 0, "conv M must be Nimg*Ho*Wo");
   if (p.batch < 1) p.batch = 1;
