@@ -261,12 +261,24 @@ def main():
         elapsed = float(tt.item())
     # ---- per-kernel roofline from the HIP events recorded inside the timed region
     by = {}
-    for tile, kind, flops, e0, e1 in prof:
-        d = by.setdefault(tile, [0.0, 0.0, 0])
+    for key, flops, e0, e1 in prof:
+        d = by.setdefault(key, [0.0, 0.0, 0])
         d[0] += flops; d[1] += e0.elapsed_time(e1) * 1e-3; d[2] += 1
     dom = max(by, key=lambda k: by[k][1])
-    names = {1: "gemm_f32_kernel<2,2,*,*> (128x128 tile)", 2: "gemm_f32_kernel<2,1,*,*> (128x64 tile)", 3: "gemm_f32_kernel<1,1,*,*> (64x64 tile)"}
+    WMWN = {1: (2, 2), 2: (2, 1), 3: (1, 1), 4: (4, 2), 5: (2, 4), 6: (4, 1)}
+    TILE = {1: "128x128", 2: "128x64", 3: "64x64", 4: "256x128", 5: "128x256", 6: "256x64"}
+    AM = {0: "dense A[M][K]", 1: "dense A[K][M]", 2: "NHWC implicit-GEMM conv", 3: "Cin=4 stem conv"}
+
+    def kname(k):      # exact symbol as rocprofv3 prints it
+        return "gemm_f32_kernel<%d, %d, %d, %d>" % (WMWN[k[0]] + (k[1], k[2]))
     ach = by[dom][0] / by[dom][1] / 1e12
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):          # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+        try:
+            traffic = json.load(open(tpath)).get(kname(dom), {}).get("hbm_bytes_per_launch")
+        except (ValueError, OSError):
+            traffic = None
     # untimed split pass for t_encode / t_update
     timers = []
     learner_round(agent, workers, cfg, shared, timers)
@@ -291,11 +303,16 @@ def main():
             "encoder_frames_per_sec": round(nW * (T + SEQ - 1 if args.dedup else T * SEQ) / t_enc, 1),
             "encoder_tflops": round(nW * (T + SEQ - 1 if args.dedup else T * SEQ) * flops_frame / t_enc / 1e12, 2),
             "update_only_samples_per_sec": round(nW * T * PPO_EPOCH / t_upd, 1),
-            "roofline": {"kernel": names[dom], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "roofline": {"kernel": kname(dom), "kernel_desc": "%s tile, %s" % (TILE[dom[0]], AM[dom[1]]),
+                         "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/hbm_traffic.json)",
+                         "flops_per_launch": round(by[dom][0] / by[dom][2], 1),
                          "launches": by[dom][2], "avg_launch_us": round(by[dom][1] / by[dom][2] * 1e6, 2),
-                         "per_tile": {names[k]: {"tflops": round(v[0] / v[1] / 1e12, 2), "time_ms_per_step": round(v[1] / args.steps * 1e3, 3),
-                                                 "launches_per_step": v[2] // args.steps} for k, v in by.items()}},
+                         "per_kernel": {kname(k): {"tflops": round(v[0] / v[1] / 1e12, 2),
+                                                   "time_ms_per_step": round(v[1] / args.steps * 1e3, 3),
+                                                   "launches_per_step": v[2] // args.steps}
+                                        for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])}},
             "last_losses": [round(x, 6) for x in losses[-1]],
         }
         if not args.no_cpu_baseline:

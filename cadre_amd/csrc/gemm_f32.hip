@@ -65,7 +65,9 @@ __global__ __launch_bounds__(256, ((WM + WN) * 2 * 64 * 36 * 4 > 80 * 1024 ? 1 :
     const int per = (nk_total + p.split_k - 1) / p.split_k;
     kt_begin = blockIdx.y * per;
     kt_end = min(nk_total, kt_begin + per);
-    C += (int64_t)blockIdx.y * p.M * p.ldc;
+    // slab s of a batched problem holds every z-slot: [split][slots][M][ldc]
+    const int64_t slots = p.batch > 1 ? min((p.batch + p.c_div - 1) / p.c_div, p.c_mod) : 1;
+    C += (int64_t)blockIdx.y * (p.batch > 1 ? slots * p.c_str : (int64_t)p.M * p.ldc);
   }
 
   // ---------------------------------------------------------------- staging setup
@@ -441,7 +443,7 @@ extern "C" int cadre_gemm_f32(const cadre_gemm_t* pp, void* stream) {
   if (p.c_mod < 1) p.c_mod = 1 << 30;
   if (p.s_mod < 1) p.s_mod = 1 << 30;
   if (p.r_mod < 1) p.r_mod = 1 << 30;
-  GEMM_CHECK(p.split_k == 1 || p.batch == 1, "split_k with batch unsupported");
+  GEMM_CHECK(p.split_k == 1 || p.batch == 1 || p.c_str >= (int64_t)p.M * p.ldc, "batched split_k needs c_str >= M*ldc");
   const int tile = p.tile ? p.tile : pick_tile(p);
   hipStream_t st = (hipStream_t)stream;
   dim3 block(256);

@@ -99,7 +99,7 @@ def stream():
 
 
 # Optional launch profiler (bench.py): when PROFILE is a list, every gemm launch is bracketed by
-# HIP events recorded on the launch stream and appended as (tile_tag, flops, start_evt, end_evt).
+# HIP events recorded on the launch stream and appended as ((tile, a_mode, b_mode), flops, start, end).
 PROFILE = None
 
 
@@ -125,5 +125,4 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, scale=None, shi
     e0.record()
     check(lib().cadre_gemm_f32(C.byref(d), stream()), "cadre_gemm_f32")
     e1.record()
-    kind = "conv" if a_mode >= 2 else "gemm"
-    PROFILE.append((lib().cadre_gemm_pick_tile(C.byref(d)), kind, 2.0 * M * N * K * max(1, batch), e0, e1))
+    PROFILE.append(((lib().cadre_gemm_pick_tile(C.byref(d)), a_mode, b_mode), 2.0 * M * N * K * max(1, batch), e0, e1))

@@ -18,6 +18,8 @@ from . import hip
 
 
 class PPOLearnerHIP:
+    SPLIT_DH = 8
+
     def __init__(self, arena, clip=0.1, value_coeff=0.1, clip_coeff=1.0, ent_coeff=0.01, seq_length=8):
         self.a = arena
         self.clip, self.vc, self.cc, self.ec = float(clip), float(value_coeff), float(clip_coeff), float(ent_coeff)
@@ -43,7 +45,7 @@ class PPOLearnerHIP:
                 Hs=z(Z, S + 1, B, a.DP), Cs=z(Z, S + 1, B, a.DP), TC=z(Z, S + 1, B, a.DP),
                 A1=z(2 * Z, B, a.hid), A2=z(2 * Z, B, a.hid), O3=z(2 * Z, B, a.NP),
                 dO3=z(2 * Z, B, a.NP), dA2=z(2 * Z, B, a.hid), dA1=z(2 * Z, B, a.hid),
-                dH=z(Z, B, a.DP), dC=z(Z, B, a.DP),
+                dH=z(Z, B, a.DP), dC=z(Z, B, a.DP), dHs=z(self.SPLIT_DH, Z, B, a.DP),
                 actions=z(2, B, dtype=torch.int64), commands=z(2, B, dtype=torch.int32),
                 old_values=z(2, B), returns=z(2, B), old_logp=z(2, B), adv=z(2, B),
                 losses=z(3),
@@ -110,7 +112,7 @@ class PPOLearnerHIP:
             if self._graphs.get(("warm",) + key):
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     self._update_body(B, inv_b)
                 self._graphs[key] = g
             else:
@@ -169,17 +171,20 @@ class PPOLearnerHIP:
                                                  hip.ptr(dC), B * DP, hip.ptr(TC[:, t + 1]), hip.ptr(Cs[:, t]),
                                                  (S + 1) * B * DP, 1, DP, (S + 1) * B * DP, B, a.D, Z, st),
                       "cadre_lstm_pointwise_bwd")
-            if t > 0:   # dh_{t-1} = dG_t W_hh
-                hip.gemm(dG[:, t], pL[a.o_whh:], dH, B, DP, H4, H4, DP, DP, b_mode=1, batch=Z,
-                         a_z=(1, 0, S * B * H4), b_z=(1, 0, sL), c_z=(1, 0, B * DP))
+            if t > 0:   # dh_{t-1} = dG_t W_hh : tiny output, K = 2120 -> split-K so >500 workgroups stream W_hh
+                hip.gemm(dG[:, t], pL[a.o_whh:], w["dHs"], B, DP, H4, H4, DP, DP, b_mode=1, batch=Z,
+                         a_z=(1, 0, S * B * H4), b_z=(1, 0, sL), c_z=(1, 0, B * DP), split_k=self.SPLIT_DH)
+                hip.check(L.cadre_splitk_reduce(hip.ptr(w["dHs"]), self.SPLIT_DH, Z * B * DP, DP, hip.ptr(dH), DP,
+                                                Z * B, DP, None, None, 0, 0.0, st), "cadre_splitk_reduce")
         # dW_hh = sum_t dG_t^T h_{t-1} ; dW_ih = sum_t dG_t^T x_t ; db_ih = db_hh = colsum(dG)
         hip.gemm(dG, Hs, gL[a.o_whh:], H4, DP, S * B, H4, DP, DP, a_mode=1, b_mode=1, batch=Z,
                  a_z=(1, 0, S * B * H4), b_z=(1, 0, (S + 1) * B * DP), c_z=(1, 0, sL))
         hip.gemm(dG, X, gL[a.o_wih:], H4, DP, S * B, H4, DP, DP, a_mode=1, b_mode=1, batch=Z,
                  a_z=(1, 0, S * B * H4), b_z=(C, 0, S * B * DP), c_z=(1, 0, sL))
-        for o_b in (a.o_bih, a.o_bhh):
-            hip.check(L.cadre_colsum(hip.ptr(dG), H4, S * B * H4, hip.ptr(gL[o_b:]), sL, S * B, H4, Z, 0, st),
-                      "cadre_colsum")
+        hip.check(L.cadre_colsum(hip.ptr(dG), H4, S * B * H4, hip.ptr(gL[a.o_bih:]), sL, S * B, H4, Z, 0, st),
+                  "cadre_colsum")
+        # b_ih and b_hh enter the gates as a sum: identical gradients (strided arena views, one copy)
+        Gr.as_strided((Z, H4), (sL, 1), a.o_bhh).copy_(Gr.as_strided((Z, H4), (sL, 1), a.o_bih))
         return w["losses"]
 
     # ------------------------------------------------------------------ optimiser (chief.py:13-21)
@@ -203,7 +208,7 @@ class PPOLearnerHIP:
             if self._graphs.get(("warm",) + key):
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     body()
                 self._graphs[key] = g
                 g.replay()

@@ -47,7 +47,8 @@ typedef struct {
   int64_t a_str, b_str, c_str, s_str, r_str;
   /* conv geometry (a_mode 2/3): input [Nimg][H][W][Cin], output [Nimg][Ho][Wo][N]       */
   int32_t H, W, Cin, Ho, Wo, KH, KW, stride, pad;
-  /* split-K: >1 writes raw partial sums to `C + s*M*ldc (+ z offsets)`; finish with
+  /* split-K: >1 writes raw partial sums, slice s to `C + s*M*ldc` (batch 1) or to
+     `C + s*slots*c_str + z-offset` (batched; slots = distinct C z-slots); finish with
      cadre_splitk_reduce.  With split_k>1 scale/shift/resid/act are ignored here.        */
   int32_t split_k;
   int32_t tile;        /* 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128,

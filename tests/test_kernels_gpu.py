@@ -81,6 +81,23 @@ def test_gemm_batched_and_splitk(hip):
     assert rel(out2, want2) < 2e-5
 
 
+def test_gemm_batched_splitk(hip):
+    """dh_{t-1} = dG_t . W_hh shape: tiny [B, 544] outputs, K = 2120, 8 nets, b_mode 1, split-K slabs."""
+    g = torch.Generator().manual_seed(8)
+    Z, M, N, K, S = 8, 24, 544, 2120, 8
+    A = torch.randn(Z, M, K, generator=g) * 0.1
+    W = torch.randn(Z, K, N, generator=g) * 0.1
+    want = torch.bmm(A, W)
+    slabs = torch.empty(S, Z, M, N, device="cuda")
+    Ad, Wd = dev(A), dev(W)
+    hip.gemm(Ad, Wd, slabs, M, N, K, K, N, N, b_mode=1, batch=Z, a_z=(1, 0, M * K), b_z=(1, 0, K * N),
+             c_z=(1, 0, M * N), split_k=S)
+    out = torch.empty(Z, M, N, device="cuda")
+    hip.check(hip.lib().cadre_splitk_reduce(slabs.data_ptr(), S, Z * M * N, N, out.data_ptr(), N, Z * M, N, None, None,
+                                            0, 0.0, hip.stream()), "reduce")
+    assert rel(out, want) < 2e-5
+
+
 @pytest.mark.parametrize("Cin,Cout,H,W,k,s,p", [(64, 64, 18, 22, 3, 1, 1), (64, 128, 18, 22, 3, 2, 1),
                                                  (64, 128, 17, 21, 1, 2, 0), (128, 160, 9, 9, 1, 1, 0),
                                                  (4, 64, 30, 36, 7, 2, 3)])

@@ -10,6 +10,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 be
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 bench.py $ARGS > $OUT/fetch.json 2> $OUT/fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 bench.py $ARGS > $OUT/write.json 2> $OUT/write.err
 python3 tools/summarize_pmc.py $OUT > $OUT/summary.txt 2>&1
+python3 tools/traffic_from_pmc.py $OUT > $OUT/traffic.json 2>> $OUT/summary.txt
 # keep only the summaries (raw traces are large)
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete
 find $OUT -name "*agent_info.csv" -delete
