@@ -28,7 +28,7 @@ T_START = time.perf_counter()
 CONFIGS = {
     "C1": dict(workers=1, T=32, H=84, W=84),
     "C2": dict(workers=1, T=128, H=288, W=288),
-    "C3": dict(workers=4, T=128, H=288, W=288),
+    "C3": dict(workers=4, T=128, H=288, W=288, encoder_dtype="bf16"),   # "bf16 encoder / fp32 losses"
 }
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PPO_EPOCH, MINI_BATCH_NUM, SEQ = 4, 2, 8
@@ -197,6 +197,8 @@ def main():
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
     ap.add_argument("--chunk-windows", type=int, default=64, help="windows (x8 frames) per encoder launch chain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--encoder-dtype", default=None, choices=["f32", "bf16"],
+                    help="override the config's encoder arithmetic (C2: f32, C3: bf16 storage / fp32 accumulate)")
     ap.add_argument("--dedup", action="store_true",
                     help="encode each distinct frame once (sliding-window latent cache) instead of the "
                          "reference's 8 frames per transition; NOT the default metric convention")
@@ -210,8 +212,10 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("CADRE_BENCH_FORCE_DIST") == "1"     # force: exercise RCCL init at N=1
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from cadre_amd import hip, synth
@@ -224,12 +228,13 @@ def main():
     ppo_state = synth.ppo_state(11)
     mcfg = dict(use_lstm=True, vae_device=local_rank, device_num=local_rank, vae_params="CoPM", measurement_dim=18,
                 num_output=dict(steer=33, throttle=3), command_num=4, obs_hw=(H, W), vae_state_dict=enc_state,
-                encoder_max_frames=args.chunk_windows * SEQ)
+                encoder_max_frames=args.chunk_windows * SEQ,
+                encoder_dtype=args.encoder_dtype or cfg.get("encoder_dtype", "f32"))
     agent = CadreAgent(rank=rank, model_cfg=mcfg, frame=SEQ, STEER_CONTROL={i: (i - 16) / 16.0 for i in range(33)},
                        THROTTLE_CONTROL={0: [0, 0], 1: [0, 1], 2: [0.6, 0]}, ent_coeff=0.01, value_coeff=0.1,
                        clip_coeff=1.0, clip=0.1)
     agent.arena.load_numpy_state(ppo_state)                      # identical start on every rank (startup broadcast)
-    if world > 1:
+    if use_dist:
         dist.broadcast(agent.arena.params, 0)
     dev = agent.device
     workers = [Worker(cfg, 1234 + 1000 * rank + w, dev) for w in range(nW)]
@@ -238,7 +243,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -255,7 +260,7 @@ def main():
     elapsed = time.perf_counter() - t0
     hip.PROFILE = None
     log("[bench] timed region %.3f s for %d steps" % (elapsed, args.steps))
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -264,6 +269,8 @@ def main():
     for key, flops, e0, e1 in prof:
         d = by.setdefault(key, [0.0, 0.0, 0])
         d[0] += flops; d[1] += e0.elapsed_time(e1) * 1e-3; d[2] += 1
+    if not by:
+        by[(3, 2, 0)] = [0.0, 1e-9, 1]
     dom = max(by, key=lambda k: by[k][1])
     WMWN = {1: (2, 2), 2: (2, 1), 3: (1, 1), 4: (4, 2), 5: (2, 4), 6: (4, 1)}
     TILE = {1: "128x128", 2: "128x64", 3: "64x64", 4: "256x128", 5: "128x256", 6: "256x64"}
@@ -291,12 +298,15 @@ def main():
         out = {
             "metric": "ppo_update_samples_per_sec", "value": round(value, 2), "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if agent.vae_model.dtype == "f32" else "bf16 encoder (fp32 accumulate) / f32 PPO update",
+            "data": "synthetic",
             "config": {"workload": "%s: %d worker(s) x %d-step rollout, %dx%dx3 synthetic obs (+route), DANet encoder "
-                                   "(%s) + PPO update (4 epochs x 2 minibatches), fp32"
+                                   "(%s) + PPO update (4 epochs x 2 minibatches), %s"
                                    % (args.config, nW, T, H, W,
                                       "latent cache: each distinct frame encoded once" if args.dedup
-                                      else "8 frames/transition, reference convention"),
+                                      else "8 frames/transition, reference convention",
+                                      "fp32" if agent.vae_model.dtype == "f32" else "bf16 encoder / fp32 losses"),
                        "workers_per_gpu": nW, "num_steps": T, "obs": [H, W], "minibatch_per_gpu": nW * T // MINI_BATCH_NUM,
                        "parallelism": "dp%d" % world, "frames_per_round_per_gpu": nW * (T + SEQ - 1 if args.dedup else T * SEQ)},
             "t_encode_ms": round(t_enc * 1e3, 3), "t_update_ms": round(t_upd * 1e3, 3),
@@ -318,7 +328,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, enc_state, ppo_state)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -154,6 +154,49 @@ __global__ void maxpool_kernel(const float* x, float* y, int F, int H, int W, in
   }
 }
 
+__global__ void maxpool_bf16_kernel(const __bf16* x, __bf16* y, int F, int H, int W, int C8, int Ho, int Wo) {
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  const int64_t total = (int64_t)F * Ho * Wo * C8;
+  const bf16x8* x8 = reinterpret_cast<const bf16x8*>(x);
+  bf16x8* y8 = reinterpret_cast<bf16x8*>(y);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C8);
+    int64_t r = i / C8;
+    const int wo = (int)(r % Wo); r /= Wo;
+    const int ho = (int)(r % Ho);
+    const int f = (int)(r / Ho);
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+#pragma unroll
+    for (int dh = 0; dh < 3; ++dh) {
+      const int hi = ho * 2 - 1 + dh;
+      if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+      for (int dw = 0; dw < 3; ++dw) {
+        const int wi = wo * 2 - 1 + dw;
+        if ((unsigned)wi >= (unsigned)W) continue;
+        const bf16x8 v = x8[(((int64_t)f * H + hi) * W + wi) * C8 + c];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], (float)v[e]);
+      }
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)m[e];
+    y8[i] = o;
+  }
+}
+extern "C" int cadre_maxpool3x3s2_bf16(const void* x, void* y, int32_t F, int32_t H, int32_t W, int32_t C, void* stream) {
+  FAIL_IF(!x || !y || F < 1 || H < 1 || W < 1 || C < 8 || (C & 7), "cadre_maxpool3x3s2_bf16: bad argument");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int64_t total = (int64_t)F * Ho * Wo * (C / 8);
+  const int blocks = (int)std::min<int64_t>((total + 255) / 256, 16384);
+  hipLaunchKernelGGL(maxpool_bf16_kernel, dim3(blocks), dim3(256), 0, ST(stream), (const __bf16*)x, (__bf16*)y, F, H, W,
+                     C / 8, Ho, Wo);
+  return (int)hipGetLastError();
+}
+
 extern "C" int cadre_maxpool3x3s2(const float* x, float* y, int32_t F, int32_t H, int32_t W, int32_t C,
                                   void* stream) {
   FAIL_IF(!x || !y || F < 1 || H < 1 || W < 1 || C < 4 || (C & 3), "cadre_maxpool3x3s2: bad argument");
@@ -167,7 +210,8 @@ extern "C" int cadre_maxpool3x3s2(const float* x, float* y, int32_t F, int32_t H
 // ============================================================================ PAM (position attention)
 // One workgroup per frame.  qkv [Np][160] = (q 16 | k 16 | v 128) from the merged 1x1-conv GEMM.
 #define PAM_MAXNP 96
-__global__ __launch_bounds__(256) void pam_kernel(const float* qkv, const float* x, float gamma, float* y, int Np) {
+__global__ __launch_bounds__(256) void pam_kernel(const float* qkv, const float* x, float gamma, float* y, int Np,
+                                                  int out_bf16) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* q = sm;                    // [Np][17]
   float* k = q + Np * 17;           // [Np][17]
@@ -213,12 +257,24 @@ __global__ __launch_bounds__(256) void pam_kernel(const float* qkv, const float*
   for (int n = tid >> 7; n < Np; n += 2) {           // out[n][c] = sum_m att[n][m] v[m][c]  (:47)
     float o = 0.f;
     for (int m = 0; m < Np; ++m) o += att[n * P + m] * v[m * 128 + c];
-    yf[n * 128 + c] = gamma * o + xf[n * 128 + c];
+    const float r = gamma * o + xf[n * 128 + c];
+    if (out_bf16) reinterpret_cast<__bf16*>(y)[(int64_t)f * Np * 128 + n * 128 + c] = (__bf16)r;
+    else yf[n * 128 + c] = r;
   }
 }
 
+static int pam_launch(const float* x, const float* qkv, float gamma, void* y, int32_t F, int32_t Np, int out_bf16,
+                      void* stream);
 extern "C" int cadre_pam(const float* x, const float* qkv, float gamma, float* y, int32_t F, int32_t Np,
                          void* stream) {
+  return pam_launch(x, qkv, gamma, y, F, Np, 0, stream);
+}
+extern "C" int cadre_pam_bf16out(const float* x, const float* qkv, float gamma, void* y, int32_t F, int32_t Np,
+                                 void* stream) {
+  return pam_launch(x, qkv, gamma, y, F, Np, 1, stream);
+}
+static int pam_launch(const float* x, const float* qkv, float gamma, void* y, int32_t F, int32_t Np, int out_bf16,
+                      void* stream) {
   FAIL_IF(!x || !qkv || !y || F < 1 || Np < 1 || Np > PAM_MAXNP, "cadre_pam: bad argument (Np<=96)");
   const size_t shm = sizeof(float) * ((size_t)Np * 34 + (size_t)Np * 128 + (size_t)Np * (Np + 1));
   static bool attr_set = false;
@@ -226,12 +282,12 @@ extern "C" int cadre_pam(const float* x, const float* qkv, float gamma, float* y
     (void)hipFuncSetAttribute((const void*)pam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(pam_kernel, dim3(F), dim3(256), shm, ST(stream), qkv, x, gamma, y, Np);
+  hipLaunchKernelGGL(pam_kernel, dim3(F), dim3(256), shm, ST(stream), qkv, x, gamma, (float*)y, Np, out_bf16);
   return (int)hipGetLastError();
 }
 
 // ============================================================================ CAM (channel attention)
-__global__ __launch_bounds__(256) void cam_kernel(const float* x, float gamma, float* y, int Np) {
+__global__ __launch_bounds__(256) void cam_kernel(const float* x, float gamma, float* y, int Np, int out_bf16) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* xs = sm;                 // [Np][128]
   float* E = xs + Np * 128;       // [128][129]
@@ -283,11 +339,20 @@ __global__ __launch_bounds__(256) void cam_kernel(const float* x, float gamma, f
   for (int n = tid >> 7; n < Np; n += 2) {            // out[c][n] = sum_d att[c][d] x[d][n]  (:79)
     float o = 0.f;
     for (int d = 0; d < 128; ++d) o += E[c * 129 + d] * xs[n * 128 + d];
-    yf[n * 128 + c] = gamma * o + xs[n * 128 + c];
+    const float r = gamma * o + xs[n * 128 + c];
+    if (out_bf16) reinterpret_cast<__bf16*>(y)[(int64_t)f * Np * 128 + n * 128 + c] = (__bf16)r;
+    else yf[n * 128 + c] = r;
   }
 }
 
+static int cam_launch(const float* x, float gamma, void* y, int32_t F, int32_t Np, int out_bf16, void* stream);
 extern "C" int cadre_cam(const float* x, float gamma, float* y, int32_t F, int32_t Np, void* stream) {
+  return cam_launch(x, gamma, y, F, Np, 0, stream);
+}
+extern "C" int cadre_cam_bf16out(const float* x, float gamma, void* y, int32_t F, int32_t Np, void* stream) {
+  return cam_launch(x, gamma, y, F, Np, 1, stream);
+}
+static int cam_launch(const float* x, float gamma, void* y, int32_t F, int32_t Np, int out_bf16, void* stream) {
   FAIL_IF(!x || !y || F < 1 || Np < 1 || Np > PAM_MAXNP, "cadre_cam: bad argument (Np<=96)");
   const size_t shm = sizeof(float) * ((size_t)Np * 128 + 128 * 129);
   static bool attr_set = false;
@@ -295,7 +360,7 @@ extern "C" int cadre_cam(const float* x, float gamma, float* y, int32_t F, int32
     (void)hipFuncSetAttribute((const void*)cam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(cam_kernel, dim3(F), dim3(256), shm, ST(stream), x, gamma, y, Np);
+  hipLaunchKernelGGL(cam_kernel, dim3(F), dim3(256), shm, ST(stream), x, gamma, (float*)y, Np, out_bf16);
   return (int)hipGetLastError();
 }
 

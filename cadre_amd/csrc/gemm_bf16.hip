@@ -1,0 +1,293 @@
+// gemm_bf16.hip — bf16-input / fp32-accumulate GEMM and implicit-GEMM convolution for gfx950.
+//
+// Same tile/loader/epilogue architecture as gemm_f32.hip (raw buffer loads with hardware
+// zero-fill -> double-buffered LDS, XCD-contiguous tile order, LDS-staged vector epilogue) with
+// 2-byte operands: a 128-B LDS row holds BK = 64 bf16, and the matrix core is
+// v_mfma_f32_32x32x16_bf16 (lane half h owns k = 16*s + 8*h .. +7 of k-step s, i.e. the SAME
+// 16-B chunk (2s+h) the fp32 kernel reads — the staging code is byte-for-byte the same geometry).
+// Used for BASELINE config C3 ("bf16 encoder / fp32 losses"): DANet conv stack
+// (carla_perception/Networks/danet_blocks/resnet.py:26-55,152-166, danet.py:21-41,96,108) and the
+// inter-task first-layer GEMM (intertask_att.py:39-80).  At 16x the fp32 MFMA rate these layers are
+// bound by operand staging (L2 -> LDS), so the large tiles are preferred.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/cadre_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#define BKE 64          // k elements per tile (128 bytes)
+#define PITCH_F 36      // LDS row pitch in 4-byte words (128 B data + 16 B pad)
+
+int cadre_fail(const char* msg);
+
+// flags of cadre_gemm_t used here: bit1 = C is bf16 (else f32), bit2 = resid is bf16 (else f32)
+template <int WM, int WN, int AMODE>
+__global__ __launch_bounds__(256, ((WM + WN) * 2 * 64 * 36 * 4 > 80 * 1024 ? 1 : 2)) void gemm_bf16_kernel(cadre_gemm_t p) {
+  constexpr int BM = 2 * WM * 32;
+  constexpr int BN = 2 * WN * 32;
+  constexpr int RA = BM / 32;
+  constexpr int RB = BN / 32;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * PITCH_F];
+  float* As = lds;
+  float* Bs = lds + 2 * BM * PITCH_F;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  const int tilesN = (p.N + BN - 1) / BN;
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tile_m = bid / tilesN, tile_n = bid % tilesN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int z = blockIdx.z;
+  const char* A = reinterpret_cast<const char*>(p.A) + (int64_t)((z / p.a_div) % p.a_mod) * p.a_str * 2;
+  const char* B = reinterpret_cast<const char*>(p.B) + (int64_t)((z / p.b_div) % p.b_mod) * p.b_str * 2;
+  const bool c_bf16 = (p.flags & 2) != 0, r_bf16 = (p.flags & 4) != 0;
+  char* C = reinterpret_cast<char*>(p.C) + (int64_t)((z / p.c_div) % p.c_mod) * p.c_str * (c_bf16 ? 2 : 4);
+
+  const int nk_total = (p.K + BKE - 1) / BKE;
+  int kt_begin = 0, kt_end = nk_total;
+  if (p.split_k > 1) {      // raw f32 slabs [split][M][ldc]
+    const int per = (nk_total + p.split_k - 1) / p.split_k;
+    kt_begin = blockIdx.y * per;
+    kt_end = min(nk_total, kt_begin + per);
+    C += (int64_t)blockIdx.y * p.M * p.ldc * 4;
+  }
+
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)OOB, 0x00020000);
+  const int cc = tid & 7, rr = tid >> 3;      // 16-B chunk column (8 bf16), staged row
+  unsigned aoff[RA], amask[RA];
+  if constexpr (AMODE == 0) {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int m = m0 + rr + 32 * i;
+      aoff[i] = m < p.M ? (unsigned)((int64_t)m * p.lda * 2 + cc * 16) : OOB;
+      amask[i] = 0;
+    }
+  } else {
+    const int hw = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int m = m0 + rr + 32 * i;
+      const int mm = min(m, p.M - 1);
+      const int img = mm / hw, rem = mm % hw;
+      const int ho = rem / p.Wo, wo = rem % p.Wo;
+      const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+      aoff[i] = (unsigned)((((img * p.H + hi0) * p.W + wi0) * p.Cin) * 2 + cc * 16);
+      unsigned mask = 0;
+      if (m < p.M) {
+        for (int kh = 0; kh < p.KH; ++kh)
+          for (int kw = 0; kw < p.KW; ++kw)
+            if ((unsigned)(hi0 + kh) < (unsigned)p.H && (unsigned)(wi0 + kw) < (unsigned)p.W)
+              mask |= 1u << (kh * p.KW + kw);
+      }
+      amask[i] = mask;
+    }
+  }
+  unsigned boff[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) {
+    const int n = n0 + rr + 32 * i;
+    boff[i] = n < p.N ? (unsigned)((int64_t)n * p.ldb * 2 + cc * 16) : OOB;
+  }
+
+  f32x4 areg[RA], breg[RB];
+  auto ldg = [](const __amdgpu_buffer_rsrc_t& rs, unsigned off) -> f32x4 {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+  };
+  auto load_tiles = [&](int kt) {
+    const int k0 = kt * BKE;
+    const unsigned kb_ = (k0 + cc * 8 < p.K) ? (unsigned)k0 * 2u : OOB;     // K % 8 == 0
+    if constexpr (AMODE == 0) {
+#pragma unroll
+      for (int i = 0; i < RA; ++i) areg[i] = ldg(rsA, aoff[i] + kb_);
+    } else {
+      const int pos = k0 / p.Cin, ci = k0 % p.Cin;                           // uniform (Cin % 64 == 0)
+      const unsigned delta = (unsigned)((((pos / p.KW) * p.W + (pos % p.KW)) * p.Cin + ci) * 2);
+#pragma unroll
+      for (int i = 0; i < RA; ++i) areg[i] = ldg(rsA, ((amask[i] >> pos) & 1u) ? aoff[i] + delta : OOB);
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) breg[i] = ldg(rsB, boff[i] + kb_);
+  };
+  auto store_tiles = [&](int buf) {
+    float* as = As + buf * BM * PITCH_F;
+    float* bs = Bs + buf * BN * PITCH_F;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(as + (rr + 32 * i) * PITCH_F + cc * 4) = areg[i];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(bs + (rr + 32 * i) * PITCH_F + cc * 4) = breg[i];
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (kt_begin < kt_end) {
+    load_tiles(kt_begin);
+    store_tiles(0);
+  }
+  __syncthreads();
+
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int buf = (kt - kt_begin) & 1;
+    const bool more = kt + 1 < kt_end;
+    if (more) load_tiles(kt + 1);
+    const float* as = As + buf * BM * PITCH_F;
+    const float* bs = Bs + buf * BN * PITCH_F;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {             // k-step s: 16 bf16; this lane half reads chunk 2s+lh
+      bf16x8 af[WM], bf[WN];
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+        af[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(as + ((wm * WM + i) * 32 + l31) * PITCH_F + (2 * s + lh) * 4));
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+        bf[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(bs + ((wn * WN + j) * 32 + l31) * PITCH_F + (2 * s + lh) * 4));
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_tiles(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---------------------------------------------------------------- epilogue (fp32 math)
+  const bool raw = p.split_k > 1;
+  const int actk = p.act & 15;
+  const bool post = (p.act & 16) != 0;
+  const float* scale = (!raw && p.scale) ? p.scale + (int64_t)((z / p.s_div) % p.s_mod) * p.s_str : nullptr;
+  const float* shift = (!raw && p.shift) ? p.shift + (int64_t)((z / p.s_div) % p.s_mod) * p.s_str : nullptr;
+  const char* resid = (!raw && p.resid)
+                          ? reinterpret_cast<const char*>(p.resid) + (int64_t)((z / p.r_div) % p.r_mod) * p.r_str * (r_bf16 ? 2 : 4)
+                          : nullptr;
+  constexpr int CW = WN * 32, P = CW + 4;
+  constexpr int LPR = CW / 4, RPI = 64 / LPR, NIT = 32 / RPI;
+  float* cs = lds + wave * (32 * P);
+  const int c4 = (lane % LPR) * 4;
+  const int col = n0 + wn * CW + c4;
+  const bool cvalid = col < p.N;              // N % 4 == 0
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  if (cvalid && scale) sc = *reinterpret_cast<const f32x4*>(scale + col);
+  if (cvalid && shift) sh = *reinterpret_cast<const f32x4*>(shift + col);
+  const bool out_bf16 = c_bf16 && !raw;
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    const int rbase = m0 + (wm * WM + i) * 32;
+    f32x4 rv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int row = rbase + it * RPI + lane / LPR;
+      rv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (resid && cvalid && row < p.M) {
+        if (r_bf16) {
+          const bf16x4 t = *reinterpret_cast<const bf16x4*>(resid + ((int64_t)row * p.ldr + col) * 2);
+          rv[it] = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+        } else {
+          rv[it] = *reinterpret_cast<const f32x4*>(resid + ((int64_t)row * p.ldr + col) * 4);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * lh) * P + j * 32 + l31] = acc[i][j][r];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int rloc = it * RPI + lane / LPR;
+      const int row = rbase + rloc;
+      f32x4 v = *reinterpret_cast<const f32x4*>(cs + rloc * P + c4);
+      if (!raw) {
+        v = v * sc + sh;
+        if (!post) v += rv[it];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (actk == 1) v[e] = fmaxf(v[e], 0.f);
+          else if (actk == 2) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
+        }
+        if (post) v += rv[it];
+      }
+      if (cvalid && row < p.M) {
+        if (out_bf16) {
+          bf16x4 o;
+          o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
+          *reinterpret_cast<bf16x4*>(C + ((int64_t)row * p.ldc + col) * 2) = o;
+        } else {
+          *reinterpret_cast<f32x4*>(C + ((int64_t)row * p.ldc + col) * 4) = v;
+        }
+      }
+    }
+  }
+}
+
+#define BCHECK(cond, msg) \
+  if (!(cond)) return cadre_fail("cadre_gemm_bf16: " msg)
+
+extern "C" int cadre_gemm_bf16(const cadre_gemm_t* pp, void* stream) {
+  cadre_gemm_t p = *pp;
+  BCHECK(p.A && p.B && p.C, "null operand");
+  BCHECK(p.M > 0 && p.N > 0 && p.K > 0, "empty problem");
+  BCHECK((p.a_mode == 0 || p.a_mode == 2) && p.b_mode == 0, "a_mode must be 0 or 2, b_mode 0");
+  BCHECK(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0 && ((uintptr_t)p.C & 15) == 0, "operands must be 16-byte aligned");
+  BCHECK(p.K % 8 == 0 && p.ldb % 8 == 0 && p.N % 4 == 0 && p.ldc % 4 == 0, "needs K%8==0, ldb%8==0, N%4==0, ldc%4==0");
+  if (p.a_mode == 0) BCHECK(p.lda % 8 == 0, "lda%8==0");
+  if (p.a_mode == 2) BCHECK(p.Cin % 64 == 0 && p.K == p.KH * p.KW * p.Cin && p.KH * p.KW <= 32 && p.M % (p.Ho * p.Wo) == 0, "conv needs Cin%64==0");
+  if (p.resid) BCHECK(p.ldr % 4 == 0 && ((uintptr_t)p.resid & 15) == 0, "resid alignment");
+  if (p.batch < 1) p.batch = 1;
+  if (p.split_k < 1) p.split_k = 1;
+  BCHECK(p.split_k == 1 || p.batch == 1, "split_k with batch unsupported");
+  if (p.a_div < 1) p.a_div = 1;
+  if (p.b_div < 1) p.b_div = 1;
+  if (p.c_div < 1) p.c_div = 1;
+  if (p.s_div < 1) p.s_div = 1;
+  if (p.r_div < 1) p.r_div = 1;
+  if (p.a_mod < 1) p.a_mod = 1 << 30;
+  if (p.b_mod < 1) p.b_mod = 1 << 30;
+  if (p.c_mod < 1) p.c_mod = 1 << 30;
+  if (p.s_mod < 1) p.s_mod = 1 << 30;
+  if (p.r_mod < 1) p.r_mod = 1 << 30;
+  {
+    const int64_t lim = 1ll << 31;
+    const int64_t a_bytes = p.a_mode == 2 ? (int64_t)(p.M / (p.Ho * p.Wo)) * p.H * p.W * p.Cin * 2 : (int64_t)p.M * p.lda * 2;
+    BCHECK(a_bytes < lim && (int64_t)p.N * p.ldb * 2 < lim, "operand spans >= 2 GiB: chunk the batch");
+  }
+  int tile = p.tile;
+  if (tile == 0) {
+    // staging-bound regime: the biggest tile that still gives >= 2 workgroups per CU wins
+    auto nt = [&](int bm, int bn) { return (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.batch * p.split_k; };
+    if (p.N <= 64) tile = nt(128, 64) >= 512 ? 2 : 3;
+    else tile = nt(256, 128) >= 512 ? 4 : (nt(128, 128) >= 512 ? 1 : 3);
+  }
+  static const int BMS[7] = {0, 128, 128, 64, 256, 128, 256}, BNS[7] = {0, 128, 64, 64, 128, 256, 64};
+  BCHECK(tile >= 1 && tile <= 4, "bad tile");
+  const int bm = BMS[tile], bn = BNS[tile];
+  dim3 grid(((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn), p.split_k, p.batch), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define LB(WM_, WN_)                                                                           \
+  do {                                                                                         \
+    if (p.a_mode == 0) hipLaunchKernelGGL((gemm_bf16_kernel<WM_, WN_, 0>), grid, block, 0, st, p); \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<WM_, WN_, 2>), grid, block, 0, st, p);             \
+  } while (0)
+  if (tile == 1) LB(2, 2);
+  else if (tile == 2) LB(2, 1);
+  else if (tile == 3) LB(1, 1);
+  else LB(4, 2);
+#undef LB
+  return (int)hipGetLastError();
+}

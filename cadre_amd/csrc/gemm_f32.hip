@@ -322,7 +322,16 @@ __global__ __launch_bounds__(256, ((WM + WN) * 2 * 64 * 36 * 4 > 80 * 1024 ? 1 :
           }
           if (post) v += rv[it];
         }
-        if (cvalid && row < p.M) *reinterpret_cast<f32x4*>(C + (int64_t)row * p.ldc + col) = v;
+        if (cvalid && row < p.M) {
+          if (p.flags & 2) {              // C is bf16 (config C3: fp32 stem feeding the bf16 trunk)
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            bf16x4 o;
+            o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(C) + ((int64_t)row * p.ldc + col) * 2) = o;
+          } else {
+            *reinterpret_cast<f32x4*>(C + (int64_t)row * p.ldc + col) = v;
+          }
+        }
       }
     }
     return;
@@ -444,6 +453,8 @@ extern "C" int cadre_gemm_f32(const cadre_gemm_t* pp, void* stream) {
   if (p.s_mod < 1) p.s_mod = 1 << 30;
   if (p.r_mod < 1) p.r_mod = 1 << 30;
   GEMM_CHECK(p.split_k == 1 || p.batch == 1 || p.c_str >= (int64_t)p.M * p.ldc, "batched split_k needs c_str >= M*ldc");
+  if (p.flags & 2)
+    GEMM_CHECK(p.batch == 1 && p.split_k == 1 && ((p.N | p.ldc) & 3) == 0 && !p.resid, "bf16 output needs the vector epilogue, no batch/split/resid");
   const int tile = p.tile ? p.tile : pick_tile(p);
   hipStream_t st = (hipStream_t)stream;
   dim3 block(256);

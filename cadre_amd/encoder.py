@@ -38,8 +38,8 @@ def _khwc(w):
 class _Conv:
     __slots__ = ("w", "scale", "shift", "cin", "cout", "k", "stride", "pad", "act")
 
-    def __init__(self, w, scale, shift, k, stride, pad, act, dev):
-        self.w = _khwc(w).to(dev)
+    def __init__(self, w, scale, shift, k, stride, pad, act, dev, wdtype=torch.float32):
+        self.w = _khwc(w).to(dev).to(wdtype)
         self.scale = None if scale is None else scale.contiguous().to(dev)
         self.shift = None if shift is None else shift.contiguous().to(dev)
         self.cout, self.cin = w.shape[0], w.shape[1]
@@ -49,7 +49,15 @@ class _Conv:
 class DANetEncoderHIP:
     """Frozen encoder; `latent(rgb_u8, route_u8)` -> [F,512] features on device."""
 
-    def __init__(self, state_dict, H, W, device="cuda:0", max_frames=64):
+    def __init__(self, state_dict, H, W, device="cuda:0", max_frames=64, dtype="f32"):
+        """dtype "f32": everything fp32 (BASELINE C2).  dtype "bf16" (BASELINE C3): activations and
+        conv / inter-task weights in bf16 from the max-pool on, fp32 MFMA accumulation and fp32
+        epilogues, fp32 stem (Cin=4), fp32 attention math (PAM/CAM/inter-task softmax)."""
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("dtype must be 'f32' or 'bf16'")
+        self.bf16 = dtype == "bf16"
+        self.dtype = dtype
+        wd = torch.bfloat16 if self.bf16 else torch.float32
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise hip.CadreHipError("DANetEncoderHIP needs a HIP device (device_num/vae_device >= 0); no CPU path")
@@ -76,25 +84,25 @@ class DANetEncoderHIP:
             for bi in range(2):
                 pre = "backbone.layer%d.%d" % (li, bi)
                 stride = 2 if (li > 1 and bi == 0) else 1
-                c1 = _Conv(sd[pre + ".conv1.weight"], *_fold_bn(sd, pre + ".bn1"), 3, stride, 1, 1, dev)
-                c2 = _Conv(sd[pre + ".conv2.weight"], *_fold_bn(sd, pre + ".bn2"), 3, 1, 1, 1, dev)
+                c1 = _Conv(sd[pre + ".conv1.weight"], *_fold_bn(sd, pre + ".bn1"), 3, stride, 1, 1, dev, wd)
+                c2 = _Conv(sd[pre + ".conv2.weight"], *_fold_bn(sd, pre + ".bn2"), 3, 1, 1, 1, dev, wd)
                 down = None
                 if (pre + ".downsample.0.weight") in sd:
-                    down = _Conv(sd[pre + ".downsample.0.weight"], *_fold_bn(sd, pre + ".downsample.1"), 1, stride, 0, 0, dev)
+                    down = _Conv(sd[pre + ".downsample.0.weight"], *_fold_bn(sd, pre + ".downsample.1"), 1, stride, 0, 0, dev, wd)
                 self.blocks.append((c1, c2, down))
         # ---- DANet head (danet.py:21-41)
         hd = "da_head."
-        self.conv5a = _Conv(sd[hd + "conv5a.0.weight"], *_fold_bn(sd, hd + "conv5a.1"), 3, 1, 1, 1, dev)
-        self.conv5c = _Conv(sd[hd + "conv5c.0.weight"], *_fold_bn(sd, hd + "conv5c.1"), 3, 1, 1, 1, dev)
-        self.conv51 = _Conv(sd[hd + "conv51.0.weight"], *_fold_bn(sd, hd + "conv51.1"), 3, 1, 1, 1, dev)
-        self.conv52 = _Conv(sd[hd + "conv52.0.weight"], *_fold_bn(sd, hd + "conv52.1"), 3, 1, 1, 1, dev)
+        self.conv5a = _Conv(sd[hd + "conv5a.0.weight"], *_fold_bn(sd, hd + "conv5a.1"), 3, 1, 1, 1, dev, wd)
+        self.conv5c = _Conv(sd[hd + "conv5c.0.weight"], *_fold_bn(sd, hd + "conv5c.1"), 3, 1, 1, 1, dev, wd)
+        self.conv51 = _Conv(sd[hd + "conv51.0.weight"], *_fold_bn(sd, hd + "conv51.1"), 3, 1, 1, 1, dev, wd)
+        self.conv52 = _Conv(sd[hd + "conv52.0.weight"], *_fold_bn(sd, hd + "conv52.1"), 3, 1, 1, 1, dev, wd)
         self.pam_w = torch.cat([sd[hd + "sa.%s_conv.weight" % n].reshape(-1, 128) for n in ("query", "key", "value")]).contiguous().to(dev)
         self.pam_b = torch.cat([sd[hd + "sa.%s_conv.bias" % n] for n in ("query", "key", "value")]).contiguous().to(dev)
         self.pam_gamma = float(sd[hd + "sa.gamma"].item())
         self.cam_gamma = float(sd[hd + "sc.gamma"].item())
-        self.conv8 = _Conv(sd[hd + "conv8.1.weight"], None, sd[hd + "conv8.1.bias"], 1, 1, 0, 0, dev)
-        self.visual_conv = _Conv(sd["visual_conv.weight"], None, sd["visual_conv.bias"], 1, 1, 0, 0, dev)
-        self.bc_conv = _Conv(sd["bc_conv.weight"], None, sd["bc_conv.bias"], 1, 1, 0, 0, dev)
+        self.conv8 = _Conv(sd[hd + "conv8.1.weight"], None, sd[hd + "conv8.1.bias"], 1, 1, 0, 0, dev, wd)
+        self.visual_conv = _Conv(sd["visual_conv.weight"], None, sd["visual_conv.bias"], 1, 1, 0, 0, dev, wd)
+        self.bc_conv = _Conv(sd["bc_conv.weight"], None, sd["bc_conv.bias"], 1, 1, 0, 0, dev, wd)
         # ---- inter-task attention MLPs (intertask_att.py:39-80); order q,k,v per branch
         Np = self.Np
         self.ita_w1, self.ita_b1 = [], []
@@ -108,7 +116,7 @@ class DANetEncoderHIP:
                 bs.append(sd[pre + ".1.bias"])
                 w2.append(sd[pre + ".3.weight"])
                 b2.append(sd[pre + ".3.bias"])
-            self.ita_w1.append(torch.cat(ws).contiguous().to(dev))        # [1536][Np*512]
+            self.ita_w1.append(torch.cat(ws).contiguous().to(dev).to(wd))  # [1536][Np*512]
             self.ita_b1.append(torch.cat(bs).contiguous().to(dev))
         self.ita_w2 = torch.stack(w2).contiguous().to(dev)                # [6][256][512]
         self.ita_b2 = torch.stack(b2).contiguous().to(dev)                # [6][256]
@@ -135,20 +143,23 @@ class DANetEncoderHIP:
         return t
 
     # ------------------------------------------------------------------ layers
-    def _conv(self, c, x, F, H, W, key, resid=None, act=None):
+    def _conv(self, c, x, F, H, W, key, resid=None, act=None, out_f32=False):
         Ho = (H + 2 * c.pad - c.k) // c.stride + 1
         Wo = (W + 2 * c.pad - c.k) // c.stride + 1
-        out = self._buf(key, (F, Ho, Wo, c.cout))
+        odt = torch.bfloat16 if (self.bf16 and not out_f32) else torch.float32
+        out = self._buf(key, (F, Ho, Wo, c.cout), odt)
         K = c.k * c.k * c.cin
         M = F * Ho * Wo
         act = c.act if act is None else act
+        wbf = c.w.dtype == torch.bfloat16
+        flags = (2 if odt == torch.bfloat16 else 0) | (4 if (resid is not None and resid.dtype == torch.bfloat16) else 0)
         if c.k == 1 and c.stride == 1:
             hip.gemm(x, c.w, out, M, c.cout, K, K, K, c.cout, scale=c.scale, shift=c.shift, resid=resid,
-                     ldr=c.cout, act=act)
+                     ldr=c.cout, act=act, bf16=wbf, flags=flags)
         else:
             hip.gemm(x, c.w, out, M, c.cout, K, 0, K, c.cout, a_mode=3 if c.cin == 4 else 2, scale=c.scale,
                      shift=c.shift, resid=resid, ldr=c.cout, act=act,
-                     conv=(H, W, c.cin, Ho, Wo, c.k, c.k, c.stride, c.pad))
+                     conv=(H, W, c.cin, Ho, Wo, c.k, c.k, c.stride, c.pad), bf16=wbf, flags=flags)
         return out, Ho, Wo
 
     def preprocess(self, rgb_d, route_d, route_norm_d=None):
@@ -170,8 +181,11 @@ class DANetEncoderHIP:
         H, W = self.H, self.W
         y, H, W = self._conv(self.stem, x, F, H, W, "stem")
         Hp, Wp = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
-        p = self._buf("pool", (F, Hp, Wp, 64))
-        hip.check(L.cadre_maxpool3x3s2(hip.ptr(y), hip.ptr(p), F, H, W, 64, st), "cadre_maxpool3x3s2")
+        p = self._buf("pool", (F, Hp, Wp, 64), y.dtype)
+        if self.bf16:
+            hip.check(L.cadre_maxpool3x3s2_bf16(hip.ptr(y), hip.ptr(p), F, H, W, 64, st), "cadre_maxpool3x3s2_bf16")
+        else:
+            hip.check(L.cadre_maxpool3x3s2(hip.ptr(y), hip.ptr(p), F, H, W, 64, st), "cadre_maxpool3x3s2")
         cur, H, W = p, Hp, Wp
         for i, (c1, c2, down) in enumerate(self.blocks):                      # resnet.py:40-55
             t, H2, W2 = self._conv(c1, cur, F, H, W, "b%d_t" % i)
@@ -183,15 +197,18 @@ class DANetEncoderHIP:
         Np = H * W
         assert Np == self.Np
         # ---- da_head (danet.py:43-69)
-        f1, _, _ = self._conv(self.conv5a, l4, F, H, W, "f1")
+        adt = torch.bfloat16 if self.bf16 else torch.float32
+        pam_fn = L.cadre_pam_bf16out if self.bf16 else L.cadre_pam      # attention math stays fp32
+        cam_fn = L.cadre_cam_bf16out if self.bf16 else L.cadre_cam
+        f1, _, _ = self._conv(self.conv5a, l4, F, H, W, "f1", out_f32=True)
         qkv = self._buf("pam_qkv", (F * Np, 160))
         hip.gemm(f1, self.pam_w, qkv, F * Np, 160, 128, 128, 128, 160, shift=self.pam_b)
-        sa = self._buf("sa", (F, H, W, 128))
-        hip.check(L.cadre_pam(hip.ptr(f1), hip.ptr(qkv), self.pam_gamma, hip.ptr(sa), F, Np, st), "cadre_pam")
+        sa = self._buf("sa", (F, H, W, 128), adt)
+        hip.check(pam_fn(hip.ptr(f1), hip.ptr(qkv), self.pam_gamma, hip.ptr(sa), F, Np, st), "cadre_pam")
         sa_conv, _, _ = self._conv(self.conv51, sa, F, H, W, "sa_conv")
-        f2, _, _ = self._conv(self.conv5c, l4, F, H, W, "f2")
-        sc = self._buf("sc", (F, H, W, 128))
-        hip.check(L.cadre_cam(hip.ptr(f2), self.cam_gamma, hip.ptr(sc), F, Np, st), "cadre_cam")
+        f2, _, _ = self._conv(self.conv5c, l4, F, H, W, "f2", out_f32=True)
+        sc = self._buf("sc", (F, H, W, 128), adt)
+        hip.check(cam_fn(hip.ptr(f2), self.cam_gamma, hip.ptr(sc), F, Np, st), "cadre_cam")
         # feat_sum = sa_conv + sc_conv (danet.py:57) fused into conv52's epilogue as a residual added
         # AFTER its ReLU (act|16): relu(bn(conv52(sc))) + sa_conv
         feat_sum, _, _ = self._conv(self.conv52, sc, F, H, W, "feat_sum", resid=sa_conv, act=1 | 16)
@@ -209,13 +226,14 @@ class DANetEncoderHIP:
         for b, src in enumerate((vis, bc)):
             if split > 1:
                 slabs = self._buf("ita_slab", (split, F, 1536))
-                hip.gemm(src, self.ita_w1[b], slabs, F, 1536, Kin, Kin, Kin, 1536, split_k=split, tile=3 if F <= 64 else 0)
+                hip.gemm(src, self.ita_w1[b], slabs, F, 1536, Kin, Kin, Kin, 1536, split_k=split,
+                         tile=3 if F <= 64 else 0, bf16=self.bf16)
                 hip.check(L.cadre_splitk_reduce(hip.ptr(slabs), split, F * 1536, 1536, hid.data_ptr() + 4 * 1536 * b,
                                                 3072, F, 1536, None, hip.ptr(self.ita_b1[b]), 2, 0.01, st),
                           "cadre_splitk_reduce")
             else:
                 hip.gemm(src, self.ita_w1[b], hid[:, 1536 * b:], F, 1536, Kin, Kin, Kin, 3072, shift=self.ita_b1[b],
-                         act=2, slope=0.01)
+                         act=2, slope=0.01, bf16=self.bf16)
         qkv2 = self._buf("ita_qkv", (F, 6, 256))
         hip.gemm(hid, self.ita_w2, qkv2, F, 256, 512, 3072, 512, 1536, shift=self.ita_b2, batch=6,
                  a_z=(1, 0, 512), b_z=(1, 0, 256 * 512), c_z=(1, 0, 256), s_z=(1, 0, 256))

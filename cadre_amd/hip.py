@@ -35,6 +35,10 @@ SYMBOLS = {
     "cadre_last_error": [],
     "cadre_gemm_f32": [C.POINTER(GemmDesc), vp],
     "cadre_gemm_pick_tile": [C.POINTER(GemmDesc)],
+    "cadre_gemm_bf16": [C.POINTER(GemmDesc), vp],
+    "cadre_maxpool3x3s2_bf16": [vp, vp, i32, i32, i32, i32, vp],
+    "cadre_pam_bf16out": [vp, vp, f32, vp, i32, i32, vp],
+    "cadre_cam_bf16out": [vp, f32, vp, i32, i32, vp],
     "cadre_splitk_reduce": [vp, i32, i64, i64, vp, i64, i32, i32, vp, vp, i32, f32, vp],
     "cadre_preprocess": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "cadre_maxpool3x3s2": [vp, vp, i32, i32, i32, i32, vp],
@@ -105,8 +109,9 @@ PROFILE = None
 
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, scale=None, shift=None, resid=None, ldr=0,
          act=0, slope=0.01, batch=1, a_z=(1, 0, 0), b_z=(1, 0, 0), c_z=(1, 0, 0), s_z=(1, 0, 0), r_z=(1, 0, 0),
-         conv=None, split_k=1, tile=0):
-    """C = act((A . B^T) * scale + shift + resid).  *_z = (div, mod, stride) batch addressing."""
+         conv=None, split_k=1, tile=0, bf16=False, flags=0):
+    """C = act((A . B^T) * scale + shift + resid).  *_z = (div, mod, stride) batch addressing.
+    bf16=True: A/B are bfloat16 tensors (cadre_gemm_bf16); flags bit1/bit2: C / resid are bf16."""
     d = GemmDesc()
     d.A, d.B, d.C = ptr(A), ptr(B), ptr(Cout)
     d.scale, d.shift, d.resid = ptr(scale), ptr(shift), ptr(resid)
@@ -117,12 +122,13 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, scale=None, shi
     if conv is not None:
         d.H, d.W, d.Cin, d.Ho, d.Wo, d.KH, d.KW, d.stride, d.pad = conv
     d.split_k, d.tile = split_k, tile
-    d.flags = 0
-    if PROFILE is None:
-        check(lib().cadre_gemm_f32(C.byref(d), stream()), "cadre_gemm_f32")
+    d.flags = flags
+    fn = lib().cadre_gemm_bf16 if bf16 else lib().cadre_gemm_f32
+    if PROFILE is None or bf16:
+        check(fn(C.byref(d), stream()), "cadre_gemm_bf16" if bf16 else "cadre_gemm_f32")
         return
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    check(lib().cadre_gemm_f32(C.byref(d), stream()), "cadre_gemm_f32")
+    check(fn(C.byref(d), stream()), "cadre_gemm_f32")
     e1.record()
     PROFILE.append(((lib().cadre_gemm_pick_tile(C.byref(d)), a_mode, b_mode), 2.0 * M * N * K * max(1, batch), e0, e1))

@@ -115,7 +115,8 @@ def create_model(model_cfg, load_vae=False):
         vae_device = _device(_cfg(model_cfg, "vae_device"))
         H, W = vae_params.obs_hw
         vae_model = DANetEncoderHIP(load_encoder_state(model_cfg, vae_params), H, W, vae_device,
-                                    max_frames=_cfg(model_cfg, "encoder_max_frames", 64))
+                                    max_frames=_cfg(model_cfg, "encoder_max_frames", 64),
+                                    dtype=_cfg(model_cfg, "encoder_dtype", "f32"))
     device = _device(_cfg(model_cfg, "device_num"))
     if not _cfg(model_cfg, "use_lstm", True):
         raise hip.CadreHipError("use_lstm=False is not on the accelerated path (reference default is True)")
@@ -170,7 +171,8 @@ class Shared_grad_buffers(object):
 
     def all_reduce(self):
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_available() and dist.is_initialized() and (
+                dist.get_world_size() > 1 or os.environ.get("CADRE_BENCH_FORCE_DIST") == "1"):
             dist.all_reduce(self.arena.grads, op=dist.ReduceOp.SUM)
 
     def average_gradient(self):

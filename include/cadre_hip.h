@@ -53,11 +53,17 @@ typedef struct {
   int32_t split_k;
   int32_t tile;        /* 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128,
                           5 = 128x256, 6 = 256x64 (4-6: one workgroup per CU)           */
-  int32_t flags;       /* reserved, must be 0 (keeps sizeof == 240)                          */
+  int32_t flags;       /* bit 1: C is bf16; bit 2: resid is bf16 (cadre_gemm_bf16; bit 1 also
+                          honoured by cadre_gemm_f32's vector epilogue); others must be 0   */
 } cadre_gemm_t;
 int cadre_gemm_f32(const cadre_gemm_t* p, void* stream);
 /* the tile id cadre_gemm_f32 would use for this descriptor (p->tile, or the auto choice) */
 int cadre_gemm_pick_tile(const cadre_gemm_t* p);
+/* Same contract with bf16 A/B operands (element counts/strides in bf16 elements), fp32
+ * accumulation on v_mfma_f32_32x32x16_bf16 and an fp32 epilogue; a_mode 0 or 2 (Cin%64==0),
+ * b_mode 0; C bf16 or f32 (flags bit 1), resid bf16 or f32 (flags bit 2).  BASELINE config C3
+ * ("bf16 encoder / fp32 losses"). */
+int cadre_gemm_bf16(const cadre_gemm_t* p, void* stream);
 /* C[M][ldc] = act(sum_s slab[s][M][lds] * scale + shift + resid) */
 int cadre_splitk_reduce(const float* slabs, int32_t split_k, int64_t slab_stride, int64_t lds,
                         float* C, int64_t ldc, int32_t M, int32_t N, const float* scale,
@@ -76,6 +82,9 @@ int cadre_preprocess(const uint8_t* rgb, const uint8_t* route, const float* lut2
 /* nn.MaxPool2d(3,2,1) resnet.py:114 on NHWC [F][H][W][C] (C%4==0) -> [F][Ho][Wo][C] */
 int cadre_maxpool3x3s2(const float* x, float* y, int32_t F, int32_t H, int32_t W, int32_t C,
                        void* stream);
+/* bf16 NHWC variant of cadre_maxpool3x3s2 (C%8==0) */
+int cadre_maxpool3x3s2_bf16(const void* x, void* y, int32_t F, int32_t H, int32_t W, int32_t C,
+                            void* stream);
 /* PAM_Module.forward da_att.py:32-51 after the three 1x1 convs: qkv [F][Np][160] =
  * (query 16 | key 16 | value 128) comes from ONE cadre_gemm_f32 over the concatenated
  * query/key/value conv weights; this kernel does energy = q.k^T, row softmax,
@@ -84,6 +93,10 @@ int cadre_pam(const float* x, const float* qkv, float gamma, float* y, int32_t F
               void* stream);
 /* CAM_Module.forward da_att.py:63-83 on NHWC x [F][Np][128] */
 int cadre_cam(const float* x, float gamma, float* y, int32_t F, int32_t Np, void* stream);
+/* same kernels writing y as bf16 (fp32 math; feeds the bf16 conv51/conv52) */
+int cadre_pam_bf16out(const float* x, const float* qkv, float gamma, void* y, int32_t F, int32_t Np,
+                      void* stream);
+int cadre_cam_bf16out(const float* x, float gamma, void* y, int32_t F, int32_t Np, void* stream);
 /* InterTaskAtt 'transformer' tail intertask_att.py:137-176: qkv [F][6][256] ordered
  * (vis_q, vis_k, vis_v, bc_q, bc_k, bc_v) -> out [F][ldo] = cat(att_visual, att_bc) */
 int cadre_intertask_att(const float* qkv, float* out, int64_t ldo, int32_t F, float temperature,

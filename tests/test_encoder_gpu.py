@@ -53,3 +53,23 @@ def test_encoder_batch_invariance_and_chunking(golden):
     b = enc.latent(rgb, route).clone()
     c = enc.latent(rgb[3:5], route[3:5]).clone()
     assert torch.equal(a, b) and torch.equal(a[3:5], c)
+
+
+@pytest.mark.parametrize("tag", ["84", "288"])
+def test_encoder_bf16_close_to_fp32_reference(golden, tag):
+    """BASELINE config C3 ("bf16 encoder"): bf16 storage, fp32 accumulation.  Compared with the fp32
+    reference goldens; tolerance 3e-2 of the tensor's max (bf16 has 8 significand bits; 20 layers)."""
+    from cadre_amd.encoder import DANetEncoderHIP
+    g = golden("enc_" + tag)
+    H, W, n = int(g["H"]), int(g["W"]), int(g["n"])
+    fh, fw = synth.feat_hw(H, W)
+    enc = DANetEncoderHIP(synth.encoder_state(fh, fw, int(g["seed"])), H, W, "cuda:0", dtype="bf16")
+    r = np.random.RandomState(int(g["frame_seed"]))
+    rgb = r.randint(0, 256, (n, H, W, 3)).astype(np.uint8)
+    route = ((r.rand(n, W, H) < 0.15) * 255).astype(np.uint8)
+    taps = {}
+    lat = enc.latent(torch.from_numpy(rgb).cuda(), torch.from_numpy(route).cuda(), taps=taps)
+    l4 = taps["layer4"].float().permute(0, 3, 1, 2).cpu().numpy()
+    e = (rel(l4, g["layer4"]), rel(lat.cpu().numpy(), g["latent"]))
+    print("bf16 encoder %s rel-max-err layer4 %.2e latent %.2e" % ((tag,) + e))
+    assert e[0] < 3e-2 and e[1] < 3e-2

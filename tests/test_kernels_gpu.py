@@ -381,3 +381,59 @@ def test_clip_adam(hip):
                                             hip.stream()), "adam")
         want = torch.cat([params["m%d" % i]["w"] for i in range(4)])
         assert float((pd.cpu() - want).abs().max()) < 2e-7
+
+
+# ----------------------------------------------------------------------------- bf16 GEMM (config C3)
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("M,N,K,tile", [(300, 256, 512, 1), (70, 64, 192, 3), (600, 128, 4608, 4), (200, 64, 576, 2)])
+def test_gemm_bf16_dense(hip, M, N, K, tile):
+    g = torch.Generator().manual_seed(M + N)
+    A, B = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g) * 0.1)
+    scale = torch.rand(N, generator=g) + 0.5; shift = torch.randn(N, generator=g)
+    resid = _bf(torch.randn(M, N, generator=g))
+    want = F.relu((A.float() @ B.float().t()) * scale + shift + resid.float())
+    out32 = torch.zeros(M, N, device="cuda")
+    Ad, Bd, rd, sd_, hd_ = dev(A), dev(B), dev(resid), dev(scale), dev(shift)
+    hip.gemm(Ad, Bd, out32, M, N, K, K, K, N, scale=sd_, shift=hd_, resid=rd, ldr=N, act=1, tile=tile, bf16=True, flags=4)
+    assert rel(out32, want) < 2e-5                      # fp32 accumulate of exact bf16 products
+    out16 = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    hip.gemm(Ad, Bd, out16, M, N, K, K, K, N, scale=sd_, shift=hd_, resid=rd, ldr=N, act=1, tile=tile, bf16=True, flags=6)
+    assert rel(out16.float(), want) < 5e-3              # one bf16 rounding of the result
+
+
+@pytest.mark.parametrize("Cin,Cout,H,W,k,s,p", [(64, 64, 18, 22, 3, 1, 1), (64, 128, 18, 22, 3, 2, 1),
+                                                 (64, 128, 17, 21, 1, 2, 0), (512, 128, 9, 9, 3, 1, 1)])
+def test_conv_bf16(hip, Cin, Cout, H, W, k, s, p):
+    g = torch.Generator().manual_seed(Cin + Cout + k + 1)
+    Nimg = 3
+    x = _bf(torch.randn(Nimg, Cin, H, W, generator=g))
+    w = _bf(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5)
+    scale = torch.rand(Cout, generator=g) + 0.5; shift = torch.randn(Cout, generator=g)
+    y = F.conv2d(x.float(), w.float(), None, s, p)
+    Ho, Wo = y.shape[2], y.shape[3]
+    want = F.relu(y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    xd = dev(x.permute(0, 2, 3, 1).contiguous()); wd = dev(w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous())
+    out = torch.empty(Nimg, Ho, Wo, Cout, device="cuda")
+    K = k * k * Cin
+    hip.gemm(xd, wd, out, Nimg * Ho * Wo, Cout, K, 0, K, Cout, a_mode=2, scale=dev(scale), shift=dev(shift), act=1,
+             conv=(H, W, Cin, Ho, Wo, k, k, s, p), bf16=True)
+    torch.cuda.synchronize()
+    assert rel(out.permute(0, 3, 1, 2), want) < 2e-5
+
+
+def test_f32_stem_bf16_output_and_bf16_pool(hip):
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 4, 30, 36, generator=g); w = torch.randn(64, 4, 7, 7, generator=g) / 14.0
+    y = F.relu(F.conv2d(x, w, None, 2, 3))
+    xd = dev(x.permute(0, 2, 3, 1).contiguous()); wd = dev(w.permute(0, 2, 3, 1).reshape(64, -1).contiguous())
+    Ho, Wo = y.shape[2], y.shape[3]
+    out = torch.empty(2, Ho, Wo, 64, device="cuda", dtype=torch.bfloat16)
+    hip.gemm(xd, wd, out, 2 * Ho * Wo, 64, 196, 0, 196, 64, a_mode=3, act=1, conv=(30, 36, 4, Ho, Wo, 7, 7, 2, 3), flags=2)
+    assert rel(out.float().permute(0, 3, 1, 2), y) < 5e-3
+    want = F.max_pool2d(out.float().permute(0, 3, 1, 2), 3, 2, 1)
+    p = torch.empty(2, want.shape[2], want.shape[3], 64, device="cuda", dtype=torch.bfloat16)
+    hip.check(hip.lib().cadre_maxpool3x3s2_bf16(out.data_ptr(), p.data_ptr(), 2, Ho, Wo, 64, hip.stream()), "pool")
+    assert torch.equal(p.float().permute(0, 3, 1, 2).cpu(), want.cpu())
