@@ -39,27 +39,45 @@ def log(*a):
 
 
 class Worker:
-    """One logical CARLA worker: synthetic sliding-window observations resident in HBM + its two storages."""
+    """One logical CARLA worker: sliding-window observations resident in HBM + its two storages.
+    Synthetic by default, or one recorded episode (cadre_amd/replay.py, config C5)."""
 
-    def __init__(self, cfg, seed, device):
+    def __init__(self, cfg, seed, device, episode=None):
         from ppo_agent.storage import RolloutStorage
         T, H, W = cfg["T"], cfg["H"], cfg["W"]
         rng = np.random.RandomState(seed)
-        nf = T + SEQ - 1
-        self.rgb = torch.from_numpy(rng.randint(0, 256, (nf, H, W, 3)).astype(np.uint8)).to(device)
-        self.route = torch.from_numpy(((rng.rand(nf, W, H) < 0.15) * 255).astype(np.uint8)).to(device)
-        meas = rng.rand(nf, 3)
-        self.win = (torch.arange(T).view(T, 1) + torch.arange(SEQ).view(1, SEQ)).reshape(-1).to(device)   # frame ids
-        self.meas = torch.from_numpy(meas).to(device)[self.win].contiguous()                             # [T*S,3] f64
+        if episode is None:
+            nf = T + SEQ - 1
+            rgb = rng.randint(0, 256, (nf, H, W, 3)).astype(np.uint8)
+            route = ((rng.rand(nf, W, H) < 0.15) * 255).astype(np.uint8)
+            meas = rng.rand(nf, 3)
+            win = (np.arange(T).reshape(T, 1) + np.arange(SEQ).reshape(1, SEQ)).reshape(-1)
+            rec = None
+        else:
+            rgb, route, meas = episode["rgb"], episode["route"], episode["measurements"]
+            win = episode["window"][:T].reshape(-1).astype(np.int64)
+            rec = episode
+        self.rgb = torch.from_numpy(rgb).to(device)
+        self.route = torch.from_numpy(route).to(device)
+        self.win = torch.from_numpy(win).to(device)                                                     # frame ids
+        self.meas = torch.from_numpy(meas).to(device)[self.win].contiguous()                            # [T*S,3] f64
         self.stor = []
-        for K in (33, 3):
+        for j, K in enumerate((33, 3)):
             s = RolloutStorage(T, MINI_BATCH_NUM, 530, SEQ, 530, True, 0.99, 0.95)
-            s.action.copy_(torch.from_numpy(rng.randint(0, K, (T + 1, 1))))
-            s.action_log_probs.copy_(torch.from_numpy((-np.log(K) + 0.1 * rng.standard_normal((T + 1, 1))).astype(np.float32)))
-            s.value_preds.copy_(torch.from_numpy((0.3 * rng.standard_normal((T + 1, 1))).astype(np.float32)))
-            s.rewards.copy_(torch.from_numpy(rng.rand(T + 1, 1).astype(np.float32)))
-            s.masks.copy_(torch.from_numpy((rng.rand(T + 1, 1) >= 0.02).astype(np.float32)))
-            s.command.copy_(torch.from_numpy(rng.randint(0, 4, (T + 1, 1)).astype(np.int32)))
+            if rec is None:
+                s.action.copy_(torch.from_numpy(rng.randint(0, K, (T + 1, 1))))
+                s.action_log_probs.copy_(torch.from_numpy((-np.log(K) + 0.1 * rng.standard_normal((T + 1, 1))).astype(np.float32)))
+                s.value_preds.copy_(torch.from_numpy((0.3 * rng.standard_normal((T + 1, 1))).astype(np.float32)))
+                s.rewards.copy_(torch.from_numpy(rng.rand(T + 1, 1).astype(np.float32)))
+                s.masks.copy_(torch.from_numpy((rng.rand(T + 1, 1) >= 0.02).astype(np.float32)))
+                s.command.copy_(torch.from_numpy(rng.randint(0, 4, (T + 1, 1)).astype(np.int32)))
+            else:
+                s.action[:T, 0] = torch.from_numpy(rec["action"][:T, j])
+                s.action_log_probs[:T, 0] = torch.from_numpy(rec["action_log_prob"][:T, j])
+                s.value_preds[:T, 0] = torch.from_numpy(rec["value"][:T, j])
+                s.rewards[:T, 0] = torch.from_numpy(rec["reward"][:T, j])
+                s.masks[:T, 0] = torch.from_numpy(1.0 - rec["done"][:T, j].astype(np.float32))
+                s.command[:T, 0] = torch.from_numpy(rec["command"][:T])
             s.to(device)
             self.stor.append(s)
 
@@ -199,6 +217,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--encoder-dtype", default=None, choices=["f32", "bf16"],
                     help="override the config's encoder arithmetic (C2: f32, C3: bf16 storage / fp32 accumulate)")
+    ap.add_argument("--replay", default=None, metavar="DIR",
+                    help="replay recorded rollouts (cadre_amd/replay.py .npz episodes) instead of synthetic ones; "
+                         "T/H/W come from the records (BASELINE config C5)")
     ap.add_argument("--dedup", action="store_true",
                     help="encode each distinct frame once (sliding-window latent cache) instead of the "
                          "reference's 8 frames per transition; NOT the default metric convention")
@@ -222,6 +243,15 @@ def main():
     from ppo_agent.agent import CadreAgent
     from ppo_agent.models import Shared_grad_buffers
     cfg = dict(CONFIGS[args.config]); cfg["chunk_windows"] = args.chunk_windows; cfg["dedup"] = args.dedup
+    episodes = None
+    if args.replay:
+        from cadre_amd import replay
+        paths = replay.list_episodes(args.replay)
+        if len(paths) < cfg["workers"] * world:
+            raise SystemExit("--replay needs >= %d episodes, found %d" % (cfg["workers"] * world, len(paths)))
+        episodes = [replay.load_episode(p) for p in paths[rank * cfg["workers"]:(rank + 1) * cfg["workers"]]]
+        cfg["T"] = min(len(e["command"]) for e in episodes)
+        cfg["H"], cfg["W"] = episodes[0]["rgb"].shape[1:3]
     H, W, T, nW = cfg["H"], cfg["W"], cfg["T"], cfg["workers"]
     fh, fw = synth.feat_hw(H, W)
     enc_state = synth.encoder_state(fh, fw, 7)
@@ -237,7 +267,7 @@ def main():
     if use_dist:
         dist.broadcast(agent.arena.params, 0)
     dev = agent.device
-    workers = [Worker(cfg, 1234 + 1000 * rank + w, dev) for w in range(nW)]
+    workers = [Worker(cfg, 1234 + 1000 * rank + w, dev, None if episodes is None else episodes[w]) for w in range(nW)]
     shared = Shared_grad_buffers(agent.model_dict, dev)
     torch.manual_seed(100 + rank)
 
@@ -300,7 +330,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if agent.vae_model.dtype == "f32" else "bf16 encoder (fp32 accumulate) / f32 PPO update",
-            "data": "synthetic",
+            "data": "synthetic" if episodes is None else "replayed records from %s" % args.replay,
             "config": {"workload": "%s: %d worker(s) x %d-step rollout, %dx%dx3 synthetic obs (+route), DANet encoder "
                                    "(%s) + PPO update (4 epochs x 2 minibatches), %s"
                                    % (args.config, nW, T, H, W,

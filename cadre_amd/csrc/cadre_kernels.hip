@@ -802,6 +802,31 @@ extern "C" int cadre_sample(const float* logits, int64_t ldl, const float* q, in
   return (int)hipGetLastError();
 }
 
+// ============================================================================ categorical evaluate (forward only)
+// Model.evaluate_actions / Categorical_1d.log_probs + entropy (models.py:199-208,
+// distributions.py:101-105) for a batch of rows; one wave per row.
+__global__ __launch_bounds__(64) void categorical_eval_kernel(const float* logits, int64_t ldl, const int64_t* actions,
+                                                              int K, float* logp, float* entropy) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const float x = lane < K ? logits[(int64_t)r * ldl + lane] : -INFINITY;
+  const float mx = wave_max(x);
+  const float se = wave_sum(lane < K ? expf(x - mx) : 0.f);
+  const float lg = x - (mx + logf(se));
+  const float mx2 = wave_max(lane < K ? lg : -INFINITY);
+  const float e2 = lane < K ? expf(lg - mx2) : 0.f;
+  const float p = e2 / wave_sum(e2);
+  const float h = wave_sum(lane < K ? -p * lg : 0.f);
+  const int a = (int)actions[r];
+  const float la = __shfl(lg, a & 63, 64);
+  if (lane == 0) { logp[r] = la; entropy[r] = h; }
+}
+extern "C" int cadre_categorical_eval(const float* logits, int64_t ldl, const int64_t* actions, int32_t R, int32_t n_out,
+                                      float* logp, float* entropy, void* stream) {
+  FAIL_IF(!logits || !actions || !logp || !entropy || R < 1 || n_out < 1 || n_out > 64, "cadre_categorical_eval: bad argument");
+  hipLaunchKernelGGL(categorical_eval_kernel, dim3(R), dim3(64), 0, ST(stream), logits, ldl, actions, n_out, logp, entropy);
+  return (int)hipGetLastError();
+}
+
 // ============================================================================ per-model clip + Adam
 __global__ void sqnorm_kernel(const float* g, const int64_t* seg_off, double* norms2) {
   const int mdl = blockIdx.y;

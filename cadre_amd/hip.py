@@ -56,6 +56,7 @@ SYMBOLS = {
     "cadre_relu_bwd": [vp, vp, i64, vp],
     "cadre_ppo_loss": [vp, i64, i64, vp, i64, i64, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, f32, vp, vp, vp, vp],
     "cadre_sample": [vp, i64, vp, i64, i32, i32, vp, vp, vp],
+    "cadre_categorical_eval": [vp, i64, vp, i32, i32, vp, vp, vp],
     "cadre_clip_adam": [vp, vp, vp, vp, vp, i32, vp, f64, f64, f64, f64, f64, i32, vp],
     "cadre_clip_adam_graph": [vp, vp, vp, vp, vp, i32, vp, f64, f64, f64, f64, f64, vp, vp],
 }

@@ -54,8 +54,8 @@ class PPOLearnerHIP:
         return w
 
     # ------------------------------------------------------------------ forward
-    def _forward(self, w, B, nets, x_div, S=None):
-        """LSTM (S steps) + both MLP towers for `Z` nets.  nets = (g0, g_stride, Z): arena net
+    def _forward(self, w, B, nets, x_div, S=None, mlp=True):
+        """LSTM (S steps) + (optionally) both MLP towers for `Z` nets.  nets = (g0, g_stride, Z): arena net
         indices g0 + i*g_stride.  Net i reads inputs X[i // x_div], h0/c0[i // x_div]."""
         a = self.a
         S = self.S if S is None else S
@@ -80,7 +80,16 @@ class PPOLearnerHIP:
             hip.check(L.cadre_lstm_pointwise_fwd(hip.ptr(Gt), H4, S * B * H4, hip.ptr(Cs[:, t]), (S + 1) * B * DP, 1,
                                                  hip.ptr(Cs[:, t + 1]), hip.ptr(Hs[:, t + 1]), hip.ptr(TC[:, t + 1]),
                                                  DP, (S + 1) * B * DP, B, a.D, Z, st), "cadre_lstm_pointwise_fwd")
-        # actor (tower 0) + critic (tower 1): z = 2*i + tower  (models.py:171-177, distributions.py:34-40)
+        if mlp:
+            self._mlp(w, B, nets, Hs[:, S], (S + 1) * B * DP)
+
+    def _mlp(self, w, B, nets, inp, inp_zstride):
+        """actor (tower 0) + critic (tower 1) of each net on `inp` ([Z][B][DP] rows, net stride
+        inp_zstride): z = 2*i + tower  (models.py:171-177, distributions.py:34-40)."""
+        a = self.a
+        g0, gs, Z = nets
+        P = a.params
+        DP, hid, NP = a.DP, a.hid, a.NP
         pP = P[a.P0 + g0 * a.size_P:]
         sT = a.size_T if gs == 1 else None
         A1, A2, O3 = w["A1"], w["A2"], w["O3"]
@@ -89,8 +98,8 @@ class PPOLearnerHIP:
                 pw, zb, nb, div, zs, cs = pP, 0, 2 * Z, 2, a.size_T, 1
             else:       # strided nets (act/get_value): one launch per tower
                 pw, zb, nb, div, zs, cs = pP[tower * a.size_T:], tower, Z, 1, gs * a.size_P, 2
-            hip.gemm(Hs[:, S], pw[a.t_w1:], A1[zb:], B, hid, DP, DP, DP, hid, shift=pw[a.t_b1:], act=1, batch=nb,
-                     a_z=(div, 0, (S + 1) * B * DP), b_z=(1, 0, zs), c_z=(1, 0, cs * B * hid), s_z=(1, 0, zs))
+            hip.gemm(inp, pw[a.t_w1:], A1[zb:], B, hid, DP, DP, DP, hid, shift=pw[a.t_b1:], act=1, batch=nb,
+                     a_z=(div, 0, inp_zstride), b_z=(1, 0, zs), c_z=(1, 0, cs * B * hid), s_z=(1, 0, zs))
             hip.gemm(A1[zb:], pw[a.t_w2:], A2[zb:], B, hid, hid, hid, hid, hid, shift=pw[a.t_b2:], act=1, batch=nb,
                      a_z=(1, 0, cs * B * hid), b_z=(1, 0, zs), c_z=(1, 0, cs * B * hid), s_z=(1, 0, zs))
             hip.gemm(A2[zb:], pw[a.t_w3:], O3[zb:], B, NP, hid, hid, hid, NP, shift=pw[a.t_b3:], batch=nb,
@@ -236,3 +245,27 @@ class PPOLearnerHIP:
         g_s, g_t = commands[0], a.C + commands[1]
         self._forward(w, 1, (g_s, g_t - g_s, 2), 1, S=S)
         return w["O3"], w["Hs"][:, S], w["Cs"][:, S]
+
+    # ------------------------------------------------------------------ stand-alone module calls
+    def lstm_module_forward(self, g, x, h0, c0):
+        """`LSTM.forward` (models.py:139-152) of arena net g: x [T*N, D] time-major (or [N, D]), hidden
+        [N, D] -> (h_T, c_T) [N, D].  Inference only."""
+        a = self.a
+        N = h0.shape[0]
+        S = x.shape[0] // N
+        w = self.workspace(N, 1, S)
+        w["X"][0].view(S * N, a.DP)[:, :a.D].copy_(x)
+        w["h0"][0][:, :a.D].copy_(h0)
+        w["c0"][0][:, :a.D].copy_(c0)
+        self._forward(w, N, (g, 1, 1), 1, S=S, mlp=False)
+        return w["Hs"][0, S, :, :a.D].clone(), w["Cs"][0, S, :, :a.D].clone()
+
+    def mlp_module_forward(self, g, feat):
+        """critic + actor of arena net g on feat [B, D] -> (raw logits [B, NP], values [B, 1]) views."""
+        a = self.a
+        B = feat.shape[0]
+        w = self.workspace(B, 1, 1)
+        inp = w["Hs"][0, 1]
+        inp[:, :a.D].copy_(feat)
+        self._mlp(w, B, (g, 1, 1), w["Hs"][:, 1], 2 * B * a.DP)
+        return w["O3"][0], w["O3"][1, :, :1]

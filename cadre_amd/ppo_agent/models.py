@@ -54,6 +54,19 @@ def get_vae_output(model_cfg):
     return obs_dim, vae_params
 
 
+def _module_net(module):
+    """(arena, learner, net index) of a module bound by create_model."""
+    arena = getattr(module, "_cadre_arena", None)
+    if arena is None:
+        raise hip.CadreHipError("module is not bound to a parameter arena (build it with create_model)")
+    learner = getattr(arena, "_learner", None)
+    if learner is None:
+        from ..learner import PPOLearnerHIP
+        arena._learner = learner = PPOLearnerHIP(arena)
+    head, _kind, c = module._cadre_name.split("_")
+    return arena, learner, arena.net_index(head, int(c))
+
+
 class LSTM(nn.Module):
     """models.py:130-152 container: `rnn` = nn.LSTMCell(input, hid) with orthogonal weights, zero biases."""
 
@@ -66,8 +79,11 @@ class LSTM(nn.Module):
         self.rnn.bias_hh.data.fill_(0)
 
     def forward(self, x, hidden_state):
-        raise RuntimeError("LSTM.forward is fused into CadreAgent.act/get_value/update_policy on the HIP path "
-                           "(cadre_amd.learner); the module is a parameter container")
+        """models.py:139-152 (inference; training gradients come from CadreAgent.update_policy):
+        one cell step if x.size(0) == h.size(0), else [T*N, D] time-major unrolled over T."""
+        arena, learner, g = _module_net(self)
+        h, c = learner.lstm_module_forward(g, x, hidden_state[0], hidden_state[1])
+        return h, (h, c)
 
 
 class Model(nn.Module):
@@ -90,6 +106,38 @@ class Model(nn.Module):
 
     def get_log_probs(self, action):
         return self.control.log_probs(action)
+
+    def get_value(self, obs_feature):
+        """models.py:195-197 (inference)."""
+        _a, learner, g = _module_net(self)
+        return learner.mlp_module_forward(g, obs_feature)[1].clone()
+
+    def act(self, obs_feature):
+        """models.py:184-189: (value, sampled action, feature).  Sampling = argmax(p/q) with q drawn
+        from the global torch CPU generator exactly like Categorical(probs).sample()."""
+        arena, learner, g = _module_net(self)
+        logits, value = learner.mlp_module_forward(g, obs_feature)
+        R, K = obs_feature.shape[0], self.control.num_outputs
+        q = torch.empty(R, K).exponential_(1).to(obs_feature.device)
+        action = torch.empty(R, dtype=torch.int64, device=obs_feature.device)
+        logp = torch.empty(R, 1, device=obs_feature.device)
+        hip.check(hip.lib().cadre_sample(hip.ptr(logits), logits.stride(0), hip.ptr(q), K, R, K, hip.ptr(action),
+                                         hip.ptr(logp), hip.stream()), "cadre_sample")
+        self.control._last_action, self.control._last_logp = action, logp
+        return value.clone(), action, obs_feature.clone().detach()
+
+    def evaluate_actions(self, obs_feature, action):
+        """models.py:199-208 forward (no autograd graph) -> (value [N,1], log_prob [N,1], entropy [N,1])."""
+        arena, learner, g = _module_net(self)
+        logits, value = learner.mlp_module_forward(g, obs_feature)
+        R = obs_feature.shape[0]
+        logp = torch.empty(R, 1, device=obs_feature.device)
+        ent = torch.empty(R, 1, device=obs_feature.device)
+        act = action.reshape(-1).to(torch.int64).contiguous()
+        hip.check(hip.lib().cadre_categorical_eval(hip.ptr(logits), logits.stride(0), hip.ptr(act), R,
+                                                   self.control.num_outputs, hip.ptr(logp), hip.ptr(ent),
+                                                   hip.stream()), "cadre_categorical_eval")
+        return value.clone(), logp, ent
 
 
 # pickle class paths of the reference (agent.py:245-271 pickles whole modules)

@@ -59,7 +59,8 @@ def learner_section(agent, steer_rollout, throttle_rollout, done, train_cfg, sha
 
 
 def train(rank, train_cfg, agent_cfg, env_cfg, rollout_cfg, traffic_light=None, counter=None,
-          shared_model_list=None, shared_grad_buffers=None, son_process_counter=None, env_cls=None, logger=None):
+          shared_model_list=None, shared_grad_buffers=None, son_process_counter=None, env_cls=None, logger=None,
+          recorder=None):
     if env_cls is None:
         from env_wrapper import EnvWrapper as env_cls        # needs the CARLA stack (reference env_wrapper.py)
     env_cfg.rank = rank
@@ -82,15 +83,20 @@ def train(rank, train_cfg, agent_cfg, env_cfg, rollout_cfg, traffic_light=None, 
     for episode in range(train_cfg.max_episode):
         for _ in range(num_steps):
             command = obs["command"]
+            raw = dict(obs, rgb=obs["rgb"].copy(), route_fig=obs["route_fig"].copy()) if recorder is not None else None
             feat, action, alp, values, hidden = agent.act(obs)
             obs, reward, done, info = env.step(agent.convert_action(action))
             ad = info["action_done"]
+            if recorder is not None:            # cadre_amd.replay.RolloutRecorder
+                recorder.step(raw, action, alp, values, reward, ad)
             steer_rollout.insert(feat, action[0], alp[0], values[0], reward[0],
                                  torch.tensor([[0.0] if ad[0] else [1.0]]), hidden, command)
             throttle_rollout.insert(feat, action[1], alp[1], values[1], reward[1],
                                     torch.tensor([[0.0] if ad[1] else [1.0]]), hidden, command)
             if done:
                 obs = env.reset()
+        if recorder is not None:
+            recorder.end_episode()
         vl, pl, el = learner_section(agent, steer_rollout, throttle_rollout, done, train_cfg, shared_grad_buffers,
                                      traffic_light=traffic_light, counter=counter,
                                      shared_model_list=shared_model_list, in_process_chief=False)

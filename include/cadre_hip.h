@@ -174,6 +174,11 @@ int cadre_ppo_loss(const float* logits, int64_t ldl, int64_t l_ns, const float* 
 int cadre_sample(const float* logits, int64_t ldl, const float* q, int64_t ldq, int32_t R,
                  int32_t n_out, int64_t* action, float* logp, void* stream);
 
+/* Model.evaluate_actions forward (models.py:199-208): per row log-prob of `actions` and entropy
+ * of Categorical(logits=raw logits) */
+int cadre_categorical_eval(const float* logits, int64_t ldl, const int64_t* actions, int32_t R,
+                           int32_t n_out, float* logp, float* entropy, void* stream);
+
 /* ---------------------------------------------------------------- optimiser
  * chief.py:13-21 + main.py:55: per-model clip_grad_norm_(max_norm) then Adam (torch defaults)
  * over a flat parameter arena made of `n_models` segments [seg_off[i], seg_off[i+1]).

@@ -106,3 +106,22 @@ def test_snapshot_key_quirk(golden):
     g = golden("insert")
     keys = sorted(str(k) for k in g["snapshot_keys"])
     assert keys == sorted(["%s_%d" % (k, c) for c in range(4) for k in ("throttle_ppo", "steer_ppo", "steer_lstm")])
+
+
+def test_rollout_record_replay_roundtrip(tmp_path):
+    """§8f-2: recorder de-duplicates the sliding window, replay reproduces every observation."""
+    from cadre_amd import replay, synth
+    steps = synth.synth_rollout(9, 20, 28, seed=4) + synth.synth_rollout(4, 20, 28, seed=5)   # one env reset inside
+    rec = replay.RolloutRecorder(str(tmp_path), worker=3)
+    for i, td in enumerate(steps):
+        obs = dict(rgb=td["rgb"], route_fig=td["route_fig"], measurements=td["measurements"], command=td["command"])
+        rec.step(obs, (i % 33, i % 3), (-0.5 * i, -0.1), (0.25 * i, 1.0), td["reward"], td["done"])
+    path = rec.end_episode()
+    ep = replay.load_episode(path)
+    assert ep["rgb"].shape[0] == (8 + 8) + (8 + 3)                      # 2 fresh windows + slides, not 13*8
+    assert replay.list_episodes(str(tmp_path), worker=3) == [path]
+    for i, td in enumerate(steps):
+        o = replay.windows(ep, i)
+        assert np.array_equal(o["rgb"], td["rgb"]) and np.array_equal(o["route_fig"], td["route_fig"])
+        assert np.array_equal(o["measurements"], td["measurements"]) and o["command"] == td["command"]
+    assert ep["action"][5].tolist() == [5, 2] and ep["done"].dtype == np.uint8

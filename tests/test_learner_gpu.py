@@ -218,3 +218,77 @@ def test_latent_cache_is_bit_identical():
             ag._out.append((feat.clone(), int(a[0]), int(a[1]), lp[0].item(), lp[1].item(), obs["route_fig"].copy()))
     for x, y in zip(a_on._out, a_off._out):
         assert torch.equal(x[0], y[0]) and x[1:5] == y[1:5] and np.array_equal(x[5], y[5])
+
+
+def test_ragged_minibatches_and_done_vs_oracle():
+    """T=50, mini_batch_num=3 -> minibatches of 16,16,16,2 (BatchSampler drop_last=False,
+    storage.py:94-97) and the done=True bootstrap (agent.py:145-147): HIP learner section vs the
+    oracle replay on identical storages."""
+    from ppo_agent.chief import chief_step
+    from ppo_agent.models import Shared_grad_buffers
+    from ppo_agent.storage import RolloutStorage
+    from ppo_agent.train import learner_section
+    from tests.helpers import oracle_learner_replay
+    T, mbn = 50, 3
+    g = dict(T=T, mbn=mbn, epochs=1, ppo_seed=11, data_seed=91, torch_seed=5,
+             names=np.array(sorted(synth.ppo_state(11))))
+    want = oracle_learner_replay(g)
+    agent = make_agent(84, 84)
+    data = fill_storages(T, 91)
+    stor = []
+    for hd in ("steer", "throttle"):
+        s = RolloutStorage(T, mbn, 530, 8, 530, True, 0.99, 0.95)
+        for k, v in data[hd].items():
+            getattr(s, k).copy_(torch.from_numpy(v))
+        s.to("cuda:0")
+        stor.append(s)
+    shared = Shared_grad_buffers(agent.model_dict, agent.device)
+    torch.manual_seed(5)
+    cfg = dict(use_adv_norm=True, ppo_epoch=1, max_grad_norm=250.0)
+    vl, pl, el = learner_section(agent, stor[0], stor[1], False, cfg, shared)
+    got = np.array([vl, pl, el]).T
+    assert got.shape == (4, 3)
+    assert rel(got, np.array(want["losses"])) < LOSS_TOL
+    names = [str(n) for n in g["names"]]
+    ps = per_model(agent.arena, agent.arena.params, names, lambda ts: float(sum(t.sum() for t in ts)))
+    assert rel(ps, want["param_sums"][-1]) < 1e-5
+    # done=True: zero bootstrap values on the host, like the reference
+    nv = agent.get_value(True, stor[0].get_last(), stor[1].get_last())
+    assert all(float(v) == 0.0 and not v.is_cuda for v in nv)
+
+
+def test_module_level_api_matches_oracle():
+    """LSTM.forward / Model.get_value / Model.evaluate_actions / Model.act called directly on the
+    modules of model_dict (reference ppo_agent/models.py:139-208), against the oracle."""
+    from oracle import ppo_ref
+    agent = make_agent(84, 84)
+    st0 = synth.ppo_state(11)
+    P = ppo_ref.to_torch_params(st0)
+    r = np.random.RandomState(2)
+    N, T = 5, 8
+    x = torch.from_numpy((r.standard_normal((T * N, 530)) * 0.5).astype(np.float32))
+    h0 = torch.from_numpy((r.standard_normal((N, 530)) * 0.1).astype(np.float32))
+    c0 = torch.from_numpy((r.standard_normal((N, 530)) * 0.1).astype(np.float32))
+    lstm = agent.model_dict["throttle_lstm_2"]
+    h, (h2, c2) = lstm(x.cuda(), (h0.cuda(), c0.cuda()))
+    wh, (_, wc) = ppo_ref.lstm_forward(x, (h0, c0), P["throttle_lstm_2"])
+    assert rel(h.cpu().numpy(), wh.numpy()) < 1e-5 and rel(c2.cpu().numpy(), wc.numpy()) < 1e-5
+    h1, _ = lstm(x[:N].cuda(), (h0.cuda(), c0.cuda()))                     # single-step branch
+    w1, _ = ppo_ref.lstm_forward(x[:N], (h0, c0), P["throttle_lstm_2"])
+    assert rel(h1.cpu().numpy(), w1.numpy()) < 1e-5
+    model = agent.model_dict["steer_ppo_1"]
+    feat = wh
+    acts = torch.from_numpy(r.randint(0, 33, (N, 1)))
+    v, lp, ent = model.evaluate_actions(feat.cuda(), acts.cuda())
+    wv, wlp, went = ppo_ref.evaluate_actions(feat, acts, P["steer_ppo_1"])
+    assert rel(v.cpu().numpy(), wv.numpy()) < 1e-5 and rel(lp.cpu().numpy(), wlp.numpy()) < 1e-5
+    assert rel(ent.cpu().numpy(), went.numpy()) < 1e-5
+    assert rel(model.get_value(feat.cuda()).cpu().numpy(), wv.numpy()) < 1e-5
+    torch.manual_seed(7)
+    value, action, _f = model.act(feat.cuda())
+    torch.manual_seed(7)
+    q = torch.empty(N, 33).exponential_(1)
+    want_a = ppo_ref.sample_from_logits(ppo_ref.categorical_logits(feat, P["steer_ppo_1"]), q)
+    assert torch.equal(action.cpu(), want_a)
+    assert rel(model.get_log_probs(action).cpu().numpy(),
+               ppo_ref.categorical_logits(feat, P["steer_ppo_1"]).gather(1, want_a.view(-1, 1)).numpy()) < 1e-5
