@@ -213,7 +213,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
-    ap.add_argument("--chunk-windows", type=int, default=64, help="windows (x8 frames) per encoder launch chain")
+    ap.add_argument("--chunk-windows", type=int, default=128, help="windows (x8 frames) per encoder launch chain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--encoder-dtype", default=None, choices=["f32", "bf16"],
                     help="override the config's encoder arithmetic (C2: f32, C3: bf16 storage / fp32 accumulate)")
@@ -355,7 +355,7 @@ def main():
                                         for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])}},
             "last_losses": [round(x, 6) for x in losses[-1]],
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # CPU baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(cfg, enc_state, ppo_state)
         print(json.dumps(out), flush=True)
     if use_dist:

@@ -48,10 +48,12 @@ __global__ __launch_bounds__(256, ((WM + WN) * 2 * 64 * 36 * 4 > 80 * 1024 ? 1 :
   // XCD's private L2 instead of being re-fetched by up to 8 L2s.  Placement only affects speed.
   const int tilesN = (p.N + BN - 1) / BN;
   int bid = blockIdx.x;
+#ifndef GEMM_NO_XCD_REMAP
   {
     const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
+#endif
   const int tile_m = bid / tilesN, tile_n = bid % tilesN;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int z = blockIdx.z;
@@ -112,6 +114,10 @@ __global__ __launch_bounds__(256, ((WM + WN) * 2 * 64 * 36 * 4 > 80 * 1024 ? 1 :
       amask[i] = mask;
     }
   } else if constexpr (AMODE == 3) {
+    // Cin == 4 stem, "row" formulation: k-tile kt = kernel row kh; its 32 k-values are the 8
+    // consecutive NHWC4 pixels wi0 .. wi0+7 of input row hi0+kh (128 contiguous bytes), of which the
+    // first KW carry weights (B is [N][KH][32], zero beyond KW*4).  One scalar delta per k-tile, no
+    // per-thread tap decode.  This thread's chunk cc is pixel wi0+cc: masked when outside the row.
     const int hw = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
@@ -119,9 +125,14 @@ __global__ __launch_bounds__(256, ((WM + WN) * 2 * 64 * 36 * 4 > 80 * 1024 ? 1 :
       const int mm = min(m, p.M - 1);
       const int img = mm / hw, rem = mm % hw;
       const int ho = rem / p.Wo, wo = rem % p.Wo;
-      // pack (hi0, wi0) relative coordinates; offsets are formed per tile (one tap per 16-B chunk)
-      aoff[i] = (unsigned)(img * p.H * p.W * 16);
-      amask[i] = m < p.M ? (((unsigned)(ho * p.stride - p.pad + 0x4000) << 16) | (unsigned)(wo * p.stride - p.pad + 0x4000)) : 0u;
+      const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+      aoff[i] = (unsigned)((((img * p.H + hi0) * p.W + wi0) * 4 + cc * 4) * 4);
+      unsigned mask = 0;
+      if (m < p.M && cc < p.KW && (unsigned)(wi0 + cc) < (unsigned)p.W) {
+        for (int kh = 0; kh < p.KH; ++kh)
+          if ((unsigned)(hi0 + kh) < (unsigned)p.H) mask |= 1u << kh;
+      }
+      amask[i] = mask;
     }
   }
   unsigned boff[RB];
@@ -158,16 +169,10 @@ __global__ __launch_bounds__(256, ((WM + WN) * 2 * 64 * 36 * 4 > 80 * 1024 ? 1 :
       const unsigned delta = (unsigned)((((pos / p.KW) * p.W + (pos % p.KW)) * p.Cin + ci) * 4);
 #pragma unroll
       for (int i = 0; i < RA; ++i) areg[i] = ldg(rsA, ((amask[i] >> pos) & 1u) ? aoff[i] + delta : OOB);
-    } else {  // stem: Cin == 4, one 16-B chunk = one (kh,kw) tap
-      const int pos = k0 / 4 + cc;
-      const int kh = pos / p.KW, kw = pos % p.KW;
-      const bool kv = pos < p.KH * p.KW;
+    } else {  // stem rows: k-tile kt is kernel row kh
+      const unsigned delta = (unsigned)(kt * p.W * 16);
 #pragma unroll
-      for (int i = 0; i < RA; ++i) {
-        const int hi = (int)(amask[i] >> 16) - 0x4000 + kh, wi = (int)(amask[i] & 0xffffu) - 0x4000 + kw;
-        const bool ok = kv && amask[i] != 0u && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-        areg[i] = ldg(rsA, ok ? aoff[i] + (unsigned)((hi * p.W + wi) * 16) : OOB);
-      }
+      for (int i = 0; i < RA; ++i) areg[i] = ldg(rsA, ((amask[i] >> kt) & 1u) ? aoff[i] + delta : OOB);
     }
     // ---- B
     if constexpr (BMODE == 0) {
@@ -255,6 +260,9 @@ __global__ __launch_bounds__(256, ((WM + WN) * 2 * 64 * 36 * 4 > 80 * 1024 ? 1 :
           bf[j] = *reinterpret_cast<const f32x4*>(bs + col * LDS_PITCH + kq);
         }
       }
+#ifdef GEMM_SETPRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -262,6 +270,9 @@ __global__ __launch_bounds__(256, ((WM + WN) * 2 * 64 * 36 * 4 > 80 * 1024 ? 1 :
 #pragma unroll
           for (int j = 0; j < WN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+#ifdef GEMM_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
     if (more) store_tiles(buf ^ 1);
     __syncthreads();
@@ -436,9 +447,8 @@ extern "C" int cadre_gemm_f32(const cadre_gemm_t* pp, void* stream) {
     b_bytes = (int64_t)(p.b_mode == 0 ? p.N : p.K) * p.ldb * 4;
     GEMM_CHECK(a_bytes < lim, "A operand spans >= 2 GiB: chunk the batch");
     GEMM_CHECK(b_bytes < lim, "B operand spans >= 2 GiB");
-    if (p.a_mode == 3) GEMM_CHECK(p.H < 0x3000 && p.W < 0x3000, "stem image too large");
   }
-  if (p.a_mode == 3) GEMM_CHECK(p.Cin == 4 && p.K == p.KH * p.KW * 4, "stem conv needs Cin==4");
+  if (p.a_mode == 3) GEMM_CHECK(p.Cin == 4 && p.KW <= 8 && p.KH <= 32 && p.K == p.KH * 32, "stem conv needs Cin==4, KW<=8, K==KH*32 (B rows [KH][32], zero past KW*4)");
   if (p.a_mode >= 2) GEMM_CHECK(p.M % (p.Ho * p.Wo) == 0 && p.stride > 0, "conv M must be Nimg*Ho*Wo");
   if (p.batch < 1) p.batch = 1;
   if (p.split_k < 1) p.split_k = 1;

@@ -31,8 +31,15 @@ def _fold_bn(sd, bn, conv_bias=None):
 
 
 def _khwc(w):
-    """OIHW -> [O][KH*KW*I] with k contiguous."""
-    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+    """OIHW -> [O][KH*KW*I] with k contiguous; the Cin=4 stem -> [O][KH][32] rows (a_mode 3: one k-tile
+    per kernel row = 8 NHWC4 pixels, zero weights past KW)."""
+    o, i, kh, kw = w.shape
+    k = w.permute(0, 2, 3, 1)
+    if i == 4 and kw <= 8:
+        rows = torch.zeros(o, kh, 32, dtype=w.dtype)
+        rows[:, :, :kw * 4] = k.reshape(o, kh, kw * 4)
+        return rows.reshape(o, kh * 32).contiguous()
+    return k.reshape(o, -1).contiguous()
 
 
 class _Conv:
@@ -148,7 +155,7 @@ class DANetEncoderHIP:
         Wo = (W + 2 * c.pad - c.k) // c.stride + 1
         odt = torch.bfloat16 if (self.bf16 and not out_f32) else torch.float32
         out = self._buf(key, (F, Ho, Wo, c.cout), odt)
-        K = c.k * c.k * c.cin
+        K = c.k * 32 if c.cin == 4 else c.k * c.k * c.cin
         M = F * Ho * Wo
         act = c.act if act is None else act
         wbf = c.w.dtype == torch.bfloat16

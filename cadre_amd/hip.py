@@ -132,4 +132,5 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, scale=None, shi
     e0.record()
     check(fn(C.byref(d), stream()), "cadre_gemm_f32")
     e1.record()
-    PROFILE.append(((lib().cadre_gemm_pick_tile(C.byref(d)), a_mode, b_mode), 2.0 * M * N * K * max(1, batch), e0, e1))
+    k_alg = conv[5] * conv[6] * conv[2] if conv is not None else K      # algorithmic K (the stem pads 196 -> 224)
+    PROFILE.append(((lib().cadre_gemm_pick_tile(C.byref(d)), a_mode, b_mode), 2.0 * M * N * k_alg * max(1, batch), e0, e1))

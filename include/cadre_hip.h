@@ -30,7 +30,8 @@ const char* cadre_last_error(void);
 typedef struct {
   const float* A;      /* a_mode 0: [M][lda] (k contiguous); 1: [K][lda] (m contiguous);
                           2: NHWC activation, implicit-GEMM conv gather (Cin%32==0);
-                          3: NHWC activation with Cin==4 (stem)                       */
+                          3: NHWC4 activation (Cin==4 stem), k-tile = one kernel row:
+                             K = KH*32, B rows laid out [KH][32] with zeros past KW*4       */
   const float* B;      /* b_mode 0: [N][ldb] (k contiguous); 1: [K][ldb] (n contiguous)  */
   float* C;            /* [M][ldc] row-major (== NHWC for convs)                         */
   const float* scale;  /* per-n multiplier or NULL (=1)   (folded eval BatchNorm)        */

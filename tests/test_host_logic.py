@@ -125,3 +125,25 @@ def test_rollout_record_replay_roundtrip(tmp_path):
         assert np.array_equal(o["rgb"], td["rgb"]) and np.array_equal(o["route_fig"], td["route_fig"])
         assert np.array_equal(o["measurements"], td["measurements"]) and o["command"] == td["command"]
     assert ep["action"][5].tolist() == [5, 2] and ep["done"].dtype == np.uint8
+
+
+def test_cabi_rejects_bad_arguments_without_launching():
+    """Error behaviour of the C ABI: negative status + readable message, checked before any HIP call
+    (so this runs without a GPU)."""
+    import ctypes as C
+    from cadre_amd import hip
+    L = hip.lib()
+    d = hip.GemmDesc()
+    assert L.cadre_gemm_f32(C.byref(d), None) == -1 and b"null operand" in L.cadre_last_error()
+    d.A, d.B, d.C, d.M, d.N, d.K = 16, 16, 16, 4, 4, 6
+    assert L.cadre_gemm_f32(C.byref(d), None) == -1 and b"K%4" in L.cadre_last_error()
+    d.K, d.lda, d.ldb, d.ldc, d.a_mode, d.Cin, d.KH, d.KW = 64, 64, 64, 4, 2, 48, 1, 1
+    assert L.cadre_gemm_f32(C.byref(d), None) == -1 and b"Cin%32" in L.cadre_last_error()
+    assert L.cadre_gemm_bf16(C.byref(d), None) == -1
+    assert L.cadre_gae(None, None, None, None, None, None, 1, 8, 0.99, 0.94, 1, None) == -1
+    assert b"cadre_gae" in L.cadre_last_error()
+    assert L.cadre_pam(16, 16, 0.5, 16, 1, 200, None) == -1 and b"Np<=96" in L.cadre_last_error()
+    assert L.cadre_sample(16, 64, 16, 64, 1, 65, 16, 16, None) == -1
+    assert L.cadre_clip_adam(16, 16, 16, 16, 16, 0, 16, 250.0, 3e-4, 0.9, 0.999, 1e-8, 1, None) == -1
+    with pytest.raises(hip.CadreHipError, match="cadre_gemm_f32"):
+        hip.check(-1, "cadre_gemm_f32")

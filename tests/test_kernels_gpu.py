@@ -112,11 +112,12 @@ def test_conv_implicit_gemm(hip, Cin, Cout, H, W, k, s, p):
     Ho, Wo = y.shape[2], y.shape[3]
     res = torch.randn(Nimg, Cout, Ho, Wo, generator=g)
     want = F.relu(y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res)
+    from cadre_amd.encoder import _khwc
     xd = dev(x.permute(0, 2, 3, 1).contiguous())
-    wd = dev(w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous())
+    wd = dev(_khwc(w))                                   # [O][KH*KW*I]; the Cin=4 stem -> [O][KH][32] rows
     rd = dev(res.permute(0, 2, 3, 1).contiguous())
     out = torch.empty(Nimg, Ho, Wo, Cout, device="cuda")
-    K = k * k * Cin
+    K = wd.shape[1]
     hip.gemm(xd, wd, out, Nimg * Ho * Wo, Cout, K, 0, K, Cout, a_mode=3 if Cin == 4 else 2, scale=dev(scale),
              shift=dev(shift), resid=rd, ldr=Cout, act=1, conv=(H, W, Cin, Ho, Wo, k, k, s, p))
     torch.cuda.synchronize()
@@ -428,10 +429,11 @@ def test_f32_stem_bf16_output_and_bf16_pool(hip):
     g = torch.Generator().manual_seed(4)
     x = torch.randn(2, 4, 30, 36, generator=g); w = torch.randn(64, 4, 7, 7, generator=g) / 14.0
     y = F.relu(F.conv2d(x, w, None, 2, 3))
-    xd = dev(x.permute(0, 2, 3, 1).contiguous()); wd = dev(w.permute(0, 2, 3, 1).reshape(64, -1).contiguous())
+    from cadre_amd.encoder import _khwc
+    xd = dev(x.permute(0, 2, 3, 1).contiguous()); wd = dev(_khwc(w))
     Ho, Wo = y.shape[2], y.shape[3]
     out = torch.empty(2, Ho, Wo, 64, device="cuda", dtype=torch.bfloat16)
-    hip.gemm(xd, wd, out, 2 * Ho * Wo, 64, 196, 0, 196, 64, a_mode=3, act=1, conv=(30, 36, 4, Ho, Wo, 7, 7, 2, 3), flags=2)
+    hip.gemm(xd, wd, out, 2 * Ho * Wo, 64, 224, 0, 224, 64, a_mode=3, act=1, conv=(30, 36, 4, Ho, Wo, 7, 7, 2, 3), flags=2)
     assert rel(out.float().permute(0, 3, 1, 2), y) < 5e-3
     want = F.max_pool2d(out.float().permute(0, 3, 1, 2), 3, 2, 1)
     p = torch.empty(2, want.shape[2], want.shape[3], 64, device="cuda", dtype=torch.bfloat16)
