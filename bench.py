@@ -343,6 +343,11 @@ def main():
             "encoder_frames_per_sec": round(nW * (T + SEQ - 1 if args.dedup else T * SEQ) / t_enc, 1),
             "encoder_tflops": round(nW * (T + SEQ - 1 if args.dedup else T * SEQ) * flops_frame / t_enc / 1e12, 2),
             "update_only_samples_per_sec": round(nW * T * PPO_EPOCH / t_upd, 1),
+            "encoder_fwd_GBps": round(sum(agent.vae_model.algorithmic_bytes(min(args.chunk_windows, T) * SEQ)
+                                          for _ in range(nW * -(-T // args.chunk_windows))) / t_enc / 1e9, 1)
+            if not args.dedup else None,
+            "encoder_fwd_GBps_note": "algorithmic bytes (SURVEY 8d layer model, weights once per chunk) / t_encode; "
+                                     "HBM peak 8000 GB/s; the fp32 conv stack is MFMA-bound (see roofline)",
             "roofline": {"kernel": kname(dom), "kernel_desc": "%s tile, %s" % (TILE[dom[0]], AM[dom[1]]),
                          "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),

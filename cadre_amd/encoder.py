@@ -263,6 +263,33 @@ class DANetEncoderHIP:
         return out
 
     # ------------------------------------------------------------------ accounting
+    def algorithmic_bytes(self, frames):
+        """Layer-wise HBM model of SURVEY.md §8(d): every fused conv / attention op reads its input once
+        and writes its output once per frame, residuals are re-read, weights are read once per batch."""
+        e = 2 if self.bf16 else 4
+        H, W = self.H, self.W
+        act = 0
+
+        def conv(c, H, W, resid=False):
+            Ho = (H + 2 * c.pad - c.k) // c.stride + 1
+            Wo = (W + 2 * c.pad - c.k) // c.stride + 1
+            return H * W * c.cin + Ho * Wo * c.cout * (2 if resid else 1), Ho, Wo
+        a, H, W = conv(self.stem, H, W); act += a
+        Hp, Wp = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        act += H * W * 64 + Hp * Wp * 64
+        H, W = Hp, Wp
+        for c1, c2, d in self.blocks:
+            a, H2, W2 = conv(c1, H, W); act += a
+            if d is not None:
+                act += conv(d, H, W)[0]
+            a, H, W = conv(c2, H2, W2, resid=True); act += a
+        Np = H * W
+        for c in (self.conv5a, self.conv5c, self.conv51, self.conv52, self.conv8, self.visual_conv, self.bc_conv):
+            act += conv(c, H, W)[0]
+        act += Np * (128 + 160) + 2 * Np * (160 + 128 + 128) + Np * 128 * 2      # PAM qkv + PAM/CAM in/out
+        act += 2 * Np * 512 + 3072 + 6 * 256 + 512                               # inter-task inputs/outputs
+        return e * act * frames + e * self.n_weights
+
     def flops_per_frame(self):
         H, W = self.H, self.W
         total = 0
