@@ -110,6 +110,58 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* rgb, con
   }
 }
 
+// bf16 variant for the C3 stem: writes the interior of a zero-padded NHWC4 bf16 image
+// [F][Hp][Wp][4] at (pad_t, pad_l); the border is never written (allocated zeroed by the caller).
+__global__ __launch_bounds__(256) void preprocess_bf16pad_kernel(const uint8_t* rgb, const uint8_t* route, const float* lut,
+                                                                 const uint32_t* frame_max, __bf16* out, uint8_t* route_norm,
+                                                                 int F, int H, int W, int Hp, int Wp, int pad_t, int pad_l) {
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  __shared__ float s_lut[256];
+  __shared__ uint8_t s_r[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  s_lut[threadIdx.x] = lut[threadIdx.x];
+  const int f = blockIdx.z, h0 = blockIdx.y * 32, w0 = blockIdx.x * 32;
+  const uint32_t mx = frame_max[f];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int wl = ty + 8 * j, w = w0 + wl, h = h0 + tx;
+    uint8_t rn = 0;
+    if (w < W && h < H) {
+      const int64_t ridx = ((int64_t)f * W + w) * H + h;
+      const uint8_t rv = route[ridx];
+      rn = mx > 0 ? (uint8_t)(rv == mx ? 1 : 0) : rv;
+      if (route_norm) route_norm[ridx] = rn;
+    }
+    s_r[wl][tx] = rn;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int hl = ty + 8 * j, h = h0 + hl, w = w0 + tx;
+    if (h < H && w < W) {
+      const uint8_t* px = rgb + (((int64_t)f * H + h) * W + w) * 3;
+      bf16x4 o;
+      o[0] = (__bf16)s_lut[px[0]]; o[1] = (__bf16)s_lut[px[1]]; o[2] = (__bf16)s_lut[px[2]]; o[3] = (__bf16)(float)s_r[tx][hl];
+      reinterpret_cast<bf16x4*>(out)[((int64_t)f * Hp + h + pad_t) * Wp + w + pad_l] = o;
+    }
+  }
+}
+extern "C" int cadre_preprocess_bf16pad(const uint8_t* rgb, const uint8_t* route, const float* lut255, void* out,
+                                        uint8_t* route_norm, uint32_t* frame_max, int32_t F, int32_t H, int32_t W,
+                                        int32_t Hp, int32_t Wp, int32_t pad_t, int32_t pad_l, void* stream) {
+  FAIL_IF(!rgb || !route || !lut255 || !out || !frame_max || F < 1 || H < 1 || W < 1 || pad_t < 0 || pad_l < 0 ||
+              Hp < H + pad_t || Wp < W + pad_l,
+          "cadre_preprocess_bf16pad: bad argument");
+  hipError_t e = hipMemsetAsync(frame_max, 0, sizeof(uint32_t) * F, ST(stream));
+  if (e != hipSuccess) return (int)e;
+  const int per = H * W;
+  dim3 g1(min(64, (per + 255) / 256), F);
+  hipLaunchKernelGGL(route_max_kernel, g1, dim3(256), 0, ST(stream), route, frame_max, per);
+  hipLaunchKernelGGL(preprocess_bf16pad_kernel, dim3((W + 31) / 32, (H + 31) / 32, F), dim3(256), 0, ST(stream), rgb,
+                     route, lut255, frame_max, (__bf16*)out, route_norm, F, H, W, Hp, Wp, pad_t, pad_l);
+  return (int)hipGetLastError();
+}
+
 extern "C" int cadre_preprocess(const uint8_t* rgb, const uint8_t* route, const float* lut255,
                                 float* out, uint8_t* route_norm, uint32_t* frame_max,
                                 int32_t F, int32_t H, int32_t W, void* stream) {

@@ -24,19 +24,22 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 int cadre_fail(const char* msg);
 
 // flags of cadre_gemm_t used here: bit1 = C is bf16 (else f32), bit2 = resid is bf16 (else f32)
-template <int WM, int WN, int AMODE>
-__global__ __launch_bounds__(256, ((WM + WN) * 2 * 64 * 36 * 4 > 80 * 1024 ? 1 : 2)) void gemm_bf16_kernel(cadre_gemm_t p) {
+// WVN = waves along N (2 -> 256 threads, 4 -> 512 threads); 2 waves along M.
+template <int WM, int WN, int AMODE, int WVN>
+__global__ __launch_bounds__(128 * WVN, ((2 * WM + WVN * WN) * 2 * 32 * 36 * 4 > 80 * 1024 ? 1 : 2)) void gemm_bf16_kernel(cadre_gemm_t p) {
+  constexpr int NT = 128 * WVN;   // threads
+  constexpr int RP = NT / 8;      // rows staged per pass (8 x 16-B chunks per 128-B row)
   constexpr int BM = 2 * WM * 32;
-  constexpr int BN = 2 * WN * 32;
-  constexpr int RA = BM / 32;
-  constexpr int RB = BN / 32;
+  constexpr int BN = WVN * WN * 32;
+  constexpr int RA = BM / RP;
+  constexpr int RB = BN / RP;
   __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * PITCH_F];
   float* As = lds;
   float* Bs = lds + 2 * BM * PITCH_F;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WVN, wn = wave % WVN;
   const int l31 = lane & 31, lh = lane >> 5;
 
   const int tilesN = (p.N + BN - 1) / BN;
@@ -70,15 +73,30 @@ __global__ __launch_bounds__(256, ((WM + WN) * 2 * 64 * 36 * 4 > 80 * 1024 ? 1 :
   if constexpr (AMODE == 0) {
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-      const int m = m0 + rr + 32 * i;
+      const int m = m0 + rr + RP * i;
       aoff[i] = m < p.M ? (unsigned)((int64_t)m * p.lda * 2 + cc * 16) : OOB;
+      amask[i] = 0;
+    }
+  } else if constexpr (AMODE == 4) {
+    // Cin == 4 stem on a ZERO-PADDED bf16 NHWC4 image [Nimg][H][W][4] (H, W = padded sizes, the halo is
+    // real zeros in memory, so no tap masks): k-tile kt holds kernel rows 2kt and 2kt+1; chunk cc is
+    // the pixel pair 2(cc&3), 2(cc&3)+1 of row 2kt + (cc>>2), counted from padded pixel (stride*ho,
+    // stride*wo).  B is [N][KH/2 rounded up][64] with zeros where kh >= KH or kw >= KW.
+    const int hw = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int m = m0 + rr + RP * i;
+      const int mm = min(m, p.M - 1);
+      const int img = mm / hw, rem = mm % hw;
+      const int ho = rem / p.Wo, wo = rem % p.Wo;
+      aoff[i] = m < p.M ? (unsigned)((((img * p.H + ho * p.stride + (cc >> 2)) * p.W + wo * p.stride + 2 * (cc & 3)) * 4) * 2) : OOB;
       amask[i] = 0;
     }
   } else {
     const int hw = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-      const int m = m0 + rr + 32 * i;
+      const int m = m0 + rr + RP * i;
       const int mm = min(m, p.M - 1);
       const int img = mm / hw, rem = mm % hw;
       const int ho = rem / p.Wo, wo = rem % p.Wo;
@@ -97,7 +115,7 @@ __global__ __launch_bounds__(256, ((WM + WN) * 2 * 64 * 36 * 4 > 80 * 1024 ? 1 :
   unsigned boff[RB];
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
-    const int n = n0 + rr + 32 * i;
+    const int n = n0 + rr + RP * i;
     boff[i] = n < p.N ? (unsigned)((int64_t)n * p.ldb * 2 + cc * 16) : OOB;
   }
 
@@ -111,6 +129,10 @@ __global__ __launch_bounds__(256, ((WM + WN) * 2 * 64 * 36 * 4 > 80 * 1024 ? 1 :
     if constexpr (AMODE == 0) {
 #pragma unroll
       for (int i = 0; i < RA; ++i) areg[i] = ldg(rsA, aoff[i] + kb_);
+    } else if constexpr (AMODE == 4) {
+      const unsigned delta = (unsigned)(2 * kt * p.W * 8);                    // two padded rows per k-tile
+#pragma unroll
+      for (int i = 0; i < RA; ++i) areg[i] = ldg(rsA, aoff[i] + delta);       // OOB rows stay >= 2 GiB
     } else {
       const int pos = k0 / p.Cin, ci = k0 % p.Cin;                           // uniform (Cin % 64 == 0)
       const unsigned delta = (unsigned)((((pos / p.KW) * p.W + (pos % p.KW)) * p.Cin + ci) * 2);
@@ -124,9 +146,9 @@ __global__ __launch_bounds__(256, ((WM + WN) * 2 * 64 * 36 * 4 > 80 * 1024 ? 1 :
     float* as = As + buf * BM * PITCH_F;
     float* bs = Bs + buf * BN * PITCH_F;
 #pragma unroll
-    for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(as + (rr + 32 * i) * PITCH_F + cc * 4) = areg[i];
+    for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(as + (rr + RP * i) * PITCH_F + cc * 4) = areg[i];
 #pragma unroll
-    for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(bs + (rr + 32 * i) * PITCH_F + cc * 4) = breg[i];
+    for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(bs + (rr + RP * i) * PITCH_F + cc * 4) = breg[i];
   };
 
   f32x16 acc[WM][WN];
@@ -243,7 +265,12 @@ extern "C" int cadre_gemm_bf16(const cadre_gemm_t* pp, void* stream) {
   cadre_gemm_t p = *pp;
   BCHECK(p.A && p.B && p.C, "null operand");
   BCHECK(p.M > 0 && p.N > 0 && p.K > 0, "empty problem");
-  BCHECK((p.a_mode == 0 || p.a_mode == 2) && p.b_mode == 0, "a_mode must be 0 or 2, b_mode 0");
+  BCHECK((p.a_mode == 0 || p.a_mode == 2 || p.a_mode == 4) && p.b_mode == 0, "a_mode must be 0, 2 or 4, b_mode 0");
+  if (p.a_mode == 4)
+    BCHECK(p.Cin == 4 && p.KW <= 8 && p.K == ((p.KH + 1) / 2) * 64 && p.M % (p.Ho * p.Wo) == 0 &&
+               (p.Ho - 1) * p.stride + 2 * ((p.KH + 1) / 2) <= p.H && (p.Wo - 1) * p.stride + 8 <= p.W && (p.W % 2) == 0 &&
+               (p.stride % 2) == 0,
+           "padded stem: Cin==4, KW<=8, K==ceil(KH/2)*64, even stride/W, padded image must cover every tap row/pixel");
   BCHECK(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0 && ((uintptr_t)p.C & 15) == 0, "operands must be 16-byte aligned");
   BCHECK(p.K % 8 == 0 && p.ldb % 8 == 0 && p.N % 4 == 0 && p.ldc % 4 == 0, "needs K%8==0, ldb%8==0, N%4==0, ldc%4==0");
   if (p.a_mode == 0) BCHECK(p.lda % 8 == 0, "lda%8==0");
@@ -264,30 +291,44 @@ extern "C" int cadre_gemm_bf16(const cadre_gemm_t* pp, void* stream) {
   if (p.r_mod < 1) p.r_mod = 1 << 30;
   {
     const int64_t lim = 1ll << 31;
-    const int64_t a_bytes = p.a_mode == 2 ? (int64_t)(p.M / (p.Ho * p.Wo)) * p.H * p.W * p.Cin * 2 : (int64_t)p.M * p.lda * 2;
+    const int64_t a_bytes = p.a_mode >= 2 ? (int64_t)(p.M / (p.Ho * p.Wo)) * p.H * p.W * p.Cin * 2 : (int64_t)p.M * p.lda * 2;
     BCHECK(a_bytes < lim && (int64_t)p.N * p.ldb * 2 < lim, "operand spans >= 2 GiB: chunk the batch");
   }
   int tile = p.tile;
   if (tile == 0) {
-    // staging-bound regime: the biggest tile that still gives >= 2 workgroups per CU wins
-    auto nt = [&](int bm, int bn) { return (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn) * p.batch * p.split_k; };
-    if (p.N <= 64) tile = nt(128, 64) >= 512 ? 2 : 3;
-    else tile = nt(256, 128) >= 512 ? 4 : (nt(128, 128) >= 512 ? 1 : 3);
+    // staging-bound regime: shape factor (dense 8192^3: 256x256 on 8 waves 1054, 128x128 826 TFLOP/s;
+    // tools/gemm_bf16_bench.py) x wave quantisation over 256 CUs x resident workgroups per CU
+    struct Cand { int id, bm, bn, per_cu; double base; };
+    static const Cand wide[3] = {{7, 256, 256, 1, 1.00}, {1, 128, 128, 2, 0.80}, {3, 64, 64, 4, 0.45}};
+    static const Cand narrow[2] = {{2, 128, 64, 2, 0.85}, {3, 64, 64, 4, 1.00}};
+    const Cand* c = p.N <= 64 ? narrow : wide;
+    const int nc = p.N <= 64 ? 2 : 3;
+    double best_e = -1.0;
+    for (int i = 0; i < nc; ++i) {
+      if (c[i].id == 7 && p.N < 256) continue;
+      const double tiles = (double)((p.M + c[i].bm - 1) / c[i].bm) * ((p.N + c[i].bn - 1) / c[i].bn) * p.batch * p.split_k;
+      const double slots = 256.0 * c[i].per_cu;
+      const double waves = tiles <= slots ? 1.0 : (double)(int64_t)((tiles + slots - 1) / slots);
+      const double useful = ((double)p.M * p.N * p.batch * p.split_k) / (tiles * c[i].bm * c[i].bn);
+      const double e = c[i].base * useful * (tiles / (waves * slots));
+      if (e > best_e) { best_e = e; tile = c[i].id; }
+    }
   }
-  static const int BMS[7] = {0, 128, 128, 64, 256, 128, 256}, BNS[7] = {0, 128, 64, 64, 128, 256, 64};
-  BCHECK(tile >= 1 && tile <= 4, "bad tile");
+  static const int BMS[8] = {0, 128, 128, 64, 256, 128, 256, 256}, BNS[8] = {0, 128, 64, 64, 128, 256, 64, 256};
+  BCHECK(tile == 1 || tile == 2 || tile == 3 || tile == 4 || tile == 7, "bad tile");
   const int bm = BMS[tile], bn = BNS[tile];
-  dim3 grid(((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn), p.split_k, p.batch), block(256);
+  dim3 grid(((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn), p.split_k, p.batch), block(tile == 7 ? 512 : 256);
   hipStream_t st = (hipStream_t)stream;
-#define LB(WM_, WN_)                                                                           \
-  do {                                                                                         \
-    if (p.a_mode == 0) hipLaunchKernelGGL((gemm_bf16_kernel<WM_, WN_, 0>), grid, block, 0, st, p); \
-    else hipLaunchKernelGGL((gemm_bf16_kernel<WM_, WN_, 2>), grid, block, 0, st, p);             \
+#define LB(WM_, WN_, WV_)                                                                             \
+  do {                                                                                                \
+    if (p.a_mode == 0) hipLaunchKernelGGL((gemm_bf16_kernel<WM_, WN_, 0, WV_>), grid, block, 0, st, p); \
+    else if (p.a_mode == 2) hipLaunchKernelGGL((gemm_bf16_kernel<WM_, WN_, 2, WV_>), grid, block, 0, st, p); \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<WM_, WN_, 4, WV_>), grid, block, 0, st, p);             \
   } while (0)
-  if (tile == 1) LB(2, 2);
-  else if (tile == 2) LB(2, 1);
-  else if (tile == 3) LB(1, 1);
-  else LB(4, 2);
-#undef LB
+  if (tile == 1) LB(2, 2, 2);
+  else if (tile == 2) LB(2, 1, 2);
+  else if (tile == 3) LB(1, 1, 2);
+  else if (tile == 4) LB(4, 2, 2);
+  else LB(4, 2, 4);          // 256 x 256, 8 waves (2 x 4), each wave 128 x 64
   return (int)hipGetLastError();
 }

@@ -42,6 +42,23 @@ def _khwc(w):
     return k.reshape(o, -1).contiguous()
 
 
+def _stem_rows_bf16(w):
+    """OIHW Cin=4 stem weights -> [O][ceil(KH/2)][64] bf16 rows for cadre_gemm_bf16 a_mode 4: k-tile kt
+    holds kernel rows 2kt, 2kt+1; within it chunk cc (8 values) = pixels 2(cc&3), 2(cc&3)+1 x 4 channels
+    of row 2kt + (cc>>2); zero where kh >= KH or kw >= KW."""
+    o, i, kh, kw = w.shape
+    nkt = (kh + 1) // 2
+    out = torch.zeros(o, nkt, 8, 2, 4, dtype=torch.float32)
+    for kt in range(nkt):
+        for cc in range(8):
+            r = 2 * kt + (cc >> 2)
+            for e2 in range(2):
+                c = 2 * (cc & 3) + e2
+                if r < kh and c < kw:
+                    out[:, kt, cc, e2, :] = w[:, :, r, c]
+    return out.reshape(o, nkt * 64).contiguous()
+
+
 class _Conv:
     __slots__ = ("w", "scale", "shift", "cin", "cout", "k", "stride", "pad", "act")
 
@@ -86,6 +103,14 @@ class DANetEncoderHIP:
         # ---- trunk (resnet.py:111-115, 152-166)
         sc, sh = _fold_bn(sd, "backbone.bn1", sd["backbone.conv1.bias"])
         self.stem = _Conv(sd["backbone.conv1.weight"], sc, sh, 7, 2, 3, 1, dev)
+        if self.bf16:
+            # bf16 stem on a zero-padded NHWC4 image (3 px halo; row pitch padded so every 8-pixel tap
+            # row is in-bounds and 16-B aligned): no halo masks, two kernel rows per 64-deep k-tile
+            self.stem_w16 = _stem_rows_bf16(sd["backbone.conv1.weight"]).to(dev).to(torch.bfloat16)
+            Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+            self.Hp = max(H + 6, (Ho - 1) * 2 + 8)
+            self.Wp = max(W + 6, (Wo - 1) * 2 + 8)
+            self.Wp += self.Wp & 1
         self.blocks = []
         for li in range(1, 5):
             for bi in range(2):
@@ -142,10 +167,10 @@ class DANetEncoderHIP:
         return ts
 
     # ------------------------------------------------------------------ workspace
-    def _buf(self, key, shape, dtype=torch.float32):
+    def _buf(self, key, shape, dtype=torch.float32, zero=False):
         t = self._ws.get(key)
         if t is None or t.shape != torch.Size(shape) or t.dtype != dtype:
-            t = torch.empty(shape, dtype=dtype, device=self.device)
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
             self._ws[key] = t
         return t
 
@@ -172,9 +197,15 @@ class DANetEncoderHIP:
     def preprocess(self, rgb_d, route_d, route_norm_d=None):
         """agent.py:43-75 on device: u8 [F,H,W,3] + u8 [F,W,H] -> f32 NHWC [F,H,W,4]."""
         F = rgb_d.shape[0]
-        x = self._buf("pre", (F, self.H, self.W, 4))
         fmax = self._buf("fmax", (F,), torch.int32)
         L = hip.lib()
+        if self.bf16:       # zero-bordered bf16 image for the bf16 stem; the border is written never
+            x = self._buf("pre_pad", (F, self.Hp, self.Wp, 4), torch.bfloat16, zero=True)
+            hip.check(L.cadre_preprocess_bf16pad(hip.ptr(rgb_d), hip.ptr(route_d), hip.ptr(self.lut255), hip.ptr(x),
+                                                 hip.ptr(route_norm_d), hip.ptr(fmax), F, self.H, self.W, self.Hp,
+                                                 self.Wp, 3, 3, hip.stream()), "cadre_preprocess_bf16pad")
+            return x
+        x = self._buf("pre", (F, self.H, self.W, 4))
         hip.check(L.cadre_preprocess(hip.ptr(rgb_d), hip.ptr(route_d), hip.ptr(self.lut255), hip.ptr(x),
                                      hip.ptr(route_norm_d), hip.ptr(fmax), F, self.H, self.W, hip.stream()),
                   "cadre_preprocess")
@@ -186,7 +217,16 @@ class DANetEncoderHIP:
         st = hip.stream()
         F = x.shape[0]
         H, W = self.H, self.W
-        y, H, W = self._conv(self.stem, x, F, H, W, "stem")
+        if self.bf16:
+            if x.dtype != torch.bfloat16 or tuple(x.shape[1:]) != (self.Hp, self.Wp, 4):
+                raise hip.CadreHipError("bf16 encoder expects the padded bf16 image from preprocess()")
+            H, W = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+            y = self._buf("stem", (F, H, W, 64), torch.bfloat16)
+            hip.gemm(x, self.stem_w16, y, F * H * W, 64, self.stem_w16.shape[1], 0, self.stem_w16.shape[1], 64, a_mode=4,
+                     scale=self.stem.scale, shift=self.stem.shift, act=1, conv=(self.Hp, self.Wp, 4, H, W, 7, 7, 2, 0),
+                     bf16=True, flags=2)
+        else:
+            y, H, W = self._conv(self.stem, x, F, H, W, "stem")
         Hp, Wp = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
         p = self._buf("pool", (F, Hp, Wp, 64), y.dtype)
         if self.bf16:

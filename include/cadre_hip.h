@@ -53,7 +53,8 @@ typedef struct {
      cadre_splitk_reduce.  With split_k>1 scale/shift/resid/act are ignored here.        */
   int32_t split_k;
   int32_t tile;        /* 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128,
-                          5 = 128x256, 6 = 256x64 (4-6: one workgroup per CU)           */
+                          5 = 128x256, 6 = 256x64 (4-6: one workgroup per CU);
+                          7 = 256x256 on 8 waves (cadre_gemm_bf16 only)                  */
   int32_t flags;       /* bit 1: C is bf16; bit 2: resid is bf16 (cadre_gemm_bf16; bit 1 also
                           honoured by cadre_gemm_f32's vector epilogue); others must be 0   */
 } cadre_gemm_t;
@@ -61,8 +62,9 @@ int cadre_gemm_f32(const cadre_gemm_t* p, void* stream);
 /* the tile id cadre_gemm_f32 would use for this descriptor (p->tile, or the auto choice) */
 int cadre_gemm_pick_tile(const cadre_gemm_t* p);
 /* Same contract with bf16 A/B operands (element counts/strides in bf16 elements), fp32
- * accumulation on v_mfma_f32_32x32x16_bf16 and an fp32 epilogue; a_mode 0 or 2 (Cin%64==0),
- * b_mode 0; C bf16 or f32 (flags bit 1), resid bf16 or f32 (flags bit 2).  BASELINE config C3
+ * accumulation on v_mfma_f32_32x32x16_bf16 and an fp32 epilogue; a_mode 0, 2 (Cin%64==0) or
+ * 4 (Cin==4 stem on a zero-padded NHWC4 image: H, W = padded sizes, pad = 0, K = ceil(KH/2)*64,
+ * B rows [ceil(KH/2)][64] = two kernel rows of 8 pixels x 4 channels, zeros elsewhere), b_mode 0; C bf16 or f32 (flags bit 1), resid bf16 or f32 (flags bit 2).  BASELINE config C3
  * ("bf16 encoder / fp32 losses"). */
 int cadre_gemm_bf16(const cadre_gemm_t* p, void* stream);
 /* C[M][ldc] = act(sum_s slab[s][M][lds] * scale + shift + resid) */
@@ -80,6 +82,12 @@ int cadre_splitk_reduce(const float* slabs, int32_t split_k, int64_t slab_stride
 int cadre_preprocess(const uint8_t* rgb, const uint8_t* route, const float* lut255,
                      float* out, uint8_t* route_norm, uint32_t* frame_max,
                      int32_t F, int32_t H, int32_t W, void* stream);
+/* Same conversion into the interior (pad_t, pad_l) of a zero-padded bf16 NHWC4 image
+ * [F][Hp][Wp][4] whose border the caller keeps zero: input of the bf16 stem (cadre_gemm_bf16
+ * a_mode 4), which then needs no halo masks. */
+int cadre_preprocess_bf16pad(const uint8_t* rgb, const uint8_t* route, const float* lut255, void* out,
+                             uint8_t* route_norm, uint32_t* frame_max, int32_t F, int32_t H, int32_t W,
+                             int32_t Hp, int32_t Wp, int32_t pad_t, int32_t pad_l, void* stream);
 /* nn.MaxPool2d(3,2,1) resnet.py:114 on NHWC [F][H][W][C] (C%4==0) -> [F][Ho][Wo][C] */
 int cadre_maxpool3x3s2(const float* x, float* y, int32_t F, int32_t H, int32_t W, int32_t C,
                        void* stream);

@@ -389,7 +389,8 @@ def _bf(x):
     return x.to(torch.bfloat16)
 
 
-@pytest.mark.parametrize("M,N,K,tile", [(300, 256, 512, 1), (70, 64, 192, 3), (600, 128, 4608, 4), (200, 64, 576, 2)])
+@pytest.mark.parametrize("M,N,K,tile", [(300, 256, 512, 1), (70, 64, 192, 3), (600, 128, 4608, 4), (200, 64, 576, 2),
+                                        (700, 512, 1152, 7), (256, 256, 64, 7)])
 def test_gemm_bf16_dense(hip, M, N, K, tile):
     g = torch.Generator().manual_seed(M + N)
     A, B = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g) * 0.1)
@@ -405,9 +406,10 @@ def test_gemm_bf16_dense(hip, M, N, K, tile):
     assert rel(out16.float(), want) < 5e-3              # one bf16 rounding of the result
 
 
-@pytest.mark.parametrize("Cin,Cout,H,W,k,s,p", [(64, 64, 18, 22, 3, 1, 1), (64, 128, 18, 22, 3, 2, 1),
-                                                 (64, 128, 17, 21, 1, 2, 0), (512, 128, 9, 9, 3, 1, 1)])
-def test_conv_bf16(hip, Cin, Cout, H, W, k, s, p):
+@pytest.mark.parametrize("Cin,Cout,H,W,k,s,p,tile", [(64, 64, 18, 22, 3, 1, 1, 0), (64, 128, 18, 22, 3, 2, 1, 0),
+                                                      (64, 128, 17, 21, 1, 2, 0, 0), (512, 128, 9, 9, 3, 1, 1, 0),
+                                                      (256, 256, 18, 18, 3, 1, 1, 7), (128, 512, 9, 9, 1, 1, 0, 7)])
+def test_conv_bf16(hip, Cin, Cout, H, W, k, s, p, tile):
     g = torch.Generator().manual_seed(Cin + Cout + k + 1)
     Nimg = 3
     x = _bf(torch.randn(Nimg, Cin, H, W, generator=g))
@@ -420,7 +422,7 @@ def test_conv_bf16(hip, Cin, Cout, H, W, k, s, p):
     out = torch.empty(Nimg, Ho, Wo, Cout, device="cuda")
     K = k * k * Cin
     hip.gemm(xd, wd, out, Nimg * Ho * Wo, Cout, K, 0, K, Cout, a_mode=2, scale=dev(scale), shift=dev(shift), act=1,
-             conv=(H, W, Cin, Ho, Wo, k, k, s, p), bf16=True)
+             conv=(H, W, Cin, Ho, Wo, k, k, s, p), bf16=True, tile=tile)
     torch.cuda.synchronize()
     assert rel(out.permute(0, 3, 1, 2), want) < 2e-5
 
