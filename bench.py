@@ -257,7 +257,7 @@ def main():
     enc_state = synth.encoder_state(fh, fw, 7)
     ppo_state = synth.ppo_state(11)
     mcfg = dict(use_lstm=True, vae_device=local_rank, device_num=local_rank, vae_params="CoPM", measurement_dim=18,
-                num_output=dict(steer=33, throttle=3), command_num=4, obs_hw=(H, W), vae_state_dict=enc_state,
+                num_output=dict(steer=33, throttle=3), command_num=4, obs_hw=(H, W), weights_init="none", vae_state_dict=enc_state,
                 encoder_max_frames=args.chunk_windows * SEQ,
                 encoder_dtype=args.encoder_dtype or cfg.get("encoder_dtype", "f32"))
     agent = CadreAgent(rank=rank, model_cfg=mcfg, frame=SEQ, STEER_CONTROL={i: (i - 16) / 16.0 for i in range(33)},

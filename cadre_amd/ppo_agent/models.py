@@ -155,8 +155,26 @@ def load_encoder_state(model_cfg, vae_params):
     return ck["autoencoder"]                                          # experiments_builder.py:446-462
 
 
+class _no_orthogonal_init(object):
+    """`weights_init='none'`: skip the 32 QR factorisations of the reference's orthogonal init (≈ 10 s on
+    a CPU) when the caller loads weights right after construction (snapshots, tests, bench)."""
+
+    def __enter__(self):
+        self._orig = nn.init.orthogonal_
+        nn.init.orthogonal_ = lambda t, gain=1: t
+        return self
+
+    def __exit__(self, *exc):
+        nn.init.orthogonal_ = self._orig
+
+
 def create_model(model_cfg, load_vae=False):
     """models.py:44-126 -> (vae_model | None, model_dict).  All 16 trainable nets live in one arena."""
+    if _cfg(model_cfg, "weights_init", "orthogonal") == "none":
+        cfg2 = dict(model_cfg)
+        cfg2["weights_init"] = "orthogonal"
+        with _no_orthogonal_init():
+            return create_model(cfg2, load_vae)
     obs_dim, vae_params = get_vae_output(model_cfg)
     vae_model = None
     if load_vae:

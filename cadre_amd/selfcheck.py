@@ -11,7 +11,7 @@ def smoke():
     H = W = 84
     sd = synth.encoder_state(3, 3, 7)
     cfg = dict(use_lstm=True, vae_device=0, device_num=0, vae_params="CoPM", measurement_dim=18,
-               num_output=dict(steer=33, throttle=3), command_num=4, obs_hw=(H, W), vae_state_dict=sd)
+               num_output=dict(steer=33, throttle=3), command_num=4, obs_hw=(H, W), weights_init="none", vae_state_dict=sd)
     agent = CadreAgent(rank=0, model_cfg=cfg, frame=8, STEER_CONTROL={i: (i - 16) / 16.0 for i in range(33)},
                        THROTTLE_CONTROL={0: [0, 0], 1: [0, 1], 2: [0.6, 0]}, ent_coeff=0.01, value_coeff=0.1,
                        clip_coeff=1.0, clip=0.1)

@@ -21,7 +21,7 @@ def make_agent(H, W, enc_seed=7, ppo_seed=11):
     from ppo_agent.agent import CadreAgent
     fh, fw = synth.feat_hw(H, W)
     cfg = dict(use_lstm=True, vae_device=0, device_num=0, vae_params="CoPM", measurement_dim=18,
-               num_output=dict(steer=33, throttle=3), command_num=4, obs_hw=(H, W),
+               num_output=dict(steer=33, throttle=3), command_num=4, obs_hw=(H, W), weights_init="none",
                vae_state_dict=synth.encoder_state(fh, fw, enc_seed))
     steer = {i: (i - 16) / 16.0 for i in range(33)}
     thr = {0: [0, 0], 1: [0, 1], 2: [0.6, 0]}
