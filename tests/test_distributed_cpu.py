@@ -22,14 +22,15 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from cadre_amd.arena import PPOArena
-        from ppo_agent.models import LSTM, Model, Shared_grad_buffers
+        from ppo_agent.models import LSTM, Model, Shared_grad_buffers, _no_orthogonal_init
         arena = PPOArena("cpu", 530, {"steer": 33, "throttle": 3}, 4)
         torch.manual_seed(0)                                   # identical init on every rank
         md = {}
-        for c in range(4):
-            for head, k in (("steer", 33), ("throttle", 3)):
-                md["%s_ppo_%d" % (head, c)] = arena.bind("%s_ppo_%d" % (head, c), Model(530, k))
-                md["%s_lstm_%d" % (head, c)] = arena.bind("%s_lstm_%d" % (head, c), LSTM(530, hid_size=530))
+        with _no_orthogonal_init():                            # 32 QR factorisations are not under test
+            for c in range(4):
+                for head, k in (("steer", 33), ("throttle", 3)):
+                    md["%s_ppo_%d" % (head, c)] = arena.bind("%s_ppo_%d" % (head, c), Model(530, k))
+                    md["%s_lstm_%d" % (head, c)] = arena.bind("%s_lstm_%d" % (head, c), LSTM(530, hid_size=530))
         p0 = arena.params.clone()
         # rank-dependent gradients written through the per-parameter views
         for name, m in md.items():
