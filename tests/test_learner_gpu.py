@@ -90,14 +90,16 @@ def test_learner_section_replay_vs_reference(golden):
     assert step == len(g["losses"])
 
 
-def test_update_policy_matches_oracle_autograd_per_param():
-    """Per-parameter gradient check of the explicit backward against oracle autograd (B=24)."""
+@pytest.mark.parametrize("B", [24, 64])
+def test_update_policy_matches_oracle_autograd_per_param(B):
+    """Per-parameter gradient check of the explicit backward against oracle autograd; B=64 is the
+    full C2 minibatch (T=128 / mini_batch_num=2)."""
     from oracle import ppo_ref
     agent = make_agent(84, 84)
     st0 = synth.ppo_state(11)
     params = ppo_ref.to_torch_params(st0, requires_grad=True)
     r = np.random.RandomState(5)
-    B, S = 24, 8
+    S = 8
     samples, dsamples = [], []
     for hd, K in (("steer", 33), ("throttle", 3)):
         tup = (torch.from_numpy((r.standard_normal((S * B, 530)) * 0.5).astype(np.float32)),
