@@ -221,6 +221,7 @@ class Shared_grad_buffers(object):
         self.arena = arena_of(model_list)
         self.device = device
         self.counter = Counter()
+        self.lock = torch.multiprocessing.Lock()          # reference models.py:223,232
         self.grads = {}
         for model_name, model in model_list.items():
             gv = self.arena.views(self.arena.grads, model_name)
@@ -230,10 +231,12 @@ class Shared_grad_buffers(object):
 
     def add_gradient(self, model_list):
         src = arena_of(model_list)
-        if src is not self.arena:
-            self.arena.grads.add_(src.grads)
-        self.all_reduce()
-        self.counter.increment()
+        with self.lock:
+            if src is not self.arena:                     # a worker agent with its own nets (reference topology)
+                self.arena.grads.add_(src.grads)
+                torch.cuda.current_stream().synchronize()
+            self.all_reduce()
+            self.counter.increment()
 
     def all_reduce(self):
         import torch.distributed as dist

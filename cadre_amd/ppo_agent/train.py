@@ -99,7 +99,8 @@ def train(rank, train_cfg, agent_cfg, env_cfg, rollout_cfg, traffic_light=None, 
             recorder.end_episode()
         vl, pl, el = learner_section(agent, steer_rollout, throttle_rollout, done, train_cfg, shared_grad_buffers,
                                      traffic_light=traffic_light, counter=counter,
-                                     shared_model_list=shared_model_list, in_process_chief=False)
+                                     shared_model_list=shared_model_list,
+                                     in_process_chief=traffic_light is None)   # no chief process -> step in-process
         if episode % train_cfg.log_interval == 0 and rank == 0 and logger is not None:
             logger.log("Episode: {}, value loss: {:.4f}, policy loss: {:.4f}, entropy loss: {:.4f}".format(
                 episode, np.mean(vl), np.mean(pl), np.mean(el)))

@@ -147,3 +147,18 @@ def test_cabi_rejects_bad_arguments_without_launching():
     assert L.cadre_clip_adam(16, 16, 16, 16, 16, 0, 16, 250.0, 3e-4, 0.9, 0.999, 1e-8, 1, None) == -1
     with pytest.raises(hip.CadreHipError, match="cadre_gemm_f32"):
         hip.check(-1, "cadre_gemm_f32")
+
+
+def test_missing_library_fails_loudly():
+    """No silent fallback: with the shared library absent every entry into the product path raises."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from cadre_amd import hip\n"
+            "try:\n"
+            "    hip.lib()\n"
+            "except hip.CadreHipError as e:\n"
+            "    print('RAISED', 'no CPU fallback' in str(e))\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CADRE_HIP_LIB="/nonexistent/libcadre_hip.so"),
+                         capture_output=True, text=True, timeout=120)
+    assert "RAISED True" in out.stdout, out.stdout + out.stderr

@@ -294,3 +294,46 @@ def test_module_level_api_matches_oracle():
     assert torch.equal(action.cpu(), want_a)
     assert rel(model.get_log_probs(action).cpu().numpy(),
                ppo_ref.categorical_logits(feat, P["steer_ppo_1"]).gather(1, want_a.view(-1, 1)).numpy()) < 1e-5
+
+
+def test_reference_topology_shared_nets_and_worker_agent():
+    """reference main.py:38-70 shape in one process: a shared model_dict (create_model(load_vae=False))
+    owned by the chief + a worker agent with its own nets.  add_gradient accumulates into the shared
+    arena, chief_step updates the shared nets, update_model pulls them — same parameters as the
+    single-arena in-process path."""
+    from ppo_agent.chief import chief_step
+    from ppo_agent.models import Shared_grad_buffers, arena_of, create_model
+    cfg = dict(use_lstm=True, vae_device=0, device_num=0, vae_params="CoPM", measurement_dim=18,
+               num_output=dict(steer=33, throttle=3), command_num=4, weights_init="none")
+    _none, shared = create_model(cfg, load_vae=False)
+    arena_of(shared).load_numpy_state(synth.ppo_state(11))
+    worker, solo = make_agent(84, 84), make_agent(84, 84)
+    worker.update_model(shared)
+    assert torch.equal(worker.arena.params, arena_of(shared).params)
+    bufs = Shared_grad_buffers(shared, worker.device)
+    solo_bufs = Shared_grad_buffers(solo.model_dict, solo.device)
+    assert set(bufs.grads) == {"%s_%s_grad" % (m, n) for m, mod in shared.items() for n, _ in mod.named_parameters()}
+    r = np.random.RandomState(3)
+    B = 8
+    samp = []
+    for K in (33, 3):
+        samp.append((torch.from_numpy((r.standard_normal((8 * B, 530)) * 0.5).astype(np.float32)).cuda(),
+                     torch.from_numpy(r.randint(0, K, (B, 1))).cuda(),
+                     torch.from_numpy((0.3 * r.standard_normal((B, 1))).astype(np.float32)).cuda(),
+                     torch.from_numpy(r.standard_normal((B, 1)).astype(np.float32)).cuda(), torch.ones(B, 1).cuda(),
+                     torch.from_numpy((-np.log(K) + 0.2 * r.standard_normal((B, 1))).astype(np.float32)).cuda(),
+                     torch.from_numpy(r.standard_normal((B, 1)).astype(np.float32)).cuda(),
+                     [torch.zeros(B, 530).cuda(), torch.zeros(B, 530).cuda()],
+                     torch.from_numpy(r.randint(0, 4, (B, 1)).astype(np.int32)).cuda()))
+    opt = torch.optim.Adam([p for m in shared.values() for p in m.parameters()], lr=3e-4)
+    for _ in range(3):
+        l_w = worker.update_policy(samp[0], samp[1])
+        bufs.add_gradient(worker.model_dict)
+        chief_step(bufs, opt, 250.0)
+        worker.update_model(shared)
+        l_s = solo.update_policy(samp[0], samp[1])
+        solo_bufs.add_gradient(solo.model_dict)
+        chief_step(solo_bufs, None, 250.0)
+        assert l_w == l_s
+        assert torch.equal(worker.arena.params, solo.arena.params)
+    assert float(arena_of(shared).grads.abs().max()) == 0.0          # chief resets the shared buffers (chief.py:22)
