@@ -643,11 +643,18 @@ extern "C" int cadre_lstm_pointwise_fwd(float* gates, int64_t ldg, int64_t g_str
 
 __global__ void lstm_bwd_kernel(const float* gates, float* dgates, int64_t ldg, int64_t g_str, const float* dh,
                                 float* dc, int64_t d_str, const float* tanh_c, const float* c_prev,
-                                int64_t c_prev_str, int c_prev_div, int64_t ldh, int64_t h_str, int B, int Hd) {
+                                int64_t c_prev_str, int c_prev_div, int64_t ldh, int64_t h_str, int B, int Hd,
+                                const int32_t* commands, int C) {
   const int z = blockIdx.z;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * Hd) return;
   const int b = i / Hd, j = i % Hd;
+  if (commands && commands[(z / C) * B + b] != z % C) {      // row of another command net: exact zeros
+    float* dgz = dgates + z * g_str + (int64_t)b * ldg;
+    dgz[j] = 0.f; dgz[Hd + j] = 0.f; dgz[2 * Hd + j] = 0.f; dgz[3 * Hd + j] = 0.f;
+    dc[z * d_str + (int64_t)b * ldh + j] = 0.f;
+    return;
+  }
   const float* g = gates + z * g_str + (int64_t)b * ldg;
   float* dg = dgates + z * g_str + (int64_t)b * ldg;
   const int64_t o = z * h_str + (int64_t)b * ldh + j;
@@ -667,12 +674,13 @@ __global__ void lstm_bwd_kernel(const float* gates, float* dgates, int64_t ldg, 
 extern "C" int cadre_lstm_pointwise_bwd(const float* gates, float* dgates, int64_t ldg, int64_t g_str,
                                         const float* dh, float* dc, int64_t d_str, const float* tanh_c,
                                         const float* c_prev, int64_t c_prev_str, int32_t c_prev_div, int64_t ldh,
-                                        int64_t h_str, int32_t B, int32_t Hd, int32_t batch, void* stream) {
+                                        int64_t h_str, int32_t B, int32_t Hd, int32_t batch, const int32_t* commands,
+                                        int32_t C, void* stream) {
   FAIL_IF(!gates || !dgates || !dh || !dc || !tanh_c || !c_prev || B < 1 || Hd < 1 || batch < 1 || c_prev_div < 1,
           "cadre_lstm_pointwise_bwd: bad argument");
   dim3 grid((B * Hd + 255) / 256, 1, batch);
   hipLaunchKernelGGL(lstm_bwd_kernel, grid, dim3(256), 0, ST(stream), gates, dgates, ldg, g_str, dh, dc, d_str,
-                     tanh_c, c_prev, c_prev_str, c_prev_div, ldh, h_str, B, Hd);
+                     tanh_c, c_prev, c_prev_str, c_prev_div, ldh, h_str, B, Hd, commands, C < 1 ? 1 : C);
   return (int)hipGetLastError();
 }
 
@@ -704,14 +712,98 @@ extern "C" int cadre_colsum(const float* X, int64_t ldx, int64_t x_str, float* o
   return (int)hipGetLastError();
 }
 
-__global__ void relu_bwd_kernel(const float* act, float* dy, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    dy[i] = act[i] > 0.f ? dy[i] : 0.f;
+__global__ void relu_bwd_kernel(const float* act, float* dy, int64_t n, const int32_t* commands, int B, int hid, int C) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    bool keep = act[i] > 0.f;
+    if (commands) {                                  // [2Z][B][hid]: tower z = 2*net + t, net = head*C + c
+      const int64_t row = i / hid;
+      const int b = (int)(row % B), net = (int)(row / B) >> 1;
+      keep = keep && commands[(net / C) * B + b] == net % C;
+    }
+    dy[i] = keep ? dy[i] : 0.f;
+  }
 }
-extern "C" int cadre_relu_bwd(const float* act, float* dy, int64_t n, void* stream) {
-  FAIL_IF(!act || !dy || n < 1, "cadre_relu_bwd: bad argument");
+extern "C" int cadre_relu_bwd(const float* act, float* dy, int64_t n, const int32_t* commands, int32_t B, int32_t hid,
+                              int32_t C, void* stream) {
+  FAIL_IF(!act || !dy || n < 1 || (commands && (B < 1 || hid < 1 || C < 1)), "cadre_relu_bwd: bad argument");
   const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
-  hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks), dim3(256), 0, ST(stream), act, dy, n);
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks), dim3(256), 0, ST(stream), act, dy, n, commands, B, hid, C);
+  return (int)hipGetLastError();
+}
+
+// ============================================================================ rows sorted by command
+// One workgroup per head; stable counting sort (rank = earlier rows with the same command), so the
+// order inside a command — and with it every reduction order downstream — is deterministic.
+__global__ __launch_bounds__(256) void sort_rows_kernel(const int32_t* commands, int B, int C, int32_t* pos, int32_t* seg) {
+  extern __shared__ int32_t s_cmd[];
+  __shared__ int32_t s_cnt[16];
+  const int hd = blockIdx.x;
+  const int32_t* cmd = commands + hd * B;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) s_cmd[b] = cmd[b];
+  if (threadIdx.x < 16) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  if ((int)threadIdx.x < C) {
+    int n = 0;
+    for (int b = 0; b < B; ++b) n += s_cmd[b] == (int)threadIdx.x;
+    s_cnt[threadIdx.x] = n;
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const int c = s_cmd[b];
+    int off = 0, rank = 0;
+    for (int k = 0; k < c; ++k) off += s_cnt[k];
+    for (int k = 0; k < b; ++k) rank += s_cmd[k] == c;
+    pos[hd * B + b] = off + rank;
+  }
+  if ((int)threadIdx.x < C) {
+    int off = 0;
+    for (int k = 0; k < (int)threadIdx.x; ++k) off += s_cnt[k];
+    seg[2 * (hd * C + threadIdx.x)] = off;
+    seg[2 * (hd * C + threadIdx.x) + 1] = s_cnt[threadIdx.x];
+  }
+}
+extern "C" int cadre_sort_rows_by_command(const int32_t* commands, int32_t B, int32_t C, int32_t* pos, int32_t* seg,
+                                          void* stream) {
+  FAIL_IF(!commands || !pos || !seg || B < 1 || B > 8192 || C < 1 || C > 16, "cadre_sort_rows_by_command: bad argument");
+  hipLaunchKernelGGL(sort_rows_kernel, dim3(2), dim3(256), B * sizeof(int32_t), ST(stream), commands, B, C, pos, seg);
+  return (int)hipGetLastError();
+}
+
+__global__ void permute_minibatch_kernel(const int32_t* pos, int B, int S, const float* X, float* Xo, int64_t ldx,
+                                         const float* h0, const float* c0, float* h0o, float* c0o, int64_t ldh,
+                                         const int64_t* actions, const int32_t* commands, const float* old_values,
+                                         const float* returns, const float* old_logp, const float* adv,
+                                         int64_t* actions_o, int32_t* commands_o, float* old_values_o,
+                                         float* returns_o, float* old_logp_o, float* adv_o) {
+  const int b = blockIdx.x, s = blockIdx.y, d = pos[b];
+  if (s < S) {
+    const float4* src = reinterpret_cast<const float4*>(X + ((int64_t)s * B + b) * ldx);
+    float4* dst = reinterpret_cast<float4*>(Xo + ((int64_t)s * B + d) * ldx);
+    for (int i = threadIdx.x; i < ldx / 4; i += blockDim.x) dst[i] = src[i];
+    return;
+  }
+  for (int i = threadIdx.x; i < ldh; i += blockDim.x) {
+    h0o[(int64_t)d * ldh + i] = h0[(int64_t)b * ldh + i];
+    c0o[(int64_t)d * ldh + i] = c0[(int64_t)b * ldh + i];
+  }
+  if (threadIdx.x == 0) {
+    actions_o[d] = actions[b]; commands_o[d] = commands[b]; old_values_o[d] = old_values[b];
+    returns_o[d] = returns[b]; old_logp_o[d] = old_logp[b]; adv_o[d] = adv[b];
+  }
+}
+extern "C" int cadre_permute_minibatch(const int32_t* pos, int32_t B, int32_t S, const float* X, float* Xo, int64_t ldx,
+                                       const float* h0, const float* c0, float* h0o, float* c0o, int64_t ldh,
+                                       const int64_t* actions, const int32_t* commands, const float* old_values,
+                                       const float* returns, const float* old_logp, const float* adv,
+                                       int64_t* actions_o, int32_t* commands_o, float* old_values_o, float* returns_o,
+                                       float* old_logp_o, float* adv_o, void* stream) {
+  FAIL_IF(!pos || !X || !Xo || !h0 || !c0 || !h0o || !c0o || !actions || !commands || !old_values || !returns ||
+              !old_logp || !adv || !actions_o || !commands_o || !old_values_o || !returns_o || !old_logp_o || !adv_o ||
+              B < 1 || S < 1 || (ldx & 3),
+          "cadre_permute_minibatch: bad argument");
+  hipLaunchKernelGGL(permute_minibatch_kernel, dim3(B, S + 1), dim3(128), 0, ST(stream), pos, B, S, X, Xo, ldx, h0, c0,
+                     h0o, c0o, ldh, actions, commands, old_values, returns, old_logp, adv, actions_o, commands_o,
+                     old_values_o, returns_o, old_logp_o, adv_o);
   return (int)hipGetLastError();
 }
 
@@ -805,6 +897,10 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const float* logits, int6
   }
 }
 
+__global__ void zero_f32_kernel(float* p, int n) {
+  if ((int)threadIdx.x < n) p[threadIdx.x] = 0.f;
+}
+
 extern "C" int cadre_ppo_loss(const float* logits, int64_t ldl, int64_t l_ns, const float* values, int64_t ldv,
                               int64_t v_ns, const int64_t* actions, const int32_t* commands, const float* old_values, const float* returns,
                               const float* old_logp, const float* adv, int32_t B, int32_t n_out_steer,
@@ -815,8 +911,9 @@ extern "C" int cadre_ppo_loss(const float* logits, int64_t ldl, int64_t l_ns, co
               !dlogits || !dvalues || B < 1 || n_out_steer < 1 || n_out_steer > MAX_NOUT || n_out_throttle < 1 ||
               n_out_throttle > MAX_NOUT || ldl < n_out_steer || ldl < n_out_throttle,
           "cadre_ppo_loss: bad argument");
-  hipError_t e = hipMemsetAsync(losses, 0, 3 * sizeof(float), ST(stream));
-  if (e != hipSuccess) return (int)e;
+  // zeroed by a kernel, not hipMemsetAsync: a memset node captured into a hipGraph was observed to
+  // replay a 0xD3 byte pattern instead of 0 on ROCm 7.2 (second replay of the update graph)
+  hipLaunchKernelGGL(zero_f32_kernel, dim3(1), dim3(64), 0, ST(stream), losses, 3);
   hipLaunchKernelGGL(ppo_loss_kernel, dim3(2), dim3(256), 0, ST(stream), logits, ldl, l_ns, values, ldv, v_ns,
                      actions, commands,
                      old_values, returns, old_logp, adv, B, n_out_steer, n_out_throttle, clip, value_coeff,

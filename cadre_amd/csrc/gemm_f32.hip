@@ -22,7 +22,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-static_assert(sizeof(cadre_gemm_t) == 240, "cadre_gemm_t layout is part of the C ABI (ctypes mirror in cadre_amd/hip.py)");
+static_assert(sizeof(cadre_gemm_t) == 264, "cadre_gemm_t layout is part of the C ABI (ctypes mirror in cadre_amd/hip.py)");
 
 #define BK 32
 #define LDS_PITCH 36
@@ -61,8 +61,26 @@ __global__ __launch_bounds__(256, ((WM + WN) * 2 * 64 * 36 * 4 > 80 * 1024 ? 1 :
   const float* B = p.B + (int64_t)((z / p.b_div) % p.b_mod) * p.b_str;
   float* C = p.C + (int64_t)((z / p.c_div) % p.c_mod) * p.c_str;
 
+  // row segments (rows sorted by command): skip what this batch entry does not own
+  int seg_beg = 0, seg_cnt = 0;
+  if (p.seg_mode) {
+    const int32_t* sg = p.row_seg + 2 * (z / p.seg_div);
+    seg_beg = sg[0];
+    seg_cnt = sg[1];
+    if (p.seg_mode == 1) {
+      const int b_lo = m0 % p.seg_period;
+      if (seg_cnt <= 0 || b_lo + BM <= seg_beg || b_lo >= seg_beg + seg_cnt) return;
+    }
+  }
   const int nk_total = (p.K + BK - 1) / BK;
   int kt_begin = 0, kt_end = nk_total;
+  int k_per = 1, k_first = 0, k_run = 1;       // seg_mode 2: k-tiles [k_first, k_first+k_run) of each period
+  if (p.seg_mode == 2) {
+    k_per = p.seg_period / BK;
+    k_first = seg_beg / BK;
+    k_run = seg_cnt > 0 ? (seg_beg + seg_cnt + BK - 1) / BK - k_first : 0;
+    kt_end = (nk_total / k_per) * k_run;
+  }
   if (p.split_k > 1) {
     const int per = (nk_total + p.split_k - 1) / p.split_k;
     kt_begin = blockIdx.y * per;
@@ -149,7 +167,8 @@ __global__ __launch_bounds__(256, ((WM + WN) * 2 * 64 * 36 * 4 > 80 * 1024 ? 1 :
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
   };
 
-  auto load_tiles = [&](int kt) {
+  auto load_tiles = [&](int kt_) {
+    const int kt = p.seg_mode == 2 ? (kt_ / k_run) * k_per + k_first + kt_ % k_run : kt_;
     const int k0 = kt * BK;
     // ---- A
     if constexpr (AMODE == 0) {
@@ -463,9 +482,16 @@ extern "C" int cadre_gemm_f32(const cadre_gemm_t* pp, void* stream) {
   if (p.s_mod < 1) p.s_mod = 1 << 30;
   if (p.r_mod < 1) p.r_mod = 1 << 30;
   GEMM_CHECK(p.split_k == 1 || p.batch == 1 || p.c_str >= (int64_t)p.M * p.ldc, "batched split_k needs c_str >= M*ldc");
+  if (p.seg_mode) {
+    GEMM_CHECK(p.row_seg && p.seg_period > 0 && p.seg_div > 0 && (p.seg_mode == 1 || p.seg_mode == 2), "bad row segment fields");
+    if (p.seg_mode == 1) GEMM_CHECK(p.seg_period % 64 == 0 && p.M % p.seg_period == 0, "seg_mode 1 needs seg_period%64==0, M%seg_period==0");
+    if (p.seg_mode == 2) GEMM_CHECK(p.seg_period % 32 == 0 && p.K % p.seg_period == 0 && p.split_k == 1 && p.a_mode == 1 && p.b_mode == 1,
+                                    "seg_mode 2 needs k-major operands, seg_period%32==0, K%seg_period==0");
+  }
   if (p.flags & 2)
     GEMM_CHECK(p.batch == 1 && p.split_k == 1 && ((p.N | p.ldc) & 3) == 0 && !p.resid, "bf16 output needs the vector epilogue, no batch/split/resid");
-  const int tile = p.tile ? p.tile : pick_tile(p);
+  int tile = p.tile ? p.tile : pick_tile(p);
+  if (p.seg_mode == 1 && (p.seg_period % 128) != 0 && tile != 3) tile = 3;     // the M tile must divide the period
   hipStream_t st = (hipStream_t)stream;
   dim3 block(256);
   if (tile < 1 || tile > 6) return cadre_fail("cadre_gemm_f32: bad tile");

@@ -26,7 +26,8 @@ class GemmDesc(C.Structure):
                 ("s_div", i32), ("s_mod", i32), ("r_div", i32), ("r_mod", i32),
                 ("a_str", i64), ("b_str", i64), ("c_str", i64), ("s_str", i64), ("r_str", i64),
                 ("H", i32), ("W", i32), ("Cin", i32), ("Ho", i32), ("Wo", i32), ("KH", i32), ("KW", i32),
-                ("stride", i32), ("pad", i32), ("split_k", i32), ("tile", i32), ("flags", i32)]
+                ("stride", i32), ("pad", i32), ("split_k", i32), ("tile", i32), ("flags", i32), ("seg_mode", i32),
+                ("row_seg", vp), ("seg_period", i32), ("seg_div", i32)]
 
 
 # name -> argtypes (restype is int unless noted); must list every symbol of include/cadre_hip.h
@@ -52,9 +53,11 @@ SYMBOLS = {
     "cadre_gather_minibatch": [vp, i64, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32,
                                vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp],
     "cadre_lstm_pointwise_fwd": [vp, i64, i64, vp, i64, i32, vp, vp, vp, i64, i64, i32, i32, i32, vp],
-    "cadre_lstm_pointwise_bwd": [vp, vp, i64, i64, vp, vp, i64, vp, vp, i64, i32, i64, i64, i32, i32, i32, vp],
+    "cadre_lstm_pointwise_bwd": [vp, vp, i64, i64, vp, vp, i64, vp, vp, i64, i32, i64, i64, i32, i32, i32, vp, i32, vp],
     "cadre_colsum": [vp, i64, i64, vp, i64, i32, i32, i32, i32, vp],
-    "cadre_relu_bwd": [vp, vp, i64, vp],
+    "cadre_relu_bwd": [vp, vp, i64, vp, i32, i32, i32, vp],
+    "cadre_sort_rows_by_command": [vp, i32, i32, vp, vp, vp],
+    "cadre_permute_minibatch": [vp, i32, i32, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "cadre_ppo_loss": [vp, i64, i64, vp, i64, i64, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, f32, vp, vp, vp, vp],
     "cadre_sample": [vp, i64, vp, i64, i32, i32, vp, vp, vp],
     "cadre_categorical_eval": [vp, i64, vp, i32, i32, vp, vp, vp],
@@ -80,7 +83,7 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = args
             fn.restype = C.c_char_p if name == "cadre_last_error" else C.c_int
-        if L.cadre_abi_version() != 1:
+        if L.cadre_abi_version() != 2:
             raise CadreHipError("libcadre_hip.so ABI version mismatch")
         _lib = L
     return _lib
@@ -111,7 +114,7 @@ PROFILE = None
 
 def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, scale=None, shift=None, resid=None, ldr=0,
          act=0, slope=0.01, batch=1, a_z=(1, 0, 0), b_z=(1, 0, 0), c_z=(1, 0, 0), s_z=(1, 0, 0), r_z=(1, 0, 0),
-         conv=None, split_k=1, tile=0, bf16=False, flags=0):
+         conv=None, split_k=1, tile=0, bf16=False, flags=0, seg=None):
     """C = act((A . B^T) * scale + shift + resid).  *_z = (div, mod, stride) batch addressing.
     bf16=True: A/B are bfloat16 tensors (cadre_gemm_bf16); flags bit1/bit2: C / resid are bf16."""
     d = GemmDesc()
@@ -125,6 +128,9 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, scale=None, shi
         d.H, d.W, d.Cin, d.Ho, d.Wo, d.KH, d.KW, d.stride, d.pad = conv
     d.split_k, d.tile = split_k, tile
     d.flags = flags
+    if seg is not None:                  # (mode, row_seg tensor, period, div)
+        d.seg_mode, d.seg_period, d.seg_div = seg[0], seg[2], seg[3]
+        d.row_seg = ptr(seg[1])
     fn = lib().cadre_gemm_bf16 if bf16 else lib().cadre_gemm_f32
     if PROFILE is None or bf16:
         check(fn(C.byref(d), stream()), "cadre_gemm_bf16" if bf16 else "cadre_gemm_f32")

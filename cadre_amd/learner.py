@@ -19,6 +19,12 @@ from . import hip
 
 class PPOLearnerHIP:
     SPLIT_DH = 8
+    SORT_MIN_B = 128
+
+    def sorted_rows(self, B):
+        """Row-sorted update (rows of a minibatch grouped by command, GEMM tiles a command net does not
+        own are skipped) pays when the update is MFMA-bound: minibatches >= 128 rows per head."""
+        return self.use_sorted and B >= self.SORT_MIN_B and B % 64 == 0
 
     def __init__(self, arena, clip=0.1, value_coeff=0.1, clip_coeff=1.0, ent_coeff=0.01, seq_length=8):
         self.a = arena
@@ -27,6 +33,7 @@ class PPOLearnerHIP:
         self._ws = {}
         self._graphs = {}
         self.use_graphs = os.environ.get("CADRE_HIP_GRAPHS", "1") != "0"
+        self.use_sorted = os.environ.get("CADRE_SORTED_UPDATE", "1") != "0"
         hip.lib()
 
     # ------------------------------------------------------------------ workspace
@@ -49,12 +56,17 @@ class PPOLearnerHIP:
                 actions=z(2, B, dtype=torch.int64), commands=z(2, B, dtype=torch.int32),
                 old_values=z(2, B), returns=z(2, B), old_logp=z(2, B), adv=z(2, B),
                 losses=z(3),
+                pos=z(2, B, dtype=torch.int32), seg=z(2 * a.C, 2, dtype=torch.int32),
             )
+            if self.sorted_rows(B) and Z == a.Z:      # unsorted staging for gather -> sort -> permute
+                w.update(Xu=z(2, S, B, a.DP), h0u=z(2, B, a.DP), c0u=z(2, B, a.DP),
+                         actions_u=z(2, B, dtype=torch.int64), commands_u=z(2, B, dtype=torch.int32),
+                         old_values_u=z(2, B), returns_u=z(2, B), old_logp_u=z(2, B), adv_u=z(2, B))
             self._ws[key] = w
         return w
 
     # ------------------------------------------------------------------ forward
-    def _forward(self, w, B, nets, x_div, S=None, mlp=True):
+    def _forward(self, w, B, nets, x_div, S=None, mlp=True, seg=None):
         """LSTM (S steps) + (optionally) both MLP towers for `Z` nets.  nets = (g0, g_stride, Z): arena net
         indices g0 + i*g_stride.  Net i reads inputs X[i // x_div], h0/c0[i // x_div]."""
         a = self.a
@@ -70,20 +82,21 @@ class PPOLearnerHIP:
         Hs.view(-1, x_div, S + 1, B, DP)[:, :, 0].copy_(w["h0"][:Z // x_div].unsqueeze(1))
         Cs.view(-1, x_div, S + 1, B, DP)[:, :, 0].copy_(w["c0"][:Z // x_div].unsqueeze(1))
         # all input projections x_t W_ih^T + b_ih: one GEMM [S*B, DP] x [DP, H4] per net
+        sg1 = None if seg is None else (1, seg, B, 1)
         hip.gemm(X, pL[a.o_wih:], G, S * B, H4, DP, DP, DP, H4, shift=pL[a.o_bih:], batch=Z,
-                 a_z=(x_div, 0, S * B * DP), b_z=(1, 0, sL), c_z=(1, 0, S * B * H4), s_z=(1, 0, sL))
+                 a_z=(x_div, 0, S * B * DP), b_z=(1, 0, sL), c_z=(1, 0, S * B * H4), s_z=(1, 0, sL), seg=sg1)
         for t in range(S):                                          # models.py:148-151
             Gt = G[:, t]
             hip.gemm(Hs[:, t], pL[a.o_whh:], Gt, B, H4, DP, DP, DP, H4, shift=pL[a.o_bhh:], resid=Gt, ldr=H4,
                      batch=Z, a_z=(1, 0, (S + 1) * B * DP), b_z=(1, 0, sL), c_z=(1, 0, S * B * H4),
-                     s_z=(1, 0, sL), r_z=(1, 0, S * B * H4))
+                     s_z=(1, 0, sL), r_z=(1, 0, S * B * H4), seg=sg1)
             hip.check(L.cadre_lstm_pointwise_fwd(hip.ptr(Gt), H4, S * B * H4, hip.ptr(Cs[:, t]), (S + 1) * B * DP, 1,
                                                  hip.ptr(Cs[:, t + 1]), hip.ptr(Hs[:, t + 1]), hip.ptr(TC[:, t + 1]),
                                                  DP, (S + 1) * B * DP, B, a.D, Z, st), "cadre_lstm_pointwise_fwd")
         if mlp:
-            self._mlp(w, B, nets, Hs[:, S], (S + 1) * B * DP)
+            self._mlp(w, B, nets, Hs[:, S], (S + 1) * B * DP, seg=seg)
 
-    def _mlp(self, w, B, nets, inp, inp_zstride):
+    def _mlp(self, w, B, nets, inp, inp_zstride, seg=None):
         """actor (tower 0) + critic (tower 1) of each net on `inp` ([Z][B][DP] rows, net stride
         inp_zstride): z = 2*i + tower  (models.py:171-177, distributions.py:34-40)."""
         a = self.a
@@ -98,31 +111,32 @@ class PPOLearnerHIP:
                 pw, zb, nb, div, zs, cs = pP, 0, 2 * Z, 2, a.size_T, 1
             else:       # strided nets (act/get_value): one launch per tower
                 pw, zb, nb, div, zs, cs = pP[tower * a.size_T:], tower, Z, 1, gs * a.size_P, 2
+            sg = None if (seg is None or not sT) else (1, seg, B, 2)      # z = 2*net + tower
             hip.gemm(inp, pw[a.t_w1:], A1[zb:], B, hid, DP, DP, DP, hid, shift=pw[a.t_b1:], act=1, batch=nb,
-                     a_z=(div, 0, inp_zstride), b_z=(1, 0, zs), c_z=(1, 0, cs * B * hid), s_z=(1, 0, zs))
+                     a_z=(div, 0, inp_zstride), b_z=(1, 0, zs), c_z=(1, 0, cs * B * hid), s_z=(1, 0, zs), seg=sg)
             hip.gemm(A1[zb:], pw[a.t_w2:], A2[zb:], B, hid, hid, hid, hid, hid, shift=pw[a.t_b2:], act=1, batch=nb,
-                     a_z=(1, 0, cs * B * hid), b_z=(1, 0, zs), c_z=(1, 0, cs * B * hid), s_z=(1, 0, zs))
+                     a_z=(1, 0, cs * B * hid), b_z=(1, 0, zs), c_z=(1, 0, cs * B * hid), s_z=(1, 0, zs), seg=sg)
             hip.gemm(A2[zb:], pw[a.t_w3:], O3[zb:], B, NP, hid, hid, hid, NP, shift=pw[a.t_b3:], batch=nb,
-                     a_z=(1, 0, cs * B * hid), b_z=(1, 0, zs), c_z=(1, 0, cs * B * NP), s_z=(1, 0, zs))
+                     a_z=(1, 0, cs * B * hid), b_z=(1, 0, zs), c_z=(1, 0, cs * B * NP), s_z=(1, 0, zs), seg=sg)
 
     # ------------------------------------------------------------------ update_policy
-    def update(self, B, inv_b):
+    def update(self, B, inv_b, sorted_rows=False):
         """Forward + loss + backward for the packed minibatch in workspace(B).  Gradients of all 16
         nets are written (not accumulated) into arena.grads.  Returns the device tensor
         losses[3] = (value_loss*vc, action_loss*cc, ent_loss*ec) (agent.py:226-237).
         The ~60-launch sequence has fixed shapes and pointers, so after one eager run it is captured
         into a hipGraph per (B, inv_b) and replayed (launch-bound otherwise: ~2 ms of host time)."""
         if not self.use_graphs:
-            return self._update_body(B, inv_b)
-        key = (B, inv_b)
+            return self._update_body(B, inv_b, sorted_rows)
+        key = (B, inv_b, sorted_rows)
         g = self._graphs.get(key)
         if g is None:
-            out = self._update_body(B, inv_b)              # eager warm-up (func attributes, lazy init)
+            out = self._update_body(B, inv_b, sorted_rows)  # eager warm-up (func attributes, lazy init)
             if self._graphs.get(("warm",) + key):
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    self._update_body(B, inv_b)
+                    self._update_body(B, inv_b, sorted_rows)
                 self._graphs[key] = g
             else:
                 self._graphs[("warm",) + key] = True
@@ -130,13 +144,19 @@ class PPOLearnerHIP:
         g.replay()
         return self.workspace(B)["losses"]
 
-    def _update_body(self, B, inv_b):
+    def _update_body(self, B, inv_b, sorted_rows=False):
         a, S = self.a, self.S
         w = self.workspace(B)
         Z, C = a.Z, a.C
         L, st = hip.lib(), hip.stream()
         DP, H4, hid, NP = a.DP, a.H4, a.hid, a.NP
-        self._forward(w, B, (0, 1, Z), C)
+        seg = w["seg"] if sorted_rows else None         # rows sorted by command: skip tiles a net does not own
+        cmd = hip.ptr(w["commands"]) if sorted_rows else None
+        sgM1 = None if seg is None else (1, seg, B, 1)  # M tiles, z = net
+        sgM2 = None if seg is None else (1, seg, B, 2)  # M tiles, z = 2*net + tower
+        sgK1 = None if seg is None else (2, seg, B, 1)  # k tiles (rows), z = net
+        sgK2 = None if seg is None else (2, seg, B, 2)
+        self._forward(w, B, (0, 1, Z), C, seg=seg)
         O3, dO3 = w["O3"], w["dO3"]
         hip.check(L.cadre_ppo_loss(hip.ptr(O3), NP, 2 * B * NP, hip.ptr(O3[1]), NP, 2 * B * NP,
                                    hip.ptr(w["actions"]), hip.ptr(w["commands"]), hip.ptr(w["old_values"]),
@@ -154,23 +174,23 @@ class PPOLearnerHIP:
         def layer_bwd(dY, n_y, Xin, ldx_, n_x, x_z, o_w, o_b, dX):
             # dW = dY^T X ; db = colsum(dY) ; dX = dY W
             hip.gemm(dY, Xin, gP[o_w:], n_y, n_x, B, n_y, ldx_, n_x, a_mode=1, b_mode=1, batch=nb,
-                     a_z=(1, 0, B * n_y), b_z=x_z, c_z=zT)
+                     a_z=(1, 0, B * n_y), b_z=x_z, c_z=zT, seg=sgK2)
             hip.check(L.cadre_colsum(hip.ptr(dY), n_y, B * n_y, hip.ptr(gP[o_b:]), sT, B, n_y, nb, 0, st), "cadre_colsum")
             if dX is not None:
                 hip.gemm(dY, pP[o_w:], dX, B, n_x, n_y, n_y, n_x, n_x, b_mode=1, batch=nb,
-                         a_z=(1, 0, B * n_y), b_z=zT, c_z=(1, 0, B * n_x))
+                         a_z=(1, 0, B * n_y), b_z=zT, c_z=(1, 0, B * n_x), seg=sgM2)
 
         layer_bwd(dO3, NP, A2, hid, hid, (1, 0, B * hid), a.t_w3, a.t_b3, dA2)
-        hip.check(L.cadre_relu_bwd(hip.ptr(A2), hip.ptr(dA2), nb * B * hid, st), "cadre_relu_bwd")
+        hip.check(L.cadre_relu_bwd(hip.ptr(A2), hip.ptr(dA2), nb * B * hid, cmd, B, hid, C, st), "cadre_relu_bwd")
         layer_bwd(dA2, hid, A1, hid, hid, (1, 0, B * hid), a.t_w2, a.t_b2, dA1)
-        hip.check(L.cadre_relu_bwd(hip.ptr(A1), hip.ptr(dA1), nb * B * hid, st), "cadre_relu_bwd")
+        hip.check(L.cadre_relu_bwd(hip.ptr(A1), hip.ptr(dA1), nb * B * hid, cmd, B, hid, C, st), "cadre_relu_bwd")
         layer_bwd(dA1, hid, Hs[:, S], DP, DP, (2, 0, (S + 1) * B * DP), a.t_w1, a.t_b1, None)
         # dh_S = dZ1_actor W1_actor + dZ1_critic W1_critic   (two launches, second accumulates)
         dH, dC = w["dH"], w["dC"]
         for tower in (0, 1):
             hip.gemm(dA1[tower:], pP[tower * sT + a.t_w1:], dH, B, DP, hid, hid, DP, DP, b_mode=1, batch=Z,
                      a_z=(1, 0, 2 * B * hid), b_z=(1, 0, a.size_P), c_z=(1, 0, B * DP),
-                     resid=dH if tower else None, ldr=DP, r_z=(1, 0, B * DP))
+                     resid=dH if tower else None, ldr=DP, r_z=(1, 0, B * DP), seg=sgM1)
         # ---------------- backward through time (autograd of models.py:148-151)
         dC.zero_()
         G, dG, Cs, TC, X = w["G"], w["dG"], w["Cs"], w["TC"], w["X"]
@@ -178,18 +198,18 @@ class PPOLearnerHIP:
         for t in range(S - 1, -1, -1):
             hip.check(L.cadre_lstm_pointwise_bwd(hip.ptr(G[:, t]), hip.ptr(dG[:, t]), H4, S * B * H4, hip.ptr(dH),
                                                  hip.ptr(dC), B * DP, hip.ptr(TC[:, t + 1]), hip.ptr(Cs[:, t]),
-                                                 (S + 1) * B * DP, 1, DP, (S + 1) * B * DP, B, a.D, Z, st),
+                                                 (S + 1) * B * DP, 1, DP, (S + 1) * B * DP, B, a.D, Z, cmd, C, st),
                       "cadre_lstm_pointwise_bwd")
             if t > 0:   # dh_{t-1} = dG_t W_hh : tiny output, K = 2120 -> split-K so >500 workgroups stream W_hh
                 hip.gemm(dG[:, t], pL[a.o_whh:], w["dHs"], B, DP, H4, H4, DP, DP, b_mode=1, batch=Z,
-                         a_z=(1, 0, S * B * H4), b_z=(1, 0, sL), c_z=(1, 0, B * DP), split_k=self.SPLIT_DH)
+                         a_z=(1, 0, S * B * H4), b_z=(1, 0, sL), c_z=(1, 0, B * DP), split_k=self.SPLIT_DH, seg=sgM1)
                 hip.check(L.cadre_splitk_reduce(hip.ptr(w["dHs"]), self.SPLIT_DH, Z * B * DP, DP, hip.ptr(dH), DP,
                                                 Z * B, DP, None, None, 0, 0.0, st), "cadre_splitk_reduce")
         # dW_hh = sum_t dG_t^T h_{t-1} ; dW_ih = sum_t dG_t^T x_t ; db_ih = db_hh = colsum(dG)
         hip.gemm(dG, Hs, gL[a.o_whh:], H4, DP, S * B, H4, DP, DP, a_mode=1, b_mode=1, batch=Z,
-                 a_z=(1, 0, S * B * H4), b_z=(1, 0, (S + 1) * B * DP), c_z=(1, 0, sL))
+                 a_z=(1, 0, S * B * H4), b_z=(1, 0, (S + 1) * B * DP), c_z=(1, 0, sL), seg=sgK1)
         hip.gemm(dG, X, gL[a.o_wih:], H4, DP, S * B, H4, DP, DP, a_mode=1, b_mode=1, batch=Z,
-                 a_z=(1, 0, S * B * H4), b_z=(C, 0, S * B * DP), c_z=(1, 0, sL))
+                 a_z=(1, 0, S * B * H4), b_z=(C, 0, S * B * DP), c_z=(1, 0, sL), seg=sgK1)
         hip.check(L.cadre_colsum(hip.ptr(dG), H4, S * B * H4, hip.ptr(gL[a.o_bih:]), sL, S * B, H4, Z, 0, st),
                   "cadre_colsum")
         # b_ih and b_hh enter the gates as a sum: identical gradients (strided arena views, one copy)

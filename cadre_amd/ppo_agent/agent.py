@@ -170,6 +170,9 @@ class CadreAgent(object):
         w = self.learner.workspace(B)
         L, st = hip.lib(), hip.stream()
         a = self.arena
+        srt = self.learner.sorted_rows(B)
+        u = "_u" if srt else ""                       # sorted mode: gather into staging, then sort + permute
+        Xk, hk, ck = ("Xu", "h0u", "c0u") if srt else ("X", "h0", "c0")
         for wi, (ss, si, sa, ts, ti, ta) in enumerate(batches):
             for hd, (stor, idx, adv) in enumerate(((ss, si, sa), (ts, ti, ta))):
                 idx_d = idx.to(self.device, non_blocking=True)
@@ -177,11 +180,23 @@ class CadreAgent(object):
                     hip.ptr(stor._obs), stor._ldo, stor.seq_length, hip.ptr(stor._hn), hip.ptr(stor._cn), stor._ldh,
                     hip.ptr(stor.action), hip.ptr(stor.value_preds), hip.ptr(stor.returns),
                     hip.ptr(stor.action_log_probs), hip.ptr(stor.command), hip.ptr(adv), hip.ptr(idx_d), Bw, a.D, a.D,
-                    B, wi * Bw, hip.ptr(w["X"][hd]), a.DP, hip.ptr(w["h0"][hd]), hip.ptr(w["c0"][hd]), a.DP,
+                    B, wi * Bw, hip.ptr(w[Xk][hd]), a.DP, hip.ptr(w[hk][hd]), hip.ptr(w[ck][hd]), a.DP,
+                    hip.ptr(w["actions" + u][hd]), hip.ptr(w["commands" + u][hd]), hip.ptr(w["old_values" + u][hd]),
+                    hip.ptr(w["returns" + u][hd]), hip.ptr(w["old_logp" + u][hd]), hip.ptr(w["adv" + u][hd]), st),
+                    "cadre_gather_minibatch")
+        if srt:
+            hip.check(L.cadre_sort_rows_by_command(hip.ptr(w["commands_u"]), B, a.C, hip.ptr(w["pos"]), hip.ptr(w["seg"]),
+                                                   st), "cadre_sort_rows_by_command")
+            for hd in (0, 1):
+                hip.check(L.cadre_permute_minibatch(
+                    hip.ptr(w["pos"][hd]), B, self.learner.S, hip.ptr(w["Xu"][hd]), hip.ptr(w["X"][hd]), a.DP,
+                    hip.ptr(w["h0u"][hd]), hip.ptr(w["c0u"][hd]), hip.ptr(w["h0"][hd]), hip.ptr(w["c0"][hd]), a.DP,
+                    hip.ptr(w["actions_u"][hd]), hip.ptr(w["commands_u"][hd]), hip.ptr(w["old_values_u"][hd]),
+                    hip.ptr(w["returns_u"][hd]), hip.ptr(w["old_logp_u"][hd]), hip.ptr(w["adv_u"][hd]),
                     hip.ptr(w["actions"][hd]), hip.ptr(w["commands"][hd]), hip.ptr(w["old_values"][hd]),
                     hip.ptr(w["returns"][hd]), hip.ptr(w["old_logp"][hd]), hip.ptr(w["adv"][hd]), st),
-                    "cadre_gather_minibatch")
-        losses = self.learner.update(B, float(nW) / B)
+                    "cadre_permute_minibatch")
+        losses = self.learner.update(B, float(nW) / B, sorted_rows=srt)
         self.arena.attach_grads(self.model_dict)
         if sync:
             return tuple(losses.tolist())

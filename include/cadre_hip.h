@@ -15,7 +15,7 @@
 extern "C" {
 #endif
 
-#define CADRE_ABI_VERSION 1
+#define CADRE_ABI_VERSION 2
 int cadre_abi_version(void);
 /* human-readable last argument error of the calling thread ("" if none) */
 const char* cadre_last_error(void);
@@ -57,6 +57,16 @@ typedef struct {
                           7 = 256x256 on 8 waves (cadre_gemm_bf16 only)                  */
   int32_t flags;       /* bit 1: C is bf16; bit 2: resid is bf16 (cadre_gemm_bf16; bit 1 also
                           honoured by cadre_gemm_f32's vector epilogue); others must be 0   */
+  /* Row segments (cadre_gemm_f32 only; PPO update with the minibatch rows sorted by command,
+     agent.py:170-182 evaluates every command net on every row and masks 3 of 4): batch entry z
+     owns rows [row_seg[2*(z/seg_div)], +row_seg[2*(z/seg_div)+1]) of every period of
+     `seg_period` rows.  seg_mode 1: M-tiles that own no row of their period return without
+     writing; seg_mode 2: k-tiles (k = row index, K % seg_period == 0) outside the segment are
+     not multiplied.  Rows of other nets inside a computed tile are still multiplied — callers
+     keep their gradients exactly zero (cadre_relu_bwd / cadre_lstm_pointwise_bwd masks).   */
+  int32_t seg_mode;    /* 0 off                                                               */
+  const int32_t* row_seg;
+  int32_t seg_period, seg_div;
 } cadre_gemm_t;
 int cadre_gemm_f32(const cadre_gemm_t* p, void* stream);
 /* the tile id cadre_gemm_f32 would use for this descriptor (p->tile, or the auto choice) */
@@ -154,12 +164,30 @@ int cadre_lstm_pointwise_bwd(const float* gates, float* dgates, int64_t ldg, int
                              const float* dh, float* dc, int64_t d_str, const float* tanh_c,
                              const float* c_prev,
                              int64_t c_prev_str, int32_t c_prev_div, int64_t ldh, int64_t h_str,
-                             int32_t B, int32_t Hd, int32_t batch, void* stream);
+                             int32_t B, int32_t Hd, int32_t batch, const int32_t* commands, int32_t C,
+                             void* stream);
+/* (commands != NULL: net z = head*C + c only keeps rows whose command is c; the other rows get
+ * dgates = 0 and dc = 0 whatever dh holds — see cadre_gemm_t.seg_mode.) */
 /* column sums: out[z][n] (+)= sum_m X[z][m][n]  (bias gradients) */
 int cadre_colsum(const float* X, int64_t ldx, int64_t x_str, float* out, int64_t o_str,
                  int32_t M, int32_t N, int32_t batch, int32_t accumulate, void* stream);
-/* y = relu'(act) * dy elementwise ([rows][ld], batch), in place on dy */
-int cadre_relu_bwd(const float* act, float* dy, int64_t n, void* stream);
+/* y = relu'(act) * dy elementwise, in place on dy.  Optional ownership mask (commands != NULL): the
+ * buffers are [2*Z][B][hid] (tower z = 2*net + t, net = head*C + c); rows whose command differs from
+ * the net's c are set to exactly 0. */
+int cadre_relu_bwd(const float* act, float* dy, int64_t n, const int32_t* commands, int32_t B,
+                   int32_t hid, int32_t C, void* stream);
+/* Stable sort of each head's B minibatch rows by command: pos[hd][b] = sorted position of row b,
+ * seg[hd*C + c] = (begin, count) of command c.  commands/pos are [2][B] i32, seg is [2*C][2] i32. */
+int cadre_sort_rows_by_command(const int32_t* commands, int32_t B, int32_t C, int32_t* pos, int32_t* seg,
+                               void* stream);
+/* Apply pos to one head's packed minibatch (cadre_gather_minibatch outputs): dst row pos[b] = src row b
+ * for X [S][B][ldx], h0/c0 [B][ldh] and the six per-row scalars. */
+int cadre_permute_minibatch(const int32_t* pos, int32_t B, int32_t S, const float* X, float* Xo, int64_t ldx,
+                            const float* h0, const float* c0, float* h0o, float* c0o, int64_t ldh,
+                            const int64_t* actions, const int32_t* commands, const float* old_values,
+                            const float* returns, const float* old_logp, const float* adv, int64_t* actions_o,
+                            int32_t* commands_o, float* old_values_o, float* returns_o, float* old_logp_o,
+                            float* adv_o, void* stream);
 
 /* ---------------------------------------------------------------- policy head + PPO loss
  * Replaces Model.evaluate_actions (models.py:199-208), Categorical_1d (distributions.py:

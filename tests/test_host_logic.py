@@ -20,8 +20,8 @@ def test_cabi_exports_every_declared_symbol():
     L = ctypes.CDLL(hip.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert hip.lib().cadre_abi_version() == 1
-    assert ctypes.sizeof(hip.GemmDesc) == 240      # static_assert-ed in gemm_f32.hip
+    assert hip.lib().cadre_abi_version() == 2
+    assert ctypes.sizeof(hip.GemmDesc) == 264      # static_assert-ed in gemm_f32.hip
 
 
 def test_no_cpu_fallback():

@@ -266,7 +266,7 @@ def test_lstm_pointwise_fwd_bwd(hip):
     dG = torch.zeros(Z, B, ldg, device="cuda")
     hip.check(L.cadre_lstm_pointwise_bwd(Gd.data_ptr(), dG.data_ptr(), ldg, B * ldg, dhd.data_ptr(), dcd.data_ptr(),
                                          B * ldh, tcd.data_ptr(), c0d.data_ptr(), B * ldh, 4, ldh, B * ldh, B, Hd, Z,
-                                         hip.stream()), "lb")
+                                         None, 4, hip.stream()), "lb")
     # Gr.grad accumulated both backward calls: second call's contribution = full; subtract first
     Gr2 = G.clone().requires_grad_(True); c0r2 = c0.clone().requires_grad_(True)
     i, f, gg, o = Gr2.chunk(4, -1)
@@ -287,7 +287,7 @@ def test_colsum_relu_bwd(hip):
     assert rel(out, X.sum(1) + 1) < 1e-5
     a = torch.randn(1000); dy = torch.randn(1000); dyd = dev(dy.clone())
     ad = dev(a)
-    hip.check(hip.lib().cadre_relu_bwd(ad.data_ptr(), dyd.data_ptr(), 1000, hip.stream()), "relu_bwd")
+    hip.check(hip.lib().cadre_relu_bwd(ad.data_ptr(), dyd.data_ptr(), 1000, None, 0, 0, 0, hip.stream()), "relu_bwd")
     assert torch.equal(dyd.cpu(), dy * (a > 0))
 
 
@@ -441,3 +441,71 @@ def test_f32_stem_bf16_output_and_bf16_pool(hip):
     p = torch.empty(2, want.shape[2], want.shape[3], 64, device="cuda", dtype=torch.bfloat16)
     hip.check(hip.lib().cadre_maxpool3x3s2_bf16(out.data_ptr(), p.data_ptr(), 2, Ho, Wo, 64, hip.stream()), "pool")
     assert torch.equal(p.float().permute(0, 3, 1, 2).cpu(), want.cpu())
+
+
+# ----------------------------------------------------------------------------- row-sorted update support
+def test_sort_rows_and_permute(hip):
+    g = torch.Generator().manual_seed(12)
+    B, C, S, ld = 96, 4, 3, 16
+    cmds = torch.randint(0, C, (2, B), generator=g, dtype=torch.int32)
+    cmds[1, :50] = 3
+    cd = dev(cmds); pos = torch.empty(2, B, dtype=torch.int32, device="cuda"); seg = torch.empty(2 * C, 2, dtype=torch.int32, device="cuda")
+    L = hip.lib()
+    hip.check(L.cadre_sort_rows_by_command(cd.data_ptr(), B, C, pos.data_ptr(), seg.data_ptr(), hip.stream()), "sort")
+    for hd in range(2):
+        order = torch.sort(cmds[hd], stable=True).indices            # order[d] = source row of sorted slot d
+        want_pos = torch.empty(B, dtype=torch.int64); want_pos[order] = torch.arange(B)
+        assert torch.equal(pos[hd].cpu().long(), want_pos)
+        cnt = torch.bincount(cmds[hd].long(), minlength=C)
+        off = torch.cumsum(cnt, 0) - cnt
+        assert torch.equal(seg[hd * C:(hd + 1) * C].cpu().long(), torch.stack([off, cnt], 1))
+    X = torch.randn(S, B, ld, generator=g); h0 = torch.randn(B, ld, generator=g); c0 = torch.randn(B, ld, generator=g)
+    sc = [torch.randint(0, 9, (B,), generator=g), cmds[0].clone(), torch.randn(B, generator=g), torch.randn(B, generator=g),
+          torch.randn(B, generator=g), torch.randn(B, generator=g)]
+    ins = [dev(t) for t in [X, h0, c0] + sc]
+    outs = [torch.zeros_like(t) for t in ins]
+    hip.check(L.cadre_permute_minibatch(pos[0].data_ptr(), B, S, ins[0].data_ptr(), outs[0].data_ptr(), ld,
+                                        ins[1].data_ptr(), ins[2].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), ld,
+                                        *[t.data_ptr() for t in ins[3:]], *[t.data_ptr() for t in outs[3:]], hip.stream()),
+              "permute")
+    order = torch.sort(cmds[0], stable=True).indices
+    assert torch.equal(outs[0].cpu(), X[:, order]) and torch.equal(outs[1].cpu(), h0[order])
+    assert torch.equal(outs[4].cpu(), cmds[0][order]) and torch.equal(outs[8].cpu(), sc[5][order])
+
+
+def test_gemm_row_segments(hip):
+    """seg_mode 1: only M tiles that intersect the batch entry's row segment are written;
+    seg_mode 2: only k tiles (rows) of the segment are multiplied."""
+    g = torch.Generator().manual_seed(21)
+    Z, P, S, N, K = 4, 128, 2, 96, 64
+    seg = torch.tensor([[0, 40], [40, 0], [40, 70], [110, 18]], dtype=torch.int32)       # an empty net, ragged bounds
+    A = torch.randn(Z, S * P, K, generator=g); W = torch.randn(Z, N, K, generator=g)
+    out = torch.full((Z, S * P, N), 7.0, device="cuda")
+    Ad, Wd, sd_ = dev(A), dev(W), dev(seg)
+    hip.gemm(Ad, Wd, out, S * P, N, K, K, K, N, batch=Z, a_z=(1, 0, S * P * K), b_z=(1, 0, N * K), c_z=(1, 0, S * P * N),
+             seg=(1, sd_, P, 1), tile=3)
+    full = torch.bmm(A, W.transpose(1, 2))
+    o = out.cpu()
+    for z in range(Z):
+        b, c = int(seg[z, 0]), int(seg[z, 1])
+        for t in range(S):
+            for m0 in range(0, P, 64):
+                rows = slice(t * P + m0, t * P + m0 + 64)
+                owned = c > 0 and not (m0 + 64 <= b or m0 >= b + c)
+                if owned:
+                    assert rel(o[z, rows], full[z, rows]) < 2e-5
+                else:
+                    assert float((o[z, rows] - 7.0).abs().max()) == 0.0               # skipped tile: untouched
+    # K mode: dW[z] = sum over the segment's rows (k-tile granularity: rows outside must be zero in dY)
+    dY = torch.randn(Z, S * P, N, generator=g)
+    for z in range(Z):
+        b, c = int(seg[z, 0]), int(seg[z, 1])
+        mask = torch.zeros(P); mask[b:b + c] = 1
+        dY[z] *= mask.repeat(S).view(-1, 1)                                           # callers keep foreign rows at 0
+    X = torch.randn(S * P, K, generator=g)
+    dW = torch.full((Z, N, K), 3.0, device="cuda")
+    dYd, Xd = dev(dY), dev(X)
+    hip.gemm(dYd, Xd, dW, N, K, S * P, N, K, K, a_mode=1, b_mode=1, batch=Z, a_z=(1, 0, S * P * N), b_z=(1, 1, 0),
+             c_z=(1, 0, N * K), seg=(2, sd_, P, 1))
+    want = torch.stack([dY[z].t() @ X for z in range(Z)])
+    assert rel(dW, want) < 2e-5 and float(dW[1].abs().max()) == 0.0

@@ -337,3 +337,41 @@ def test_reference_topology_shared_nets_and_worker_agent():
         assert l_w == l_s
         assert torch.equal(worker.arena.params, solo.arena.params)
     assert float(arena_of(shared).grads.abs().max()) == 0.0          # chief resets the shared buffers (chief.py:22)
+
+
+@pytest.mark.parametrize("Bw,nW", [(128, 1), (64, 4)])
+def test_row_sorted_update_equals_unsorted(Bw, nW):
+    """Minibatches >= 128 rows per head: rows sorted by command + GEMM tile skipping (stale rows of other
+    command nets are masked to exact zeros in the backward) must reproduce the unsorted path: same
+    losses, same gradients up to fp32 summation order — over several updates so that skipped tiles
+    really hold stale data from earlier minibatches."""
+    from ppo_agent.storage import RolloutStorage
+    a_s, a_u = make_agent(84, 84), make_agent(84, 84)
+    a_u.learner.use_sorted = False
+    assert a_s.learner.sorted_rows(Bw * nW) and not a_u.learner.sorted_rows(Bw * nW)
+    T = 2 * Bw
+    stor = []
+    for w in range(nW):
+        data = fill_storages(T, 700 + w)
+        pair = []
+        for hd in ("steer", "throttle"):
+            s = RolloutStorage(T, 2, 530, 8, 530, True, 0.99, 0.95)
+            for k, v in data[hd].items():
+                getattr(s, k).copy_(torch.from_numpy(v))
+            if w == 0 and hd == "steer":
+                s.command[: T // 2] = 2                      # a heavily unbalanced command mix for one head
+            s.to("cuda:0")
+            s.compute_returns(torch.tensor([0.05 * (w + 1)]))
+            pair.append(s)
+        stor.append(pair)
+    g = torch.Generator().manual_seed(1)
+    for it in range(4):
+        idx = [torch.randperm(T, generator=g)[:Bw] for _ in range(2 * nW)]
+        batches = [(stor[w][0], idx[2 * w], stor[w][0].advantages, stor[w][1], idx[2 * w + 1], stor[w][1].advantages)
+                   for w in range(nW)]
+        l_s = a_s.update_policy_from_storages(batches)
+        l_u = a_u.update_policy_from_storages(batches)
+        assert rel(l_s, l_u) < 1e-5, (it, l_s, l_u)
+        gs, gu = a_s.arena.grads, a_u.arena.grads
+        assert float((gs - gu).abs().max() / gu.abs().max()) < 2e-5, it
+        assert torch.isfinite(gs).all()
