@@ -132,7 +132,7 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, scale=None, shi
         d.seg_mode, d.seg_period, d.seg_div = seg[0], seg[2], seg[3]
         d.row_seg = ptr(seg[1])
     fn = lib().cadre_gemm_bf16 if bf16 else lib().cadre_gemm_f32
-    if PROFILE is None or bf16:
+    if PROFILE is None or bf16 or torch.cuda.is_current_stream_capturing():
         check(fn(C.byref(d), stream()), "cadre_gemm_bf16" if bf16 else "cadre_gemm_f32")
         return
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
