@@ -27,19 +27,22 @@ static_assert(sizeof(cadre_gemm_t) == 264, "cadre_gemm_t layout is part of the C
 #define BK 32
 #define LDS_PITCH 36
 
-template <int WM, int WN, int AMODE, int BMODE>
-__global__ __launch_bounds__(256, ((WM + WN) * 2 * 64 * 36 * 4 > 80 * 1024 ? 1 : 2)) void gemm_f32_kernel(cadre_gemm_t p) {
+// WVN = waves along N (2 -> 256 threads, 4 -> 512 threads); 2 waves along M.
+template <int WM, int WN, int AMODE, int BMODE, int WVN = 2>
+__global__ __launch_bounds__(128 * WVN, ((2 * WM + WVN * WN) * 2 * 32 * 36 * 4 > 80 * 1024 ? 1 : 2)) void gemm_f32_kernel(cadre_gemm_t p) {
+  constexpr int NT = 128 * WVN;   // threads
+  constexpr int RP = NT / 8;      // rows staged per pass (8 x 16-B chunks per 128-B row)
   constexpr int BM = 2 * WM * 32;
-  constexpr int BN = 2 * WN * 32;
-  constexpr int RA = BM / 32;  // 16-B chunks per thread per A tile (k-contiguous staging)
-  constexpr int RB = BN / 32;
+  constexpr int BN = WVN * WN * 32;
+  constexpr int RA = BM / RP;     // 16-B chunks per thread per A tile
+  constexpr int RB = BN / RP;
   __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDS_PITCH];
   float* As = lds;
   float* Bs = lds + 2 * BM * LDS_PITCH;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WVN, wn = wave % WVN;
   const int l31 = lane & 31, lh = lane >> 5;
 
   // XCD-aware tile order (cdna_hip_programming.md T1, bijective form): workgroups are dealt
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256, ((WM + WN) * 2 * 64 * 36 * 4 > 80 * 1024 ? 1 :
   if constexpr (AMODE == 0) {
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-      const int m = m0 + rr + 32 * i;
+      const int m = m0 + rr + RP * i;
       aoff[i] = m < p.M ? (unsigned)(((int64_t)m * p.lda + cc * 4) * 4) : OOB;
       amask[i] = 0;
     }
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256, ((WM + WN) * 2 * 64 * 36 * 4 > 80 * 1024 ? 1 :
     const int hw = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-      const int m = m0 + rr + 32 * i;
+      const int m = m0 + rr + RP * i;
       const int mm = min(m, p.M - 1);
       const int img = mm / hw, rem = mm % hw;
       const int ho = rem / p.Wo, wo = rem % p.Wo;
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256, ((WM + WN) * 2 * 64 * 36 * 4 > 80 * 1024 ? 1 :
     const int hw = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-      const int m = m0 + rr + 32 * i;
+      const int m = m0 + rr + RP * i;
       const int mm = min(m, p.M - 1);
       const int img = mm / hw, rem = mm % hw;
       const int ho = rem / p.Wo, wo = rem % p.Wo;
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(256, ((WM + WN) * 2 * 64 * 36 * 4 > 80 * 1024 ? 1 :
   if constexpr (BMODE == 0) {
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-      const int n = n0 + rr + 32 * i;
+      const int n = n0 + rr + RP * i;
       boff[i] = n < p.N ? (unsigned)(((int64_t)n * p.ldb + cc * 4) * 4) : OOB;
     }
   }
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(256, ((WM + WN) * 2 * 64 * 36 * 4 > 80 * 1024 ? 1 :
     } else if constexpr (AMODE == 1) {
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
-        const int id = tid + 256 * i;
+        const int id = tid + NT * i;
         const int kk = id / (BM / 4), mc = id % (BM / 4);
         const int k = k0 + kk, m = m0 + mc * 4;
         areg[i] = ldg(rsA, (k < p.K && m < p.M) ? (unsigned)(((int64_t)k * p.lda + m) * 4) : OOB);
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(256, ((WM + WN) * 2 * 64 * 36 * 4 > 80 * 1024 ? 1 :
     } else {
 #pragma unroll
       for (int i = 0; i < RB; ++i) {
-        const int id = tid + 256 * i;
+        const int id = tid + NT * i;
         const int kk = id / (BN / 4), nc = id % (BN / 4);
         const int k = k0 + kk, n = n0 + nc * 4;
         breg[i] = ldg(rsB, (k < p.K && n < p.N) ? (unsigned)(((int64_t)k * p.ldb + n) * 4) : OOB);
@@ -214,19 +217,19 @@ __global__ __launch_bounds__(256, ((WM + WN) * 2 * 64 * 36 * 4 > 80 * 1024 ? 1 :
     float* bs = Bs + buf * BN * LDS_PITCH;
     if constexpr (AMODE == 1) {
 #pragma unroll
-      for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(as + (tid + 256 * i) * 4) = areg[i];
+      for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(as + (tid + NT * i) * 4) = areg[i];
     } else {
 #pragma unroll
       for (int i = 0; i < RA; ++i)
-        *reinterpret_cast<f32x4*>(as + (rr + 32 * i) * LDS_PITCH + cc * 4) = areg[i];
+        *reinterpret_cast<f32x4*>(as + (rr + RP * i) * LDS_PITCH + cc * 4) = areg[i];
     }
     if constexpr (BMODE == 1) {
 #pragma unroll
-      for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(bs + (tid + 256 * i) * 4) = breg[i];
+      for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(bs + (tid + NT * i) * 4) = breg[i];
     } else {
 #pragma unroll
       for (int i = 0; i < RB; ++i)
-        *reinterpret_cast<f32x4*>(bs + (rr + 32 * i) * LDS_PITCH + cc * 4) = breg[i];
+        *reinterpret_cast<f32x4*>(bs + (rr + RP * i) * LDS_PITCH + cc * 4) = breg[i];
     }
   };
 
@@ -493,9 +496,9 @@ extern "C" int cadre_gemm_f32(const cadre_gemm_t* pp, void* stream) {
   int tile = p.tile ? p.tile : pick_tile(p);
   if (p.seg_mode == 1 && (p.seg_period % 128) != 0 && tile != 3) tile = 3;     // the M tile must divide the period
   hipStream_t st = (hipStream_t)stream;
-  dim3 block(256);
-  if (tile < 1 || tile > 6) return cadre_fail("cadre_gemm_f32: bad tile");
-  static const int BMS[7] = {0, 128, 128, 64, 256, 128, 256}, BNS[7] = {0, 128, 64, 64, 128, 256, 64};
+  dim3 block(tile == 8 ? 512 : 256);
+  if (tile < 1 || tile > 8 || tile == 7) return cadre_fail("cadre_gemm_f32: bad tile");
+  static const int BMS[9] = {0, 128, 128, 64, 256, 128, 256, 0, 128}, BNS[9] = {0, 128, 64, 64, 128, 256, 64, 0, 128};
   const int bm = BMS[tile], bn = BNS[tile];
   if (p.a_mode >= 2 && p.b_mode != 0) return cadre_fail("cadre_gemm_f32: conv needs b_mode 0");
   dim3 grid(((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn), p.split_k, p.batch);
@@ -507,7 +510,8 @@ extern "C" int cadre_gemm_f32(const cadre_gemm_t* pp, void* stream) {
     else if (tile == 3) LAUNCH(1, 1, AM_, BM_); \
     else if (tile == 4) LAUNCH(4, 2, AM_, BM_); \
     else if (tile == 5) LAUNCH(2, 4, AM_, BM_); \
-    else LAUNCH(4, 1, AM_, BM_);              \
+    else if (tile == 6) LAUNCH(4, 1, AM_, BM_); \
+    else hipLaunchKernelGGL((gemm_f32_kernel<2, 1, AM_, BM_, 4>), grid, block, 0, st, p); \
   } while (0)
   switch (p.a_mode * 2 + p.b_mode) {
     case 0: LAUNCH_TILE(0, 0); break;

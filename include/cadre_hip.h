@@ -54,7 +54,8 @@ typedef struct {
   int32_t split_k;
   int32_t tile;        /* 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128,
                           5 = 128x256, 6 = 256x64 (4-6: one workgroup per CU);
-                          7 = 256x256 on 8 waves (cadre_gemm_bf16 only)                  */
+                          7 = 256x256 on 8 waves (cadre_gemm_bf16 only);
+                          8 = 128x128 on 8 waves (cadre_gemm_f32 only)                   */
   int32_t flags;       /* bit 1: C is bf16; bit 2: resid is bf16 (cadre_gemm_bf16; bit 1 also
                           honoured by cadre_gemm_f32's vector epilogue); others must be 0   */
   /* Row segments (cadre_gemm_f32 only; PPO update with the minibatch rows sorted by command,

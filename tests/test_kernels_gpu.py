@@ -29,7 +29,7 @@ def hip():
 
 # ----------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("M,N,K,tile", [(200, 136, 544, 1), (77, 50, 64, 3), (300, 64, 96, 2), (64, 2120, 544, 0),
-                                        (5, 33, 128, 3)])
+                                        (5, 33, 128, 3), (300, 200, 544, 8)])
 @pytest.mark.parametrize("a_mode,b_mode", [(0, 0), (0, 1), (1, 0), (1, 1)])
 def test_gemm_modes(hip, M, N, K, tile, a_mode, b_mode):
     if a_mode == 1 and M % 4:
@@ -98,10 +98,11 @@ def test_gemm_batched_splitk(hip):
     assert rel(out, want) < 2e-5
 
 
-@pytest.mark.parametrize("Cin,Cout,H,W,k,s,p", [(64, 64, 18, 22, 3, 1, 1), (64, 128, 18, 22, 3, 2, 1),
-                                                 (64, 128, 17, 21, 1, 2, 0), (128, 160, 9, 9, 1, 1, 0),
-                                                 (4, 64, 30, 36, 7, 2, 3)])
-def test_conv_implicit_gemm(hip, Cin, Cout, H, W, k, s, p):
+@pytest.mark.parametrize("Cin,Cout,H,W,k,s,p,tile", [(64, 64, 18, 22, 3, 1, 1, 0), (64, 128, 18, 22, 3, 2, 1, 0),
+                                                      (64, 128, 17, 21, 1, 2, 0, 0), (128, 160, 9, 9, 1, 1, 0, 0),
+                                                      (4, 64, 30, 36, 7, 2, 3, 0), (128, 256, 18, 18, 3, 1, 1, 8),
+                                                      (4, 64, 30, 36, 7, 2, 3, 8)])
+def test_conv_implicit_gemm(hip, Cin, Cout, H, W, k, s, p, tile):
     g = torch.Generator().manual_seed(Cin + Cout + k)
     Nimg = 3
     x = torch.randn(Nimg, Cin, H, W, generator=g)
@@ -119,7 +120,7 @@ def test_conv_implicit_gemm(hip, Cin, Cout, H, W, k, s, p):
     out = torch.empty(Nimg, Ho, Wo, Cout, device="cuda")
     K = wd.shape[1]
     hip.gemm(xd, wd, out, Nimg * Ho * Wo, Cout, K, 0, K, Cout, a_mode=3 if Cin == 4 else 2, scale=dev(scale),
-             shift=dev(shift), resid=rd, ldr=Cout, act=1, conv=(H, W, Cin, Ho, Wo, k, k, s, p))
+             shift=dev(shift), resid=rd, ldr=Cout, act=1, conv=(H, W, Cin, Ho, Wo, k, k, s, p), tile=tile)
     torch.cuda.synchronize()
     assert rel(out.permute(0, 3, 1, 2), want) < 2e-5
 

@@ -34,8 +34,10 @@ def desc(x, w, out, M, N, K, conv, a_mode, tile):
 
 F = 512
 cases = [("layer1 3x3 64->64 @72 t3", 72, 72, 64, 64, 3, 1, 1, 3), ("layer2 3x3 128 @36 t3", 36, 36, 128, 128, 3, 1, 1, 3),
-         ("layer2 3x3 128 @36 t1", 36, 36, 128, 128, 3, 1, 1, 1), ("layer3 3x3 256 @18 t3", 18, 18, 256, 256, 3, 1, 1, 3),
-         ("layer4 3x3 512 @9 t3", 9, 9, 512, 512, 3, 1, 1, 3), ("dense 4096^3 t1", 0, 0, 0, 0, 0, 0, 0, 1)]
+         ("layer2 3x3 128 @36 t1", 36, 36, 128, 128, 3, 1, 1, 1), ("layer2 3x3 128 @36 t8", 36, 36, 128, 128, 3, 1, 1, 8),
+         ("layer3 3x3 256 @18 t3", 18, 18, 256, 256, 3, 1, 1, 3), ("layer3 3x3 256 @18 t8", 18, 18, 256, 256, 3, 1, 1, 8),
+         ("layer4 3x3 512 @9 t3", 9, 9, 512, 512, 3, 1, 1, 3), ("layer4 3x3 512 @9 t8", 9, 9, 512, 512, 3, 1, 1, 8),
+         ("dense 4096^3 t1", 0, 0, 0, 0, 0, 0, 0, 1), ("dense 4096^3 t8", 0, 0, 0, 0, 0, 0, 0, 8)]
 st = torch.cuda.current_stream().cuda_stream
 for name, H, W, ci, co, k, s, p, tile in cases:
     if H:
