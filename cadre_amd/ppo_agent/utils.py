@@ -49,3 +49,23 @@ def init(module, weight_init, bias_init, gain=1):
     if module.bias is not None:
         bias_init(module.bias.data)
     return module
+
+
+def init_normc_(weight, gain=1):
+    """reference ppo_agent/utils.py:27-29 (imported by the reference models.py)."""
+    import torch
+    weight.normal_(0, 1)
+    weight *= gain / torch.sqrt(weight.pow(2).sum(1, keepdim=True))
+
+
+class AddBias(__import__("torch").nn.Module):
+    """reference ppo_agent/utils.py:7-19 (used only by the dead DiagGaussian heads; kept importable)."""
+
+    def __init__(self, bias):
+        super().__init__()
+        import torch.nn as nn
+        self._bias = nn.Parameter(bias.unsqueeze(1))
+
+    def forward(self, x):
+        b = self._bias.t().view(1, -1) if x.dim() == 2 else self._bias.t().view(1, -1, 1, 1)
+        return x + b
