@@ -15,10 +15,14 @@ from .utils import Counter, init
 
 
 def _cfg(cfg, key, default=None):
+    """cfg.key or cfg['key'] (addict ConfigDict, plain dict or attr-dict), `default` when absent."""
     try:
         return cfg[key]
-    except (KeyError, TypeError):
-        return getattr(cfg, key, default)
+    except (KeyError, TypeError, IndexError):
+        try:
+            return getattr(cfg, key, default)
+        except (KeyError, AttributeError):
+            return default
 
 
 def _device(num):

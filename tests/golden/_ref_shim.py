@@ -31,6 +31,25 @@ def install(challenge_dir):
         pkg = types.ModuleType("carla_perception")
         pkg.__path__ = [os.path.join(REF, "carla_perception")]
         sys.modules["carla_perception"] = pkg
+    # The reference's ppo_agent/ has no __init__.py (namespace package), so this repo's regular
+    # `ppo_agent` package would shadow it whatever the sys.path order: pin the name to the reference
+    # directory explicitly, and refuse to run if the mirror was imported first.
+    for name in list(sys.modules):
+        if name == "ppo_agent" or name.startswith("ppo_agent."):
+            mod = sys.modules[name]
+            if not getattr(mod, "__file__", "").startswith(REF) and getattr(mod, "__path__", [""])[0] != os.path.join(REF, "ppo_agent"):
+                raise RuntimeError("this repo's ppo_agent mirror is already imported; run the generator in a fresh process")
+    if "ppo_agent" not in sys.modules:
+        ref_pkg = types.ModuleType("ppo_agent")
+        ref_pkg.__path__ = [os.path.join(REF, "ppo_agent")]
+        sys.modules["ppo_agent"] = ref_pkg
+
+
+def assert_reference(module):
+    """Fail loudly if `module` did not come from /root/reference."""
+    f = getattr(module, "__file__", "") or ""
+    if not f.startswith(REF):
+        raise RuntimeError("expected the reference implementation, got %s" % f)
     # utils.logger is imported by ppo_agent.agent; it needs tabulate/dateutil (installed)
 
 

@@ -54,6 +54,8 @@ def ref_danet(feat_h, feat_w, seed=SEED_ENC):
     (InterTaskAtt hard-codes 5x8, intertask_att.py:17-18,31)."""
     from carla_perception.Config.auto_danet import danet_config
     from carla_perception.Networks.danet import DANet
+    import carla_perception.Networks.danet as _danet_mod
+    shim.assert_reference(_danet_mod)
     cfg = danet_config()
     net = DANet(cfg.networks["autoencoder"])
     if (feat_h, feat_w) != (5, 8):
@@ -93,6 +95,8 @@ def ref_agent(seed=SEED_PPO):
         os.makedirs(os.path.dirname(ck), exist_ok=True)
         _net, _mine, sd = ref_danet(5, 8)
         torch.save({"autoencoder": sd}, ck)
+    import ppo_agent.agent
+    shim.assert_reference(ppo_agent.agent)
     from ppo_agent.agent import CadreAgent
     steer = {i: (i - 16) / 16.0 for i in range(33)}
     thr = {0: [0, 0], 1: [0, 1], 2: [0.6, 0]}
@@ -139,6 +143,8 @@ def gen_enc(tag, H, W, n=2):
 
 
 def gen_gae():
+    import ppo_agent.storage
+    shim.assert_reference(ppo_agent.storage)
     from ppo_agent.storage import RolloutStorage
     out = {}
     for T in (32, 128, 200):
