@@ -375,3 +375,34 @@ def test_row_sorted_update_equals_unsorted(Bw, nW):
         gs, gu = a_s.arena.grads, a_u.arena.grads
         assert float((gs - gu).abs().max() / gu.abs().max()) < 2e-5, it
         assert torch.isfinite(gs).all()
+
+
+def test_full_size_learner_section_vs_oracle():
+    """BASELINE C2 sizes (T=128, mini_batch_num=2 -> minibatch 64, fused-gather + hipGraph path):
+    get_value, GAE, advantage normalisation and one epoch of updates + clip + Adam vs the oracle."""
+    from ppo_agent.models import Shared_grad_buffers
+    from ppo_agent.storage import RolloutStorage
+    from ppo_agent.train import learner_section
+    from tests.helpers import oracle_learner_replay
+    T, mbn = 128, 2
+    g = dict(T=T, mbn=mbn, epochs=1, ppo_seed=11, data_seed=123, torch_seed=8, names=np.array(sorted(synth.ppo_state(11))))
+    want = oracle_learner_replay(g)
+    agent = make_agent(84, 84)
+    data = fill_storages(T, 123)
+    stor = []
+    for hd in ("steer", "throttle"):
+        s = RolloutStorage(T, mbn, 530, 8, 530, True, 0.99, 0.95)
+        for k, v in data[hd].items():
+            getattr(s, k).copy_(torch.from_numpy(v))
+        s.to("cuda:0")
+        stor.append(s)
+    shared = Shared_grad_buffers(agent.model_dict, agent.device)
+    torch.manual_seed(8)
+    vl, pl, el = learner_section(agent, stor[0], stor[1], False, dict(use_adv_norm=True, ppo_epoch=1, max_grad_norm=250.0), shared)
+    assert rel(np.array([vl, pl, el]).T, np.array(want["losses"])) < LOSS_TOL
+    for hd, s in zip(("steer", "throttle"), stor):
+        mine = s.advantages.cpu().numpy()[:, 0]
+        assert np.array_equal(np.argsort(mine, kind="stable"), np.argsort(want["adv_" + hd][:, 0], kind="stable"))
+    names = [str(n) for n in g["names"]]
+    ps = per_model(agent.arena, agent.arena.params, names, lambda ts: float(sum(t.sum() for t in ts)))
+    assert rel(ps, want["param_sums"][-1]) < 1e-5
