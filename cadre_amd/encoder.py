@@ -93,6 +93,8 @@ class DANetEncoderHIP:
         dev = self.device
         fh, fw = synth.feat_hw(H, W)
         self.fh, self.fw, self.Np = fh, fw, fh * fw
+        # identity of the loaded checkpoint (CadreAgent.ensemble_act shares one pass between equal encoders)
+        self.fingerprint = (dtype, H, W) + tuple(float(sd[k].sum(dtype=torch.float64)) for k in sorted(sd))
         if self.Np > 96:
             raise hip.CadreHipError("layer-4 map %dx%d > 96 positions not supported by the PAM/CAM kernels" % (fh, fw))
         need = 512 * self.Np

@@ -101,8 +101,10 @@ class CadreAgent(object):
     def act(self, tick_data):
         """agent.py:114-141.  Sampling consumes the global torch CPU generator exactly like the
         reference (one exponential_(1) draw of n_out floats per head, steer first)."""
-        command = tick_data["command"]
-        ppo_feature = self.get_latent_feature(tick_data)
+        return self.act_from_feature(self.get_latent_feature(tick_data), tick_data["command"])
+
+    def act_from_feature(self, ppo_feature, command):
+        """The part of `act` after the encoder (agent.py:116-141) on a given [S,530] feature window."""
         O3, _, _ = self.learner.infer(ppo_feature, (command, command))
         nS, nT = self.arena.n_out
         q_s = torch.empty(1, nS).exponential_(1)
@@ -221,6 +223,25 @@ class CadreAgent(object):
         if n > 1 and ctl[-1] < 0.5:
             ctl[-1] = 0.0
         return ctl
+
+    @staticmethod
+    def ensemble_act(agent_group, tick_data):
+        """eval.py:52-60's loop `[agent.act(obs) for agent in agent_group]` with ONE encoder pass: every
+        agent of an evaluation ensemble loads the same frozen encoder checkpoint (models.py:54-70; the
+        ppo_model snapshots hold no encoder), so the latent window is computed once by the first agent
+        and the others run only their LSTM + heads.  Same outputs and the same global-RNG consumption
+        order as the loop (agent 0 steer, agent 0 throttle, agent 1 steer, ...); refuses agents whose
+        encoder weights differ.  Returns the list of `act` tuples."""
+        lead = agent_group[0]
+        for a in agent_group[1:]:
+            if a.vae_model is not lead.vae_model and a.vae_model.fingerprint != lead.vae_model.fingerprint:
+                raise ValueError("ensemble_act: agents hold different encoder weights; call act() per agent")
+        feat = lead.get_latent_feature(tick_data)
+        out = []
+        for a in agent_group:
+            f = feat if a.device == feat.device else feat.to(a.device)
+            out.append(a.act_from_feature(f, tick_data["command"]))
+        return out
 
     # ------------------------------------------------------------------ snapshots
     def save_snapshot(self, model_path, fix_missing_lstm=False):

@@ -406,3 +406,34 @@ def test_full_size_learner_section_vs_oracle():
     names = [str(n) for n in g["names"]]
     ps = per_model(agent.arena, agent.arena.params, names, lambda ts: float(sum(t.sum() for t in ts)))
     assert rel(ps, want["param_sums"][-1]) < 1e-5
+
+
+def test_ensemble_act_equals_per_agent_loop():
+    """eval.py:52-60: the ensemble with one shared encoder pass returns what the per-agent act() loop
+    returns (actions bit-exact, same RNG consumption), and refuses agents with different encoders."""
+    from ppo_agent.agent import CadreAgent
+    steps = synth.synth_rollout(3, 84, 84, seed=21)
+    group_a = [make_agent(84, 84, ppo_seed=11 + i) for i in range(3)]
+    group_b = [make_agent(84, 84, ppo_seed=11 + i) for i in range(3)]
+
+    def obs_of(td):
+        return dict(rgb=td["rgb"], route_fig=td["route_fig"].copy(), measurements=td["measurements"], command=td["command"])
+    torch.manual_seed(5)
+    loop = []
+    for td in steps:
+        o = obs_of(td)
+        loop.append([ag.act(o) for ag in group_a])
+    torch.manual_seed(5)
+    for i, td in enumerate(steps):
+        o = obs_of(td)
+        ens = CadreAgent.ensemble_act(group_b, o)
+        assert set(np.unique(o["route_fig"])) <= {0, 1}
+        for (f0, a0, lp0, v0, _), (f1, a1, lp1, v1, _) in zip(loop[i], ens):
+            assert torch.equal(f0, f1)
+            assert [int(a0[0]), int(a0[1])] == [int(a1[0]), int(a1[1])]
+            assert torch.equal(lp0[0], lp1[0]) and torch.equal(lp0[1], lp1[1])
+            assert torch.equal(v0[0], v1[0]) and torch.equal(v0[1], v1[1])
+        assert group_b[0].avg_action([e[1] for e in ens]) == group_a[0].avg_action([e[1] for e in loop[i]])
+    other = make_agent(84, 84, enc_seed=8)
+    with pytest.raises(ValueError):
+        CadreAgent.ensemble_act([group_b[0], other], obs_of(steps[0]))
