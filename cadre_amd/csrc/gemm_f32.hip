@@ -17,6 +17,7 @@
 // same permutation on A and B, so the products pair correctly.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "../../include/cadre_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -26,6 +27,9 @@ static_assert(sizeof(cadre_gemm_t) == 264, "cadre_gemm_t layout is part of the C
 
 #define BK 32
 #define LDS_PITCH 36
+#ifndef GEMM_NSETS
+#define GEMM_NSETS 2      // register sets = k-tiles of global loads in flight per wave
+#endif
 
 // WVN = waves along N (2 -> 256 threads, 4 -> 512 threads); 2 waves along M.
 template <int WM, int WN, int AMODE, int BMODE, int WVN = 2>
@@ -165,71 +169,89 @@ __global__ __launch_bounds__(128 * WVN, ((2 * WM + WVN * WN) * 2 * 32 * 36 * 4 >
     }
   }
 
-  f32x4 areg[RA], breg[RB];
+  // NS register sets hold tiles in flight; set s is written to LDS and re-requested NS tiles ahead.
+  constexpr int NS = GEMM_NSETS;
+  constexpr int U = (NS % 2 == 0) ? NS : 2 * NS;     // steps per unrolled group: set and LDS-buffer parity both static
+  f32x4 areg[NS][RA], breg[NS][RB];
   auto ldg = [](const __amdgpu_buffer_rsrc_t& rs, unsigned off) -> f32x4 {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
   };
 
-  auto load_tiles = [&](int kt_) {
-    const int kt = p.seg_mode == 2 ? (kt_ / k_run) * k_per + k_first + kt_ % k_run : kt_;
+  // Request k-tile kt_ into register set rs.  Tiles past the end resolve to OOB offsets (zero fill),
+  // so the k-loop can issue its loads unconditionally.
+  auto load_tiles = [&](int kt_, int rs) {
+#ifdef ABL_NOGLOAD   // ablation: keep the LDS writes, skip the global loads after the first tile
+    if (kt_ != kt_begin) return;
+#endif
+    const int kr = max(k_run, 1);
+    const int kt = p.seg_mode == 2 ? (kt_ / kr) * k_per + k_first + kt_ % kr : kt_;
     const int k0 = kt * BK;
     // ---- A
     if constexpr (AMODE == 0) {
       const unsigned kb_ = (k0 + cc * 4 < p.K) ? (unsigned)k0 * 4u : OOB;   // K % 4 == 0
 #pragma unroll
-      for (int i = 0; i < RA; ++i) areg[i] = ldg(rsA, aoff[i] + kb_);
+      for (int i = 0; i < RA; ++i) areg[rs][i] = ldg(rsA, aoff[i] + kb_);
     } else if constexpr (AMODE == 1) {
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
         const int id = tid + NT * i;
         const int kk = id / (BM / 4), mc = id % (BM / 4);
         const int k = k0 + kk, m = m0 + mc * 4;
-        areg[i] = ldg(rsA, (k < p.K && m < p.M) ? (unsigned)(((int64_t)k * p.lda + m) * 4) : OOB);
+        areg[rs][i] = ldg(rsA, (k < p.K && m < p.M) ? (unsigned)(((int64_t)k * p.lda + m) * 4) : OOB);
       }
     } else if constexpr (AMODE == 2) {
       const int pos = k0 / p.Cin, ci = k0 % p.Cin;             // uniform per tile (Cin % 32 == 0)
       const unsigned delta = (unsigned)((((pos / p.KW) * p.W + (pos % p.KW)) * p.Cin + ci) * 4);
+      const unsigned bit = pos < 32 ? 1u << pos : 0u;
 #pragma unroll
-      for (int i = 0; i < RA; ++i) areg[i] = ldg(rsA, ((amask[i] >> pos) & 1u) ? aoff[i] + delta : OOB);
+      for (int i = 0; i < RA; ++i) areg[rs][i] = ldg(rsA, (amask[i] & bit) ? aoff[i] + delta : OOB);
     } else {  // stem rows: k-tile kt is kernel row kh
       const unsigned delta = (unsigned)(kt * p.W * 16);
+      const unsigned bit = kt < 32 ? 1u << kt : 0u;
 #pragma unroll
-      for (int i = 0; i < RA; ++i) areg[i] = ldg(rsA, ((amask[i] >> kt) & 1u) ? aoff[i] + delta : OOB);
+      for (int i = 0; i < RA; ++i) areg[rs][i] = ldg(rsA, (amask[i] & bit) ? aoff[i] + delta : OOB);
     }
     // ---- B
     if constexpr (BMODE == 0) {
       const unsigned kb_ = (k0 + cc * 4 < p.K) ? (unsigned)k0 * 4u : OOB;
 #pragma unroll
-      for (int i = 0; i < RB; ++i) breg[i] = ldg(rsB, boff[i] + kb_);
+      for (int i = 0; i < RB; ++i) breg[rs][i] = ldg(rsB, boff[i] + kb_);
     } else {
 #pragma unroll
       for (int i = 0; i < RB; ++i) {
         const int id = tid + NT * i;
         const int kk = id / (BN / 4), nc = id % (BN / 4);
         const int k = k0 + kk, n = n0 + nc * 4;
-        breg[i] = ldg(rsB, (k < p.K && n < p.N) ? (unsigned)(((int64_t)k * p.ldb + n) * 4) : OOB);
+        breg[rs][i] = ldg(rsB, (k < p.K && n < p.N) ? (unsigned)(((int64_t)k * p.ldb + n) * 4) : OOB);
       }
     }
   };
 
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](int buf, int rs) {
     float* as = As + buf * BM * LDS_PITCH;
     float* bs = Bs + buf * BN * LDS_PITCH;
+#ifdef ABL_NOSTORE   // ablation: keep the loads alive, skip the LDS writes
+#pragma unroll
+    for (int i = 0; i < RA; ++i) asm volatile("" ::"v"(areg[rs][i]));
+#pragma unroll
+    for (int i = 0; i < RB; ++i) asm volatile("" ::"v"(breg[rs][i]));
+    return;
+#endif
     if constexpr (AMODE == 1) {
 #pragma unroll
-      for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(as + (tid + NT * i) * 4) = areg[i];
+      for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(as + (tid + NT * i) * 4) = areg[rs][i];
     } else {
 #pragma unroll
       for (int i = 0; i < RA; ++i)
-        *reinterpret_cast<f32x4*>(as + (rr + RP * i) * LDS_PITCH + cc * 4) = areg[i];
+        *reinterpret_cast<f32x4*>(as + (rr + RP * i) * LDS_PITCH + cc * 4) = areg[rs][i];
     }
     if constexpr (BMODE == 1) {
 #pragma unroll
-      for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(bs + (tid + NT * i) * 4) = breg[i];
+      for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(bs + (tid + NT * i) * 4) = breg[rs][i];
     } else {
 #pragma unroll
       for (int i = 0; i < RB; ++i)
-        *reinterpret_cast<f32x4*>(bs + (rr + RP * i) * LDS_PITCH + cc * 4) = breg[i];
+        *reinterpret_cast<f32x4*>(bs + (rr + RP * i) * LDS_PITCH + cc * 4) = breg[rs][i];
     }
   };
 
@@ -241,17 +263,8 @@ __global__ __launch_bounds__(128 * WVN, ((2 * WM + WVN * WN) * 2 * 32 * 36 * 4 >
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (kt_begin < kt_end) {
-    load_tiles(kt_begin);
-    store_tiles(0);
-  }
-  __syncthreads();
-
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int buf = (kt - kt_begin) & 1;
-    const bool more = kt + 1 < kt_end;
-    if (more) load_tiles(kt + 1);  // global loads in flight under the MFMAs below
-
+  // One k-tile of MFMAs from LDS buffer `buf`; `staging()` runs behind the first fragment reads.
+  auto compute = [&](int buf, auto&& staging) {
     const float* as = As + buf * BM * LDS_PITCH;
     const float* bs = Bs + buf * BN * LDS_PITCH;
 #pragma unroll
@@ -267,7 +280,11 @@ __global__ __launch_bounds__(128 * WVN, ((2 * WM + WVN * WN) * 2 * 32 * 36 * 4 >
           af[i][2] = as[(kq + 2) * BM + row];
           af[i][3] = as[(kq + 3) * BM + row];
         } else {
+#ifdef ABL_NOLDSREAD
+          af[i] = f32x4{(float)row, (float)kq, 1.f, 2.f};
+#else
           af[i] = *reinterpret_cast<const f32x4*>(as + row * LDS_PITCH + kq);
+#endif
         }
       }
 #pragma unroll
@@ -279,12 +296,14 @@ __global__ __launch_bounds__(128 * WVN, ((2 * WM + WVN * WN) * 2 * 32 * 36 * 4 >
           bf[j][2] = bs[(kq + 2) * BN + col];
           bf[j][3] = bs[(kq + 3) * BN + col];
         } else {
+#ifdef ABL_NOLDSREAD
+          bf[j] = f32x4{(float)col, (float)kq, 1.f, 2.f};
+#else
           bf[j] = *reinterpret_cast<const f32x4*>(bs + col * LDS_PITCH + kq);
+#endif
         }
       }
-#ifdef GEMM_SETPRIO
-      __builtin_amdgcn_s_setprio(1);
-#endif
+      if (kb == 0) staging();
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -292,13 +311,56 @@ __global__ __launch_bounds__(128 * WVN, ((2 * WM + WVN * WN) * 2 * 32 * 36 * 4 >
 #pragma unroll
           for (int j = 0; j < WN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
-#ifdef GEMM_SETPRIO
-      __builtin_amdgcn_s_setprio(0);
-#endif
     }
-    if (more) store_tiles(buf ^ 1);
+  };
+
+  // k-loop.  Iteration t: barrier; compute tile t from LDS buffer t&1; behind its first fragment reads,
+  // write tile t+1 (register set (t+1)%NS, requested NS iterations ago) into the buffer compute(t-1)
+  // just released and re-request that set for tile t+1+NS.  No wave then waits on its own loads or LDS
+  // writes in front of a barrier (the old order — request, compute, write, barrier — cost 6-8 %: every
+  // tile ended in s_waitcnt vmcnt(0) -> 4 ds_write -> s_waitcnt lgkmcnt(0) -> s_barrier), and a global
+  // load has NS iterations to land.  The loop runs in groups of U steps with nothing conditional
+  // inside, so hipcc's counted s_waitcnt vmcnt(N) stay exact.
+  auto step = [&](auto uc, int kt) {
+    constexpr int u = decltype(uc)::value;
+#ifndef ABL_NOBAR
     __syncthreads();
+#endif
+    compute(u & 1, [&] {
+#ifndef ABL_NOLOAD
+      store_tiles((u + 1) & 1, (u + 1) % NS);
+      load_tiles(kt + 1 + NS, (u + 1) % NS);
+#endif
+    });
+  };
+  load_tiles(kt_begin, 0);
+  store_tiles(0, 0);
+#pragma unroll
+  for (int j = 1; j <= NS; ++j) load_tiles(kt_begin + j, j % NS);
+  int kt = kt_begin;
+  for (; kt + U <= kt_end; kt += U) {
+    step(std::integral_constant<int, 0>{}, kt);
+    step(std::integral_constant<int, 1>{}, kt + 1);
+    if constexpr (U > 2) {
+      step(std::integral_constant<int, 2>{}, kt + 2);
+      step(std::integral_constant<int, 3>{}, kt + 3);
+    }
+    if constexpr (U > 4) {
+      step(std::integral_constant<int, 4>{}, kt + 4);
+      step(std::integral_constant<int, 5>{}, kt + 5);
+    }
   }
+  if (kt < kt_end) step(std::integral_constant<int, 0>{}, kt);
+  if (kt + 1 < kt_end) step(std::integral_constant<int, 1>{}, kt + 1);
+  if constexpr (U > 2) {
+    if (kt + 2 < kt_end) step(std::integral_constant<int, 2>{}, kt + 2);
+    if (kt + 3 < kt_end) step(std::integral_constant<int, 3>{}, kt + 3);
+  }
+  if constexpr (U > 4) {
+    if (kt + 4 < kt_end) step(std::integral_constant<int, 4>{}, kt + 4);
+  }
+  __syncthreads();      // every wave is done reading: the epilogue re-uses the staging buffers
+
 
   // ---------------------------------------------------------------- epilogue
   const bool raw = p.split_k > 1;
