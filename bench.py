@@ -302,12 +302,12 @@ def main():
     if not by:
         by[(3, 2, 0)] = [0.0, 1e-9, 1]
     dom = max(by, key=lambda k: by[k][1])
-    WMWN = {1: (2, 2), 2: (2, 1), 3: (1, 1), 4: (4, 2), 5: (2, 4), 6: (4, 1)}
-    TILE = {1: "128x128", 2: "128x64", 3: "64x64", 4: "256x128", 5: "128x256", 6: "256x64"}
+    WMWN = {1: (2, 2), 2: (2, 1), 3: (1, 1), 4: (4, 2), 5: (2, 4), 6: (4, 1), 8: (2, 1)}
+    TILE = {1: "128x128", 2: "128x64", 3: "64x64", 4: "256x128", 5: "128x256", 6: "256x64", 8: "128x128 (8 waves)"}
     AM = {0: "dense A[M][K]", 1: "dense A[K][M]", 2: "NHWC implicit-GEMM conv", 3: "Cin=4 stem conv"}
 
     def kname(k):      # exact symbol as rocprofv3 prints it
-        return "gemm_f32_kernel<%d, %d, %d, %d>" % (WMWN[k[0]] + (k[1], k[2]))
+        return "gemm_f32_kernel<%d, %d, %d, %d%s>" % (WMWN[k[0]] + (k[1], k[2], ", 4" if k[0] == 8 else ""))
     ach = by[dom][0] / by[dom][1] / 1e12
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")

@@ -64,9 +64,14 @@ __global__ __launch_bounds__(128 * WVN, ((2 * WM + WVN * WN) * 2 * 32 * 36 * 4 >
   const int tile_m = bid / tilesN, tile_n = bid % tilesN;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int z = blockIdx.z;
-  const float* A = p.A + (int64_t)((z / p.a_div) % p.a_mod) * p.a_str;
-  const float* B = p.B + (int64_t)((z / p.b_div) % p.b_mod) * p.b_str;
-  float* C = p.C + (int64_t)((z / p.c_div) % p.c_mod) * p.c_str;
+  const float* A = p.A;
+  const float* B = p.B;
+  float* C = p.C;
+  if (p.batch > 1) {     // (the six scalar divisions below are ~400 SALU instructions: skip them for plain launches)
+    A += (int64_t)((z / p.a_div) % p.a_mod) * p.a_str;
+    B += (int64_t)((z / p.b_div) % p.b_mod) * p.b_str;
+    C += (int64_t)((z / p.c_div) % p.c_mod) * p.c_str;
+  }
 
   // row segments (rows sorted by command): skip what this batch entry does not own
   int seg_beg = 0, seg_cnt = 0;
@@ -117,45 +122,52 @@ __global__ __launch_bounds__(128 * WVN, ((2 * WM + WVN * WN) * 2 * 32 * 36 * 4 >
       aoff[i] = m < p.M ? (unsigned)(((int64_t)m * p.lda + cc * 4) * 4) : OOB;
       amask[i] = 0;
     }
-  } else if constexpr (AMODE == 2) {
+  } else if constexpr (AMODE >= 2) {
     // implicit-GEMM gather, decoded once per staged row: byte offset of the receptive field's
     // top-left tap (negative in the top halo -> wraps to OOB, masked anyway) + in-bounds tap mask.
+    // The tile's first row m0 is decoded with scalar divisions (wave-uniform -> SALU); a staged row is
+    // m0 + r with r < BM, so its (img, ho, wo) follow from two small carries.  floor(x / d) for
+    // 0 <= x < 2^16 is exact as (int)((x + 0.5f) * (1.0f / d)): the argument stays 0.5/d away from
+    // every integer, far more than the rounding error — no per-lane integer division.
     const int hw = p.Ho * p.Wo;
+    const int img0 = m0 / hw, rem0 = m0 % hw;
+    const int ho0 = rem0 / p.Wo, wo0 = rem0 % p.Wo;
+    const float inv_wo = 1.0f / (float)p.Wo, inv_ho = 1.0f / (float)p.Ho;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-      const int m = m0 + rr + RP * i;
-      const int mm = min(m, p.M - 1);
-      const int img = mm / hw, rem = mm % hw;
-      const int ho = rem / p.Wo, wo = rem % p.Wo;
+      const int r = rr + RP * i;
+      const int m = m0 + r;
+#ifdef ABL_NOPRO   // ablation: no im2col decode
+      aoff[i] = (unsigned)(((m > 2 * p.W + 4 ? m - 2 * p.W - 4 : 0) * p.Cin + cc * 4) * 4); amask[i] = m < p.M ? 0x1FF : 0; continue;
+#endif
+      const int x = wo0 + r;
+      const int q1 = (int)(((float)x + 0.5f) * inv_wo);
+      const int wo = x - __mul24(q1, p.Wo);
+      const int y = ho0 + q1;
+      const int q2 = (int)(((float)y + 0.5f) * inv_ho);
+      const int ho = y - __mul24(q2, p.Ho);
+      const int img = img0 + q2;
       const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-      aoff[i] = (unsigned)((((img * p.H + hi0) * p.W + wi0) * p.Cin + cc * 4) * 4);
       unsigned mask = 0;
-      if (m < p.M) {
-        for (int kh = 0; kh < p.KH; ++kh)
+      if constexpr (AMODE == 2) {
+        aoff[i] = (unsigned)((((img * p.H + hi0) * p.W + wi0) * p.Cin + cc * 4) * 4);
+        if (m < p.M) {     // separable: (rows inside) x (columns inside)
+          unsigned colm = 0;
           for (int kw = 0; kw < p.KW; ++kw)
-            if ((unsigned)(hi0 + kh) < (unsigned)p.H && (unsigned)(wi0 + kw) < (unsigned)p.W)
-              mask |= 1u << (kh * p.KW + kw);
-      }
-      amask[i] = mask;
-    }
-  } else if constexpr (AMODE == 3) {
-    // Cin == 4 stem, "row" formulation: k-tile kt = kernel row kh; its 32 k-values are the 8
-    // consecutive NHWC4 pixels wi0 .. wi0+7 of input row hi0+kh (128 contiguous bytes), of which the
-    // first KW carry weights (B is [N][KH][32], zero beyond KW*4).  One scalar delta per k-tile, no
-    // per-thread tap decode.  This thread's chunk cc is pixel wi0+cc: masked when outside the row.
-    const int hw = p.Ho * p.Wo;
-#pragma unroll
-    for (int i = 0; i < RA; ++i) {
-      const int m = m0 + rr + RP * i;
-      const int mm = min(m, p.M - 1);
-      const int img = mm / hw, rem = mm % hw;
-      const int ho = rem / p.Wo, wo = rem % p.Wo;
-      const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-      aoff[i] = (unsigned)((((img * p.H + hi0) * p.W + wi0) * 4 + cc * 4) * 4);
-      unsigned mask = 0;
-      if (m < p.M && cc < p.KW && (unsigned)(wi0 + cc) < (unsigned)p.W) {
-        for (int kh = 0; kh < p.KH; ++kh)
-          if ((unsigned)(hi0 + kh) < (unsigned)p.H) mask |= 1u << kh;
+            if ((unsigned)(wi0 + kw) < (unsigned)p.W) colm |= 1u << kw;
+          for (int kh = 0; kh < p.KH; ++kh)
+            if ((unsigned)(hi0 + kh) < (unsigned)p.H) mask |= colm << (kh * p.KW);
+        }
+      } else {
+        // Cin == 4 stem, "row" formulation: k-tile kt = kernel row kh; its 32 k-values are the 8
+        // consecutive NHWC4 pixels wi0 .. wi0+7 of input row hi0+kh (128 contiguous bytes), of which the
+        // first KW carry weights (B is [N][KH][32], zero beyond KW*4).  One scalar delta per k-tile, no
+        // per-thread tap decode.  This thread's chunk cc is pixel wi0+cc: masked when outside the row.
+        aoff[i] = (unsigned)((((img * p.H + hi0) * p.W + wi0) * 4 + cc * 4) * 4);
+        if (m < p.M && cc < p.KW && (unsigned)(wi0 + cc) < (unsigned)p.W) {
+          for (int kh = 0; kh < p.KH; ++kh)
+            if ((unsigned)(hi0 + kh) < (unsigned)p.H) mask |= 1u << kh;
+        }
       }
       amask[i] = mask;
     }
@@ -363,18 +375,32 @@ __global__ __launch_bounds__(128 * WVN, ((2 * WM + WVN * WN) * 2 * 32 * 36 * 4 >
 
 
   // ---------------------------------------------------------------- epilogue
+#ifdef ABL_NOEPI   // ablation: no epilogue (one never-taken store keeps the accumulators alive)
+  if (acc[0][0][0] == 12345.678f) p.C[0] = acc[0][0][1] + acc[WM - 1][WN - 1][15];
+  return;
+#endif
   const bool raw = p.split_k > 1;
   const int actk = p.act & 15;
   const bool post = (p.act & 16) != 0;   // residual added after the activation
-  const float* scale = (!raw && p.scale) ? p.scale + (int64_t)((z / p.s_div) % p.s_mod) * p.s_str : nullptr;
-  const float* shift = (!raw && p.shift) ? p.shift + (int64_t)((z / p.s_div) % p.s_mod) * p.s_str : nullptr;
-  const float* resid = (!raw && p.resid) ? p.resid + (int64_t)((z / p.r_div) % p.r_mod) * p.r_str : nullptr;
+  const float* scale = raw ? nullptr : p.scale;
+  const float* shift = raw ? nullptr : p.shift;
+  const float* resid = raw ? nullptr : p.resid;
+  if (p.batch > 1) {
+    const int64_t so = (int64_t)((z / p.s_div) % p.s_mod) * p.s_str;
+    if (scale) scale += so;
+    if (shift) shift += so;
+    if (resid) resid += (int64_t)((z / p.r_div) % p.r_mod) * p.r_str;
+  }
   const bool vec_ok = ((p.N | p.ldc | (resid ? p.ldr : 0)) & 3) == 0 && (((uintptr_t)C | (uintptr_t)resid) & 15) == 0;
   if (vec_ok) {
     // Stage each wave's accumulator tile through its own LDS slice so that global traffic is whole
     // 16-B-per-lane row segments: residual read and output write are each R/rows_per_instr wide
     // instructions per lane instead of 16*WM*WN scalar ones.  (The k-loop's last barrier has passed,
-    // so the staging buffers are free.)
+    // so the staging buffers are free.)  The body is instantiated per (activation, residual) so that
+    // it is straight-line code — with the modes as run-time uniforms hipcc branched per element — and
+    // C / resid go through buffer descriptors rebased at the tile's first row: 32-bit offsets, rows
+    // past M dropped by the hardware bounds check, no exec masking.  (Short-K convs spend up to 6 %
+    // of their time here: tools/ablate_proepi.sh.)
     constexpr int CW = WN * 32, P = CW + 4;
     constexpr int LPR = CW / 4;          // lanes per row
     constexpr int RPI = 64 / LPR;        // rows per wave-instruction
@@ -383,51 +409,77 @@ __global__ __launch_bounds__(128 * WVN, ((2 * WM + WVN * WN) * 2 * 32 * 36 * 4 >
     const int c4 = (lane % LPR) * 4;
     const int col = n0 + wn * CW + c4;
     const bool cvalid = col < p.N;
+    const bool c16 = (p.flags & 2) != 0;      // C is bf16 (config C3: fp32 stem feeding the bf16 trunk)
+    const int esz = c16 ? 2 : 4;
+    const int64_t rows_left = (int64_t)p.M - m0;
+    auto window = [](int64_t bytes) { return (int)(bytes < 0x7fffffff ? bytes : 0x7fffffff); };
+    const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(reinterpret_cast<char*>(C) + (int64_t)m0 * p.ldc * esz), 0, window(rows_left * p.ldc * esz), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(resid ? resid + (int64_t)m0 * p.ldr : p.C), 0, resid ? window(rows_left * p.ldr * 4) : 0, 0x00020000);
+    const int lrow = lane / LPR;
+    const unsigned coff = cvalid ? (unsigned)((lrow * p.ldc + col) * esz) : OOB;     // row `lrow` of the tile
+    const unsigned roff = cvalid ? (unsigned)((lrow * p.ldr + col) * 4) : OOB;
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (cvalid && scale) sc = *reinterpret_cast<const f32x4*>(scale + col);
     if (cvalid && shift) sh = *reinterpret_cast<const f32x4*>(shift + col);
+    const float slope = p.slope;
+
+    auto body = [&](auto actc, auto resc) {
+      constexpr int ACT = decltype(actc)::value;      // -1 raw split-K slab, 0 none, 1 ReLU, 2 LeakyReLU
+      constexpr bool RES = decltype(resc)::value;
 #pragma unroll
-    for (int i = 0; i < WM; ++i) {          // one 32-row slab of the wave tile at a time
-      const int rbase = m0 + (wm * WM + i) * 32;
-      f32x4 rv[NIT];
+      for (int i = 0; i < WM; ++i) {          // one 32-row slab of the wave tile at a time
+        const int r0 = (wm * WM + i) * 32;    // slab's first row inside the tile
+        f32x4 rv[NIT];
+        if constexpr (RES) {
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int row = rbase + it * RPI + lane / LPR;
-        rv[it] = (resid && cvalid && row < p.M) ? *reinterpret_cast<const f32x4*>(resid + (int64_t)row * p.ldr + col)
-                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-#pragma unroll
-      for (int j = 0; j < WN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          cs[((r & 3) + 8 * (r >> 2) + 4 * lh) * P + j * 32 + l31] = acc[i][j][r];
-      // same-wave producer/consumer: LDS ops of one wave execute in order, no barrier needed
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int rloc = it * RPI + lane / LPR;
-        const int row = rbase + rloc;
-        f32x4 v = *reinterpret_cast<const f32x4*>(cs + rloc * P + c4);
-        if (!raw) {
-          v = v * sc + sh;
-          if (!post) v += rv[it];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (actk == 1) v[e] = fmaxf(v[e], 0.f);
-            else if (actk == 2) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
-          }
-          if (post) v += rv[it];
+          for (int it = 0; it < NIT; ++it)
+            rv[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, (int)(roff + (unsigned)((r0 + it * RPI) * p.ldr * 4)), 0, 0));
         }
-        if (cvalid && row < p.M) {
-          if (p.flags & 2) {              // C is bf16 (config C3: fp32 stem feeding the bf16 trunk)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            cs[((r & 3) + 8 * (r >> 2) + 4 * lh) * P + j * 32 + l31] = acc[i][j][r];
+        // same-wave producer/consumer: LDS ops of one wave execute in order, no barrier needed
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(cs + (it * RPI + lrow) * P + c4);
+          if constexpr (ACT >= 0) {
+            v = v * sc + sh;
+            if constexpr (RES) { if (!post) v += rv[it]; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if constexpr (ACT == 1) v[e] = fmaxf(v[e], 0.f);
+              if constexpr (ACT == 2) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
+            }
+            if constexpr (RES) { if (post) v += rv[it]; }
+          }
+          const unsigned off = coff + (unsigned)((r0 + it * RPI) * p.ldc * esz);
+          if (c16) {
             typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
             bf16x4 o;
             o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
-            *reinterpret_cast<bf16x4*>(reinterpret_cast<char*>(C) + ((int64_t)row * p.ldc + col) * 2) = o;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rsC, (int)off, 0, 0);
           } else {
-            *reinterpret_cast<f32x4*>(C + (int64_t)row * p.ldc + col) = v;
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, (int)off, 0, 0);
           }
         }
       }
+    };
+    using std::integral_constant;
+    if (raw) body(integral_constant<int, -1>{}, integral_constant<bool, false>{});
+    else if (resid) {
+      if (actk == 1) body(integral_constant<int, 1>{}, integral_constant<bool, true>{});
+      else if (actk == 2) body(integral_constant<int, 2>{}, integral_constant<bool, true>{});
+      else body(integral_constant<int, 0>{}, integral_constant<bool, true>{});
+    } else {
+      if (actk == 1) body(integral_constant<int, 1>{}, integral_constant<bool, false>{});
+      else if (actk == 2) body(integral_constant<int, 2>{}, integral_constant<bool, false>{});
+      else body(integral_constant<int, 0>{}, integral_constant<bool, false>{});
     }
     return;
   }
@@ -486,21 +538,33 @@ int cadre_fail(const char* msg);
 static int pick_tile(const cadre_gemm_t& p) {
   const int batch = p.batch < 1 ? 1 : p.batch, sk = p.split_k < 1 ? 1 : p.split_k;
   struct Cand { int id, bm, bn, per_cu; double base; };
-  // dense: the 128x128 tile's operand reuse wins (131 vs 124 TFLOP/s at 4096^3); implicit-GEMM conv:
-  // four 64x64 workgroups per CU (4 waves/SIMD) hide the gather latency better (119-123 vs 112-117)
-  static const Cand big[2] = {{1, 128, 128, 2, 1.00}, {3, 64, 64, 4, 0.94}};
-  static const Cand big_conv[2] = {{1, 128, 128, 2, 0.96}, {3, 64, 64, 4, 1.00}};
+  // measured with the staged k-loop (profiles/r01_gemm_tile_sweep_staged.txt), F=512:
+  //   dense 4096^3: 128x128 on 8 waves 146, 128x128 on 4 waves 142, 64x64 131 TFLOP/s
+  //   conv N=128 (layer2): 8-wave 128x128 130 vs 64x64 126;  N=256: 129 vs 131;  N=512: 121 vs 131
+  // (the 64x64 tile keeps four workgroups per CU, which hides the gather better once N tiles multiply)
+  static const Cand big[2] = {{8, 128, 128, 2, 1.00}, {3, 64, 64, 4, 0.92}};
+  static const Cand conv128[2] = {{8, 128, 128, 2, 1.03}, {3, 64, 64, 4, 1.00}};
+  static const Cand conv_wide[2] = {{8, 128, 128, 2, 0.93}, {3, 64, 64, 4, 1.00}};
   static const Cand narrow[2] = {{2, 128, 64, 2, 0.88}, {3, 64, 64, 4, 1.00}};
+  const Cand* big_conv = p.N <= 128 ? conv128 : conv_wide;
   const Cand* c = p.N <= 64 ? narrow : (p.a_mode >= 2 ? big_conv : big);
   int best = c[0].id;
   double best_e = -1.0;
+  // matrix-pipe saturation with r workgroups resident on a CU (4-wave / 8-wave workgroups)
+  static const double sat4[5] = {0.55, 0.55, 0.80, 0.93, 1.00}, sat8[3] = {0.85, 0.85, 1.00};
   for (int i = 0; i < 2; ++i) {
     const double tiles = (double)((p.M + c[i].bm - 1) / c[i].bm) * ((p.N + c[i].bn - 1) / c[i].bn) * batch * sk;
-    const double slots = 256.0 * c[i].per_cu;
-    const double waves = tiles <= slots ? 1.0 : (double)(int64_t)((tiles + slots - 1) / slots);
-    // useful fraction of the padded tile grid (edge tiles) x quantisation x shape factor
+    // useful fraction of the padded tile grid (edge tiles)
     const double useful = ((double)p.M * p.N * batch * sk) / (tiles * c[i].bm * c[i].bn);
-    const double e = c[i].base * useful * (tiles / (waves * slots));
+    // a CU's throughput does not depend on how many of its tiles are resident at once, so the tail is
+    // per CU: ceil(tiles/256) tile-times for tiles/256 tiles of work
+    const double per_cu = tiles / 256.0;
+    const double quant = per_cu / (double)(int64_t)(per_cu + 0.999999);
+    const double r = per_cu < c[i].per_cu ? (per_cu < 1.0 ? 1.0 : per_cu) : (double)c[i].per_cu;
+    const double* st = c[i].id == 8 ? sat8 : sat4;
+    const int r0 = (int)r;
+    const double s_r = st[r0] + (r - r0) * ((r0 + 1 <= c[i].per_cu ? st[r0 + 1] : st[r0]) - st[r0]);
+    const double e = c[i].base * useful * quant * s_r / st[c[i].per_cu];
     if (e > best_e) { best_e = e; best = c[i].id; }
   }
   return best;
