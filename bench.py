@@ -296,7 +296,7 @@ def main():
         elapsed = float(tt.item())
     # ---- per-kernel roofline from the HIP events recorded inside the timed region
     by = {}
-    for key, flops, e0, e1 in prof:
+    for key, flops, e0, e1, _shape in prof:
         d = by.setdefault(key, [0.0, 0.0, 0])
         d[0] += flops; d[1] += e0.elapsed_time(e1) * 1e-3; d[2] += 1
     if not by:

@@ -32,7 +32,9 @@ static_assert(sizeof(cadre_gemm_t) == 264, "cadre_gemm_t layout is part of the C
 #endif
 
 // WVN = waves along N (2 -> 256 threads, 4 -> 512 threads); 2 waves along M.
-template <int WM, int WN, int AMODE, int BMODE, int WVN = 2>
+// NS = register sets = k-tiles of global loads in flight per wave (3 and 4 measured: no gain, also not on the
+// update's skinny weight-streaming GEMMs — those are bound by one MFMA chain per SIMD, not by load latency).
+template <int WM, int WN, int AMODE, int BMODE, int WVN = 2, int NS = GEMM_NSETS>
 __global__ __launch_bounds__(128 * WVN, ((2 * WM + WVN * WN) * 2 * 32 * 36 * 4 > 80 * 1024 ? 1 : 2)) void gemm_f32_kernel(cadre_gemm_t p) {
   constexpr int NT = 128 * WVN;   // threads
   constexpr int RP = NT / 8;      // rows staged per pass (8 x 16-B chunks per 128-B row)
@@ -182,7 +184,6 @@ __global__ __launch_bounds__(128 * WVN, ((2 * WM + WVN * WN) * 2 * 32 * 36 * 4 >
   }
 
   // NS register sets hold tiles in flight; set s is written to LDS and re-requested NS tiles ahead.
-  constexpr int NS = GEMM_NSETS;
   constexpr int U = (NS % 2 == 0) ? NS : 2 * NS;     // steps per unrolled group: set and LDS-buffer parity both static
   f32x4 areg[NS][RA], breg[NS][RB];
   auto ldg = [](const __amdgpu_buffer_rsrc_t& rs, unsigned off) -> f32x4 {

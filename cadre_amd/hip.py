@@ -108,7 +108,8 @@ def stream():
 
 
 # Optional launch profiler (bench.py): when PROFILE is a list, every gemm launch is bracketed by
-# HIP events recorded on the launch stream and appended as ((tile, a_mode, b_mode), flops, start, end).
+# HIP events recorded on the launch stream and appended as ((tile, a_mode, b_mode), flops, start, end,
+# (M, N, K, batch, split_k, seg_mode)).
 PROFILE = None
 
 
@@ -140,4 +141,5 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, scale=None, shi
     check(fn(C.byref(d), stream()), "cadre_gemm_f32")
     e1.record()
     k_alg = conv[5] * conv[6] * conv[2] if conv is not None else K      # algorithmic K (the stem pads 196 -> 224)
-    PROFILE.append(((lib().cadre_gemm_pick_tile(C.byref(d)), a_mode, b_mode), 2.0 * M * N * k_alg * max(1, batch), e0, e1))
+    PROFILE.append(((lib().cadre_gemm_pick_tile(C.byref(d)), a_mode, b_mode), 2.0 * M * N * k_alg * max(1, batch), e0, e1,
+                    (M, N, K, max(1, batch), split_k, seg[0] if seg is not None else 0)))

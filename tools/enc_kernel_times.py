@@ -38,7 +38,7 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         hip.PROFILE = None
-        rows.append(([a.elapsed_time(b) for _, _, a, b in prof], [f for _, f, _, _ in prof], [k for k, _, _, _ in prof], e0.elapsed_time(e1)))
+        rows.append(([a.elapsed_time(b) for _, _, a, b, _ in prof], [f for _, f, _, _, _ in prof], [k for k, _, _, _, _ in prof], e0.elapsed_time(e1)))
     t = np.array([r[0] for r in rows])
     fl = np.array(rows[0][1])
     print("pass totals ms:", ["%.2f" % r[3] for r in rows])
