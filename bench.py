@@ -307,7 +307,7 @@ def main():
     AM = {0: "dense A[M][K]", 1: "dense A[K][M]", 2: "NHWC implicit-GEMM conv", 3: "Cin=4 stem conv"}
 
     def kname(k):      # exact symbol as rocprofv3 prints it
-        return "gemm_f32_kernel<%d, %d, %d, %d%s>" % (WMWN[k[0]] + (k[1], k[2], ", 4" if k[0] == 8 else ""))
+        return "gemm_f32_kernel<%d, %d, %d, %d, %d, 2>" % (WMWN[k[0]] + (k[1], k[2], 4 if k[0] == 8 else 2))
     ach = by[dom][0] / by[dom][1] / 1e12
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")

@@ -178,74 +178,62 @@ extern "C" int cadre_preprocess(const uint8_t* rgb, const uint8_t* route, const 
 }
 
 // ============================================================================ maxpool 3x3 s2 p1
-__global__ void maxpool_kernel(const float* x, float* y, int F, int H, int W, int C4, int Ho, int Wo) {
-  const int64_t total = (int64_t)F * Ho * Wo * C4;
-  const float4* x4 = reinterpret_cast<const float4*>(x);
-  float4* y4 = reinterpret_cast<float4*>(y);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4);
-    int64_t r = i / C4;
-    const int wo = (int)(r % Wo); r /= Wo;
-    const int ho = (int)(r % Ho);
-    const int f = (int)(r / Ho);
-    float4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+// One workgroup row per output row (f, ho): the frame/row decode is scalar, a lane owns one 16-byte
+// channel group of one output pixel; 32-bit index math (the grid-stride form spent more time in 64-bit
+// divisions than in loads).  HBM-bound: reads the stem output once (rows shared by neighbouring output
+// rows hit L2), writes a quarter of it.
+template <typename VEC, int NE, typename OP>
+__device__ __forceinline__ void maxpool_row(const VEC* x, VEC* y, int H, int W, int CV, int Ho, int Wo, OP vmax) {
+  const int row = blockIdx.x;
+  const int f = row / Ho, ho = row % Ho;
+  for (int idx = threadIdx.x; idx < Wo * CV; idx += blockDim.x) {
+  const int wo = idx / CV, c = idx % CV;
+  float m[NE];
 #pragma unroll
-    for (int dh = 0; dh < 3; ++dh) {
-      const int hi = ho * 2 - 1 + dh;
-      if ((unsigned)hi >= (unsigned)H) continue;
+  for (int e = 0; e < NE; ++e) m[e] = -INFINITY;
 #pragma unroll
-      for (int dw = 0; dw < 3; ++dw) {
-        const int wi = wo * 2 - 1 + dw;
-        if ((unsigned)wi >= (unsigned)W) continue;
-        const float4 v = x4[(((int64_t)f * H + hi) * W + wi) * C4 + c];
-        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
-      }
+  for (int dh = 0; dh < 3; ++dh) {
+    const int hi = ho * 2 - 1 + dh;
+    if ((unsigned)hi >= (unsigned)H) continue;
+    const VEC* xr = x + ((int64_t)f * H + hi) * W * CV;
+#pragma unroll
+    for (int dw = 0; dw < 3; ++dw) {
+      const int wi = wo * 2 - 1 + dw;
+      if ((unsigned)wi >= (unsigned)W) continue;
+      vmax(m, xr[wi * CV + c]);
     }
-    y4[i] = m;
+  }
+  VEC o;
+#pragma unroll
+  for (int e = 0; e < NE; ++e) o[e] = (decltype(o[0] + o[0]))m[e];
+  y[(int64_t)row * Wo * CV + idx] = o;
   }
 }
 
-__global__ void maxpool_bf16_kernel(const __bf16* x, __bf16* y, int F, int H, int W, int C8, int Ho, int Wo) {
-  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-  const int64_t total = (int64_t)F * Ho * Wo * C8;
-  const bf16x8* x8 = reinterpret_cast<const bf16x8*>(x);
-  bf16x8* y8 = reinterpret_cast<bf16x8*>(y);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C8);
-    int64_t r = i / C8;
-    const int wo = (int)(r % Wo); r /= Wo;
-    const int ho = (int)(r % Ho);
-    const int f = (int)(r / Ho);
-    float m[8];
+typedef float mp_f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 mp_bf16x8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void maxpool_kernel(const float* x, float* y, int H, int W, int C4, int Ho, int Wo) {
+  maxpool_row<mp_f32x4, 4>(reinterpret_cast<const mp_f32x4*>(x), reinterpret_cast<mp_f32x4*>(y), H, W, C4, Ho, Wo,
+                           [](float* m, const mp_f32x4& v) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+                             for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+                           });
+}
+
+__global__ __launch_bounds__(256) void maxpool_bf16_kernel(const __bf16* x, __bf16* y, int H, int W, int C8, int Ho, int Wo) {
+  maxpool_row<mp_bf16x8, 8>(reinterpret_cast<const mp_bf16x8*>(x), reinterpret_cast<mp_bf16x8*>(y), H, W, C8, Ho, Wo,
+                            [](float* m, const mp_bf16x8& v) {
 #pragma unroll
-    for (int dh = 0; dh < 3; ++dh) {
-      const int hi = ho * 2 - 1 + dh;
-      if ((unsigned)hi >= (unsigned)H) continue;
-#pragma unroll
-      for (int dw = 0; dw < 3; ++dw) {
-        const int wi = wo * 2 - 1 + dw;
-        if ((unsigned)wi >= (unsigned)W) continue;
-        const bf16x8 v = x8[(((int64_t)f * H + hi) * W + wi) * C8 + c];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], (float)v[e]);
-      }
-    }
-    bf16x8 o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (__bf16)m[e];
-    y8[i] = o;
-  }
+                              for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], (float)v[e]);
+                            });
 }
 extern "C" int cadre_maxpool3x3s2_bf16(const void* x, void* y, int32_t F, int32_t H, int32_t W, int32_t C, void* stream) {
   FAIL_IF(!x || !y || F < 1 || H < 1 || W < 1 || C < 8 || (C & 7), "cadre_maxpool3x3s2_bf16: bad argument");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  const int64_t total = (int64_t)F * Ho * Wo * (C / 8);
-  const int blocks = (int)std::min<int64_t>((total + 255) / 256, 16384);
-  hipLaunchKernelGGL(maxpool_bf16_kernel, dim3(blocks), dim3(256), 0, ST(stream), (const __bf16*)x, (__bf16*)y, F, H, W,
-                     C / 8, Ho, Wo);
+  FAIL_IF((int64_t)F * Ho > 0x7fffffff, "cadre_maxpool3x3s2_bf16: too many rows");
+  hipLaunchKernelGGL(maxpool_bf16_kernel, dim3(F * Ho), dim3(256), 0, ST(stream), (const __bf16*)x,
+                     (__bf16*)y, H, W, C / 8, Ho, Wo);
   return (int)hipGetLastError();
 }
 
@@ -253,9 +241,8 @@ extern "C" int cadre_maxpool3x3s2(const float* x, float* y, int32_t F, int32_t H
                                   void* stream) {
   FAIL_IF(!x || !y || F < 1 || H < 1 || W < 1 || C < 4 || (C & 3), "cadre_maxpool3x3s2: bad argument");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  const int64_t total = (int64_t)F * Ho * Wo * (C / 4);
-  const int blocks = (int)std::min<int64_t>((total + 255) / 256, 16384);
-  hipLaunchKernelGGL(maxpool_kernel, dim3(blocks), dim3(256), 0, ST(stream), x, y, F, H, W, C / 4, Ho, Wo);
+  FAIL_IF((int64_t)F * Ho > 0x7fffffff, "cadre_maxpool3x3s2: too many rows");
+  hipLaunchKernelGGL(maxpool_kernel, dim3(F * Ho), dim3(256), 0, ST(stream), x, y, H, W, C / 4, Ho, Wo);
   return (int)hipGetLastError();
 }
 

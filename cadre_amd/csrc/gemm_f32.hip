@@ -31,14 +31,14 @@ static_assert(sizeof(cadre_gemm_t) == 264, "cadre_gemm_t layout is part of the C
 #define GEMM_NSETS 2      // register sets = k-tiles of global loads in flight per wave
 #endif
 
-// WVN = waves along N (2 -> 256 threads, 4 -> 512 threads); 2 waves along M.
+// WVM x WVN = waves along M x N (64 threads each); each wave owns WM x WN MFMA tiles of 32x32.
 // NS = register sets = k-tiles of global loads in flight per wave (3 and 4 measured: no gain, also not on the
 // update's skinny weight-streaming GEMMs — those are bound by one MFMA chain per SIMD, not by load latency).
-template <int WM, int WN, int AMODE, int BMODE, int WVN = 2, int NS = GEMM_NSETS>
-__global__ __launch_bounds__(128 * WVN, ((2 * WM + WVN * WN) * 2 * 32 * 36 * 4 > 80 * 1024 ? 1 : 2)) void gemm_f32_kernel(cadre_gemm_t p) {
-  constexpr int NT = 128 * WVN;   // threads
+template <int WM, int WN, int AMODE, int BMODE, int WVN = 2, int NS = GEMM_NSETS, int WVM = 2>
+__global__ __launch_bounds__(64 * WVM * WVN, ((WVM * WM + WVN * WN) * 2 * 32 * 36 * 4 > 80 * 1024 ? 1 : 2)) void gemm_f32_kernel(cadre_gemm_t p) {
+  constexpr int NT = 64 * WVM * WVN;   // threads
   constexpr int RP = NT / 8;      // rows staged per pass (8 x 16-B chunks per 128-B row)
-  constexpr int BM = 2 * WM * 32;
+  constexpr int BM = WVM * WM * 32;
   constexpr int BN = WVN * WN * 32;
   constexpr int RA = BM / RP;     // 16-B chunks per thread per A tile
   constexpr int RB = BN / RP;
@@ -548,6 +548,8 @@ static int pick_tile(const cadre_gemm_t& p) {
   static const Cand conv_wide[2] = {{8, 128, 128, 2, 0.93}, {3, 64, 64, 4, 1.00}};
   static const Cand narrow[2] = {{2, 128, 64, 2, 0.88}, {3, 64, 64, 4, 1.00}};
   const Cand* big_conv = p.N <= 128 ? conv128 : conv_wide;
+  // row-sorted minibatch (each batch entry owns one run of rows per period): 32-row tiles skip the most
+  if (p.seg_mode == 1 && (p.N >= 96 || p.seg_period % 64 != 0)) return 9;
   const Cand* c = p.N <= 64 ? narrow : (p.a_mode >= 2 ? big_conv : big);
   int best = c[0].id;
   double best_e = -1.0;
@@ -614,19 +616,20 @@ extern "C" int cadre_gemm_f32(const cadre_gemm_t* pp, void* stream) {
   GEMM_CHECK(p.split_k == 1 || p.batch == 1 || p.c_str >= (int64_t)p.M * p.ldc, "batched split_k needs c_str >= M*ldc");
   if (p.seg_mode) {
     GEMM_CHECK(p.row_seg && p.seg_period > 0 && p.seg_div > 0 && (p.seg_mode == 1 || p.seg_mode == 2), "bad row segment fields");
-    if (p.seg_mode == 1) GEMM_CHECK(p.seg_period % 64 == 0 && p.M % p.seg_period == 0, "seg_mode 1 needs seg_period%64==0, M%seg_period==0");
+    if (p.seg_mode == 1) GEMM_CHECK(p.seg_period % 32 == 0 && p.M % p.seg_period == 0, "seg_mode 1 needs seg_period%32==0, M%seg_period==0");
     if (p.seg_mode == 2) GEMM_CHECK(p.seg_period % 32 == 0 && p.K % p.seg_period == 0 && p.split_k == 1 && p.a_mode == 1 && p.b_mode == 1,
                                     "seg_mode 2 needs k-major operands, seg_period%32==0, K%seg_period==0");
   }
   if (p.flags & 2)
     GEMM_CHECK(p.batch == 1 && p.split_k == 1 && ((p.N | p.ldc) & 3) == 0 && !p.resid, "bf16 output needs the vector epilogue, no batch/split/resid");
   int tile = p.tile ? p.tile : pick_tile(p);
-  if (p.seg_mode == 1 && (p.seg_period % 128) != 0 && tile != 3) tile = 3;     // the M tile must divide the period
   hipStream_t st = (hipStream_t)stream;
-  dim3 block(tile == 8 ? 512 : 256);
-  if (tile < 1 || tile > 8 || tile == 7) return cadre_fail("cadre_gemm_f32: bad tile");
-  static const int BMS[9] = {0, 128, 128, 64, 256, 128, 256, 0, 128}, BNS[9] = {0, 128, 64, 64, 128, 256, 64, 0, 128};
+  if (tile < 1 || tile > 10 || tile == 7) return cadre_fail("cadre_gemm_f32: bad tile");
+  // 9: 32x128 on 4 waves (1x4) for row-sorted skinny GEMMs; 10: 128x64 on 8 waves (4x2) for N <= 64 convs
+  static const int BMS[11] = {0, 128, 128, 64, 256, 128, 256, 0, 128, 32, 128}, BNS[11] = {0, 128, 64, 64, 128, 256, 64, 0, 128, 128, 64};
+  if (p.seg_mode == 1 && p.seg_period % BMS[tile] != 0) tile = p.seg_period % 64 == 0 ? 3 : 9;     // the M tile must divide the period
   const int bm = BMS[tile], bn = BNS[tile];
+  dim3 block(tile == 8 || tile == 10 ? 512 : 256);
   if (p.a_mode >= 2 && p.b_mode != 0) return cadre_fail("cadre_gemm_f32: conv needs b_mode 0");
   dim3 grid(((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn), p.split_k, p.batch);
 #define LAUNCH(WM_, WN_, AM_, BM_) hipLaunchKernelGGL((gemm_f32_kernel<WM_, WN_, AM_, BM_>), grid, block, 0, st, p)
@@ -638,6 +641,8 @@ extern "C" int cadre_gemm_f32(const cadre_gemm_t* pp, void* stream) {
     else if (tile == 4) LAUNCH(4, 2, AM_, BM_); \
     else if (tile == 5) LAUNCH(2, 4, AM_, BM_); \
     else if (tile == 6) LAUNCH(4, 1, AM_, BM_); \
+    else if (tile == 9) hipLaunchKernelGGL((gemm_f32_kernel<1, 1, AM_, BM_, 4, GEMM_NSETS, 1>), grid, block, 0, st, p); \
+    else if (tile == 10) hipLaunchKernelGGL((gemm_f32_kernel<1, 1, AM_, BM_, 2, GEMM_NSETS, 4>), grid, block, 0, st, p); \
     else hipLaunchKernelGGL((gemm_f32_kernel<2, 1, AM_, BM_, 4>), grid, block, 0, st, p); \
   } while (0)
   switch (p.a_mode * 2 + p.b_mode) {

@@ -19,12 +19,14 @@ from . import hip
 
 class PPOLearnerHIP:
     SPLIT_DH = 8
-    SORT_MIN_B = 128
+    SORT_MIN_B = 64
 
     def sorted_rows(self, B):
         """Row-sorted update (rows of a minibatch grouped by command, GEMM tiles a command net does not
-        own are skipped) pays when the update is MFMA-bound: minibatches >= 128 rows per head."""
-        return self.use_sorted and B >= self.SORT_MIN_B and B % 64 == 0
+        own are skipped; 32-row M tiles).  At minibatch 64 a command net owns ~16 of the 64 rows, so the
+        unsorted form spends 4x the fp32-MFMA time the update needs — and its skinny GEMMs are bound by
+        exactly that (one MFMA chain per SIMD), not by the weight stream."""
+        return self.use_sorted and B >= self.SORT_MIN_B and B % 32 == 0
 
     def __init__(self, arena, clip=0.1, value_coeff=0.1, clip_coeff=1.0, ent_coeff=0.01, seq_length=8):
         self.a = arena
@@ -134,15 +136,32 @@ class PPOLearnerHIP:
             out = self._update_body(B, inv_b, sorted_rows)  # eager warm-up (func attributes, lazy init)
             if self._graphs.get(("warm",) + key):
                 torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    self._update_body(B, inv_b, sorted_rows)
+                g = self._capture(lambda: self._update_body(B, inv_b, sorted_rows))
                 self._graphs[key] = g
             else:
                 self._graphs[("warm",) + key] = True
             return out
         g.replay()
         return self.workspace(B)["losses"]
+
+    @staticmethod
+    def _capture(fn):
+        """Capture fn() into a hipGraph.  The cyclic garbage collector is held off for the duration:
+        a finaliser that runs inside the capture window (an older agent's graphs or tensors being
+        destroyed) issues HIP calls that are illegal while the stream is capturing and aborts the
+        process from a destructor."""
+        import gc
+        g = torch.cuda.CUDAGraph()
+        was = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        try:
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                fn()
+        finally:
+            if was:
+                gc.enable()
+        return g
 
     def _update_body(self, B, inv_b, sorted_rows=False):
         a, S = self.a, self.S
@@ -236,9 +255,7 @@ class PPOLearnerHIP:
         if g is None:
             if self._graphs.get(("warm",) + key):
                 torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    body()
+                g = self._capture(body)
                 self._graphs[key] = g
                 g.replay()
                 return

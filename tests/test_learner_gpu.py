@@ -339,9 +339,9 @@ def test_reference_topology_shared_nets_and_worker_agent():
     assert float(arena_of(shared).grads.abs().max()) == 0.0          # chief resets the shared buffers (chief.py:22)
 
 
-@pytest.mark.parametrize("Bw,nW", [(128, 1), (64, 4)])
+@pytest.mark.parametrize("Bw,nW", [(128, 1), (64, 4), (64, 1), (96, 1)])
 def test_row_sorted_update_equals_unsorted(Bw, nW):
-    """Minibatches >= 128 rows per head: rows sorted by command + GEMM tile skipping (stale rows of other
+    """Minibatches >= 64 rows per head: rows sorted by command + GEMM tile skipping (stale rows of other
     command nets are masked to exact zeros in the backward) must reproduce the unsorted path: same
     losses, same gradients up to fp32 summation order — over several updates so that skipped tiles
     really hold stale data from earlier minibatches."""

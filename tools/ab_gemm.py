@@ -37,10 +37,25 @@ cases = [("layer1 3x3 64->64 @72 t3", 72, 72, 64, 64, 3, 1, 1, 3), ("layer2 3x3 
          ("layer2 3x3 128 @36 t1", 36, 36, 128, 128, 3, 1, 1, 1), ("layer2 3x3 128 @36 t8", 36, 36, 128, 128, 3, 1, 1, 8),
          ("layer3 3x3 256 @18 t3", 18, 18, 256, 256, 3, 1, 1, 3), ("layer3 3x3 256 @18 t8", 18, 18, 256, 256, 3, 1, 1, 8),
          ("layer4 3x3 512 @9 t3", 9, 9, 512, 512, 3, 1, 1, 3), ("layer4 3x3 512 @9 t8", 9, 9, 512, 512, 3, 1, 1, 8),
-         ("dense 4096^3 t1", 0, 0, 0, 0, 0, 0, 0, 1), ("dense 4096^3 t8", 0, 0, 0, 0, 0, 0, 0, 8)]
+         ("dense 4096^3 t1", 0, 0, 0, 0, 0, 0, 0, 1), ("dense 4096^3 t8", 0, 0, 0, 0, 0, 0, 0, 8),
+         ("lstm step 64x2120x544 x8 t3", -1, 64, 2120, 544, 8, 0, 0, 3), ("lstm step 64x2120x544 x8 t9", -1, 64, 2120, 544, 8, 0, 0, 9),
+         ("lstm step 64x2120x544 x8 t2", -1, 64, 2120, 544, 8, 0, 0, 2),
+         ("lstm step 64x2120x544 x8 t9 seg16", -1, 64, 2120, 544, 8, 16, 0, 9), ("lstm step 64x2120x544 x8 t3 seg16", -1, 64, 2120, 544, 8, 16, 0, 3)]
+if os.environ.get("AB_ONLY"):
+    cases = [c for c in cases if os.environ["AB_ONLY"] in c[0]]
 st = torch.cuda.current_stream().cuda_stream
 for name, H, W, ci, co, k, s, p, tile in cases:
-    if H:
+    if H == -1:        # batched skinny GEMM: (name, -1, M, N, K, batch, ...)
+        M, N, K, Z = W, ci, co, k
+        x = torch.randn(Z, M, K, device="cuda"); w = torch.randn(Z, N, K, device="cuda") * 0.05; out = torch.empty(Z, M, N, device="cuda")
+        d = desc(x, w, out, M, N, K, None, 0, tile)
+        d.batch = Z
+        d.a_str, d.b_str, d.c_str = M * K, N * K, M * N
+        d.a_mod = d.b_mod = d.c_mod = 1 << 30
+        if s:          # row-sorted: batch entry z owns rows [s*(z%4), s*(z%4)+s) of the 64-row period
+            segt = torch.tensor([[s * (z % 4), s] for z in range(Z)], dtype=torch.int32, device="cuda")
+            d.seg_mode, d.seg_period, d.seg_div, d.row_seg = 1, M, 1, segt.data_ptr()
+    elif H:
         Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         x = torch.randn(F, H, W, ci, device="cuda"); w = torch.randn(co, k * k * ci, device="cuda") * 0.05
         out = torch.empty(F, Ho, Wo, co, device="cuda")
@@ -59,5 +74,6 @@ for name, H, W, ci, co, k, s, p, tile in cases:
             assert rc == 0
             if rnd >= 2:
                 times[n].append(e0.elapsed_time(e1) * 1e-3)
-    row = "  ".join("%s %6.1f" % (n, 2.0 * M * N * K / sorted(t)[len(t) // 2] / 1e12) for n, t in times.items())
+    Zb = max(1, d.batch)
+    row = "  ".join("%s %6.1f (%6.1f us)" % (n, 2.0 * M * N * K * Zb / sorted(t)[len(t) // 2] / 1e12, sorted(t)[len(t) // 2] * 1e6) for n, t in times.items())
     print("%-28s TFLOP/s: %s" % (name, row), flush=True)

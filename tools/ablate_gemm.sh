@@ -10,5 +10,6 @@ bash tools/ab_build.sh nobar -DABL_NOLOAD -DABL_NOBAR &
 bash tools/ab_build.sh nolds -DABL_NOLOAD -DABL_NOBAR -DABL_NOLDSREAD &
 bash tools/ab_build.sh nostore -DABL_NOSTORE &
 bash tools/ab_build.sh nogload -DABL_NOGLOAD &
+bash tools/ab_build.sh noepi -DABL_NOEPI &
 wait
-python tools/ab_gemm.py base=cadre_amd/csrc/libcadre_hip.so nostore=/tmp/v_nostore.so nogload=/tmp/v_nogload.so noload=/tmp/v_noload.so nobar=/tmp/v_nobar.so nolds=/tmp/v_nolds.so 2>&1 | tail -12
+python tools/ab_gemm.py base=cadre_amd/csrc/libcadre_hip.so nostore=/tmp/v_nostore.so nogload=/tmp/v_nogload.so noload=/tmp/v_noload.so nobar=/tmp/v_nobar.so nolds=/tmp/v_nolds.so noepi=/tmp/v_noepi.so 2>&1 | tail -14

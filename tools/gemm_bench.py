@@ -62,7 +62,7 @@ def main():
     for name, H, W, ci, co, k, s, p, res in cases:
         row = []
         for tl in tiles:
-            if tl in (1, 4, 5, 8) and co <= 64:
+            if tl in (1, 4, 5, 8, 9) and co <= 64:
                 row.append("   --  ")
                 continue
             tf, t = conv_case(F, H, W, ci, co, k, s, p, res, tile=tl)

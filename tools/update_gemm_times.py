@@ -14,28 +14,36 @@ from tests.test_learner_gpu import make_agent  # noqa: E402
 
 
 def main():
-    B, S = 64, 8
+    from ppo_agent.storage import RolloutStorage
+    from tests.helpers import fill_storages
+    B = 64
+    T = 2 * B
     agent = make_agent(84, 84)
-    r = np.random.RandomState(5)
-    ds = []
-    for hd, K in (("steer", 33), ("throttle", 3)):
-        tup = (torch.from_numpy((r.standard_normal((S * B, 530)) * 0.5).astype(np.float32)),
-               torch.from_numpy(r.randint(0, K, (B, 1)).astype(np.int64)),
-               torch.from_numpy((0.3 * r.standard_normal((B, 1))).astype(np.float32)),
-               torch.from_numpy(r.standard_normal((B, 1)).astype(np.float32)), torch.ones(B, 1),
-               torch.from_numpy((-np.log(K) + 0.2 * r.standard_normal((B, 1))).astype(np.float32)),
-               torch.from_numpy(r.standard_normal((B, 1)).astype(np.float32)),
-               [torch.from_numpy((0.1 * r.standard_normal((B, 530))).astype(np.float32)),
-                torch.from_numpy((0.1 * r.standard_normal((B, 530))).astype(np.float32))],
-               torch.from_numpy(r.randint(0, 4, (B, 1)).astype(np.int32)))
-        ds.append(tuple(x.cuda() if not isinstance(x, list) else [y.cuda() for y in x] for x in tup))
+    if os.environ.get("UNSORTED"):
+        agent.learner.use_sorted = False
+    data = fill_storages(T, 700)
+    pair = []
+    for hd in ("steer", "throttle"):
+        st = RolloutStorage(T, 2, 530, 8, 530, True, 0.99, 0.95)
+        for k, v in data[hd].items():
+            getattr(st, k).copy_(torch.from_numpy(v))
+        st.to("cuda:0")
+        st.compute_returns(torch.tensor([0.05]))
+        pair.append(st)
+    g = torch.Generator().manual_seed(1)
+    idx = [torch.randperm(T, generator=g)[:B] for _ in range(2)]
+    batches = [(pair[0], idx[0], pair[0].advantages, pair[1], idx[1], pair[1].advantages)]
+    print("sorted rows:", agent.learner.sorted_rows(B))
+
+    def run():
+        agent.update_policy_from_storages(batches)
     for _ in range(3):
-        agent.update_policy(ds[0], ds[1])
+        run()
     torch.cuda.synchronize()
     agg = {}
     for rep in range(5):
         hip.PROFILE = prof = []
-        agent.update_policy(ds[0], ds[1])
+        run()
         torch.cuda.synchronize()
         hip.PROFILE = None
         for key, flops, e0, e1, shape in prof:
