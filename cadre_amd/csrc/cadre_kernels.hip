@@ -178,35 +178,38 @@ extern "C" int cadre_preprocess(const uint8_t* rgb, const uint8_t* route, const 
 }
 
 // ============================================================================ maxpool 3x3 s2 p1
-// One workgroup row per output row (f, ho): the frame/row decode is scalar, a lane owns one 16-byte
-// channel group of one output pixel; 32-bit index math (the grid-stride form spent more time in 64-bit
-// divisions than in loads).  HBM-bound: reads the stem output once (rows shared by neighbouring output
-// rows hit L2), writes a quarter of it.
+// One workgroup per MP_ROWS consecutive output rows of a frame: the frame/row decode is scalar, a lane owns
+// one 16-byte channel group of one output pixel.  HBM-bound (stem output read once + a quarter written:
+// 6.8 GB in 1.4 ms at 288x288 x 1024 frames); MP_ROWS = 4 (row reuse inside a workgroup) measured no better.
+#define MP_ROWS 1
 template <typename VEC, int NE, typename OP>
 __device__ __forceinline__ void maxpool_row(const VEC* x, VEC* y, int H, int W, int CV, int Ho, int Wo, OP vmax) {
-  const int row = blockIdx.x;
-  const int f = row / Ho, ho = row % Ho;
-  for (int idx = threadIdx.x; idx < Wo * CV; idx += blockDim.x) {
-  const int wo = idx / CV, c = idx % CV;
-  float m[NE];
+  const int groups = (Ho + MP_ROWS - 1) / MP_ROWS;
+  const int f = blockIdx.x / groups, hg = blockIdx.x % groups;
+  for (int ho = hg * MP_ROWS; ho < min(Ho, (hg + 1) * MP_ROWS); ++ho) {
+    const int row = f * Ho + ho;
+    for (int idx = threadIdx.x; idx < Wo * CV; idx += blockDim.x) {
+      const int wo = idx / CV, c = idx % CV;
+      float m[NE];
 #pragma unroll
-  for (int e = 0; e < NE; ++e) m[e] = -INFINITY;
+      for (int e = 0; e < NE; ++e) m[e] = -INFINITY;
 #pragma unroll
-  for (int dh = 0; dh < 3; ++dh) {
-    const int hi = ho * 2 - 1 + dh;
-    if ((unsigned)hi >= (unsigned)H) continue;
-    const VEC* xr = x + ((int64_t)f * H + hi) * W * CV;
+      for (int dh = 0; dh < 3; ++dh) {
+        const int hi = ho * 2 - 1 + dh;
+        if ((unsigned)hi >= (unsigned)H) continue;
+        const VEC* xr = x + ((int64_t)f * H + hi) * W * CV;
 #pragma unroll
-    for (int dw = 0; dw < 3; ++dw) {
-      const int wi = wo * 2 - 1 + dw;
-      if ((unsigned)wi >= (unsigned)W) continue;
-      vmax(m, xr[wi * CV + c]);
+        for (int dw = 0; dw < 3; ++dw) {
+          const int wi = wo * 2 - 1 + dw;
+          if ((unsigned)wi >= (unsigned)W) continue;
+          vmax(m, xr[wi * CV + c]);
+        }
+      }
+      VEC o;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) o[e] = (decltype(o[0] + o[0]))m[e];
+      y[(int64_t)row * Wo * CV + idx] = o;
     }
-  }
-  VEC o;
-#pragma unroll
-  for (int e = 0; e < NE; ++e) o[e] = (decltype(o[0] + o[0]))m[e];
-  y[(int64_t)row * Wo * CV + idx] = o;
   }
 }
 
@@ -232,7 +235,7 @@ extern "C" int cadre_maxpool3x3s2_bf16(const void* x, void* y, int32_t F, int32_
   FAIL_IF(!x || !y || F < 1 || H < 1 || W < 1 || C < 8 || (C & 7), "cadre_maxpool3x3s2_bf16: bad argument");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   FAIL_IF((int64_t)F * Ho > 0x7fffffff, "cadre_maxpool3x3s2_bf16: too many rows");
-  hipLaunchKernelGGL(maxpool_bf16_kernel, dim3(F * Ho), dim3(256), 0, ST(stream), (const __bf16*)x,
+  hipLaunchKernelGGL(maxpool_bf16_kernel, dim3(F * ((Ho + MP_ROWS - 1) / MP_ROWS)), dim3(256), 0, ST(stream), (const __bf16*)x,
                      (__bf16*)y, H, W, C / 8, Ho, Wo);
   return (int)hipGetLastError();
 }
@@ -242,7 +245,7 @@ extern "C" int cadre_maxpool3x3s2(const float* x, float* y, int32_t F, int32_t H
   FAIL_IF(!x || !y || F < 1 || H < 1 || W < 1 || C < 4 || (C & 3), "cadre_maxpool3x3s2: bad argument");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   FAIL_IF((int64_t)F * Ho > 0x7fffffff, "cadre_maxpool3x3s2: too many rows");
-  hipLaunchKernelGGL(maxpool_kernel, dim3(F * Ho), dim3(256), 0, ST(stream), x, y, H, W, C / 4, Ho, Wo);
+  hipLaunchKernelGGL(maxpool_kernel, dim3(F * ((Ho + MP_ROWS - 1) / MP_ROWS)), dim3(256), 0, ST(stream), x, y, H, W, C / 4, Ho, Wo);
   return (int)hipGetLastError();
 }
 
