@@ -11,6 +11,7 @@
 // bound by operand staging (L2 -> LDS), so the large tiles are preferred.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "../../include/cadre_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -25,7 +26,9 @@ int cadre_fail(const char* msg);
 
 // flags of cadre_gemm_t used here: bit1 = C is bf16 (else f32), bit2 = resid is bf16 (else f32)
 // WVN = waves along N (2 -> 256 threads, 4 -> 512 threads); 2 waves along M.
-template <int WM, int WN, int AMODE, int WVN>
+// NS = register sets of staged tiles (see gemm_f32.hip: the k-loop stages the next tile behind the first
+// fragment reads of the current one); 1 for the 256-wide tiles, whose accumulators leave no room for two.
+template <int WM, int WN, int AMODE, int WVN, int NS>
 __global__ __launch_bounds__(128 * WVN, ((2 * WM + WVN * WN) * 2 * 32 * 36 * 4 > 80 * 1024 ? 1 : 2)) void gemm_bf16_kernel(cadre_gemm_t p) {
   constexpr int NT = 128 * WVN;   // threads
   constexpr int RP = NT / 8;      // rows staged per pass (8 x 16-B chunks per 128-B row)
@@ -51,10 +54,15 @@ __global__ __launch_bounds__(128 * WVN, ((2 * WM + WVN * WN) * 2 * 32 * 36 * 4 >
   const int tile_m = bid / tilesN, tile_n = bid % tilesN;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int z = blockIdx.z;
-  const char* A = reinterpret_cast<const char*>(p.A) + (int64_t)((z / p.a_div) % p.a_mod) * p.a_str * 2;
-  const char* B = reinterpret_cast<const char*>(p.B) + (int64_t)((z / p.b_div) % p.b_mod) * p.b_str * 2;
+  const char* A = reinterpret_cast<const char*>(p.A);
+  const char* B = reinterpret_cast<const char*>(p.B);
   const bool c_bf16 = (p.flags & 2) != 0, r_bf16 = (p.flags & 4) != 0;
-  char* C = reinterpret_cast<char*>(p.C) + (int64_t)((z / p.c_div) % p.c_mod) * p.c_str * (c_bf16 ? 2 : 4);
+  char* C = reinterpret_cast<char*>(p.C);
+  if (p.batch > 1) {
+    A += (int64_t)((z / p.a_div) % p.a_mod) * p.a_str * 2;
+    B += (int64_t)((z / p.b_div) % p.b_mod) * p.b_str * 2;
+    C += (int64_t)((z / p.c_div) % p.c_mod) * p.c_str * (c_bf16 ? 2 : 4);
+  }
 
   const int nk_total = (p.K + BKE - 1) / BKE;
   int kt_begin = 0, kt_end = nk_total;
@@ -77,39 +85,43 @@ __global__ __launch_bounds__(128 * WVN, ((2 * WM + WVN * WN) * 2 * 32 * 36 * 4 >
       aoff[i] = m < p.M ? (unsigned)((int64_t)m * p.lda * 2 + cc * 16) : OOB;
       amask[i] = 0;
     }
-  } else if constexpr (AMODE == 4) {
-    // Cin == 4 stem on a ZERO-PADDED bf16 NHWC4 image [Nimg][H][W][4] (H, W = padded sizes, the halo is
-    // real zeros in memory, so no tap masks): k-tile kt holds kernel rows 2kt and 2kt+1; chunk cc is
-    // the pixel pair 2(cc&3), 2(cc&3)+1 of row 2kt + (cc>>2), counted from padded pixel (stride*ho,
-    // stride*wo).  B is [N][KH/2 rounded up][64] with zeros where kh >= KH or kw >= KW.
-    const int hw = p.Ho * p.Wo;
-#pragma unroll
-    for (int i = 0; i < RA; ++i) {
-      const int m = m0 + rr + RP * i;
-      const int mm = min(m, p.M - 1);
-      const int img = mm / hw, rem = mm % hw;
-      const int ho = rem / p.Wo, wo = rem % p.Wo;
-      aoff[i] = m < p.M ? (unsigned)((((img * p.H + ho * p.stride + (cc >> 2)) * p.W + wo * p.stride + 2 * (cc & 3)) * 4) * 2) : OOB;
-      amask[i] = 0;
-    }
   } else {
+    // conv rows: scalar decode of the tile's first row + float-reciprocal carries (gemm_f32.hip)
     const int hw = p.Ho * p.Wo;
+    const int img0 = m0 / hw, rem0 = m0 % hw;
+    const int ho0 = rem0 / p.Wo, wo0 = rem0 % p.Wo;
+    const float inv_wo = 1.0f / (float)p.Wo, inv_ho = 1.0f / (float)p.Ho;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-      const int m = m0 + rr + RP * i;
-      const int mm = min(m, p.M - 1);
-      const int img = mm / hw, rem = mm % hw;
-      const int ho = rem / p.Wo, wo = rem % p.Wo;
-      const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-      aoff[i] = (unsigned)((((img * p.H + hi0) * p.W + wi0) * p.Cin) * 2 + cc * 16);
-      unsigned mask = 0;
-      if (m < p.M) {
-        for (int kh = 0; kh < p.KH; ++kh)
+      const int r = rr + RP * i;
+      const int m = m0 + r;
+      const int x = wo0 + r;
+      const int q1 = (int)(((float)x + 0.5f) * inv_wo);
+      const int wo = x - __mul24(q1, p.Wo);
+      const int y = ho0 + q1;
+      const int q2 = (int)(((float)y + 0.5f) * inv_ho);
+      const int ho = y - __mul24(q2, p.Ho);
+      const int img = img0 + q2;
+      if constexpr (AMODE == 4) {
+        // Cin == 4 stem on a ZERO-PADDED bf16 NHWC4 image [Nimg][H][W][4] (H, W = padded sizes, the halo is
+        // real zeros in memory, so no tap masks): k-tile kt holds kernel rows 2kt and 2kt+1; chunk cc is
+        // the pixel pair 2(cc&3), 2(cc&3)+1 of row 2kt + (cc>>2), counted from padded pixel (stride*ho,
+        // stride*wo).  B is [N][KH/2 rounded up][64] with zeros where kh >= KH or kw >= KW.
+        aoff[i] = m < p.M ? (unsigned)((((img * p.H + ho * p.stride + (cc >> 2)) * p.W + wo * p.stride + 2 * (cc & 3)) * 4) * 2) : OOB;
+        amask[i] = 0;
+      } else {
+        const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+        aoff[i] = (unsigned)((((img * p.H + hi0) * p.W + wi0) * p.Cin) * 2 + cc * 16);
+        unsigned mask = 0;
+        if (m < p.M) {     // separable: (rows inside) x (columns inside)
+          unsigned colm = 0;
           for (int kw = 0; kw < p.KW; ++kw)
-            if ((unsigned)(hi0 + kh) < (unsigned)p.H && (unsigned)(wi0 + kw) < (unsigned)p.W)
-              mask |= 1u << (kh * p.KW + kw);
+            if ((unsigned)(wi0 + kw) < (unsigned)p.W) colm |= 1u << kw;
+          for (int kh = 0; kh < p.KH; ++kh)
+            if ((unsigned)(hi0 + kh) < (unsigned)p.H) mask |= colm << (kh * p.KW);
+        }
+        amask[i] = mask;
       }
-      amask[i] = mask;
     }
   }
   unsigned boff[RB];
@@ -119,36 +131,39 @@ __global__ __launch_bounds__(128 * WVN, ((2 * WM + WVN * WN) * 2 * 32 * 36 * 4 >
     boff[i] = n < p.N ? (unsigned)((int64_t)n * p.ldb * 2 + cc * 16) : OOB;
   }
 
-  f32x4 areg[RA], breg[RB];
+  f32x4 areg[NS][RA], breg[NS][RB];
   auto ldg = [](const __amdgpu_buffer_rsrc_t& rs, unsigned off) -> f32x4 {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
   };
-  auto load_tiles = [&](int kt) {
+  // request k-tile kt into register set rs; tiles past the end resolve to OOB offsets (zero fill)
+  auto load_tiles = [&](int kt, int rs) {
     const int k0 = kt * BKE;
     const unsigned kb_ = (k0 + cc * 8 < p.K) ? (unsigned)k0 * 2u : OOB;     // K % 8 == 0
     if constexpr (AMODE == 0) {
 #pragma unroll
-      for (int i = 0; i < RA; ++i) areg[i] = ldg(rsA, aoff[i] + kb_);
+      for (int i = 0; i < RA; ++i) areg[rs][i] = ldg(rsA, aoff[i] + kb_);
     } else if constexpr (AMODE == 4) {
       const unsigned delta = (unsigned)(2 * kt * p.W * 8);                    // two padded rows per k-tile
+      const bool in = kt < nk_total;                                          // (past-the-end tiles must not touch memory)
 #pragma unroll
-      for (int i = 0; i < RA; ++i) areg[i] = ldg(rsA, aoff[i] + delta);       // OOB rows stay >= 2 GiB
+      for (int i = 0; i < RA; ++i) areg[rs][i] = ldg(rsA, in ? aoff[i] + delta : OOB);   // OOB rows stay >= 2 GiB
     } else {
       const int pos = k0 / p.Cin, ci = k0 % p.Cin;                           // uniform (Cin % 64 == 0)
       const unsigned delta = (unsigned)((((pos / p.KW) * p.W + (pos % p.KW)) * p.Cin + ci) * 2);
+      const unsigned bit = pos < 32 ? 1u << pos : 0u;
 #pragma unroll
-      for (int i = 0; i < RA; ++i) areg[i] = ldg(rsA, ((amask[i] >> pos) & 1u) ? aoff[i] + delta : OOB);
+      for (int i = 0; i < RA; ++i) areg[rs][i] = ldg(rsA, (amask[i] & bit) ? aoff[i] + delta : OOB);
     }
 #pragma unroll
-    for (int i = 0; i < RB; ++i) breg[i] = ldg(rsB, boff[i] + kb_);
+    for (int i = 0; i < RB; ++i) breg[rs][i] = ldg(rsB, boff[i] + kb_);
   };
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](int buf, int rs) {
     float* as = As + buf * BM * PITCH_F;
     float* bs = Bs + buf * BN * PITCH_F;
 #pragma unroll
-    for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(as + (rr + RP * i) * PITCH_F + cc * 4) = areg[i];
+    for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(as + (rr + RP * i) * PITCH_F + cc * 4) = areg[rs][i];
 #pragma unroll
-    for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(bs + (rr + RP * i) * PITCH_F + cc * 4) = breg[i];
+    for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(bs + (rr + RP * i) * PITCH_F + cc * 4) = breg[rs][i];
   };
 
   f32x16 acc[WM][WN];
@@ -159,16 +174,8 @@ __global__ __launch_bounds__(128 * WVN, ((2 * WM + WVN * WN) * 2 * 32 * 36 * 4 >
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (kt_begin < kt_end) {
-    load_tiles(kt_begin);
-    store_tiles(0);
-  }
-  __syncthreads();
-
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int buf = (kt - kt_begin) & 1;
-    const bool more = kt + 1 < kt_end;
-    if (more) load_tiles(kt + 1);
+  // one k-tile of MFMAs from LDS buffer `buf`; `staging()` runs behind the first fragment reads
+  auto compute = [&](int buf, auto&& staging) {
     const float* as = As + buf * BM * PITCH_F;
     const float* bs = Bs + buf * BN * PITCH_F;
 #pragma unroll
@@ -180,25 +187,52 @@ __global__ __launch_bounds__(128 * WVN, ((2 * WM + WVN * WN) * 2 * 32 * 36 * 4 >
 #pragma unroll
       for (int j = 0; j < WN; ++j)
         bf[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(bs + ((wn * WN + j) * 32 + l31) * PITCH_F + (2 * s + lh) * 4));
+      if (s == 0) staging();
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < WN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
-    if (more) store_tiles(buf ^ 1);
+  };
+  // k-loop (same order as gemm_f32.hip): barrier; first fragment reads of tile t; write tile t+1 (register
+  // set (t+1)%NS) into the buffer compute(t-1) released and re-request the set for tile t+1+NS; MFMAs.
+  constexpr int U = (NS % 2 == 0) ? NS : 2 * NS;
+  auto step = [&](auto uc, int kt) {
+    constexpr int u = decltype(uc)::value;
     __syncthreads();
+    compute(u & 1, [&] {
+      store_tiles((u + 1) & 1, (u + 1) % NS);
+      load_tiles(kt + 1 + NS, (u + 1) % NS);
+    });
+  };
+  load_tiles(kt_begin, 0);
+  store_tiles(0, 0);
+#pragma unroll
+  for (int j = 1; j <= NS; ++j) load_tiles(kt_begin + j, j % NS);
+  int kt = kt_begin;
+  for (; kt + U <= kt_end; kt += U) {
+    step(std::integral_constant<int, 0>{}, kt);
+    step(std::integral_constant<int, 1>{}, kt + 1);
   }
+  if (kt < kt_end) step(std::integral_constant<int, 0>{}, kt);
+  __syncthreads();      // every wave is done reading: the epilogue re-uses the staging buffers
 
   // ---------------------------------------------------------------- epilogue (fp32 math)
+  // Straight-line per (activation, residual kind) with buffer loads/stores rebased at the tile's first
+  // row (see gemm_f32.hip): 32-bit offsets, rows >= M dropped by the hardware bounds check.
   const bool raw = p.split_k > 1;
   const int actk = p.act & 15;
   const bool post = (p.act & 16) != 0;
-  const float* scale = (!raw && p.scale) ? p.scale + (int64_t)((z / p.s_div) % p.s_mod) * p.s_str : nullptr;
-  const float* shift = (!raw && p.shift) ? p.shift + (int64_t)((z / p.s_div) % p.s_mod) * p.s_str : nullptr;
-  const char* resid = (!raw && p.resid)
-                          ? reinterpret_cast<const char*>(p.resid) + (int64_t)((z / p.r_div) % p.r_mod) * p.r_str * (r_bf16 ? 2 : 4)
-                          : nullptr;
+  const float* scale = raw ? nullptr : p.scale;
+  const float* shift = raw ? nullptr : p.shift;
+  const char* resid = raw ? nullptr : reinterpret_cast<const char*>(p.resid);
+  if (p.batch > 1) {
+    const int64_t so = (int64_t)((z / p.s_div) % p.s_mod) * p.s_str;
+    if (scale) scale += so;
+    if (shift) shift += so;
+    if (resid) resid += (int64_t)((z / p.r_div) % p.r_mod) * p.r_str * (r_bf16 ? 2 : 4);
+  }
   constexpr int CW = WN * 32, P = CW + 4;
   constexpr int LPR = CW / 4, RPI = 64 / LPR, NIT = 32 / RPI;
   float* cs = lds + wave * (32 * P);
@@ -209,53 +243,79 @@ __global__ __launch_bounds__(128 * WVN, ((2 * WM + WVN * WN) * 2 * 32 * 36 * 4 >
   if (cvalid && scale) sc = *reinterpret_cast<const f32x4*>(scale + col);
   if (cvalid && shift) sh = *reinterpret_cast<const f32x4*>(shift + col);
   const bool out_bf16 = c_bf16 && !raw;
+  const int esz = out_bf16 ? 2 : 4, rsz = r_bf16 ? 2 : 4;
+  const int64_t rows_left = (int64_t)p.M - m0;
+  auto window = [](int64_t bytes) { return (int)(bytes < 0x7fffffff ? bytes : 0x7fffffff); };
+  const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc((void*)(C + (int64_t)m0 * p.ldc * esz), 0,
+                                                                       window(rows_left * p.ldc * esz), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(resid ? resid + (int64_t)m0 * p.ldr * rsz : (const char*)p.C), 0, resid ? window(rows_left * p.ldr * rsz) : 0, 0x00020000);
+  const int lrow = lane / LPR;
+  const unsigned coff = cvalid ? (unsigned)((lrow * p.ldc + col) * esz) : OOB;
+  const unsigned roff = cvalid ? (unsigned)((lrow * p.ldr + col) * rsz) : OOB;
+  const float slope = p.slope;
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+  auto body = [&](auto actc, auto resc) {
+    constexpr int ACT = decltype(actc)::value;      // -1 raw split-K slab, 0 none, 1 ReLU, 2 LeakyReLU
+    constexpr int RES = decltype(resc)::value;      // 0 none, 1 f32 residual, 2 bf16 residual
 #pragma unroll
-  for (int i = 0; i < WM; ++i) {
-    const int rbase = m0 + (wm * WM + i) * 32;
-    f32x4 rv[NIT];
+    for (int i = 0; i < WM; ++i) {
+      const int r0 = (wm * WM + i) * 32;
+      f32x4 rv[NIT];
+      if constexpr (RES != 0) {
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int row = rbase + it * RPI + lane / LPR;
-      rv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (resid && cvalid && row < p.M) {
-        if (r_bf16) {
-          const bf16x4 t = *reinterpret_cast<const bf16x4*>(resid + ((int64_t)row * p.ldr + col) * 2);
-          rv[it] = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
-        } else {
-          rv[it] = *reinterpret_cast<const f32x4*>(resid + ((int64_t)row * p.ldr + col) * 4);
+        for (int it = 0; it < NIT; ++it) {
+          const unsigned off = roff + (unsigned)((r0 + it * RPI) * p.ldr * rsz);
+          if constexpr (RES == 2) {
+            const bf16x4 t = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rsR, (int)off, 0, 0));
+            rv[it] = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+          } else {
+            rv[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, (int)off, 0, 0));
+          }
         }
       }
-    }
 #pragma unroll
-    for (int j = 0; j < WN; ++j)
+      for (int j = 0; j < WN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * lh) * P + j * 32 + l31] = acc[i][j][r];
+        for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * lh) * P + j * 32 + l31] = acc[i][j][r];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int rloc = it * RPI + lane / LPR;
-      const int row = rbase + rloc;
-      f32x4 v = *reinterpret_cast<const f32x4*>(cs + rloc * P + c4);
-      if (!raw) {
-        v = v * sc + sh;
-        if (!post) v += rv[it];
+      for (int it = 0; it < NIT; ++it) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(cs + (it * RPI + lrow) * P + c4);
+        if constexpr (ACT >= 0) {
+          v = v * sc + sh;
+          if constexpr (RES != 0) { if (!post) v += rv[it]; }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (actk == 1) v[e] = fmaxf(v[e], 0.f);
-          else if (actk == 2) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
+          for (int e = 0; e < 4; ++e) {
+            if constexpr (ACT == 1) v[e] = fmaxf(v[e], 0.f);
+            if constexpr (ACT == 2) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
+          }
+          if constexpr (RES != 0) { if (post) v += rv[it]; }
         }
-        if (post) v += rv[it];
-      }
-      if (cvalid && row < p.M) {
+        const unsigned off = coff + (unsigned)((r0 + it * RPI) * p.ldc * esz);
         if (out_bf16) {
           bf16x4 o;
           o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
-          *reinterpret_cast<bf16x4*>(C + ((int64_t)row * p.ldc + col) * 2) = o;
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rsC, (int)off, 0, 0);
         } else {
-          *reinterpret_cast<f32x4*>(C + ((int64_t)row * p.ldc + col) * 4) = v;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, (int)off, 0, 0);
         }
       }
     }
-  }
+  };
+  using std::integral_constant;
+#define BODY_ACT(RES_)                                                                   \
+  do {                                                                                   \
+    if (actk == 1) body(integral_constant<int, 1>{}, integral_constant<int, RES_>{});    \
+    else if (actk == 2) body(integral_constant<int, 2>{}, integral_constant<int, RES_>{}); \
+    else body(integral_constant<int, 0>{}, integral_constant<int, RES_>{});              \
+  } while (0)
+  if (raw) body(integral_constant<int, -1>{}, integral_constant<int, 0>{});
+  else if (!resid) BODY_ACT(0);
+  else if (r_bf16) BODY_ACT(2);
+  else BODY_ACT(1);
+#undef BODY_ACT
 }
 
 #define BCHECK(cond, msg) \
@@ -319,16 +379,16 @@ extern "C" int cadre_gemm_bf16(const cadre_gemm_t* pp, void* stream) {
   const int bm = BMS[tile], bn = BNS[tile];
   dim3 grid(((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn), p.split_k, p.batch), block(tile == 7 ? 512 : 256);
   hipStream_t st = (hipStream_t)stream;
-#define LB(WM_, WN_, WV_)                                                                             \
+#define LB(WM_, WN_, WV_, NS_)                                                                        \
   do {                                                                                                \
-    if (p.a_mode == 0) hipLaunchKernelGGL((gemm_bf16_kernel<WM_, WN_, 0, WV_>), grid, block, 0, st, p); \
-    else if (p.a_mode == 2) hipLaunchKernelGGL((gemm_bf16_kernel<WM_, WN_, 2, WV_>), grid, block, 0, st, p); \
-    else hipLaunchKernelGGL((gemm_bf16_kernel<WM_, WN_, 4, WV_>), grid, block, 0, st, p);             \
+    if (p.a_mode == 0) hipLaunchKernelGGL((gemm_bf16_kernel<WM_, WN_, 0, WV_, NS_>), grid, block, 0, st, p); \
+    else if (p.a_mode == 2) hipLaunchKernelGGL((gemm_bf16_kernel<WM_, WN_, 2, WV_, NS_>), grid, block, 0, st, p); \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<WM_, WN_, 4, WV_, NS_>), grid, block, 0, st, p);        \
   } while (0)
-  if (tile == 1) LB(2, 2, 2);
-  else if (tile == 2) LB(2, 1, 2);
-  else if (tile == 3) LB(1, 1, 2);
-  else if (tile == 4) LB(4, 2, 2);
-  else LB(4, 2, 4);          // 256 x 256, 8 waves (2 x 4), each wave 128 x 64
+  if (tile == 1) LB(2, 2, 2, 2);
+  else if (tile == 2) LB(2, 1, 2, 2);
+  else if (tile == 3) LB(1, 1, 2, 2);
+  else if (tile == 4) LB(4, 2, 2, 1);
+  else LB(4, 2, 4, 1);          // 256 x 256, 8 waves (2 x 4), each wave 128 x 64
   return (int)hipGetLastError();
 }

@@ -33,7 +33,7 @@ def desc(x, w, out, M, N, K, conv, a_mode, tile):
 
 
 F = 512
-cases = [("layer1 3x3 64->64 @72 t3", 72, 72, 64, 64, 3, 1, 1, 3), ("layer2 3x3 128 @36 t3", 36, 36, 128, 128, 3, 1, 1, 3),
+cases = [("stem 7x7s2 4->64 @288 t3", 288, 288, 4, 64, 7, 2, 3, 3), ("layer1 3x3 64->64 @72 t3", 72, 72, 64, 64, 3, 1, 1, 3), ("layer2 3x3 128 @36 t3", 36, 36, 128, 128, 3, 1, 1, 3),
          ("layer2 3x3 128 @36 t1", 36, 36, 128, 128, 3, 1, 1, 1), ("layer2 3x3 128 @36 t8", 36, 36, 128, 128, 3, 1, 1, 8),
          ("layer3 3x3 256 @18 t3", 18, 18, 256, 256, 3, 1, 1, 3), ("layer3 3x3 256 @18 t8", 18, 18, 256, 256, 3, 1, 1, 8),
          ("layer4 3x3 512 @9 t3", 9, 9, 512, 512, 3, 1, 1, 3), ("layer4 3x3 512 @9 t8", 9, 9, 512, 512, 3, 1, 1, 8),
@@ -57,10 +57,11 @@ for name, H, W, ci, co, k, s, p, tile in cases:
             d.seg_mode, d.seg_period, d.seg_div, d.row_seg = 1, M, 1, segt.data_ptr()
     elif H:
         Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
-        x = torch.randn(F, H, W, ci, device="cuda"); w = torch.randn(co, k * k * ci, device="cuda") * 0.05
+        Kc = k * 32 if ci == 4 else k * k * ci
+        x = torch.randn(F, H, W, ci, device="cuda"); w = torch.randn(co, Kc, device="cuda") * 0.05
         out = torch.empty(F, Ho, Wo, co, device="cuda")
-        M, N, K = F * Ho * Wo, co, k * k * ci
-        d = desc(x, w, out, M, N, K, (H, W, ci, Ho, Wo, k, k, s, p), 2, tile)
+        M, N, K = F * Ho * Wo, co, Kc
+        d = desc(x, w, out, M, N, K, (H, W, ci, Ho, Wo, k, k, s, p), 3 if ci == 4 else 2, tile)
     else:
         M = N = K = 4096
         x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda"); out = torch.empty(M, N, device="cuda")
