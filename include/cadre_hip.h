@@ -55,14 +55,16 @@ typedef struct {
   int32_t tile;        /* 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 256x128,
                           5 = 128x256, 6 = 256x64 (4-6: one workgroup per CU);
                           7 = 256x256 on 8 waves (cadre_gemm_bf16 only);
-                          8 = 128x128 on 8 waves (cadre_gemm_f32 only)                   */
+                          8 = 128x128 on 8 waves, 9 = 32x128 on 4 waves (row-sorted
+                          minibatches: skips in 32-row steps), 10 = 128x64 on 8 waves
+                          (8-10: cadre_gemm_f32 only)                                      */
   int32_t flags;       /* bit 1: C is bf16; bit 2: resid is bf16 (cadre_gemm_bf16; bit 1 also
                           honoured by cadre_gemm_f32's vector epilogue); others must be 0   */
   /* Row segments (cadre_gemm_f32 only; PPO update with the minibatch rows sorted by command,
      agent.py:170-182 evaluates every command net on every row and masks 3 of 4): batch entry z
      owns rows [row_seg[2*(z/seg_div)], +row_seg[2*(z/seg_div)+1]) of every period of
-     `seg_period` rows.  seg_mode 1: M-tiles that own no row of their period return without
-     writing; seg_mode 2: k-tiles (k = row index, K % seg_period == 0) outside the segment are
+     `seg_period` rows (seg_period % 32 == 0; the M tile must divide it: 32- or 64-row tiles).
+     seg_mode 1: M-tiles that own no row of their period return without writing; seg_mode 2: k-tiles (k = row index, K % seg_period == 0) outside the segment are
      not multiplied.  Rows of other nets inside a computed tile are still multiplied — callers
      keep their gradients exactly zero (cadre_relu_bwd / cadre_lstm_pointwise_bwd masks).   */
   int32_t seg_mode;    /* 0 off                                                               */
