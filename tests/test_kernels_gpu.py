@@ -29,7 +29,7 @@ def hip():
 
 # ----------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("M,N,K,tile", [(200, 136, 544, 1), (77, 50, 64, 3), (300, 64, 96, 2), (64, 2120, 544, 0),
-                                        (5, 33, 128, 3), (300, 200, 544, 8)])
+                                        (5, 33, 128, 3), (300, 200, 544, 8), (70, 300, 96, 9), (300, 100, 160, 10)])
 @pytest.mark.parametrize("a_mode,b_mode", [(0, 0), (0, 1), (1, 0), (1, 1)])
 def test_gemm_modes(hip, M, N, K, tile, a_mode, b_mode):
     if a_mode == 1 and M % 4:
@@ -101,7 +101,8 @@ def test_gemm_batched_splitk(hip):
 @pytest.mark.parametrize("Cin,Cout,H,W,k,s,p,tile", [(64, 64, 18, 22, 3, 1, 1, 0), (64, 128, 18, 22, 3, 2, 1, 0),
                                                       (64, 128, 17, 21, 1, 2, 0, 0), (128, 160, 9, 9, 1, 1, 0, 0),
                                                       (4, 64, 30, 36, 7, 2, 3, 0), (128, 256, 18, 18, 3, 1, 1, 8),
-                                                      (4, 64, 30, 36, 7, 2, 3, 8)])
+                                                      (4, 64, 30, 36, 7, 2, 3, 8), (64, 64, 18, 22, 3, 1, 1, 10),
+                                                      (4, 64, 30, 36, 7, 2, 3, 10), (128, 256, 10, 13, 3, 2, 1, 9)])
 def test_conv_implicit_gemm(hip, Cin, Cout, H, W, k, s, p, tile):
     g = torch.Generator().manual_seed(Cin + Cout + k)
     Nimg = 3
@@ -474,25 +475,29 @@ def test_sort_rows_and_permute(hip):
     assert torch.equal(outs[4].cpu(), cmds[0][order]) and torch.equal(outs[8].cpu(), sc[5][order])
 
 
-def test_gemm_row_segments(hip):
+@pytest.mark.parametrize("P,tile,BM,segs", [(128, 3, 64, [[0, 40], [40, 0], [40, 70], [110, 18]]),
+                                            (128, 9, 32, [[0, 40], [40, 0], [40, 70], [110, 18]]),
+                                            (96, 0, 32, [[0, 10], [10, 30], [40, 0], [40, 56]]),     # 32-row periods: auto -> tile 9
+                                            (64, 0, 32, [[0, 16], [16, 16], [32, 31], [63, 1]])])
+def test_gemm_row_segments(hip, P, tile, BM, segs):
     """seg_mode 1: only M tiles that intersect the batch entry's row segment are written;
     seg_mode 2: only k tiles (rows) of the segment are multiplied."""
     g = torch.Generator().manual_seed(21)
-    Z, P, S, N, K = 4, 128, 2, 96, 64
-    seg = torch.tensor([[0, 40], [40, 0], [40, 70], [110, 18]], dtype=torch.int32)       # an empty net, ragged bounds
+    Z, S, N, K = 4, 2, 96, 64
+    seg = torch.tensor(segs, dtype=torch.int32)       # an empty net, ragged bounds
     A = torch.randn(Z, S * P, K, generator=g); W = torch.randn(Z, N, K, generator=g)
     out = torch.full((Z, S * P, N), 7.0, device="cuda")
     Ad, Wd, sd_ = dev(A), dev(W), dev(seg)
     hip.gemm(Ad, Wd, out, S * P, N, K, K, K, N, batch=Z, a_z=(1, 0, S * P * K), b_z=(1, 0, N * K), c_z=(1, 0, S * P * N),
-             seg=(1, sd_, P, 1), tile=3)
+             seg=(1, sd_, P, 1), tile=tile)
     full = torch.bmm(A, W.transpose(1, 2))
     o = out.cpu()
     for z in range(Z):
         b, c = int(seg[z, 0]), int(seg[z, 1])
         for t in range(S):
-            for m0 in range(0, P, 64):
-                rows = slice(t * P + m0, t * P + m0 + 64)
-                owned = c > 0 and not (m0 + 64 <= b or m0 >= b + c)
+            for m0 in range(0, P, BM):
+                rows = slice(t * P + m0, t * P + m0 + BM)
+                owned = c > 0 and not (m0 + BM <= b or m0 >= b + c)
                 if owned:
                     assert rel(o[z, rows], full[z, rows]) < 2e-5
                 else:
@@ -509,4 +514,7 @@ def test_gemm_row_segments(hip):
     hip.gemm(dYd, Xd, dW, N, K, S * P, N, K, K, a_mode=1, b_mode=1, batch=Z, a_z=(1, 0, S * P * N), b_z=(1, 1, 0),
              c_z=(1, 0, N * K), seg=(2, sd_, P, 1))
     want = torch.stack([dY[z].t() @ X for z in range(Z)])
-    assert rel(dW, want) < 2e-5 and float(dW[1].abs().max()) == 0.0
+    assert rel(dW, want) < 2e-5
+    for z in range(Z):
+        if int(seg[z, 1]) == 0:
+            assert float(dW[z].abs().max()) == 0.0                                        # empty net: exact zeros

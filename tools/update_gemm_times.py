@@ -16,7 +16,7 @@ from tests.test_learner_gpu import make_agent  # noqa: E402
 def main():
     from ppo_agent.storage import RolloutStorage
     from tests.helpers import fill_storages
-    B = 64
+    B = int(os.environ.get("B", "64"))
     T = 2 * B
     agent = make_agent(84, 84)
     if os.environ.get("UNSORTED"):
