@@ -518,3 +518,37 @@ def test_gemm_row_segments(hip, P, tile, BM, segs):
     for z in range(Z):
         if int(seg[z, 1]) == 0:
             assert float(dW[z].abs().max()) == 0.0                                        # empty net: exact zeros
+
+
+def test_conv_decode_random_geometries(hip):
+    """The im2col row decode (scalar division of the tile's first row + float-reciprocal carries) against
+    F.conv2d on seeded random geometries: odd sizes, strides, 1-pixel-high / very wide maps, frame counts that
+    leave partial tiles, every conv-capable tile; fp32 and bf16 kernels."""
+    from cadre_amd.encoder import _khwc
+    r = np.random.RandomState(1234)
+    cases = [(1, 64, 64, 1, 700, 3, 1, 1), (5, 64, 128, 3, 2, 3, 1, 1), (2, 128, 64, 31, 17, 3, 2, 1), (7, 64, 64, 9, 9, 1, 1, 0)]
+    for _ in range(14):
+        k = int(r.choice([1, 3]))
+        cases.append((int(r.randint(1, 7)), int(r.choice([64, 128])), int(r.choice([64, 96, 128])), int(r.randint(1, 40)),
+                      int(r.randint(1, 80)), k, int(r.choice([1, 2])), k // 2))
+    for ci, (Nimg, Cin, Cout, H, W, k, s, p) in enumerate(cases):
+        g = torch.Generator().manual_seed(ci)
+        x = torch.randn(Nimg, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+        shift = torch.randn(Cout, generator=g)
+        want = F.conv2d(x, w, shift, s, p)
+        Ho, Wo = want.shape[2], want.shape[3]
+        xd, wd, sh = dev(x.permute(0, 2, 3, 1).contiguous()), dev(_khwc(w)), dev(shift)
+        K = wd.shape[1]
+        for tile in (0, 2, 3, 8, 9, 10):
+            out = torch.full((Nimg, Ho, Wo, Cout), 9.0, device="cuda")
+            hip.gemm(xd, wd, out, Nimg * Ho * Wo, Cout, K, 0, K, Cout, a_mode=2, shift=sh, conv=(H, W, Cin, Ho, Wo, k, k, s, p),
+                     tile=tile)
+            assert rel(out.permute(0, 3, 1, 2), want) < 2e-5, (cases[ci], tile)
+        x16, w16 = xd.to(torch.bfloat16), wd.to(torch.bfloat16)
+        want16 = F.conv2d(x16.float().permute(0, 3, 1, 2).cpu(), w.to(torch.bfloat16).float(), shift, s, p)
+        for tile in (0, 1, 3):
+            out = torch.full((Nimg, Ho, Wo, Cout), 9.0, device="cuda")
+            hip.gemm(x16, w16, out, Nimg * Ho * Wo, Cout, K, 0, K, Cout, a_mode=2, shift=sh, conv=(H, W, Cin, Ho, Wo, k, k, s, p),
+                     tile=tile, bf16=True)
+            assert rel(out.permute(0, 3, 1, 2), want16) < 1e-4, (cases[ci], tile, "bf16")
