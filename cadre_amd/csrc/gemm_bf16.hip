@@ -25,14 +25,14 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 int cadre_fail(const char* msg);
 
 // flags of cadre_gemm_t used here: bit1 = C is bf16 (else f32), bit2 = resid is bf16 (else f32)
-// WVN = waves along N (2 -> 256 threads, 4 -> 512 threads); 2 waves along M.
+// WVM x WVN = waves along M x N (64 threads each).
 // NS = register sets of staged tiles (see gemm_f32.hip: the k-loop stages the next tile behind the first
 // fragment reads of the current one); 1 for the 256-wide tiles, whose accumulators leave no room for two.
-template <int WM, int WN, int AMODE, int WVN, int NS>
-__global__ __launch_bounds__(128 * WVN, ((2 * WM + WVN * WN) * 2 * 32 * 36 * 4 > 80 * 1024 ? 1 : 2)) void gemm_bf16_kernel(cadre_gemm_t p) {
-  constexpr int NT = 128 * WVN;   // threads
+template <int WM, int WN, int AMODE, int WVN, int NS, int WVM = 2>
+__global__ __launch_bounds__(64 * WVM * WVN, ((WVM * WM + WVN * WN) * 2 * 32 * 36 * 4 > 80 * 1024 ? 1 : 2)) void gemm_bf16_kernel(cadre_gemm_t p) {
+  constexpr int NT = 64 * WVM * WVN;   // threads
   constexpr int RP = NT / 8;      // rows staged per pass (8 x 16-B chunks per 128-B row)
-  constexpr int BM = 2 * WM * 32;
+  constexpr int BM = WVM * WM * 32;
   constexpr int BN = WVN * WN * 32;
   constexpr int RA = BM / RP;
   constexpr int RB = BN / RP;
@@ -360,7 +360,7 @@ extern "C" int cadre_gemm_bf16(const cadre_gemm_t* pp, void* stream) {
     // tools/gemm_bf16_bench.py) x wave quantisation over 256 CUs x resident workgroups per CU
     struct Cand { int id, bm, bn, per_cu; double base; };
     static const Cand wide[3] = {{7, 256, 256, 1, 1.00}, {1, 128, 128, 2, 0.80}, {3, 64, 64, 4, 0.45}};
-    static const Cand narrow[2] = {{2, 128, 64, 2, 0.85}, {3, 64, 64, 4, 1.00}};
+    static const Cand narrow[2] = {{10, 128, 64, 2, 1.05}, {3, 64, 64, 4, 1.00}};     // layer 1 @72x72: 437 vs 416 TFLOP/s
     const Cand* c = p.N <= 64 ? narrow : wide;
     const int nc = p.N <= 64 ? 2 : 3;
     double best_e = -1.0;
@@ -374,21 +374,25 @@ extern "C" int cadre_gemm_bf16(const cadre_gemm_t* pp, void* stream) {
       if (e > best_e) { best_e = e; tile = c[i].id; }
     }
   }
-  static const int BMS[8] = {0, 128, 128, 64, 256, 128, 256, 256}, BNS[8] = {0, 128, 64, 64, 128, 256, 64, 256};
-  BCHECK(tile == 1 || tile == 2 || tile == 3 || tile == 4 || tile == 7, "bad tile");
+  // 10: 128x64 on 8 waves (4x2), 11: 256x64 on 8 waves (4x2, each wave 64x32) — the N <= 64 layers are bound by
+  // L2 -> LDS staging bytes per FLOP, which only a taller tile lowers
+  static const int BMS[12] = {0, 128, 128, 64, 256, 128, 256, 256, 0, 0, 128, 256}, BNS[12] = {0, 128, 64, 64, 128, 256, 64, 256, 0, 0, 64, 64};
+  BCHECK(tile == 1 || tile == 2 || tile == 3 || tile == 4 || tile == 7 || tile == 10 || tile == 11, "bad tile");
   const int bm = BMS[tile], bn = BNS[tile];
-  dim3 grid(((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn), p.split_k, p.batch), block(tile == 7 ? 512 : 256);
+  dim3 grid(((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn), p.split_k, p.batch), block(tile == 7 || tile >= 10 ? 512 : 256);
   hipStream_t st = (hipStream_t)stream;
-#define LB(WM_, WN_, WV_, NS_)                                                                        \
+#define LB(WM_, WN_, WV_, NS_, WVM_)                                                                  \
   do {                                                                                                \
-    if (p.a_mode == 0) hipLaunchKernelGGL((gemm_bf16_kernel<WM_, WN_, 0, WV_, NS_>), grid, block, 0, st, p); \
-    else if (p.a_mode == 2) hipLaunchKernelGGL((gemm_bf16_kernel<WM_, WN_, 2, WV_, NS_>), grid, block, 0, st, p); \
-    else hipLaunchKernelGGL((gemm_bf16_kernel<WM_, WN_, 4, WV_, NS_>), grid, block, 0, st, p);        \
+    if (p.a_mode == 0) hipLaunchKernelGGL((gemm_bf16_kernel<WM_, WN_, 0, WV_, NS_, WVM_>), grid, block, 0, st, p); \
+    else if (p.a_mode == 2) hipLaunchKernelGGL((gemm_bf16_kernel<WM_, WN_, 2, WV_, NS_, WVM_>), grid, block, 0, st, p); \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<WM_, WN_, 4, WV_, NS_, WVM_>), grid, block, 0, st, p);  \
   } while (0)
-  if (tile == 1) LB(2, 2, 2, 2);
-  else if (tile == 2) LB(2, 1, 2, 2);
-  else if (tile == 3) LB(1, 1, 2, 2);
-  else if (tile == 4) LB(4, 2, 2, 1);
-  else LB(4, 2, 4, 1);          // 256 x 256, 8 waves (2 x 4), each wave 128 x 64
+  if (tile == 1) LB(2, 2, 2, 2, 2);
+  else if (tile == 2) LB(2, 1, 2, 2, 2);
+  else if (tile == 3) LB(1, 1, 2, 2, 2);
+  else if (tile == 4) LB(4, 2, 2, 1, 2);
+  else if (tile == 10) LB(1, 1, 2, 2, 4);
+  else if (tile == 11) LB(2, 1, 2, 2, 4);
+  else LB(4, 2, 4, 1, 2);          // 256 x 256, 8 waves (2 x 4), each wave 128 x 64
   return (int)hipGetLastError();
 }

@@ -392,6 +392,7 @@ def _bf(x):
 
 
 @pytest.mark.parametrize("M,N,K,tile", [(300, 256, 512, 1), (70, 64, 192, 3), (600, 128, 4608, 4), (200, 64, 576, 2),
+                                        (300, 64, 576, 10), (600, 128, 320, 11),
                                         (700, 512, 1152, 7), (256, 256, 64, 7)])
 def test_gemm_bf16_dense(hip, M, N, K, tile):
     g = torch.Generator().manual_seed(M + N)
