@@ -306,10 +306,12 @@ def main():
     TPL = {1: (2, 2, 2, 2), 2: (2, 1, 2, 2), 3: (1, 1, 2, 2), 4: (4, 2, 2, 2), 5: (2, 4, 2, 2), 6: (4, 1, 2, 2), 8: (2, 1, 4, 2),
            9: (1, 1, 4, 1), 10: (1, 1, 2, 4)}
     TILE = {1: "128x128", 2: "128x64", 3: "64x64", 4: "256x128", 5: "128x256", 6: "256x64", 8: "128x128 (8 waves)",
-            9: "32x128", 10: "128x64 (8 waves)"}
+            9: "32x128", 10: "128x64 (8 waves)", 12: "64x64, 8 M-tiles per workgroup"}
     AM = {0: "dense A[M][K]", 1: "dense A[K][M]", 2: "NHWC implicit-GEMM conv", 3: "Cin=4 stem conv"}
 
     def kname(k):      # exact symbol as rocprofv3 prints it
+        if k[0] == 12:
+            return "conv_stream_f32_kernel<%d>" % k[1]
         wm_, wn_, wvn_, wvm_ = TPL[k[0]]
         return "gemm_f32_kernel<%d, %d, %d, %d, %d, 2, %d>" % (wm_, wn_, k[1], k[2], wvn_, wvm_)
     ach = by[dom][0] / by[dom][1] / 1e12

@@ -530,6 +530,8 @@ __global__ void splitk_reduce_kernel(const float* slabs, int split_k, int64_t sl
 extern thread_local char g_cadre_err[256];
 int cadre_fail(const char* msg);
 
+int cadre_conv_stream_f32_launch(const cadre_gemm_t& p, void* stream);     // conv_stream_f32.hip (tile 12)
+
 #define GEMM_CHECK(cond, msg) \
   if (!(cond)) return cadre_fail("cadre_gemm_f32: " msg)
 
@@ -548,6 +550,12 @@ static int pick_tile(const cadre_gemm_t& p) {
   static const Cand conv_wide[2] = {{8, 128, 128, 2, 0.93}, {3, 64, 64, 4, 1.00}};
   static const Cand narrow[2] = {{2, 128, 64, 2, 0.88}, {3, 64, 64, 4, 1.00}};
   const Cand* big_conv = p.N <= 128 ? conv128 : conv_wide;
+  // Cin = 4 stem (7 k-tiles per 64x64 tile): several M-tiles per workgroup with the prefetch running across
+  // tile boundaries, conv_stream_f32.hip — 101 vs 94 TFLOP/s; on K >= 576 the one-tile kernel's second
+  // register set is worth more than the hidden start-up (121 vs 125, 128 vs 134)
+  if (p.a_mode == 3 && batch == 1 && sk == 1 && !p.seg_mode && p.M >= 64 * 2048 &&
+      ((p.N | p.ldc | (p.resid ? p.ldr : 0)) & 3) == 0 && (((uintptr_t)p.C | (uintptr_t)p.resid) & 15) == 0)
+    return 12;
   // row-sorted minibatch (each batch entry owns one run of rows per period): 32-row tiles skip the most
   if (p.seg_mode == 1 && (p.N >= 96 || p.seg_period % 64 != 0)) return 9;
   const Cand* c = p.N <= 64 ? narrow : (p.a_mode >= 2 ? big_conv : big);
@@ -623,6 +631,7 @@ extern "C" int cadre_gemm_f32(const cadre_gemm_t* pp, void* stream) {
   if (p.flags & 2)
     GEMM_CHECK(p.batch == 1 && p.split_k == 1 && ((p.N | p.ldc) & 3) == 0 && !p.resid, "bf16 output needs the vector epilogue, no batch/split/resid");
   int tile = p.tile ? p.tile : pick_tile(p);
+  if (tile == 12) return cadre_conv_stream_f32_launch(p, stream);      // 64x64 conv, several M-tiles per workgroup
   hipStream_t st = (hipStream_t)stream;
   if (tile < 1 || tile > 10 || tile == 7) return cadre_fail("cadre_gemm_f32: bad tile");
   // 9: 32x128 on 4 waves (1x4) for row-sorted skinny GEMMs; 10: 128x64 on 8 waves (4x2) for N <= 64 convs

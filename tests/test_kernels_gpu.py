@@ -102,7 +102,8 @@ def test_gemm_batched_splitk(hip):
                                                       (64, 128, 17, 21, 1, 2, 0, 0), (128, 160, 9, 9, 1, 1, 0, 0),
                                                       (4, 64, 30, 36, 7, 2, 3, 0), (128, 256, 18, 18, 3, 1, 1, 8),
                                                       (4, 64, 30, 36, 7, 2, 3, 8), (64, 64, 18, 22, 3, 1, 1, 10),
-                                                      (4, 64, 30, 36, 7, 2, 3, 10), (128, 256, 10, 13, 3, 2, 1, 9)])
+                                                      (4, 64, 30, 36, 7, 2, 3, 10), (128, 256, 10, 13, 3, 2, 1, 9),
+                                                      (64, 64, 18, 22, 3, 1, 1, 12), (4, 64, 30, 36, 7, 2, 3, 12), (64, 128, 17, 21, 1, 2, 0, 12)])
 def test_conv_implicit_gemm(hip, Cin, Cout, H, W, k, s, p, tile):
     g = torch.Generator().manual_seed(Cin + Cout + k)
     Nimg = 3
@@ -541,7 +542,7 @@ def test_conv_decode_random_geometries(hip):
         Ho, Wo = want.shape[2], want.shape[3]
         xd, wd, sh = dev(x.permute(0, 2, 3, 1).contiguous()), dev(_khwc(w)), dev(shift)
         K = wd.shape[1]
-        for tile in (0, 2, 3, 8, 9, 10):
+        for tile in (0, 2, 3, 8, 9, 10, 12):
             out = torch.full((Nimg, Ho, Wo, Cout), 9.0, device="cuda")
             hip.gemm(xd, wd, out, Nimg * Ho * Wo, Cout, K, 0, K, Cout, a_mode=2, shift=sh, conv=(H, W, Cin, Ho, Wo, k, k, s, p),
                      tile=tile)
