@@ -20,6 +20,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 #define BKE 64          // k elements per tile (128 bytes)
+#ifndef BF16_NS_SMALL
+#define BF16_NS_SMALL 2  // register sets of the 64-wide tiles
+#endif
 #define PITCH_F 36      // LDS row pitch in 4-byte words (128 B data + 16 B pad)
 
 int cadre_fail(const char* msg);
@@ -214,8 +217,16 @@ __global__ __launch_bounds__(64 * WVM * WVN, ((WVM * WM + WVN * WN) * 2 * 32 * 3
   for (; kt + U <= kt_end; kt += U) {
     step(std::integral_constant<int, 0>{}, kt);
     step(std::integral_constant<int, 1>{}, kt + 1);
+    if constexpr (U > 2) {
+      step(std::integral_constant<int, 2>{}, kt + 2);
+      step(std::integral_constant<int, 3>{}, kt + 3);
+    }
   }
   if (kt < kt_end) step(std::integral_constant<int, 0>{}, kt);
+  if (kt + 1 < kt_end) step(std::integral_constant<int, 1>{}, kt + 1);
+  if constexpr (U > 2) {
+    if (kt + 2 < kt_end) step(std::integral_constant<int, 2>{}, kt + 2);
+  }
   __syncthreads();      // every wave is done reading: the epilogue re-uses the staging buffers
 
   // ---------------------------------------------------------------- epilogue (fp32 math)
@@ -318,6 +329,8 @@ __global__ __launch_bounds__(64 * WVM * WVN, ((WVM * WM + WVN * WN) * 2 * 32 * 3
 #undef BODY_ACT
 }
 
+int cadre_conv_stream_bf16_launch(const cadre_gemm_t& p, void* stream);     // conv_stream_bf16.hip (tile 12)
+
 #define BCHECK(cond, msg) \
   if (!(cond)) return cadre_fail("cadre_gemm_bf16: " msg)
 
@@ -355,6 +368,8 @@ extern "C" int cadre_gemm_bf16(const cadre_gemm_t* pp, void* stream) {
     BCHECK(a_bytes < lim && (int64_t)p.N * p.ldb * 2 < lim, "operand spans >= 2 GiB: chunk the batch");
   }
   int tile = p.tile;
+  // N <= 64 convs (stage-1 convs, padded stem): several M-tiles per workgroup, conv_stream_bf16.hip (444 vs 431)
+  if (tile == 0 && p.N <= 64 && p.a_mode >= 2 && p.batch == 1 && p.split_k == 1 && p.K >= 128 && p.M >= 64 * 2048) tile = 12;
   if (tile == 0) {
     // staging-bound regime: shape factor (dense 8192^3: 256x256 on 8 waves 1054, 128x128 826 TFLOP/s;
     // tools/gemm_bf16_bench.py) x wave quantisation over 256 CUs x resident workgroups per CU
@@ -376,6 +391,7 @@ extern "C" int cadre_gemm_bf16(const cadre_gemm_t* pp, void* stream) {
   }
   // 10: 128x64 on 8 waves (4x2), 11: 256x64 on 8 waves (4x2, each wave 64x32) — the N <= 64 layers are bound by
   // L2 -> LDS staging bytes per FLOP, which only a taller tile lowers
+  if (tile == 12) return cadre_conv_stream_bf16_launch(p, stream);       // 64x64 conv, several M-tiles per workgroup
   static const int BMS[12] = {0, 128, 128, 64, 256, 128, 256, 256, 0, 0, 128, 256}, BNS[12] = {0, 128, 64, 64, 128, 256, 64, 256, 0, 0, 64, 64};
   BCHECK(tile == 1 || tile == 2 || tile == 3 || tile == 4 || tile == 7 || tile == 10 || tile == 11, "bad tile");
   const int bm = BMS[tile], bn = BNS[tile];
@@ -389,10 +405,10 @@ extern "C" int cadre_gemm_bf16(const cadre_gemm_t* pp, void* stream) {
   } while (0)
   if (tile == 1) LB(2, 2, 2, 2, 2);
   else if (tile == 2) LB(2, 1, 2, 2, 2);
-  else if (tile == 3) LB(1, 1, 2, 2, 2);
+  else if (tile == 3) LB(1, 1, 2, BF16_NS_SMALL, 2);
   else if (tile == 4) LB(4, 2, 2, 1, 2);
-  else if (tile == 10) LB(1, 1, 2, 2, 4);
-  else if (tile == 11) LB(2, 1, 2, 2, 4);
+  else if (tile == 10) LB(1, 1, 2, BF16_NS_SMALL, 4);
+  else if (tile == 11) LB(2, 1, 2, BF16_NS_SMALL, 4);
   else LB(4, 2, 4, 1, 2);          // 256 x 256, 8 waves (2 x 4), each wave 128 x 64
   return (int)hipGetLastError();
 }

@@ -412,7 +412,8 @@ def test_gemm_bf16_dense(hip, M, N, K, tile):
 
 @pytest.mark.parametrize("Cin,Cout,H,W,k,s,p,tile", [(64, 64, 18, 22, 3, 1, 1, 0), (64, 128, 18, 22, 3, 2, 1, 0),
                                                       (64, 128, 17, 21, 1, 2, 0, 0), (512, 128, 9, 9, 3, 1, 1, 0),
-                                                      (256, 256, 18, 18, 3, 1, 1, 7), (128, 512, 9, 9, 1, 1, 0, 7)])
+                                                      (256, 256, 18, 18, 3, 1, 1, 7), (128, 512, 9, 9, 1, 1, 0, 7),
+                                                      (64, 64, 18, 22, 3, 1, 1, 12), (128, 192, 11, 9, 3, 2, 1, 12)])
 def test_conv_bf16(hip, Cin, Cout, H, W, k, s, p, tile):
     g = torch.Generator().manual_seed(Cin + Cout + k + 1)
     Nimg = 3
@@ -429,6 +430,33 @@ def test_conv_bf16(hip, Cin, Cout, H, W, k, s, p, tile):
              conv=(H, W, Cin, Ho, Wo, k, k, s, p), bf16=True, tile=tile)
     torch.cuda.synchronize()
     assert rel(out.permute(0, 3, 1, 2), want) < 2e-5
+
+
+@pytest.mark.parametrize("tile", [3, 10, 12])
+def test_bf16_padded_stem(hip, tile):
+    """cadre_gemm_bf16 a_mode 4: 7x7/s2 stem on the zero-padded bf16 NHWC4 image (encoder C3 path), every tile
+    that serves N = 64 incl. the streamed kernel (several M-tiles per workgroup)."""
+    from cadre_amd.encoder import _stem_rows_bf16
+    g = torch.Generator().manual_seed(9)
+    Nimg, H, W = 5, 46, 58
+    x = _bf(torch.randn(Nimg, 4, H, W, generator=g)); x[:, 3] = 0
+    w = _bf(torch.randn(64, 4, 7, 7, generator=g) / 14.0)
+    scale = torch.rand(64, generator=g) + 0.5; shift = torch.randn(64, generator=g)
+    y = F.conv2d(x.float(), w.float(), None, 2, 3)
+    Ho, Wo = y.shape[2], y.shape[3]
+    want = F.relu(y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    Hp, Wp = max(H + 6, (Ho - 1) * 2 + 8), max(W + 6, (Wo - 1) * 2 + 8)
+    Wp += Wp & 1
+    xp = torch.zeros(Nimg, Hp, Wp, 4)
+    xp[:, 3:3 + H, 3:3 + W] = x.permute(0, 2, 3, 1)
+    xd = dev(xp).to(torch.bfloat16)
+    wd = dev(_stem_rows_bf16(w)).to(torch.bfloat16)
+    out = torch.empty(Nimg, Ho, Wo, 64, device="cuda", dtype=torch.bfloat16)
+    K = wd.shape[1]
+    hip.gemm(xd, wd, out, Nimg * Ho * Wo, 64, K, 0, K, 64, a_mode=4, scale=dev(scale), shift=dev(shift), act=1,
+             conv=(Hp, Wp, 4, Ho, Wo, 7, 7, 2, 0), bf16=True, flags=2, tile=tile)
+    torch.cuda.synchronize()
+    assert rel(out.float().permute(0, 3, 1, 2), want) < 6e-3          # bf16 output rounding
 
 
 def test_f32_stem_bf16_output_and_bf16_pool(hip):
@@ -549,7 +577,7 @@ def test_conv_decode_random_geometries(hip):
             assert rel(out.permute(0, 3, 1, 2), want) < 2e-5, (cases[ci], tile)
         x16, w16 = xd.to(torch.bfloat16), wd.to(torch.bfloat16)
         want16 = F.conv2d(x16.float().permute(0, 3, 1, 2).cpu(), w.to(torch.bfloat16).float(), shift, s, p)
-        for tile in (0, 1, 3):
+        for tile in (0, 1, 3) + ((12,) if K >= 128 else ()):          # the streamed kernel needs two k-tiles
             out = torch.full((Nimg, Ho, Wo, Cout), 9.0, device="cuda")
             hip.gemm(x16, w16, out, Nimg * Ho * Wo, Cout, K, 0, K, Cout, a_mode=2, shift=sh, conv=(H, W, Cin, Ho, Wo, k, k, s, p),
                      tile=tile, bf16=True)
