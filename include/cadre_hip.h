@@ -57,7 +57,9 @@ typedef struct {
                           7 = 256x256 on 8 waves (cadre_gemm_bf16 only);
                           8 = 128x128 on 8 waves, 9 = 32x128 on 4 waves (row-sorted
                           minibatches: skips in 32-row steps), 10 = 128x64 on 8 waves
-                          (8-10: cadre_gemm_f32 only)                                      */
+                          (8, 9: cadre_gemm_f32 only; 10 also cadre_gemm_bf16, which adds
+                          11 = 256x64 on 8 waves); 12 = 64x64 conv with several M-tiles per
+                          workgroup (plain conv launches only: a_mode 2/3 fp32, 2/4 bf16)   */
   int32_t flags;       /* bit 1: C is bf16; bit 2: resid is bf16 (cadre_gemm_bf16; bit 1 also
                           honoured by cadre_gemm_f32's vector epilogue); others must be 0   */
   /* Row segments (cadre_gemm_f32 only; PPO update with the minibatch rows sorted by command,
