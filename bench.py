@@ -174,7 +174,7 @@ def cpu_baseline(cfg, enc_state, ppo_state):
     td = synth.synth_rollout(2, H, W, seed=1)
     t0 = time.perf_counter()
     nwin = 0
-    while nwin < 1 or (time.perf_counter() - t0 < 6.0 and nwin < 16):
+    while nwin < 1 or (time.perf_counter() - t0 < 8.0 and nwin < 128):      # ~8 s of encoder windows
         encoder_ref.latent_feature(td[nwin % 2]["rgb"], td[nwin % 2]["route_fig"], td[nwin % 2]["measurements"], enc_state)
         nwin += 1
     t_win = (time.perf_counter() - t0) / nwin
@@ -193,7 +193,7 @@ def cpu_baseline(cfg, enc_state, ppo_state):
                      [torch.zeros(B, 530), torch.zeros(B, 530)], torch.from_numpy(r.randint(0, 4, (B, 1)).astype(np.int32))))
     t0 = time.perf_counter()
     nup = 0
-    while nup < 1 or (time.perf_counter() - t0 < 6.0 and nup < 16):
+    while nup < 1 or (time.perf_counter() - t0 < 8.0 and nup < 128):          # ~8 s of update steps
         ppo_ref.update_policy(params, samp[0], samp[1])
         grads = {m: {k: p.grad for k, p in d.items()} for m, d in params.items()}
         ppo_ref.chief_step(params, grads, adam, nup + 1)
