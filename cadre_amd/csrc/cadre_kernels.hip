@@ -971,9 +971,22 @@ __global__ void sqnorm_kernel(const float* g, const int64_t* seg_off, double* no
   const int mdl = blockIdx.y;
   const int64_t lo = seg_off[mdl], hi = seg_off[mdl + 1];
   double s = 0.0;
-  for (int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (int64_t)gridDim.x * blockDim.x) {
-    const double v = g[i];
-    s += v * v;
+  if ((lo & 3) == 0) {          // arena segments start on 16-byte boundaries: 16 B per lane
+    const int64_t n4 = (hi - lo) >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(g + lo);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+      const float4 v = g4[i];
+      s += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < ((hi - lo) & 3)) {
+      const double v = g[lo + (n4 << 2) + threadIdx.x];
+      s += v * v;
+    }
+  } else {
+    for (int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (int64_t)gridDim.x * blockDim.x) {
+      const double v = g[i];
+      s += v * v;
+    }
   }
   s = wave_sum_d(s);
   __shared__ double part[4];
