@@ -821,16 +821,18 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const float* logits, int6
   const int K = hd == 0 ? n_steer : n_throttle;
   __shared__ float red[3][4];
   float s_act = 0.f, s_val = 0.f, s_ent = 0.f;
+  // zero the gradients of the masked-out command nets (agent.py:178-182 multiply by 0): the whole [B][ldl]
+  // block of each of this head's four nets, coalesced; the owning net's entries are overwritten below
+  for (int cc = 0; cc < 4; ++cc) {
+    float* dl = dlogits + (int64_t)(hd * 4 + cc) * l_ns;
+    for (int64_t i = threadIdx.x; i < (int64_t)B * ldl; i += 256) dl[i] = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) dvalues[(int64_t)(hd * 4 + cc) * v_ns + (int64_t)b * ldv] = 0.f;
+  }
+  __syncthreads();
   for (int b = threadIdx.x; b < B; b += 256) {
     const int row = hd * B + b;                    // per-head sample arrays are [2][B]
     const int c = commands[row];
     const int a = (int)actions[row];
-    // zero the gradients of the three masked-out command nets (agent.py:178-182 multiply by 0)
-    for (int cc = 0; cc < 4; ++cc) {
-      float* dl = dlogits + (int64_t)(hd * 4 + cc) * l_ns + (int64_t)b * ldl;
-      for (int k = 0; k < ldl; ++k) dl[k] = 0.f;
-      dvalues[(int64_t)(hd * 4 + cc) * v_ns + (int64_t)b * ldv] = 0.f;
-    }
     if (c < 0 || c > 3) continue;
     const int net = hd * 4 + c;
     const float* x = logits + (int64_t)net * l_ns + (int64_t)b * ldl;
