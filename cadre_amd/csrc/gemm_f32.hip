@@ -69,16 +69,22 @@ __global__ __launch_bounds__(64 * WVM * WVN, ((WVM * WM + WVN * WN) * 2 * 32 * 3
   const float* A = p.A;
   const float* B = p.B;
   float* C = p.C;
-  if (p.batch > 1) {     // (the six scalar divisions below are ~400 SALU instructions: skip them for plain launches)
-    A += (int64_t)((z / p.a_div) % p.a_mod) * p.a_str;
-    B += (int64_t)((z / p.b_div) % p.b_mod) * p.b_str;
-    C += (int64_t)((z / p.c_div) % p.c_mod) * p.c_str;
+  // batch entry -> operand slot: (z / div) % mod.  A scalar division is ~60 dependent SALU instructions, and the
+  // update's skinny GEMMs are short enough to notice: take the common cases (div 1, mod not reached) by branch.
+  auto slot = [](int zz, int dv, int md) {
+    const int q = dv == 1 ? zz : zz / dv;
+    return q < md ? q : q % md;
+  };
+  if (p.batch > 1) {
+    A += (int64_t)slot(z, p.a_div, p.a_mod) * p.a_str;
+    B += (int64_t)slot(z, p.b_div, p.b_mod) * p.b_str;
+    C += (int64_t)slot(z, p.c_div, p.c_mod) * p.c_str;
   }
 
   // row segments (rows sorted by command): skip what this batch entry does not own
   int seg_beg = 0, seg_cnt = 0;
   if (p.seg_mode) {
-    const int32_t* sg = p.row_seg + 2 * (z / p.seg_div);
+    const int32_t* sg = p.row_seg + 2 * (p.seg_div == 1 ? z : z / p.seg_div);
     seg_beg = sg[0];
     seg_cnt = sg[1];
     if (p.seg_mode == 1) {
@@ -387,10 +393,10 @@ __global__ __launch_bounds__(64 * WVM * WVN, ((WVM * WM + WVN * WN) * 2 * 32 * 3
   const float* shift = raw ? nullptr : p.shift;
   const float* resid = raw ? nullptr : p.resid;
   if (p.batch > 1) {
-    const int64_t so = (int64_t)((z / p.s_div) % p.s_mod) * p.s_str;
+    const int64_t so = (int64_t)slot(z, p.s_div, p.s_mod) * p.s_str;
     if (scale) scale += so;
     if (shift) shift += so;
-    if (resid) resid += (int64_t)((z / p.r_div) % p.r_mod) * p.r_str;
+    if (resid) resid += (int64_t)slot(z, p.r_div, p.r_mod) * p.r_str;
   }
   const bool vec_ok = ((p.N | p.ldc | (resid ? p.ldr : 0)) & 3) == 0 && (((uintptr_t)C | (uintptr_t)resid) & 15) == 0;
   if (vec_ok) {
