@@ -162,3 +162,30 @@ def test_missing_library_fails_loudly():
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CADRE_HIP_LIB="/nonexistent/libcadre_hip.so"),
                          capture_output=True, text=True, timeout=120)
     assert "RAISED True" in out.stdout, out.stdout + out.stderr
+
+
+def test_gemm_tile_choice_is_host_logic():
+    """cadre_gemm_pick_tile runs on the host (no launch): the shapes of the hot path get the tiles DESIGN.md
+    documents, and an explicit tile id is passed through."""
+    import ctypes as C
+    from cadre_amd import hip
+    L = hip.lib()
+
+    def pick(M, N, K, a_mode=0, batch=1, split_k=1, seg=0, period=0, tile=0):
+        d = hip.GemmDesc()
+        d.M, d.N, d.K, d.a_mode, d.batch, d.split_k, d.tile = M, N, K, a_mode, batch, split_k, tile
+        d.seg_mode, d.seg_period = seg, period
+        d.ldc = N
+        return L.cadre_gemm_pick_tile(C.byref(d))
+    F = 1024
+    assert pick(F * 144 * 144, 64, 224, a_mode=3) == 12            # Cin=4 stem: streamed 64x64
+    assert pick(F * 72 * 72, 64, 576, a_mode=2) == 3               # stage 1 (N = 64)
+    assert pick(F * 36 * 36, 128, 1152, a_mode=2) == 8             # stage 2 (N = 128): 128x128 on 8 waves
+    assert pick(F * 18 * 18, 256, 2304, a_mode=2) == 3
+    assert pick(F * 81, 512, 4608, a_mode=2) == 3
+    assert pick(F * 81, 128, 4608, a_mode=2) == 3                  # head convs: too few tiles for the big one
+    assert pick(4096, 4096, 4096) == 8                             # big dense
+    assert pick(64, 2120, 544, batch=8) == 3                       # unsorted recurrent step
+    assert pick(64, 2120, 544, batch=8, seg=1, period=64) == 9     # row-sorted: 32-row tiles
+    assert pick(512, 2120, 544, batch=8, seg=1, period=64) == 9
+    assert pick(300, 200, 544, tile=2) == 2
