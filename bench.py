@@ -31,6 +31,8 @@ CONFIGS = {
     "C3": dict(workers=4, T=128, H=288, W=288, encoder_dtype="bf16"),   # "bf16 encoder / fp32 losses"
 }
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
+PEAK_HBM_GBPS = 8000.0              # MI355X_MICROARCH.md: HBM3E peak (6.3 TB/s achievable)
 PPO_EPOCH, MINI_BATCH_NUM, SEQ = 4, 2, 8
 
 
@@ -135,7 +137,7 @@ def learner_round(agent, workers, cfg, shared, timers=None):
             batches = [(wk.stor[0], idx[i][0][b], advs[i][0], wk.stor[1], idx[i][1][b], advs[i][1])
                        for i, wk in enumerate(workers)]
             dev_losses.append(agent.update_policy_from_storages(batches, sync=False))
-            shared.add_gradient(agent.model_dict)                 # RCCL all-reduce(SUM) when world_size > 1
+            shared.add_gradient(agent.model_dict)                 # hand-off; chief_step runs the RCCL all-reduce(SUM)
             chief_step(shared, None, 250.0)
     losses = torch.stack(dev_losses).tolist()                     # the round's single host sync
     if timers is not None:
@@ -207,6 +209,172 @@ def cpu_baseline(cfg, enc_state, ppo_state):
                                                    nW * PPO_EPOCH * MINI_BATCH_NUM))
 
 
+# tile id -> (WM, WN, WVN, WVM) template arguments of gemm_f32_kernel<WM, WN, AMODE, BMODE, WVN, NS, WVM>
+TPL_F32 = {1: (2, 2, 2, 2), 2: (2, 1, 2, 2), 3: (1, 1, 2, 2), 4: (4, 2, 2, 2), 5: (2, 4, 2, 2), 6: (4, 1, 2, 2), 8: (2, 1, 4, 2),
+           9: (1, 1, 4, 1), 10: (1, 1, 2, 4)}
+# tile id -> (WM, WN, WVN, NS, WVM) of gemm_bf16_kernel<WM, WN, AMODE, WVN, NS, WVM>
+TPL_BF16 = {1: (2, 2, 2, 2, 2), 2: (2, 1, 2, 2, 2), 3: (1, 1, 2, 2, 2), 4: (4, 2, 2, 1, 2), 7: (4, 2, 4, 1, 2),
+            10: (1, 1, 2, 2, 4), 11: (2, 1, 2, 2, 4)}
+TILE = {1: "128x128", 2: "128x64", 3: "64x64", 4: "256x128", 5: "128x256", 6: "256x64", 7: "256x256 (8 waves)",
+        8: "128x128 (8 waves)", 9: "32x128", 10: "128x64 (8 waves)", 11: "256x64 (8 waves)",
+        12: "64x64, 8 M-tiles per workgroup"}
+AM = {0: "dense A[M][K]", 1: "dense A[K][M]", 2: "NHWC implicit-GEMM conv", 3: "Cin=4 stem conv",
+      4: "Cin=4 stem conv on the zero-padded image"}
+
+
+def kname(k):
+    """Exact kernel symbol as rocprofv3 prints it, from a hip.PROFILE key."""
+    if k[0] == "bf16":
+        _, tile, am = k
+        if tile == 12:
+            return "conv_stream_bf16_kernel<%d>" % am
+        wm_, wn_, wvn_, ns_, wvm_ = TPL_BF16[tile]
+        return "gemm_bf16_kernel<%d, %d, %d, %d, %d, %d>" % (wm_, wn_, am, wvn_, ns_, wvm_)
+    if k[0] == 12:
+        return "conv_stream_f32_kernel<%d>" % k[1]
+    wm_, wn_, wvn_, wvm_ = TPL_F32[k[0]]
+    return "gemm_f32_kernel<%d, %d, %d, %d, %d, 2, %d>" % (wm_, wn_, k[1], k[2], wvn_, wvm_)
+
+
+def roofline_of(prof, steps):
+    """Dominant (most time) GEMM/conv kernel of the timed region, priced against BOTH roofs:
+    t_mfma = algorithmic FLOPs / MFMA peak of its dtype, t_hbm = algorithmic bytes / HBM peak; the larger
+    one is the bound, frac = that time / measured time."""
+    by = {}
+    for key, flops, e0, e1, _shape, nbytes in prof:
+        d = by.setdefault(key, [0.0, 0.0, 0, 0.0])
+        d[0] += flops; d[1] += e0.elapsed_time(e1) * 1e-3; d[2] += 1; d[3] += nbytes
+    if not by:
+        return None, {}
+    dom = max(by, key=lambda k: by[k][1])
+    fl, t, n, nb = by[dom]
+    bf16 = dom[0] == "bf16"
+    peak_tf = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+    t_mfma, t_hbm = fl / (peak_tf * 1e12), nb / (PEAK_HBM_GBPS * 1e9)
+    tile, am = (dom[1], dom[2]) if bf16 else (dom[0], dom[1])
+    r = {"kernel": kname(dom), "kernel_desc": "%s tile, %s%s" % (TILE.get(tile, tile), AM.get(am, am), ", bf16" if bf16 else ""),
+         "flops_per_launch": round(fl / n, 1), "bytes_per_launch": round(nb / n, 1), "launches": n,
+         "avg_launch_us": round(t / n * 1e6, 2),
+         "mfma_frac": round(t_mfma / t, 4), "hbm_frac": round(t_hbm / t, 4),
+         "achieved_tflops": round(fl / t / 1e12, 2), "achieved_GBps": round(nb / t / 1e9, 1)}
+    if t_mfma >= t_hbm:
+        r.update(bound="mfma", achieved=round(fl / t / 1e12, 2), peak=peak_tf, unit="TFLOP/s", frac=round(t_mfma / t, 4))
+    else:
+        r.update(bound="hbm", achieved=round(nb / t / 1e9, 1), peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(t_hbm / t, 4))
+    r["per_kernel"] = {kname(k): {"tflops": round(v[0] / v[1] / 1e12, 2), "GBps": round(v[3] / v[1] / 1e9, 1),
+                                  "time_ms_per_step": round(v[1] / steps * 1e3, 3), "launches_per_step": v[2] // steps}
+                       for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])}
+    return dom, r
+
+
+def run_config(name, args, rank, local_rank, world, use_dist, steps, warmup, episodes_dir=None):
+    """Build the agent + workers of BASELINE config `name`, warm up, time `steps` learner rounds (barrier +
+    synchronize on both sides, MAX over ranks) and return the result dict (rank 0) plus what cpu_baseline needs."""
+    import torch.distributed as dist
+    from cadre_amd import hip, synth
+    from ppo_agent.agent import CadreAgent
+    from ppo_agent.models import Shared_grad_buffers
+    cfg = dict(CONFIGS[name]); cfg["chunk_windows"] = args.chunk_windows; cfg["dedup"] = args.dedup
+    episodes = None
+    if episodes_dir:
+        from cadre_amd import replay
+        paths = replay.list_episodes(episodes_dir)
+        if len(paths) < cfg["workers"] * world:
+            raise SystemExit("--replay needs >= %d episodes, found %d" % (cfg["workers"] * world, len(paths)))
+        episodes = [replay.load_episode(p) for p in paths[rank * cfg["workers"]:(rank + 1) * cfg["workers"]]]
+        cfg["T"] = min(len(e["command"]) for e in episodes)
+        cfg["H"], cfg["W"] = episodes[0]["rgb"].shape[1:3]
+    H, W, T, nW = cfg["H"], cfg["W"], cfg["T"], cfg["workers"]
+    fh, fw = synth.feat_hw(H, W)
+    enc_state = synth.encoder_state(fh, fw, 7)
+    ppo_state = synth.ppo_state(11)
+    enc_dtype = args.encoder_dtype or cfg.get("encoder_dtype", "f32")
+    mcfg = dict(use_lstm=True, vae_device=local_rank, device_num=local_rank, vae_params="CoPM", measurement_dim=18,
+                num_output=dict(steer=33, throttle=3), command_num=4, obs_hw=(H, W), weights_init="none", vae_state_dict=enc_state,
+                encoder_max_frames=args.chunk_windows * SEQ, encoder_dtype=enc_dtype)
+    agent = CadreAgent(rank=rank, model_cfg=mcfg, frame=SEQ, STEER_CONTROL={i: (i - 16) / 16.0 for i in range(33)},
+                       THROTTLE_CONTROL={0: [0, 0], 1: [0, 1], 2: [0.6, 0]}, ent_coeff=0.01, value_coeff=0.1,
+                       clip_coeff=1.0, clip=0.1)
+    agent.arena.load_numpy_state(ppo_state)                      # identical start on every rank (startup broadcast)
+    if use_dist:
+        dist.broadcast(agent.arena.params, 0)
+    dev = agent.device
+    workers = [Worker(cfg, 1234 + 1000 * rank + w, dev, None if episodes is None else episodes[w]) for w in range(nW)]
+    shared = Shared_grad_buffers(agent.model_dict, dev)
+    torch.manual_seed(100 + rank)
+
+    def sync():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    log("[bench] %s setup done, %d worker(s), %.1f s since start" % (name, nW, time.perf_counter() - T_START))
+    for _ in range(warmup):
+        learner_round(agent, workers, cfg, shared)
+    sync()
+    log("[bench] %s warmup done %.1f s" % (name, time.perf_counter() - T_START))
+    hip.PROFILE = prof = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        losses = learner_round(agent, workers, cfg, shared)
+    sync()
+    elapsed = time.perf_counter() - t0
+    hip.PROFILE = None
+    log("[bench] %s timed region %.3f s for %d steps" % (name, elapsed, steps))
+    if use_dist:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    # ---- per-kernel roofline from the HIP events recorded (on the launch stream) inside the timed region
+    dom, roof = roofline_of(prof, steps)
+    if roof is not None:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):          # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+            try:
+                traffic = json.load(open(tpath)).get(roof["kernel"], {}).get("hbm_bytes_per_launch")
+            except (ValueError, OSError):
+                traffic = None
+        roof["traffic"] = traffic
+        roof["traffic_unit"] = "HBM bytes per launch (rocprofv3 PMC, profiles/hbm_traffic.json)"
+    # untimed split pass for t_encode / t_update
+    timers = []
+    learner_round(agent, workers, cfg, shared, timers)
+    t_enc, t_upd = timers[0]
+    ms = elapsed / steps * 1e3
+    frames = nW * (T + SEQ - 1 if args.dedup else T * SEQ)
+    flops_frame = agent.vae_model.flops_per_frame()
+    enc_bytes = sum(agent.vae_model.algorithmic_bytes(min(args.chunk_windows, T) * SEQ)
+                    for _ in range(nW * -(-T // args.chunk_windows)))
+    out = {
+        "value": round(world * nW * T / (elapsed / steps), 2), "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup,
+        "dtype": "f32" if enc_dtype == "f32" else "bf16 encoder (fp32 accumulate) / f32 PPO update",
+        "data": "synthetic" if episodes is None else "replayed records from %s" % episodes_dir,
+        "config": {"workload": "%s: %d worker(s) x %d-step rollout, %dx%dx3 synthetic obs (+route), DANet encoder "
+                               "(%s) + PPO update (4 epochs x 2 minibatches), %s"
+                               % (name, nW, T, H, W,
+                                  "latent cache: each distinct frame encoded once" if args.dedup
+                                  else "8 frames/transition, reference convention",
+                                  "fp32" if enc_dtype == "f32" else "bf16 encoder / fp32 losses"),
+                   "workers_per_gpu": nW, "num_steps": T, "obs": [H, W], "minibatch_per_gpu": nW * T // MINI_BATCH_NUM,
+                   "parallelism": "dp%d" % world, "frames_per_round_per_gpu": frames},
+        "t_encode_ms": round(t_enc * 1e3, 3), "t_update_ms": round(t_upd * 1e3, 3),
+        "encoder_frames_per_sec": round(frames / t_enc, 1),
+        "encoder_tflops": round(frames * flops_frame / t_enc / 1e12, 2),
+        "update_only_samples_per_sec": round(nW * T * PPO_EPOCH / t_upd, 1),
+        "encoder_fwd_GBps": round(enc_bytes / t_enc / 1e9, 1) if not args.dedup else None,
+        "encoder_fwd_hbm_frac": round(enc_bytes / t_enc / 1e9 / PEAK_HBM_GBPS, 4) if not args.dedup else None,
+        "encoder_fwd_GBps_note": "algorithmic bytes (SURVEY 8d layer model, weights once per chunk) / t_encode vs HBM peak "
+                                 "8000 GB/s; the fp32 conv stack is MFMA-bound (see roofline)",
+        "roofline": roof,
+        "last_losses": [round(x, 6) for x in losses[-1]],
+    }
+    del workers, shared, agent
+    torch.cuda.empty_cache()
+    return out, cfg, enc_state, ppo_state
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -215,6 +383,7 @@ def main():
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
     ap.add_argument("--chunk-windows", type=int, default=128, help="windows (x8 frames) per encoder launch chain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c3", action="store_true", help="skip the extra C3 section (4 workers/GPU, bf16 encoder) of the line")
     ap.add_argument("--encoder-dtype", default=None, choices=["f32", "bf16"],
                     help="override the config's encoder arithmetic (C2: f32, C3: bf16 storage / fp32 accumulate)")
     ap.add_argument("--replay", default=None, metavar="DIR",
@@ -239,133 +408,20 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from cadre_amd import hip, synth
-    from ppo_agent.agent import CadreAgent
-    from ppo_agent.models import Shared_grad_buffers
-    cfg = dict(CONFIGS[args.config]); cfg["chunk_windows"] = args.chunk_windows; cfg["dedup"] = args.dedup
-    episodes = None
-    if args.replay:
-        from cadre_amd import replay
-        paths = replay.list_episodes(args.replay)
-        if len(paths) < cfg["workers"] * world:
-            raise SystemExit("--replay needs >= %d episodes, found %d" % (cfg["workers"] * world, len(paths)))
-        episodes = [replay.load_episode(p) for p in paths[rank * cfg["workers"]:(rank + 1) * cfg["workers"]]]
-        cfg["T"] = min(len(e["command"]) for e in episodes)
-        cfg["H"], cfg["W"] = episodes[0]["rgb"].shape[1:3]
-    H, W, T, nW = cfg["H"], cfg["W"], cfg["T"], cfg["workers"]
-    fh, fw = synth.feat_hw(H, W)
-    enc_state = synth.encoder_state(fh, fw, 7)
-    ppo_state = synth.ppo_state(11)
-    mcfg = dict(use_lstm=True, vae_device=local_rank, device_num=local_rank, vae_params="CoPM", measurement_dim=18,
-                num_output=dict(steer=33, throttle=3), command_num=4, obs_hw=(H, W), weights_init="none", vae_state_dict=enc_state,
-                encoder_max_frames=args.chunk_windows * SEQ,
-                encoder_dtype=args.encoder_dtype or cfg.get("encoder_dtype", "f32"))
-    agent = CadreAgent(rank=rank, model_cfg=mcfg, frame=SEQ, STEER_CONTROL={i: (i - 16) / 16.0 for i in range(33)},
-                       THROTTLE_CONTROL={0: [0, 0], 1: [0, 1], 2: [0.6, 0]}, ent_coeff=0.01, value_coeff=0.1,
-                       clip_coeff=1.0, clip=0.1)
-    agent.arena.load_numpy_state(ppo_state)                      # identical start on every rank (startup broadcast)
-    if use_dist:
-        dist.broadcast(agent.arena.params, 0)
-    dev = agent.device
-    workers = [Worker(cfg, 1234 + 1000 * rank + w, dev, None if episodes is None else episodes[w]) for w in range(nW)]
-    shared = Shared_grad_buffers(agent.model_dict, dev)
-    torch.manual_seed(100 + rank)
-
-    def sync():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    log("[bench] setup done, %d worker(s), %.1f s since start" % (nW, time.perf_counter() - T_START))
-    for _ in range(args.warmup):
-        learner_round(agent, workers, cfg, shared)
-    sync()
-    log("[bench] warmup done %.1f s" % (time.perf_counter() - T_START))
-    hip.PROFILE = prof = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        losses = learner_round(agent, workers, cfg, shared)
-    sync()
-    elapsed = time.perf_counter() - t0
-    hip.PROFILE = None
-    log("[bench] timed region %.3f s for %d steps" % (elapsed, args.steps))
-    if use_dist:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    # ---- per-kernel roofline from the HIP events recorded inside the timed region
-    by = {}
-    for key, flops, e0, e1, _shape in prof:
-        d = by.setdefault(key, [0.0, 0.0, 0])
-        d[0] += flops; d[1] += e0.elapsed_time(e1) * 1e-3; d[2] += 1
-    if not by:
-        by[(3, 2, 0)] = [0.0, 1e-9, 1]
-    dom = max(by, key=lambda k: by[k][1])
-    # tile id -> (WM, WN, WVN, WVM) template arguments of gemm_f32_kernel<WM, WN, AMODE, BMODE, WVN, NS, WVM>
-    TPL = {1: (2, 2, 2, 2), 2: (2, 1, 2, 2), 3: (1, 1, 2, 2), 4: (4, 2, 2, 2), 5: (2, 4, 2, 2), 6: (4, 1, 2, 2), 8: (2, 1, 4, 2),
-           9: (1, 1, 4, 1), 10: (1, 1, 2, 4)}
-    TILE = {1: "128x128", 2: "128x64", 3: "64x64", 4: "256x128", 5: "128x256", 6: "256x64", 8: "128x128 (8 waves)",
-            9: "32x128", 10: "128x64 (8 waves)", 12: "64x64, 8 M-tiles per workgroup"}
-    AM = {0: "dense A[M][K]", 1: "dense A[K][M]", 2: "NHWC implicit-GEMM conv", 3: "Cin=4 stem conv"}
-
-    def kname(k):      # exact symbol as rocprofv3 prints it
-        if k[0] == 12:
-            return "conv_stream_f32_kernel<%d>" % k[1]
-        wm_, wn_, wvn_, wvm_ = TPL[k[0]]
-        return "gemm_f32_kernel<%d, %d, %d, %d, %d, 2, %d>" % (wm_, wn_, k[1], k[2], wvn_, wvm_)
-    ach = by[dom][0] / by[dom][1] / 1e12
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tpath):          # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
-        try:
-            traffic = json.load(open(tpath)).get(kname(dom), {}).get("hbm_bytes_per_launch")
-        except (ValueError, OSError):
-            traffic = None
-    # untimed split pass for t_encode / t_update
-    timers = []
-    learner_round(agent, workers, cfg, shared, timers)
-    t_enc, t_upd = timers[0]
-
+    res, cfg, enc_state, ppo_state = run_config(args.config, args, rank, local_rank, world, use_dist, args.steps, args.warmup,
+                                                args.replay)
+    out = {"metric": "ppo_update_samples_per_sec", "value": res.pop("value"), "unit": "samples/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": res.pop("ms_per_step"), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None}
+    res.pop("steps"); res.pop("warmup")
+    out.update(res)
+    # BASELINE configs C3 / C4 (num_processes = 4 per GPU, minibatch 256, bf16 encoder / fp32 losses) in the same line:
+    # the 1 -> 8 GPU scaling target is defined on this shape (C4 = C3 on every GPU + the gradient all-reduce)
+    if args.config == "C2" and not args.no_c3 and not args.replay and not args.dedup and args.encoder_dtype is None:
+        c3, _c, _e, _p = run_config("C3", args, rank, local_rank, world, use_dist, max(2, min(args.steps, 3)), 1)
+        c3["metric"], c3["unit"], c3["n_gpus"] = "ppo_update_samples_per_sec", "samples/s", world
+        out["c3"] = c3
     if rank == 0:
-        ms = elapsed / args.steps * 1e3
-        value = world * nW * T / (elapsed / args.steps)
-        flops_frame = agent.vae_model.flops_per_frame()
-        out = {
-            "metric": "ppo_update_samples_per_sec", "value": round(value, 2), "unit": "samples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if agent.vae_model.dtype == "f32" else "bf16 encoder (fp32 accumulate) / f32 PPO update",
-            "data": "synthetic" if episodes is None else "replayed records from %s" % args.replay,
-            "config": {"workload": "%s: %d worker(s) x %d-step rollout, %dx%dx3 synthetic obs (+route), DANet encoder "
-                                   "(%s) + PPO update (4 epochs x 2 minibatches), %s"
-                                   % (args.config, nW, T, H, W,
-                                      "latent cache: each distinct frame encoded once" if args.dedup
-                                      else "8 frames/transition, reference convention",
-                                      "fp32" if agent.vae_model.dtype == "f32" else "bf16 encoder / fp32 losses"),
-                       "workers_per_gpu": nW, "num_steps": T, "obs": [H, W], "minibatch_per_gpu": nW * T // MINI_BATCH_NUM,
-                       "parallelism": "dp%d" % world, "frames_per_round_per_gpu": nW * (T + SEQ - 1 if args.dedup else T * SEQ)},
-            "t_encode_ms": round(t_enc * 1e3, 3), "t_update_ms": round(t_upd * 1e3, 3),
-            "encoder_frames_per_sec": round(nW * (T + SEQ - 1 if args.dedup else T * SEQ) / t_enc, 1),
-            "encoder_tflops": round(nW * (T + SEQ - 1 if args.dedup else T * SEQ) * flops_frame / t_enc / 1e12, 2),
-            "update_only_samples_per_sec": round(nW * T * PPO_EPOCH / t_upd, 1),
-            "encoder_fwd_GBps": round(sum(agent.vae_model.algorithmic_bytes(min(args.chunk_windows, T) * SEQ)
-                                          for _ in range(nW * -(-T // args.chunk_windows))) / t_enc / 1e9, 1)
-            if not args.dedup else None,
-            "encoder_fwd_GBps_note": "algorithmic bytes (SURVEY 8d layer model, weights once per chunk) / t_encode; "
-                                     "HBM peak 8000 GB/s; the fp32 conv stack is MFMA-bound (see roofline)",
-            "roofline": {"kernel": kname(dom), "kernel_desc": "%s tile, %s" % (TILE[dom[0]], AM[dom[1]]),
-                         "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                         "traffic": traffic, "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/hbm_traffic.json)",
-                         "flops_per_launch": round(by[dom][0] / by[dom][2], 1),
-                         "launches": by[dom][2], "avg_launch_us": round(by[dom][1] / by[dom][2] * 1e6, 2),
-                         "per_kernel": {kname(k): {"tflops": round(v[0] / v[1] / 1e12, 2),
-                                                   "time_ms_per_step": round(v[1] / args.steps * 1e3, 3),
-                                                   "launches_per_step": v[2] // args.steps}
-                                        for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])}},
-            "last_losses": [round(x, 6) for x in losses[-1]],
-        }
         if not args.no_cpu_baseline and world == 1:          # CPU baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(cfg, enc_state, ppo_state)
         print(json.dumps(out), flush=True)

@@ -124,7 +124,18 @@ class PPOArena:
                 self._bound.append((p, gv[name]))
         module._cadre_arena = self
         module._cadre_name = model_name
+        control = getattr(module, "control", None)        # Categorical_1d stand-alone API (distributions.py:66-105)
+        if control is not None:
+            control._cadre_arena = self
+            control._cadre_name = model_name
         return module
+
+    def __getstate__(self):
+        """Pickling (reference main.py:57-70 hands the shared nets to spawned processes): the tensors travel
+        as HIP-IPC handles; the learner (hipGraphs, workspaces) is per process and is rebuilt on first use."""
+        d = dict(self.__dict__)
+        d.pop("_learner", None)
+        return d
 
     def attach_grads(self, model_dict=None):
         """(Re-)attach arena gradient views — `zero_grad(set_to_none=True)` by a caller detaches them."""

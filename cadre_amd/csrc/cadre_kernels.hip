@@ -978,6 +978,39 @@ extern "C" int cadre_categorical_eval(const float* logits, int64_t ldl, const in
   return (int)hipGetLastError();
 }
 
+// Categorical_1d.forward (distributions.py:66-83): normalised logits, probs and per-row mode.
+__global__ __launch_bounds__(64) void categorical_dist_kernel(const float* raw, int64_t ldl, int K, float* logits_out,
+                                                              float* probs_out, int64_t* mode_out) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const float x = lane < K ? raw[(int64_t)r * ldl + lane] : -INFINITY;
+  const float mx = wave_max(x);
+  const float se = wave_sum(lane < K ? expf(x - mx) : 0.f);
+  const float lg = x - (mx + logf(se));
+  const float mx2 = wave_max(lane < K ? lg : -INFINITY);
+  const float e2 = lane < K ? expf(lg - mx2) : 0.f;
+  const float p = e2 / wave_sum(e2);
+  if (lane < K) {
+    if (logits_out) logits_out[(int64_t)r * K + lane] = lg;
+    if (probs_out) probs_out[(int64_t)r * K + lane] = p;
+  }
+  float best = lane < K ? p : -INFINITY;
+  int bi = lane;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  if (lane == 0 && mode_out) mode_out[r] = bi;
+}
+extern "C" int cadre_categorical_dist(const float* raw, int64_t ldl, int32_t R, int32_t n_out, float* logits_out,
+                                      float* probs_out, int64_t* mode_out, void* stream) {
+  FAIL_IF(!raw || R < 1 || n_out < 1 || n_out > 64 || ldl < n_out, "cadre_categorical_dist: bad argument");
+  hipLaunchKernelGGL(categorical_dist_kernel, dim3(R), dim3(64), 0, ST(stream), raw, ldl, n_out, logits_out, probs_out,
+                     mode_out);
+  return (int)hipGetLastError();
+}
+
 // ============================================================================ per-model clip + Adam
 __global__ void sqnorm_kernel(const float* g, const int64_t* seg_off, double* norms2) {
   const int mdl = blockIdx.y;

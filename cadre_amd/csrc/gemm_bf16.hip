@@ -334,6 +334,36 @@ int cadre_conv_stream_bf16_launch(const cadre_gemm_t& p, void* stream);     // c
 #define BCHECK(cond, msg) \
   if (!(cond)) return cadre_fail("cadre_gemm_bf16: " msg)
 
+// Tile choice (host logic).  12 = conv_stream_bf16.hip (64x64, several M-tiles per workgroup).
+static int pick_tile_bf16(const cadre_gemm_t& p) {
+  int tile = p.tile;
+  const int batch = p.batch < 1 ? 1 : p.batch, sk = p.split_k < 1 ? 1 : p.split_k;
+  // N <= 64 convs (stage-1 convs, padded stem): several M-tiles per workgroup, conv_stream_bf16.hip (444 vs 431)
+  if (tile == 0 && p.N <= 64 && p.a_mode >= 2 && batch == 1 && sk == 1 && p.K >= 128 && p.M >= 64 * 2048) tile = 12;
+  if (tile == 0) {
+    // staging-bound regime: shape factor (dense 8192^3: 256x256 on 8 waves 1054, 128x128 826 TFLOP/s;
+    // tools/gemm_bf16_bench.py) x wave quantisation over 256 CUs x resident workgroups per CU
+    struct Cand { int id, bm, bn, per_cu; double base; };
+    static const Cand wide[3] = {{7, 256, 256, 1, 1.00}, {1, 128, 128, 2, 0.80}, {3, 64, 64, 4, 0.45}};
+    static const Cand narrow[2] = {{10, 128, 64, 2, 1.05}, {3, 64, 64, 4, 1.00}};     // layer 1 @72x72: 437 vs 416 TFLOP/s
+    const Cand* c = p.N <= 64 ? narrow : wide;
+    const int nc = p.N <= 64 ? 2 : 3;
+    double best_e = -1.0;
+    for (int i = 0; i < nc; ++i) {
+      if (c[i].id == 7 && p.N < 256) continue;
+      const double tiles = (double)((p.M + c[i].bm - 1) / c[i].bm) * ((p.N + c[i].bn - 1) / c[i].bn) * batch * sk;
+      const double slots = 256.0 * c[i].per_cu;
+      const double waves = tiles <= slots ? 1.0 : (double)(int64_t)((tiles + slots - 1) / slots);
+      const double useful = ((double)p.M * p.N * batch * sk) / (tiles * c[i].bm * c[i].bn);
+      const double e = c[i].base * useful * (tiles / (waves * slots));
+      if (e > best_e) { best_e = e; tile = c[i].id; }
+    }
+  }
+  return tile;
+}
+
+extern "C" int cadre_gemm_bf16_pick_tile(const cadre_gemm_t* pp) { return pick_tile_bf16(*pp); }
+
 extern "C" int cadre_gemm_bf16(const cadre_gemm_t* pp, void* stream) {
   cadre_gemm_t p = *pp;
   BCHECK(p.A && p.B && p.C, "null operand");
@@ -367,28 +397,7 @@ extern "C" int cadre_gemm_bf16(const cadre_gemm_t* pp, void* stream) {
     const int64_t a_bytes = p.a_mode >= 2 ? (int64_t)(p.M / (p.Ho * p.Wo)) * p.H * p.W * p.Cin * 2 : (int64_t)p.M * p.lda * 2;
     BCHECK(a_bytes < lim && (int64_t)p.N * p.ldb * 2 < lim, "operand spans >= 2 GiB: chunk the batch");
   }
-  int tile = p.tile;
-  // N <= 64 convs (stage-1 convs, padded stem): several M-tiles per workgroup, conv_stream_bf16.hip (444 vs 431)
-  if (tile == 0 && p.N <= 64 && p.a_mode >= 2 && p.batch == 1 && p.split_k == 1 && p.K >= 128 && p.M >= 64 * 2048) tile = 12;
-  if (tile == 0) {
-    // staging-bound regime: shape factor (dense 8192^3: 256x256 on 8 waves 1054, 128x128 826 TFLOP/s;
-    // tools/gemm_bf16_bench.py) x wave quantisation over 256 CUs x resident workgroups per CU
-    struct Cand { int id, bm, bn, per_cu; double base; };
-    static const Cand wide[3] = {{7, 256, 256, 1, 1.00}, {1, 128, 128, 2, 0.80}, {3, 64, 64, 4, 0.45}};
-    static const Cand narrow[2] = {{10, 128, 64, 2, 1.05}, {3, 64, 64, 4, 1.00}};     // layer 1 @72x72: 437 vs 416 TFLOP/s
-    const Cand* c = p.N <= 64 ? narrow : wide;
-    const int nc = p.N <= 64 ? 2 : 3;
-    double best_e = -1.0;
-    for (int i = 0; i < nc; ++i) {
-      if (c[i].id == 7 && p.N < 256) continue;
-      const double tiles = (double)((p.M + c[i].bm - 1) / c[i].bm) * ((p.N + c[i].bn - 1) / c[i].bn) * p.batch * p.split_k;
-      const double slots = 256.0 * c[i].per_cu;
-      const double waves = tiles <= slots ? 1.0 : (double)(int64_t)((tiles + slots - 1) / slots);
-      const double useful = ((double)p.M * p.N * p.batch * p.split_k) / (tiles * c[i].bm * c[i].bn);
-      const double e = c[i].base * useful * (tiles / (waves * slots));
-      if (e > best_e) { best_e = e; tile = c[i].id; }
-    }
-  }
+  const int tile = pick_tile_bf16(p);
   // 10: 128x64 on 8 waves (4x2), 11: 256x64 on 8 waves (4x2, each wave 64x32) — the N <= 64 layers are bound by
   // L2 -> LDS staging bytes per FLOP, which only a taller tile lowers
   if (tile == 12) return cadre_conv_stream_bf16_launch(p, stream);       // 64x64 conv, several M-tiles per workgroup

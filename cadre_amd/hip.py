@@ -37,6 +37,7 @@ SYMBOLS = {
     "cadre_gemm_f32": [C.POINTER(GemmDesc), vp],
     "cadre_gemm_pick_tile": [C.POINTER(GemmDesc)],
     "cadre_gemm_bf16": [C.POINTER(GemmDesc), vp],
+    "cadre_gemm_bf16_pick_tile": [C.POINTER(GemmDesc)],
     "cadre_maxpool3x3s2_bf16": [vp, vp, i32, i32, i32, i32, vp],
     "cadre_pam_bf16out": [vp, vp, f32, vp, i32, i32, vp],
     "cadre_cam_bf16out": [vp, f32, vp, i32, i32, vp],
@@ -61,6 +62,7 @@ SYMBOLS = {
     "cadre_ppo_loss": [vp, i64, i64, vp, i64, i64, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, f32, vp, vp, vp, vp],
     "cadre_sample": [vp, i64, vp, i64, i32, i32, vp, vp, vp],
     "cadre_categorical_eval": [vp, i64, vp, i32, i32, vp, vp, vp],
+    "cadre_categorical_dist": [vp, i64, i32, i32, vp, vp, vp, vp],
     "cadre_clip_adam": [vp, vp, vp, vp, vp, i32, vp, f64, f64, f64, f64, f64, i32, vp],
     "cadre_clip_adam_graph": [vp, vp, vp, vp, vp, i32, vp, f64, f64, f64, f64, f64, vp, vp],
 }
@@ -83,7 +85,7 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = args
             fn.restype = C.c_char_p if name == "cadre_last_error" else C.c_int
-        if L.cadre_abi_version() != 2:
+        if L.cadre_abi_version() != 3:
             raise CadreHipError("libcadre_hip.so ABI version mismatch")
         _lib = L
     return _lib
@@ -108,8 +110,10 @@ def stream():
 
 
 # Optional launch profiler (bench.py): when PROFILE is a list, every gemm launch is bracketed by
-# HIP events recorded on the launch stream and appended as ((tile, a_mode, b_mode), flops, start, end,
-# (M, N, K, batch, split_k, seg_mode)).
+# HIP events recorded on the launch stream and appended as (key, flops, start, end, shape, bytes):
+#   key   = (tile, a_mode, b_mode) for cadre_gemm_f32, ("bf16", tile, a_mode) for cadre_gemm_bf16
+#   flops = algorithmic FLOPs of the launch, bytes = algorithmic HBM bytes (each operand once)
+#   shape = (M, N, K, batch, split_k, seg_mode)
 PROFILE = None
 
 
@@ -133,13 +137,23 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, scale=None, shi
         d.seg_mode, d.seg_period, d.seg_div = seg[0], seg[2], seg[3]
         d.row_seg = ptr(seg[1])
     fn = lib().cadre_gemm_bf16 if bf16 else lib().cadre_gemm_f32
-    if PROFILE is None or bf16 or torch.cuda.is_current_stream_capturing():
-        check(fn(C.byref(d), stream()), "cadre_gemm_bf16" if bf16 else "cadre_gemm_f32")
+    name = "cadre_gemm_bf16" if bf16 else "cadre_gemm_f32"
+    if PROFILE is None or torch.cuda.is_current_stream_capturing():
+        check(fn(C.byref(d), stream()), name)
         return
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    check(fn(C.byref(d), stream()), "cadre_gemm_f32")
+    check(fn(C.byref(d), stream()), name)
     e1.record()
-    k_alg = conv[5] * conv[6] * conv[2] if conv is not None else K      # algorithmic K (the stem pads 196 -> 224)
-    PROFILE.append(((lib().cadre_gemm_pick_tile(C.byref(d)), a_mode, b_mode), 2.0 * M * N * k_alg * max(1, batch), e0, e1,
-                    (M, N, K, max(1, batch), split_k, seg[0] if seg is not None else 0)))
+    nb = max(1, batch)
+    k_alg = conv[5] * conv[6] * conv[2] if conv is not None else K      # algorithmic K (the stems pad 196 -> 224 / 256)
+    esz = 2 if bf16 else 4
+    a_bytes = (M // (conv[3] * conv[4])) * conv[0] * conv[1] * conv[2] * esz if conv is not None else M * K * esz * nb
+    c_esz = 2 if (flags & 2) else 4
+    r_esz = 2 if (flags & 4) else 4
+    nbytes = a_bytes + N * k_alg * esz * nb + M * N * c_esz * nb * max(1, split_k) + (M * N * r_esz * nb if resid is not None else 0)
+    if bf16:
+        key = ("bf16", lib().cadre_gemm_bf16_pick_tile(C.byref(d)), a_mode)
+    else:
+        key = (lib().cadre_gemm_pick_tile(C.byref(d)), a_mode, b_mode)
+    PROFILE.append((key, 2.0 * M * N * k_alg * nb, e0, e1, (M, N, K, nb, split_k, seg[0] if seg is not None else 0), nbytes))

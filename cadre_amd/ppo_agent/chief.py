@@ -4,6 +4,8 @@ clear the buffers and flip the traffic light — as ONE fused HIP pass over the 
 (cadre_clip_adam) instead of 16 clip calls + a 112-tensor optimizer.step()."""
 import time
 
+import torch
+
 from ..learner import PPOLearnerHIP
 
 
@@ -12,10 +14,18 @@ def _hyper(optimizer):
     return g["lr"], tuple(g.get("betas", (0.9, 0.999))), g.get("eps", 1e-8)
 
 
-def chief_step(shared_grad_buffers, optimizer, max_grad_norm):
-    """One optimiser step (chief.py:13-23) on the arena behind `shared_grad_buffers`."""
+def chief_step(shared_grad_buffers, optimizer, max_grad_norm, lr=None):
+    """One optimiser step (chief.py:13-23) on the arena behind `shared_grad_buffers`: the pending
+    cross-rank SUM of the gradient arena (one RCCL all-reduce per optimiser step, however many worker
+    agents of this process handed gradients in), then per-model clip + Adam, then clear the buffers.
+    Hyper-parameters come from `optimizer` (the reference's optim.Adam, main.py:52) or, without one,
+    from `lr` (train_cfg.lr) with Adam's defaults."""
     arena = shared_grad_buffers.arena
-    lr, betas, eps = _hyper(optimizer) if optimizer is not None else (3e-4, (0.9, 0.999), 1e-8)
+    shared_grad_buffers.all_reduce()
+    if optimizer is not None:
+        lr, betas, eps = _hyper(optimizer)
+    else:
+        lr, betas, eps = (3e-4 if lr is None else float(lr)), (0.9, 0.999), 1e-8
     step = getattr(arena, "_learner", None)
     if step is None:
         arena._learner = step = PPOLearnerHIP(arena)
@@ -28,6 +38,10 @@ def chief(update_threshold, traffic_light, counter, shared_model_list, shared_gr
     while True:
         if counter.get() >= update_threshold:
             chief_step(shared_grad_buffers, optimizer, max_grad_norm)
+            # separate-process mode (main.py:57-60): the workers' weight pull and next add_gradient run on
+            # their own streams in other processes — the clip+Adam graph and the gradient clear must have
+            # finished on the device before the light flips
+            torch.cuda.current_stream().synchronize()
             counter.reset()
             traffic_light.switch()
         elif son_process_counter.get() >= total_thread:

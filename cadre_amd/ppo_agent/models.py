@@ -191,6 +191,9 @@ def create_model(model_cfg, load_vae=False):
     if not _cfg(model_cfg, "use_lstm", True):
         raise hip.CadreHipError("use_lstm=False is not on the accelerated path (reference default is True)")
     command_num = _cfg(model_cfg, "command_num")
+    if command_num != 4:
+        raise hip.CadreHipError("command_num=%r: the HIP loss / row-sort kernels are built for the reference's 4 "
+                                "navigation commands (agent_config.py: command_num=4)" % (command_num,))
     n_out = _cfg(model_cfg, "num_output")
     arena = PPOArena(device, obs_dim, {"steer": n_out["steer"], "throttle": n_out["throttle"]}, command_num)
     model_dict = {}
@@ -234,23 +237,37 @@ class Shared_grad_buffers(object):
                     self.grads[model_name + "_" + name + "_grad"] = gv[name]
 
     def add_gradient(self, model_list):
+        """models.py:231-239: accumulate one worker's gradients (SUM).  Nets bound to this arena already
+        wrote their gradients into it (update_policy writes, it does not accumulate), so only a foreign
+        arena is added.  The cross-rank reduction is a separate step (`all_reduce`, run once per
+        optimiser step by `chief_step`) — several worker agents of one process feeding this buffer must
+        not be all-reduced once each."""
         src = arena_of(model_list)
         with self.lock:
             if src is not self.arena:                     # a worker agent with its own nets (reference topology)
                 self.arena.grads.add_(src.grads)
-                torch.cuda.current_stream().synchronize()
-            self.all_reduce()
+                if self.arena.grads.is_cuda:              # the worker overwrites src.grads in its next update
+                    torch.cuda.current_stream().synchronize()
+            self._pending = True
             self.counter.increment()
 
     def all_reduce(self):
+        """One RCCL all-reduce(SUM) of the flat gradient arena over all ranks (chief.py:18 sums, never
+        averages); a no-op outside torch.distributed, at world_size 1, or when nothing was handed in
+        since the last reduction."""
         import torch.distributed as dist
+        if not getattr(self, "_pending", False):
+            return
+        self._pending = False
         if dist.is_available() and dist.is_initialized() and (
                 dist.get_world_size() > 1 or os.environ.get("CADRE_BENCH_FORCE_DIST") == "1"):
             dist.all_reduce(self.arena.grads, op=dist.ReduceOp.SUM)
+            self.n_allreduce = getattr(self, "n_allreduce", 0) + 1
 
     def average_gradient(self):
         self.arena.grads.div_(max(1, self.counter.get()))
 
     def reset(self):
         self.counter.reset()
+        self._pending = False
         self.arena.grads.zero_()

@@ -13,6 +13,23 @@ from .storage import RolloutStorage
 from .utils import check_exist
 
 
+def _get(cfg, key, default=None):
+    try:
+        return cfg[key]
+    except (KeyError, TypeError, IndexError):
+        return getattr(cfg, key, default)
+
+
+def _default_logger():
+    """The reference logs per-episode losses through utils.logger.logger (train.py:11,104-110); use it when
+    the Cadre checkout is importable, else stay silent."""
+    try:
+        from utils.logger import logger
+        return logger
+    except Exception:
+        return None
+
+
 def learner_section(agent, steer_rollout, throttle_rollout, done, train_cfg, shared_grad_buffers,
                     optimizer=None, traffic_light=None, counter=None, shared_model_list=None, in_process_chief=True,
                     fused_gather=True):
@@ -43,7 +60,7 @@ def learner_section(agent, steer_rollout, throttle_rollout, done, train_cfg, sha
                 vl.append(v); pl.append(p); el.append(e)
             if in_process_chief:
                 shared_grad_buffers.add_gradient(agent.model_dict)
-                chief_step(shared_grad_buffers, optimizer, train_cfg["max_grad_norm"])
+                chief_step(shared_grad_buffers, optimizer, train_cfg["max_grad_norm"], lr=_get(train_cfg, "lr"))
             else:
                 signal_init = traffic_light.get()
                 shared_grad_buffers.add_gradient(agent.model_dict)
@@ -63,6 +80,8 @@ def train(rank, train_cfg, agent_cfg, env_cfg, rollout_cfg, traffic_light=None, 
           recorder=None):
     if env_cls is None:
         from env_wrapper import EnvWrapper as env_cls        # needs the CARLA stack (reference env_wrapper.py)
+    if logger is None:
+        logger = _default_logger()
     env_cfg.rank = rank
     for k in ("port", "routes", "scenarios", "town"):
         env_cfg[k] = env_cfg[k][rank]
@@ -78,6 +97,9 @@ def train(rank, train_cfg, agent_cfg, env_cfg, rollout_cfg, traffic_light=None, 
     rollout_cfg.hidden_size = hidden_size
     steer_rollout = RolloutStorage(**rollout_cfg); steer_rollout.to(device)
     throttle_rollout = RolloutStorage(**rollout_cfg); throttle_rollout.to(device)
+    if shared_grad_buffers is None:              # single-process use: the agent's own arena is the shared one
+        from .models import Shared_grad_buffers
+        shared_grad_buffers = Shared_grad_buffers(agent.model_dict, device)
     obs = env.reset()
     done = False
     for episode in range(train_cfg.max_episode):
@@ -106,5 +128,6 @@ def train(rank, train_cfg, agent_cfg, env_cfg, rollout_cfg, traffic_light=None, 
                 episode, np.mean(vl), np.mean(pl), np.mean(el)))
         if episode % train_cfg.save_interval == 0 and rank == 0:
             agent.save_snapshot(os.path.join(model_dir, "ppo_model_{}.pt".format(episode)))
-    son_process_counter.increment()
+    if son_process_counter is not None:
+        son_process_counter.increment()
     print("process {} finished.".format(rank))

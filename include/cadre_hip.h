@@ -15,7 +15,7 @@
 extern "C" {
 #endif
 
-#define CADRE_ABI_VERSION 2
+#define CADRE_ABI_VERSION 3
 int cadre_abi_version(void);
 /* human-readable last argument error of the calling thread ("" if none) */
 const char* cadre_last_error(void);
@@ -82,6 +82,8 @@ int cadre_gemm_pick_tile(const cadre_gemm_t* p);
  * B rows [ceil(KH/2)][64] = two kernel rows of 8 pixels x 4 channels, zeros elsewhere), b_mode 0; C bf16 or f32 (flags bit 1), resid bf16 or f32 (flags bit 2).  BASELINE config C3
  * ("bf16 encoder / fp32 losses"). */
 int cadre_gemm_bf16(const cadre_gemm_t* p, void* stream);
+/* tile id cadre_gemm_bf16 would launch for this descriptor (host logic, no launch) */
+int cadre_gemm_bf16_pick_tile(const cadre_gemm_t* p);
 /* C[M][ldc] = act(sum_s slab[s][M][lds] * scale + shift + resid) */
 int cadre_splitk_reduce(const float* slabs, int32_t split_k, int64_t slab_stride, int64_t lds,
                         float* C, int64_t ldc, int32_t M, int32_t N, const float* scale,
@@ -220,6 +222,11 @@ int cadre_sample(const float* logits, int64_t ldl, const float* q, int64_t ldq, 
  * of Categorical(logits=raw logits) */
 int cadre_categorical_eval(const float* logits, int64_t ldl, const int64_t* actions, int32_t R,
                            int32_t n_out, float* logp, float* entropy, void* stream);
+/* Categorical_1d.forward (distributions.py:66-83): what Categorical(logits=raw) exposes — normalised
+ * `logits` = raw - logsumexp(raw) and `probs` = softmax(logits), [R][n_out] each (dense rows), plus the
+ * per-row argmax of probs (first maximum, `mode`).  Any of the three outputs may be NULL. */
+int cadre_categorical_dist(const float* raw, int64_t ldl, int32_t R, int32_t n_out, float* logits_out,
+                           float* probs_out, int64_t* mode_out, void* stream);
 
 /* ---------------------------------------------------------------- optimiser
  * chief.py:13-21 + main.py:55: per-model clip_grad_norm_(max_norm) then Adam (torch defaults)

@@ -67,3 +67,55 @@ def oracle_learner_replay(g, max_steps=None):
             ppo_ref.chief_step(params, grads, adam, step)
             out["param_sums"].append([float(sum(p.data.double().sum() for p in params[n].values())) for n in names])
     return out
+
+
+# ----------------------------------------------------------------------------- reference train() plumbing
+class AD(dict):
+    """attr-dict stand-in for addict's ConfigDict (reference ppo_agent/meta/config.py): cfg.key and cfg['key']."""
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+class SyntheticEnv(object):
+    """Stand-in for reference env_wrapper.EnvWrapper (no CARLA in this image): deterministic synthetic
+    observations with the interface train.py:50-75 uses (reset / step / work_dir).  Seeds torch's global CPU
+    generator, so agent initialisation and action sampling are identical across launch topologies."""
+
+    def __init__(self, env_cfg):
+        self.cfg = env_cfg
+        self.work_dir = env_cfg["work_dir"]
+        H, W = env_cfg["obs_hw"]
+        self.steps = synth.synth_rollout(env_cfg["total_steps"] + 2, H, W, seed=4242 + int(env_cfg["rank"]))
+        self.i = 0
+        torch.manual_seed(999 + int(env_cfg["rank"]))
+
+    def _obs(self):
+        td = self.steps[self.i % len(self.steps)]
+        return dict(rgb=td["rgb"], route_fig=td["route_fig"].copy(), measurements=td["measurements"],
+                    command=td["command"])
+
+    def reset(self):
+        return self._obs()
+
+    def step(self, action):
+        td = self.steps[self.i % len(self.steps)]
+        self.i += 1
+        done = bool(td["done"].any())
+        return self._obs(), [float(td["reward"][0]), float(td["reward"][1])], done, {"action_done": [bool(td["done"][0]), bool(td["done"][1])]}
+
+
+def topology_cfgs(work_dir, H=84, W=84, T=8, episodes=2):
+    """The four config dicts reference main.py:28-33 reads from config_files/agent_config.py, sized for a test."""
+    fh, fw = synth.feat_hw(H, W)
+    model_cfg = AD(use_lstm=True, vae_device=0, device_num=0, vae_params="CoPM", measurement_dim=18,
+                   num_output=AD(steer=33, throttle=3), command_num=4, obs_hw=(H, W), weights_init="none",
+                   vae_state_dict=synth.encoder_state(fh, fw, 7), latent_cache=True)
+    agent_cfg = AD(rank=0, model_cfg=model_cfg, frame=8, STEER_CONTROL={i: (i - 16) / 16.0 for i in range(33)},
+                   THROTTLE_CONTROL={0: [0, 0], 1: [0, 1], 2: [0.6, 0]}, ent_coeff=0.01, value_coeff=0.1,
+                   clip_coeff=1.0, clip=0.1)
+    env_cfg = AD(num_processes=1, port=[2000], routes=["r"], scenarios=["s"], town=["Town01"], work_dir=work_dir,
+                 obs_hw=(H, W), total_steps=T * episodes, rank=0)
+    rollout_cfg = AD(num_steps=T, mini_batch_num=2, feature_dims=530, seq_length=8, use_gae=True, gamma=0.99, tau=0.95)
+    train_cfg = AD(max_episode=episodes, ppo_epoch=1, use_adv_norm=True, max_grad_norm=250.0, lr=3e-4,
+                   log_interval=1, save_interval=1)
+    return train_cfg, agent_cfg, env_cfg, rollout_cfg

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Plays reference main.py:24-72 on one GPU with a synthetic env: the parent builds the shared nets on the
+device, `Shared_grad_buffers`, `optim.Adam`, TrafficLight/Counter, then SPAWNS one `chief` process and one
+`train` worker, handing everything over by pickling (HIP-IPC tensor handles) exactly like the reference
+launcher.  Afterwards the same two episodes are run with the in-process hand-off and the two final snapshots
+are compared.  Run as its own process (tests/test_topology_gpu.py does):
+
+    python -m tests.spawn_topology_driver OUT_DIR
+"""
+import copy
+import functools
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def main(out_dir):
+    import torch
+    import torch.multiprocessing as mp
+    import torch.optim as optim
+    from cadre_amd import synth
+    from ppo_agent.chief import chief
+    from ppo_agent.models import Shared_grad_buffers, arena_of, create_model
+    from ppo_agent.train import train
+    from ppo_agent.utils import Counter, TrafficLight
+    from tests.helpers import SyntheticEnv, topology_cfgs
+    try:
+        mp.set_start_method("spawn")
+    except RuntimeError:
+        pass
+    res = {}
+    snaps = {}
+    for mode in ("spawned", "in_process"):
+        work = os.path.join(out_dir, mode)
+        os.makedirs(work, exist_ok=True)
+        train_cfg, agent_cfg, env_cfg, rollout_cfg = topology_cfgs(work)
+        _, shared = create_model(agent_cfg.model_cfg, load_vae=False)          # main.py:38
+        arena_of(shared).load_numpy_state(synth.ppo_state(11))
+        plist = []
+        for name in shared:                                                    # main.py:40-43
+            shared[name] = shared[name].share_memory()
+            plist += list(shared[name].parameters())
+        device = torch.device("cuda:" + str(agent_cfg.model_cfg.device_num))
+        bufs = Shared_grad_buffers(shared, device)
+        if mode == "spawned":
+            light, counter, sons = TrafficLight(), Counter(), Counter()
+            opt = optim.Adam(plist, lr=train_cfg.lr)
+            procs = [mp.Process(target=chief, args=(1, light, counter, shared, bufs, opt, sons,
+                                                     train_cfg.max_grad_norm, 1))]
+            procs.append(mp.Process(target=functools.partial(train, env_cls=SyntheticEnv), args=(
+                0, train_cfg, copy.deepcopy(agent_cfg), copy.deepcopy(env_cfg), rollout_cfg, light, counter, shared,
+                bufs, sons)))
+            for p in procs:
+                p.start()
+            for p in procs:
+                p.join(540)
+            res["exitcodes"] = [p.exitcode for p in procs]
+            for p in procs:
+                if p.is_alive():
+                    p.terminate()
+            res["steps_by_chief"] = None
+        else:
+            sons = Counter()
+            train(0, train_cfg, copy.deepcopy(agent_cfg), copy.deepcopy(env_cfg), rollout_cfg, None, None, shared,
+                  bufs, sons, env_cls=SyntheticEnv)
+        torch.cuda.synchronize()
+        snap = os.path.join(work, "models", "ppo_model_%d.pt" % (train_cfg.max_episode - 1))
+        res[mode + "_snapshot"] = os.path.exists(snap)
+        if os.path.exists(snap):
+            snaps[mode] = torch.load(snap, map_location="cpu", weights_only=False)
+        res[mode + "_shared_param_sum"] = float(arena_of(shared).params.double().sum())
+    if len(snaps) == 2:
+        worst, n = 0.0, 0
+        for name in snaps["spawned"]:
+            a, b = snaps["spawned"][name].state_dict(), snaps["in_process"][name].state_dict()
+            for k in a:
+                worst = max(worst, float((a[k] - b[k]).abs().max()))
+                n += 1
+        res["tensors_compared"] = n
+        res["max_abs_param_diff"] = worst
+        init = synth.ppo_state(11)
+        moved = max(float((snaps["spawned"][m].state_dict()[k] - torch.from_numpy(init[m][k])).abs().max())
+                    for m in snaps["spawned"] for k in snaps["spawned"][m].state_dict())
+        res["max_abs_update"] = moved
+    print("TOPOLOGY_RESULT " + json.dumps(res), flush=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1]))

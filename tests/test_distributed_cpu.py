@@ -1,5 +1,5 @@
 """CPU, world_size 2 over gloo: the data-parallel gradient hand-off of the N>1 path.
-`Shared_grad_buffers.add_gradient` must SUM (not average — chief.py:18, models.py:237) the flat
+`Shared_grad_buffers.add_gradient` + `all_reduce` must SUM (not average — chief.py:18, models.py:237) the flat
 gradient arena across ranks, leave every rank with identical sums, and the reference key scheme
 ('<model>_<param>_grad') must alias the reduced buffer.  (On the GPU box the same call runs
 over RCCL; the arena/views/bookkeeping exercised here are device-independent host logic.)"""
@@ -38,8 +38,20 @@ def _worker(rank, world, port, q):
                 p.grad.fill_(float(rank + 1))
         shared = Shared_grad_buffers(md, torch.device("cpu"))
         shared.add_gradient(md)
-        want = float(sum(r + 1 for r in range(world)))
-        ok = True
+        # a second worker agent of this process with its own nets (reference topology, main.py:63-68):
+        # accumulated locally; the cross-rank SUM then runs ONCE per optimiser step (chief_step), not per
+        # add_gradient — per-call all-reduces would count the first worker's gradients `world` times over
+        arena2 = PPOArena("cpu", 530, {"steer": 33, "throttle": 3}, 4)
+        md2 = {}
+        with _no_orthogonal_init():
+            md2["steer_ppo_0"] = arena2.bind("steer_ppo_0", Model(530, 33))
+        arena2.grads.fill_(10.0 * (rank + 1))
+        arena2.grads.view(-1)[arena.o_whh:arena.o_whh + 2120 * 544].view(2120, 544)[:, 530:] = 0
+        shared.add_gradient(md2)
+        ok = shared.counter.get() == 2
+        shared.all_reduce()
+        shared.all_reduce()                                    # idempotent until the next hand-in
+        want = float(sum(11 * (r + 1) for r in range(world)))
         for key, g in shared.grads.items():
             ok &= bool((g == want).all())
         w = md["steer_lstm_2"].rnn.weight_hh

@@ -20,7 +20,7 @@ def test_cabi_exports_every_declared_symbol():
     L = ctypes.CDLL(hip.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert hip.lib().cadre_abi_version() == 2
+    assert hip.lib().cadre_abi_version() == 3
     assert ctypes.sizeof(hip.GemmDesc) == 264      # static_assert-ed in gemm_f32.hip
 
 
@@ -189,3 +189,57 @@ def test_gemm_tile_choice_is_host_logic():
     assert pick(64, 2120, 544, batch=8, seg=1, period=64) == 9     # row-sorted: 32-row tiles
     assert pick(512, 2120, 544, batch=8, seg=1, period=64) == 9
     assert pick(300, 200, 544, tile=2) == 2
+
+
+def test_drop_in_package_keeps_reference_meta_importable(tmp_path):
+    """The reference's ppo_agent/ is a namespace package that also holds ppo_agent/meta/ (main.py:4, eval.py:4,
+    simple_test.py:2: `from ppo_agent.meta.config import Config`).  With both roots on sys.path — in either
+    order — the hot-path modules must resolve to this repo and `ppo_agent.meta.*` to the Cadre checkout."""
+    import subprocess
+    import sys
+    fake = tmp_path / "cadre_checkout"
+    (fake / "ppo_agent" / "meta").mkdir(parents=True)
+    (fake / "ppo_agent" / "meta" / "config.py").write_text("class Config(object):\n    where = 'reference'\n")
+    (fake / "ppo_agent" / "agent.py").write_text("raise ImportError('the reference module must be shadowed')\n")
+    code = ("import os, ppo_agent\n"
+            "from ppo_agent.meta.config import Config\n"                       # main.py:4
+            "from ppo_agent.models import create_model, Shared_grad_buffers, get_vae_output\n"   # main.py:6,11 train.py:4
+            "from ppo_agent.chief import chief\n"                               # main.py:8
+            "from ppo_agent.utils import TrafficLight, Counter, check_exist\n"  # main.py:9 train.py:8
+            "from ppo_agent.train import train\n"                               # main.py:13
+            "from ppo_agent.agent import CadreAgent\n"                          # eval.py:5 train.py:1
+            "from ppo_agent.storage import RolloutStorage\n"                    # train.py:2
+            "from ppo_agent.distributions import Categorical_1d\n"
+            "import ppo_agent.agent as a, ppo_agent.meta.config as c\n"
+            "assert Config.where == 'reference'\n"
+            "assert os.path.realpath(a.__file__).startswith(os.path.realpath(%r)), a.__file__\n"
+            "assert os.path.realpath(c.__file__).startswith(os.path.realpath(%r)), c.__file__\n"
+            "print('ok')\n" % (ROOT, str(fake)))
+    for order in ((ROOT, str(fake)), (str(fake), ROOT)):
+        env = dict(os.environ, PYTHONPATH=os.pathsep.join(order))
+        p = subprocess.run([sys.executable, "-B", "-c", code], cwd=str(tmp_path), env=env, capture_output=True, text=True)
+        assert p.returncode == 0 and p.stdout.strip() == "ok", (order, p.stdout, p.stderr[-2000:])
+
+
+def test_arena_pickle_drops_process_local_state():
+    """reference main.py:57-70 pickles the shared nets into spawned processes: the arena must not drag the
+    learner (hipGraphs) along and the bound parameters / gradient views must come back attachable."""
+    import pickle
+
+    import torch
+    from cadre_amd.arena import PPOArena
+    from ppo_agent.models import LSTM, _no_orthogonal_init
+    arena = PPOArena("cpu", 530, {"steer": 33, "throttle": 3}, 4)
+    with _no_orthogonal_init():
+        m = arena.bind("steer_lstm_1", LSTM(530, hid_size=530))
+    arena._learner = object()
+    assert "_learner" not in arena.__getstate__()
+    m2 = pickle.loads(pickle.dumps(m))
+    a2 = m2._cadre_arena
+    assert not hasattr(a2, "_learner") and a2 is not arena
+    assert tuple(m2.rnn.weight_hh.shape) == (2120, 530) and m2._cadre_name == "steer_lstm_1"
+    assert torch.equal(m2.rnn.weight_hh.detach(), m.rnn.weight_hh.detach())
+    # (storage aliasing between the unpickled views and the unpickled arena is a property of
+    #  torch.multiprocessing's HIP-IPC reductions: tests/test_topology_gpu.py checks it on the device)
+    a2.attach_grads()
+    assert m2.rnn.weight_hh.grad is not None and tuple(m2.rnn.weight_hh.grad.shape) == (2120, 530)

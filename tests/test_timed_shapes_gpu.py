@@ -1,0 +1,216 @@
+"""GPU: parity AT THE SHAPES bench.py TIMES (BASELINE configs C2 and C3), not only at the small
+golden shapes.
+
+  * C2 encoder: the two 288x288 golden frames (tests/golden/enc_288.npz, imported reference) placed
+    at positions 0 and 1023 of a 1024-frame chunk — the tile choices of the timed run (streamed stem,
+    8-wave 128x128 conv tile, 2 GiB buffer windows) are the ones under test, and the result must be
+    bit-identical to the 2-frame run (batch invariance at full size).
+  * C3 update: W = 4 workers x minibatch 64 = 256 rows in one launch chain must equal the SUM of four
+    reference `update_policy` gradient sets (reference ppo_agent/models.py:231-239, train.py:93-102),
+    computed by the oracle per worker.
+  * C3 bf16 contract: bf16 encoder features -> fp32 heads/losses against the fp32
+    oracle end to end, tolerances written below.
+"""
+import numpy as np
+import pytest
+import torch
+
+from cadre_amd import synth
+from tests.helpers import fill_storages
+from tests.test_learner_gpu import make_agent, rel
+
+pytestmark = pytest.mark.gpu
+
+ENC_TOL = 2e-4            # fp32 encoder vs reference goldens (same bar as tests/test_encoder_gpu.py)
+# ---- C3 contract ("bf16 encoder / fp32 losses"): bf16 storage of activations and conv weights (8
+# significand bits, ~4e-3 per rounding, 20 layers deep), fp32 accumulation, fp32 heads and losses.
+C3_FEAT_TOL = 2e-2        # max |feat_bf16 - feat_fp32| / max |feat_fp32|   (measured ~1e-2)
+C3_LOSS_TOL = 5e-2        # each of the three update_policy losses, relative, vs oracle-on-fp32
+C3_VALUE_TOL = 5e-2       # critic values / log-probs of act(): abs error relative to max(1, |ref|)
+C3_MARGIN = 0.25          # action indices must agree wherever the fp32 top-2 gap of log(p/q) exceeds this
+
+
+def test_c2_encoder_goldens_inside_1024_frame_chunk(golden):
+    from cadre_amd import hip
+    from cadre_amd.encoder import DANetEncoderHIP
+    g = golden("enc_288")
+    H, W, n = int(g["H"]), int(g["W"]), int(g["n"])
+    assert (H, W, n) == (288, 288, 2)
+    sd = synth.encoder_state(*synth.feat_hw(H, W), int(g["seed"]))
+    r = np.random.RandomState(int(g["frame_seed"]))
+    rgb2 = torch.from_numpy(r.randint(0, 256, (n, H, W, 3)).astype(np.uint8)).cuda()
+    route2 = torch.from_numpy(((r.rand(n, W, H) < 0.15) * 255).astype(np.uint8)).cuda()
+    small = DANetEncoderHIP(sd, H, W, "cuda:0", max_frames=2)
+    lat2 = small.latent(rgb2, route2).clone()
+    del small
+    F = 1024
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    rgb = torch.randint(0, 256, (F, H, W, 3), dtype=torch.uint8, device="cuda", generator=gen)
+    route = ((torch.rand(F, W, H, device="cuda", generator=gen) < 0.15) * 255).to(torch.uint8)
+    rgb[0], rgb[F - 1] = rgb2[0], rgb2[1]
+    route[0], route[F - 1] = route2[0], route2[1]
+    enc = DANetEncoderHIP(sd, H, W, "cuda:0", max_frames=F)
+    hip.PROFILE = prof = []
+    try:
+        lat = enc.latent(rgb, route)
+        torch.cuda.synchronize()
+    finally:
+        hip.PROFILE = None
+    tiles = {k[0] for k, *_ in prof}
+    launched = {(k[0], shape[0], shape[1]) for k, _f, _a, _b, shape, _nb in prof}
+    # the timed run's tile choices: streamed stem (12), 8-wave 128x128 for the N = 128 convs (8), 64x64 (3)
+    assert 12 in tiles and 8 in tiles and 3 in tiles, sorted(tiles)
+    assert any(t == 12 and m == F * 144 * 144 for t, m, _n in launched), sorted(launched)[:8]
+    got = torch.stack([lat[0], lat[F - 1]])
+    e = rel(got.cpu().numpy(), g["latent"])
+    print("288x288 goldens inside a 1024-frame chunk: latent rel-max-err %.2e, tiles %s" % (e, sorted(tiles)))
+    assert e < ENC_TOL
+    assert torch.equal(got, lat2), "per-frame results must not depend on the batch they were computed in"
+    assert bool(torch.isfinite(lat).all())
+
+
+def _worker_storages(nW, T, seed0, device):
+    from ppo_agent.storage import RolloutStorage
+    cpu, dev = [], []
+    for w in range(nW):
+        data = fill_storages(T, seed0 + w)
+        r = np.random.RandomState(900 + w)
+        pair_c, pair_d = [], []
+        for hd in ("steer", "throttle"):
+            d = dict(data[hd])
+            d["returns"] = r.standard_normal((T + 1, 1)).astype(np.float32)
+            adv = r.standard_normal((T, 1)).astype(np.float32)
+            s = RolloutStorage(T, 2, 530, 8, 530, True, 0.99, 0.95)
+            for k, v in d.items():
+                getattr(s, k).copy_(torch.from_numpy(v))
+            s.to(device)
+            s.advantages.copy_(torch.from_numpy(adv))
+            pair_d.append(s)
+            pair_c.append(({k: torch.from_numpy(v) for k, v in d.items()}, torch.from_numpy(adv)))
+        cpu.append(pair_c)
+        dev.append(pair_d)
+    return cpu, dev
+
+
+@pytest.mark.parametrize("sorted_rows", [True, False])
+def test_c3_update_is_sum_of_per_worker_reference_updates(sorted_rows, monkeypatch):
+    """num_processes = 4, minibatch 256 per GPU: one batched update == sum over the 4 workers of the
+    reference's per-worker update_policy (each worker normalises by ITS minibatch: sum of means)."""
+    from oracle import ppo_ref
+    monkeypatch.setenv("CADRE_SORTED_UPDATE", "1" if sorted_rows else "0")
+    nW, T, Bw = 4, 128, 64
+    agent = make_agent(84, 84)
+    assert agent.learner.sorted_rows(nW * Bw) == sorted_rows
+    cpu, dev = _worker_storages(nW, T, 700, "cuda:0")
+    r = np.random.RandomState(17)
+    idx = [(torch.from_numpy(r.permutation(T)[:Bw]), torch.from_numpy(r.permutation(T)[:Bw])) for _ in range(nW)]
+    st0 = synth.ppo_state(11)
+    params = ppo_ref.to_torch_params(st0, requires_grad=True)
+    gsum = {m: {k: torch.zeros_like(p) for k, p in d.items()} for m, d in params.items()}
+    lsum = np.zeros(3)
+    for w in range(nW):
+        (ss, sa), (ts, ta) = cpu[w]
+        l3 = ppo_ref.update_policy(params, ppo_ref.gather_minibatch(ss, idx[w][0], sa),
+                                   ppo_ref.gather_minibatch(ts, idx[w][1], ta))
+        lsum += np.array(l3)
+        for m, d in params.items():
+            for k, p in d.items():
+                gsum[m][k] += p.grad
+    batches = [(dev[w][0], idx[w][0], dev[w][0].advantages, dev[w][1], idx[w][1], dev[w][1].advantages)
+               for w in range(nW)]
+    for rep in range(3):                               # eager, capture, hipGraph replay
+        got = agent.update_policy_from_storages(batches, sync=True)
+        assert rel(got, lsum) < 1e-4, (rep, got, lsum)
+        worst = 0.0
+        for mn, d in gsum.items():
+            gv = agent.arena.views(agent.arena.grads, mn)
+            scale = max(float(t.abs().max()) for t in d.values())
+            for k, t in d.items():
+                err = float((gv[k].cpu() - t).abs().max()) / max(scale, 1e-12)
+                worst = max(worst, err)
+                assert err < 2e-4, (rep, mn, k, err)
+    print("W=4 x 64 (%s): losses rel %.2e, worst per-parameter gradient error %.2e"
+          % ("row-sorted" if sorted_rows else "unsorted", rel(got, lsum), worst))
+
+
+def test_c3_bf16_contract_end_to_end():
+    """bf16 encoder -> fp32 LSTM/heads/losses vs the fp32 oracle on the same observations."""
+    from oracle import encoder_ref, ppo_ref
+    from ppo_agent.agent import CadreAgent
+    H = W = 84
+    n = 12
+    sd = synth.encoder_state(3, 3, 7)
+    cfg = dict(use_lstm=True, vae_device=0, device_num=0, vae_params="CoPM", measurement_dim=18,
+               num_output=dict(steer=33, throttle=3), command_num=4, obs_hw=(H, W), weights_init="none",
+               vae_state_dict=sd, encoder_dtype="bf16", latent_cache=False)
+    agent = CadreAgent(rank=0, model_cfg=cfg, frame=8, STEER_CONTROL={i: (i - 16) / 16.0 for i in range(33)},
+                       THROTTLE_CONTROL={0: [0, 0], 1: [0, 1], 2: [0.6, 0]}, ent_coeff=0.01, value_coeff=0.1,
+                       clip_coeff=1.0, clip=0.1)
+    st0 = synth.ppo_state(11)
+    agent.arena.load_numpy_state(st0)
+    params = ppo_ref.to_torch_params(st0)
+    steps = synth.synth_rollout(n, H, W, seed=77)
+    feats_ref, feats, agree, decided = [], [], 0, 0
+    worst_v = 0.0
+    for i, td in enumerate(steps):
+        want = encoder_ref.latent_feature(td["rgb"], td["route_fig"], td["measurements"], sd)
+        feats_ref.append(want)
+        torch.manual_seed(1000 + i)
+        feat, a, lp, v, _h = agent.act(dict(rgb=td["rgb"], route_fig=td["route_fig"].copy(),
+                                             measurements=td["measurements"], command=td["command"]))
+        feats.append(feat.cpu().clone())
+        # oracle act on the fp32 features with the same exponential draws
+        torch.manual_seed(1000 + i)
+        c = td["command"]
+        for hd, K, j in (("steer", 33, 0), ("throttle", 3, 1)):
+            with torch.no_grad():
+                x, _ = ppo_ref.lstm_forward(want, (torch.zeros(1, 530), torch.zeros(1, 530)), params["%s_lstm_%d" % (hd, c)])
+                logits = ppo_ref.categorical_logits(x, params["%s_ppo_%d" % (hd, c)])
+                val = ppo_ref.mlp3(x, params["%s_ppo_%d" % (hd, c)], "critic")
+            q = torch.empty(1, K).exponential_(1)
+            score = (logits - torch.log(q))[0]
+            top = torch.topk(score, 2).values
+            a_ref = int(torch.argmax(score))
+            assert a_ref == int(ppo_ref.sample_from_logits(logits, q))
+            if float(top[0] - top[1]) > C3_MARGIN:
+                decided += 1
+                assert int(a[j]) == a_ref, (i, hd, float(top[0] - top[1]))
+            agree += int(int(a[j]) == a_ref)
+            ev = abs(v[j].item() - val.item()) / max(1.0, abs(val.item()))
+            el = abs(lp[j].item() - logits[0, a_ref].item()) / max(1.0, abs(logits[0, a_ref].item())) if int(a[j]) == a_ref else 0.0
+            worst_v = max(worst_v, ev, el)
+    fr, fb = torch.stack(feats_ref), torch.stack(feats)
+    e_feat = float((fb - fr).abs().max() / fr.abs().max())
+    print("C3 contract: feature rel-max-err %.2e, value/log-prob err %.2e, actions agree %d/%d (%d above margin %.2f)"
+          % (e_feat, worst_v, agree, 2 * n, decided, C3_MARGIN))
+    assert e_feat < C3_FEAT_TOL and worst_v < C3_VALUE_TOL
+    assert decided >= n                                   # the margin rule really decides most draws
+    # one update_policy on the 12 windows: HIP on bf16 features vs oracle on fp32 features
+    r = np.random.RandomState(3)
+    B = n
+
+    def samples(feat_stack, to):
+        out = []
+        for K in (33, 3):
+            rr = np.random.RandomState(40 + K)
+            obs = feat_stack.permute(1, 0, 2).reshape(8 * B, 530)          # time-major [S*B, D]
+            t = (obs, torch.from_numpy(rr.randint(0, K, (B, 1)).astype(np.int64)),
+                 torch.from_numpy((0.3 * rr.standard_normal((B, 1))).astype(np.float32)),
+                 torch.from_numpy(rr.standard_normal((B, 1)).astype(np.float32)), torch.ones(B, 1),
+                 torch.from_numpy((-np.log(K) + 0.2 * rr.standard_normal((B, 1))).astype(np.float32)),
+                 torch.from_numpy(rr.standard_normal((B, 1)).astype(np.float32)),
+                 [torch.zeros(B, 530), torch.zeros(B, 530)],
+                 torch.from_numpy(rr.randint(0, 4, (B, 1)).astype(np.int32)))
+            out.append(tuple(to(x) if not isinstance(x, list) else [to(y) for y in x] for x in t))
+        return out
+    p2 = ppo_ref.to_torch_params(st0, requires_grad=True)
+    s_ref = samples(fr, lambda x: x.contiguous())
+    want_l = ppo_ref.update_policy(p2, s_ref[0], s_ref[1])
+    s_dev = samples(fb, lambda x: x.contiguous().cuda())
+    got_l = agent.update_policy(s_dev[0], s_dev[1])
+    e_loss = max(abs(a_ - b_) / max(abs(b_), 1e-12) for a_, b_ in zip(got_l, want_l))
+    gn_ref = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for d in p2.values() for p in d.values())))
+    gn = float(agent.arena.grads.double().norm())
+    print("C3 contract: losses rel err %.2e (got %s want %s), |grad| %.4f vs %.4f" % (e_loss, got_l, want_l, gn, gn_ref))
+    assert e_loss < C3_LOSS_TOL
+    assert abs(gn - gn_ref) / gn_ref < C3_LOSS_TOL

@@ -1,0 +1,48 @@
+"""GPU: the two launch topologies that cannot be tested inside the pytest process.
+
+  * reference main.py:57-70 — one `chief` process + `train` workers started with the `spawn` method, the
+    shared nets / `Shared_grad_buffers` / optimizer handed over by pickling (HIP-IPC handles of views into the
+    parameter arena).  Two episodes (two worker<->chief barrier rounds each); the worker's final snapshot must
+    equal the one the in-process hand-off produces, bit for bit.
+  * RCCL (`nccl` backend) initialised on the real device at world_size 1: `add_gradient` + `chief_step`
+    all-reduce the gradient arena once per optimiser step and leave the same parameters as without
+    torch.distributed.
+
+Each runs in its own fresh process (tests/spawn_topology_driver.py, tests/rccl_world1_driver.py)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(module, args, tag, timeout=900):
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-m", module] + args, cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith(tag + " ")]
+    assert p.returncode == 0 and lines, "driver failed rc=%s\nstdout:\n%s\nstderr:\n%s" % (
+        p.returncode, p.stdout[-3000:], p.stderr[-6000:])
+    return json.loads(lines[-1][len(tag) + 1:])
+
+
+def test_spawned_chief_and_worker_match_in_process_handoff(tmp_path):
+    res = _run("tests.spawn_topology_driver", [str(tmp_path)], "TOPOLOGY_RESULT")
+    print(res)
+    assert res["exitcodes"] == [0, 0]
+    assert res["spawned_snapshot"] and res["in_process_snapshot"]
+    assert res["tensors_compared"] >= 12 * 4 and res["max_abs_update"] > 0.0      # the optimiser really stepped
+    assert res["max_abs_param_diff"] == 0.0
+    assert res["spawned_shared_param_sum"] == res["in_process_shared_param_sum"]
+
+
+def test_rccl_allreduce_on_device_world1():
+    res = _run("tests.rccl_world1_driver", [], "RCCL_RESULT")
+    print(res)
+    assert res["backend"] == "nccl" and res["world"] == 1 and res["warmup_sum"] == 4.0
+    assert res["allreduce_calls"] == 3 and res["allreduce_calls_nodist"] == 0     # one per optimiser step
+    assert res["params_equal"] and res["losses_equal"] and res["broadcast_equal"]

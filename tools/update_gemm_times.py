@@ -46,7 +46,7 @@ def main():
         run()
         torch.cuda.synchronize()
         hip.PROFILE = None
-        for key, flops, e0, e1, shape in prof:
+        for key, flops, e0, e1, shape, _nbytes in prof:
             a = agg.setdefault((key, shape), [0, 0.0, flops])
             a[0] += 1; a[1] += e0.elapsed_time(e1) * 1e3
     tot = 0.0
