@@ -72,7 +72,12 @@ def oracle_learner_replay(g, max_steps=None):
 # ----------------------------------------------------------------------------- reference train() plumbing
 class AD(dict):
     """attr-dict stand-in for addict's ConfigDict (reference ppo_agent/meta/config.py): cfg.key and cfg['key']."""
-    __getattr__ = dict.__getitem__
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
     __setattr__ = dict.__setitem__
 
 
