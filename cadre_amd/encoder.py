@@ -12,6 +12,8 @@ Weights come in the reference's state_dict naming so a real `net_epoch<N>` check
 (`{'autoencoder': state_dict}`, experiments_builder.py:442-462) drops in.  Any input size
 whose layer-4 map has <= 96 positions is supported (the reference hard-codes 5x8).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -40,6 +42,15 @@ def _khwc(w):
         rows[:, :, :kw * 4] = k.reshape(o, kh, kw * 4)
         return rows.reshape(o, kh * 32).contiguous()
     return k.reshape(o, -1).contiguous()
+
+
+def _stem_taps(w, ntaps):
+    """OIHW Cin=4 stem weights -> tap-major [O][ntaps][4] (tap = ky*KW + kx, zero taps appended): the B operand of
+    the fused front (cadre_stem_pool): K = 4*ntaps instead of the row formulation's KH*32."""
+    o, i, kh, kw = w.shape
+    out = torch.zeros(o, ntaps, i, dtype=torch.float32)
+    out[:, :kh * kw] = w.permute(0, 2, 3, 1).reshape(o, kh * kw, i)
+    return out.reshape(o, ntaps * i).contiguous()
 
 
 def _stem_rows_bf16(w):
@@ -105,6 +116,11 @@ class DANetEncoderHIP:
         # ---- trunk (resnet.py:111-115, 152-166)
         sc, sh = _fold_bn(sd, "backbone.bn1", sd["backbone.conv1.bias"])
         self.stem = _Conv(sd["backbone.conv1.weight"], sc, sh, 7, 2, 3, 1, dev)
+        # fused front (pack -> LUT -> stem conv + BN + ReLU -> max-pool in one kernel, stem_pool.hip)
+        self.fused_stem = bool(hip.lib().cadre_stem_pool_supported(H, W)) and os.environ.get("CADRE_FUSED_STEM", "1") != "0"
+        if self.fused_stem:
+            wt = _stem_taps(sd["backbone.conv1.weight"], 52 if self.bf16 else 50)
+            self.stem_taps = wt.to(dev).to(torch.bfloat16 if self.bf16 else torch.float32)
         if self.bf16:
             # bf16 stem on a zero-padded NHWC4 image (3 px halo; row pitch padded so every 8-pixel tap
             # row is in-bounds and 16-B aligned): no halo masks, two kernel rows per 64-deep k-tile
@@ -201,6 +217,11 @@ class DANetEncoderHIP:
         F = rgb_d.shape[0]
         fmax = self._buf("fmax", (F,), torch.int32)
         L = hip.lib()
+        if self.fused_stem:  # packed u8 pixels (one dword each): the LUT conversion happens inside the stem kernel
+            x = self._buf("packed", (F, self.H, self.W), torch.int32)
+            hip.check(L.cadre_pack_obs(hip.ptr(rgb_d), hip.ptr(route_d), hip.ptr(x), hip.ptr(route_norm_d), hip.ptr(fmax),
+                                       F, self.H, self.W, hip.stream()), "cadre_pack_obs")
+            return x
         if self.bf16:       # zero-bordered bf16 image for the bf16 stem; the border is written never
             x = self._buf("pre_pad", (F, self.Hp, self.Wp, 4), torch.bfloat16, zero=True)
             hip.check(L.cadre_preprocess_bf16pad(hip.ptr(rgb_d), hip.ptr(route_d), hip.ptr(self.lut255), hip.ptr(x),
@@ -219,6 +240,16 @@ class DANetEncoderHIP:
         st = hip.stream()
         F = x.shape[0]
         H, W = self.H, self.W
+        if x.dtype == torch.int32:              # packed observation from preprocess(): fused front
+            if not self.fused_stem or tuple(x.shape[1:]) != (H, W):
+                raise hip.CadreHipError("packed observation does not match this encoder (fused front off or wrong size)")
+            Hs, Ws = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+            Hp, Wp = (Hs + 2 - 3) // 2 + 1, (Ws + 2 - 3) // 2 + 1
+            p = self._buf("pool", (F, Hp, Wp, 64), torch.bfloat16 if self.bf16 else torch.float32)
+            hip.check(L.cadre_stem_pool(hip.ptr(x), hip.ptr(self.stem_taps), hip.ptr(self.stem.scale), hip.ptr(self.stem.shift),
+                                        hip.ptr(self.lut255), hip.ptr(p), F, H, W, 1 if self.bf16 else 0,
+                                        Hp * Wp * 64, Wp * 64, 64, 0, st), "cadre_stem_pool")
+            return self._trunk(p, F, Hp, Wp, out, ldo, taps)
         if self.bf16:
             if x.dtype != torch.bfloat16 or tuple(x.shape[1:]) != (self.Hp, self.Wp, 4):
                 raise hip.CadreHipError("bf16 encoder expects the padded bf16 image from preprocess()")
@@ -235,7 +266,15 @@ class DANetEncoderHIP:
             hip.check(L.cadre_maxpool3x3s2_bf16(hip.ptr(y), hip.ptr(p), F, H, W, 64, st), "cadre_maxpool3x3s2_bf16")
         else:
             hip.check(L.cadre_maxpool3x3s2(hip.ptr(y), hip.ptr(p), F, H, W, 64, st), "cadre_maxpool3x3s2")
-        cur, H, W = p, Hp, Wp
+        return self._trunk(p, F, Hp, Wp, out, ldo, taps)
+
+    def _trunk(self, p, F, H, W, out, ldo, taps):
+        """layer1..layer4, DANet head and inter-task attention on the pooled stem map p [F,H,W,64]."""
+        L = hip.lib()
+        st = hip.stream()
+        cur = p
+        if taps is not None:
+            taps["pool"] = p
         for i, (c1, c2, down) in enumerate(self.blocks):                      # resnet.py:40-55
             t, H2, W2 = self._conv(c1, cur, F, H, W, "b%d_t" % i)
             idt = cur

@@ -582,3 +582,54 @@ def test_conv_decode_random_geometries(hip):
             hip.gemm(x16, w16, out, Nimg * Ho * Wo, Cout, K, 0, K, Cout, a_mode=2, shift=sh, conv=(H, W, Cin, Ho, Wo, k, k, s, p),
                      tile=tile, bf16=True)
             assert rel(out.permute(0, 3, 1, 2), want16) < 1e-4, (cases[ci], tile, "bf16")
+
+
+@pytest.mark.parametrize("H,W,F", [(84, 84, 3), (144, 256, 2), (288, 288, 2)])
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_fused_stem_pool(hip, H, W, F, dtype):
+    """cadre_pack_obs + cadre_stem_pool (LUT -> conv 7x7/s2 + BN + ReLU -> max-pool 3x3/s2 in one kernel) vs torch-CPU
+    fp32 on the reference's own formulation (agent.py:46, resnet.py:111-115,168-172); the band decomposition
+    (which wave computes which pooled rows) must not change a single bit."""
+    import torch.nn.functional as Fn
+    from cadre_amd import synth
+    from cadre_amd.encoder import DANetEncoderHIP
+    sd = synth.encoder_state(*synth.feat_hw(H, W), 7)
+    enc = DANetEncoderHIP(sd, H, W, "cuda:0", max_frames=64, dtype=dtype)
+    assert enc.fused_stem
+    r = np.random.RandomState(H + W)
+    rgb = r.randint(0, 256, (F, H, W, 3)).astype(np.uint8)
+    route = ((r.rand(F, W, H) < 0.15) * 255).astype(np.uint8)
+    route[F - 1] = 0                                                      # a frame whose route max is 0
+    rgb_d, route_d = torch.from_numpy(rgb).cuda(), torch.from_numpy(route).cuda()
+    rn = torch.empty_like(route_d)
+    taps = {}
+    enc.forward_nhwc(enc.preprocess(rgb_d, route_d, rn), taps=taps)
+    got = taps["pool"].float().cpu()
+    # reference
+    x = np.zeros((F, 4, H, W), np.float32)
+    x[:, :3] = (rgb.transpose(0, 3, 1, 2) / 255.).astype(np.float32)
+    rt = route.copy()
+    for i in range(F):
+        if rt[i].max() > 0:
+            rt[i] = (1.0 * rt[i] / rt[i].max()).astype(np.uint8)          # agent.py:51-54 quirk
+    x[:, 3] = rt.transpose(0, 2, 1).astype(np.float32)
+    assert np.array_equal(rn.cpu().numpy(), rt)
+    w = torch.from_numpy(sd["backbone.conv1.weight"]) if not isinstance(sd["backbone.conv1.weight"], torch.Tensor) else sd["backbone.conv1.weight"]
+    t = lambda k: torch.as_tensor(sd[k]).float()
+    y = Fn.conv2d(torch.from_numpy(x), t("backbone.conv1.weight"), t("backbone.conv1.bias"), stride=2, padding=3)
+    y = Fn.batch_norm(y, t("backbone.bn1.running_mean"), t("backbone.bn1.running_var"), t("backbone.bn1.weight"),
+                      t("backbone.bn1.bias"), False, 0.0, 1e-5)
+    want = Fn.max_pool2d(torch.relu(y), 3, 2, 1).permute(0, 2, 3, 1)
+    err = float((got - want).abs().max() / want.abs().max())
+    print("fused front %dx%d %s: rel-max-err %.2e" % (H, W, dtype, err))
+    assert tuple(got.shape) == tuple(want.shape)
+    assert err < (2e-5 if dtype == "f32" else 2e-2)
+    # band invariance: the same frames inside a larger batch (fewer bands per frame) -> identical bits
+    big = 48
+    rgb_b = torch.from_numpy(r.randint(0, 256, (big, H, W, 3)).astype(np.uint8)).cuda()
+    route_b = torch.from_numpy(((r.rand(big, W, H) < 0.15) * 255).astype(np.uint8)).cuda()
+    rgb_b[5:5 + F], route_b[5:5 + F] = rgb_d, route_d
+    first = taps["pool"].clone()
+    taps2 = {}
+    enc.forward_nhwc(enc.preprocess(rgb_b, route_b), taps=taps2)
+    assert torch.equal(taps2["pool"][5:5 + F], first)
