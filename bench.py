@@ -217,7 +217,7 @@ TPL_BF16 = {1: (2, 2, 2, 2, 2), 2: (2, 1, 2, 2, 2), 3: (1, 1, 2, 2, 2), 4: (4, 2
             10: (1, 1, 2, 2, 4), 11: (2, 1, 2, 2, 4)}
 TILE = {1: "128x128", 2: "128x64", 3: "64x64", 4: "256x128", 5: "128x256", 6: "256x64", 7: "256x256 (8 waves)",
         8: "128x128 (8 waves)", 9: "32x128", 10: "128x64 (8 waves)", 11: "256x64 (8 waves)",
-        12: "64x64, 8 M-tiles per workgroup"}
+        12: "64x64, 8 M-tiles per workgroup", 64: "32x64 per autonomous wave, weights resident in LDS"}
 AM = {0: "dense A[M][K]", 1: "dense A[K][M]", 2: "NHWC implicit-GEMM conv", 3: "Cin=4 stem conv",
       4: "Cin=4 stem conv on the zero-padded image"}
 
@@ -228,6 +228,8 @@ def kname(k):
         _, tile, am = k
         if tile == 12:
             return "conv_stream_bf16_kernel<%d>" % am
+        if tile == 64:
+            return "conv3x3_c64_bf16_kernel"
         wm_, wn_, wvn_, ns_, wvm_ = TPL_BF16[tile]
         return "gemm_bf16_kernel<%d, %d, %d, %d, %d, %d>" % (wm_, wn_, am, wvn_, ns_, wvm_)
     if k[0] == 12:

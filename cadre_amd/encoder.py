@@ -116,6 +116,7 @@ class DANetEncoderHIP:
         # ---- trunk (resnet.py:111-115, 152-166)
         sc, sh = _fold_bn(sd, "backbone.bn1", sd["backbone.conv1.bias"])
         self.stem = _Conv(sd["backbone.conv1.weight"], sc, sh, 7, 2, 3, 1, dev)
+        self.c64_kernel = os.environ.get("CADRE_C64_KERNEL", "1") != "0"
         # fused front (pack -> LUT -> stem conv + BN + ReLU -> max-pool in one kernel, stem_pool.hip)
         self.fused_stem = bool(hip.lib().cadre_stem_pool_supported(H, W)) and os.environ.get("CADRE_FUSED_STEM", "1") != "0"
         if self.fused_stem:
@@ -203,7 +204,12 @@ class DANetEncoderHIP:
         act = c.act if act is None else act
         wbf = c.w.dtype == torch.bfloat16
         flags = (2 if odt == torch.bfloat16 else 0) | (4 if (resid is not None and resid.dtype == torch.bfloat16) else 0)
-        if c.k == 1 and c.stride == 1:
+        if (wbf and self.c64_kernel and c.k == 3 and c.stride == 1 and c.pad == 1 and c.cin == 64 and c.cout == 64
+                and odt == torch.bfloat16 and (act & 16) == 0 and (resid is None or resid.dtype == torch.bfloat16)
+                and M * 128 < 2 ** 31):
+            # stage-1 convs of the bf16 encoder: HBM-bound, weights resident in LDS, autonomous LDS-DMA-fed waves
+            hip.conv3x3_c64_bf16(x, c.w, c.scale, c.shift, resid, out, F, H, W, 1 if act == 1 else 0)
+        elif c.k == 1 and c.stride == 1:
             hip.gemm(x, c.w, out, M, c.cout, K, K, K, c.cout, scale=c.scale, shift=c.shift, resid=resid,
                      ldr=c.cout, act=act, bf16=wbf, flags=flags)
         else:

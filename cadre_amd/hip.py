@@ -38,6 +38,7 @@ SYMBOLS = {
     "cadre_gemm_pick_tile": [C.POINTER(GemmDesc)],
     "cadre_gemm_bf16": [C.POINTER(GemmDesc), vp],
     "cadre_gemm_bf16_pick_tile": [C.POINTER(GemmDesc)],
+    "cadre_conv3x3_c64_bf16": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "cadre_maxpool3x3s2_bf16": [vp, vp, i32, i32, i32, i32, vp],
     "cadre_pam_bf16out": [vp, vp, f32, vp, i32, i32, vp],
     "cadre_cam_bf16out": [vp, f32, vp, i32, i32, vp],
@@ -160,3 +161,19 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, scale=None, shi
     else:
         key = (lib().cadre_gemm_pick_tile(C.byref(d)), a_mode, b_mode)
     PROFILE.append((key, 2.0 * M * N * k_alg * nb, e0, e1, (M, N, K, nb, split_k, seg[0] if seg is not None else 0), nbytes))
+
+
+def conv3x3_c64_bf16(x, w, scale, shift, resid, out, F, H, W, relu):
+    """cadre_conv3x3_c64_bf16 with the same profiling hook as gemm(): key ("bf16", 64, 2)."""
+    fn = lib().cadre_conv3x3_c64_bf16
+    args = (ptr(x), ptr(w), ptr(scale), ptr(shift), ptr(resid), ptr(out), F, H, W, relu, stream())
+    if PROFILE is None or torch.cuda.is_current_stream_capturing():
+        check(fn(*args), "cadre_conv3x3_c64_bf16")
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(fn(*args), "cadre_conv3x3_c64_bf16")
+    e1.record()
+    M = F * H * W
+    nbytes = M * 64 * 2 * (3 if resid is not None else 2) + 64 * 576 * 2
+    PROFILE.append((("bf16", 64, 2), 2.0 * M * 64 * 576, e0, e1, (M, 64, 576, 1, 1, 0), nbytes))

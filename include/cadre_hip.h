@@ -84,6 +84,13 @@ int cadre_gemm_pick_tile(const cadre_gemm_t* p);
 int cadre_gemm_bf16(const cadre_gemm_t* p, void* stream);
 /* tile id cadre_gemm_bf16 would launch for this descriptor (host logic, no launch) */
 int cadre_gemm_bf16_pick_tile(const cadre_gemm_t* p);
+/* Stage-1 convolutions of the bf16 encoder (resnet.py:26-55, layer1): 3x3 / stride 1 / pad 1, 64 -> 64 channels
+ * on dense NHWC bf16 x [F][H][W][64], w bf16 [64][576] (k = (kh*3 + kw)*64 + ci), y = act(conv * scale + shift
+ * (+ resid)), bf16 out.  HBM-bound layer: weights resident in LDS, autonomous waves fed by LDS-DMA rings
+ * (conv3x3_c64_bf16.hip).  Same k order, MFMA and epilogue arithmetic as cadre_gemm_bf16 a_mode 2. */
+int cadre_conv3x3_c64_bf16(const void* x, const void* w, const float* scale, const float* shift,
+                           const void* resid, void* out, int32_t F, int32_t H, int32_t W, int32_t relu,
+                           void* stream);
 /* C[M][ldc] = act(sum_s slab[s][M][lds] * scale + shift + resid) */
 int cadre_splitk_reduce(const float* slabs, int32_t split_k, int64_t slab_stride, int64_t lds,
                         float* C, int64_t ldc, int32_t M, int32_t N, const float* scale,

@@ -633,3 +633,32 @@ def test_fused_stem_pool(hip, H, W, F, dtype):
     taps2 = {}
     enc.forward_nhwc(enc.preprocess(rgb_b, route_b), taps=taps2)
     assert torch.equal(taps2["pool"][5:5 + F], first)
+
+
+@pytest.mark.parametrize("F,H,W,use_resid,relu", [(3, 18, 22, False, 1), (2, 72, 72, True, 1), (5, 9, 9, True, 0), (70, 21, 21, True, 1)])
+def test_conv3x3_c64_bf16(hip, F, H, W, use_resid, relu):
+    """Autonomous-wave stage-1 conv (LDS-DMA ring, resident weights) vs torch fp32 on the same bf16 operands and vs the
+    generic cadre_gemm_bf16 implicit-GEMM path (same k order and epilogue arithmetic: expected bit-identical)."""
+    r = np.random.RandomState(F * 1000 + H)
+    x = torch.from_numpy(r.standard_normal((F, H, W, 64)).astype(np.float32)).cuda().bfloat16()
+    w = torch.from_numpy((r.standard_normal((64, 3, 3, 64)) * 0.05).astype(np.float32)).cuda().bfloat16()
+    sc = torch.from_numpy((0.5 + r.rand(64)).astype(np.float32)).cuda()
+    sh = torch.from_numpy(r.standard_normal(64).astype(np.float32)).cuda()
+    res = torch.from_numpy(r.standard_normal((F, H, W, 64)).astype(np.float32)).cuda().bfloat16() if use_resid else None
+    out = torch.full((F, H, W, 64), 7.0, device="cuda", dtype=torch.bfloat16)
+    hip.conv3x3_c64_bf16(x, w.reshape(64, 576), sc, sh, res, out, F, H, W, relu)
+    ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2).cpu(), w.float().permute(0, 3, 1, 2).cpu(), padding=1)
+    ref = ref.permute(0, 2, 3, 1) * sc.cpu() + sh.cpu()
+    if use_resid:
+        ref = ref + res.float().cpu()
+    if relu:
+        ref = torch.relu(ref)
+    err = float((out.float().cpu() - ref).abs().max() / ref.abs().max())
+    out2 = torch.empty_like(out)
+    M = F * H * W
+    hip.gemm(x, w.reshape(64, 576), out2, M, 64, 576, 0, 576, 64, a_mode=2, scale=sc, shift=sh, resid=res, ldr=64,
+             act=relu, conv=(H, W, 64, H, W, 3, 3, 1, 1), bf16=True, flags=2 | (4 if use_resid else 0))
+    same = bool(torch.equal(out, out2))
+    print("conv3x3_c64 F=%d %dx%d: rel-max-err vs torch %.2e, bit-identical to cadre_gemm_bf16: %s" % (F, H, W, err, same))
+    assert err < 1.5e-2          # one bf16 rounding of the output
+    assert float((out.float() - out2.float()).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
