@@ -253,7 +253,7 @@ class DANetEncoderHIP:
             Hp, Wp = (Hs + 2 - 3) // 2 + 1, (Ws + 2 - 3) // 2 + 1
             p = self._buf("pool", (F, Hp, Wp, 64), torch.bfloat16 if self.bf16 else torch.float32)
             hip.check(L.cadre_stem_pool(hip.ptr(x), hip.ptr(self.stem_taps), hip.ptr(self.stem.scale), hip.ptr(self.stem.shift),
-                                        hip.ptr(self.lut255), hip.ptr(p), F, H, W, 1 if self.bf16 else 0,
+                                        hip.ptr(p), F, H, W, 1 if self.bf16 else 0,
                                         Hp * Wp * 64, Wp * 64, 64, 0, st), "cadre_stem_pool")
             return self._trunk(p, F, Hp, Wp, out, ldo, taps)
         if self.bf16:

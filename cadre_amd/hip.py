@@ -47,7 +47,8 @@ SYMBOLS = {
     "cadre_preprocess_bf16pad": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "cadre_maxpool3x3s2": [vp, vp, i32, i32, i32, i32, vp],
     "cadre_pack_obs": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
-    "cadre_stem_pool": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, i64, vp],
+    "cadre_stem_pool": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, i64, vp],
+    "cadre_div255_selfcheck": [vp, vp, vp],
     "cadre_stem_pool_supported": [i32, i32],
     "cadre_pam": [vp, vp, f32, vp, i32, i32, vp],
     "cadre_cam": [vp, f32, vp, i32, i32, vp],

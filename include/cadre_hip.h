@@ -117,15 +117,18 @@ int cadre_preprocess_bf16pad(const uint8_t* rgb, const uint8_t* route, const flo
  * that every byte takes the same /255 LUT (LUT[255] == 1.0f exactly).  route_norm / frame_max as above. */
 int cadre_pack_obs(const uint8_t* rgb, const uint8_t* route, uint32_t* out, uint8_t* route_norm,
                    uint32_t* frame_max, int32_t F, int32_t H, int32_t W, void* stream);
-/* Fused encoder front: packed observation -> /255 LUT -> conv1 7x7/s2/p3 (4 -> 64) + folded BN + ReLU ->
+/* Fused encoder front: packed observation -> /255 -> conv1 7x7/s2/p3 (4 -> 64) + folded BN + ReLU ->
  * MaxPool2d(3,2,1)  (agent.py:46, resnet.py:111-115,168-172) in one kernel; the stem map never reaches HBM.
  * wt: tap-major weights [64][taps][4] (tap = ky*7 + kx; fp32: 50 taps, bf16: 52 taps, zero padded).
  * out: pooled map, element (f, p, c, ch) at out_off + f*out_frame + p*out_row + c*out_px + ch (f32, or bf16 when
  * bf16 != 0, which also selects bf16 MFMA).  Geometries: cadre_stem_pool_supported(H, W) (host logic). */
 int cadre_stem_pool(const uint32_t* img, const void* wt, const float* scale, const float* shift,
-                    const float* lut255, void* out, int32_t F, int32_t H, int32_t W, int32_t bf16,
+                    void* out, int32_t F, int32_t H, int32_t W, int32_t bf16,
                     int64_t out_frame, int64_t out_row, int32_t out_px, int64_t out_off, void* stream);
 int cadre_stem_pool_supported(int32_t H, int32_t W);
+/* The fused front converts bytes arithmetically (x * fl(1/255) + one Newton correction) instead of through the
+ * table: counts, into *mismatches (device int32), the i in 0..255 for which that differs from lut255[i]; must be 0. */
+int cadre_div255_selfcheck(const float* lut255, int32_t* mismatches, void* stream);
 /* nn.MaxPool2d(3,2,1) resnet.py:114 on NHWC [F][H][W][C] (C%4==0) -> [F][Ho][Wo][C] */
 int cadre_maxpool3x3s2(const float* x, float* y, int32_t F, int32_t H, int32_t W, int32_t C,
                        void* stream);

@@ -662,3 +662,12 @@ def test_conv3x3_c64_bf16(hip, F, H, W, use_resid, relu):
     print("conv3x3_c64 F=%d %dx%d: rel-max-err vs torch %.2e, bit-identical to cadre_gemm_bf16: %s" % (F, H, W, err, same))
     assert err < 1.5e-2          # one bf16 rounding of the output
     assert float((out.float() - out2.float()).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+
+
+def test_div255_arithmetic_is_the_reference_table(hip):
+    """agent.py:46 `rgb / 255.` (double division, float32 store): the fused front's multiply + Newton correction
+    must reproduce it for every byte."""
+    lut = torch.from_numpy((np.arange(256) / 255.).astype(np.float32)).cuda()
+    bad = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+    hip.check(hip.lib().cadre_div255_selfcheck(hip.ptr(lut), hip.ptr(bad), hip.stream()), "cadre_div255_selfcheck")
+    assert int(bad.item()) == 0
