@@ -16,6 +16,7 @@
 //     are 16 bytes per lane.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/cadre_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -206,6 +207,162 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_bf16_kernel(c64_args a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// v2: every input pixel is brought into LDS ONCE.  The workgroup (4 waves x 32 positions = one 128-position tile per
+// step) streams the activation through a 512-slot ring over the flattened position axis (one slot = one pixel =
+// 128 B): tap (kh, kw) of output position p is pixel p + (kh-1)*W + (kw-1), i.e. ring index
+// (p - P0 + kh*W + kw) & 511 with the ring anchored at L0 = P0 - W - 1 — nine taps = nine address offsets into the
+// same resident pixels, the taps that fall outside the frame (row / column halo) are zeroed on the fragment with the
+// per-position 9-bit mask.  Per tile the workgroup issues ONE block of 128 new pixels (16 LDS-DMA pieces, 4 per wave)
+// instead of nine 32-pixel stages per wave: 9x fewer bytes through the L2 -> LDS path, 9x fewer DMA instructions, and
+// the block being loaded is not needed before the next tile: a whole tile of lead time.  One workgroup barrier per tile
+// (publishes the block every wave waited for with its own vmcnt, and fences the overwrite of the oldest block).
+#define C64_R 512                  // ring slots (pixels)
+#define C64_V2_LDS (64 * C64_WPITCH + C64_R * 128 + 4 * C64_SLAB)
+
+template <bool RESID>
+__global__ __launch_bounds__(256, 1) void conv3x3_c64_bf16_v2_kernel(c64_args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* wl = smem;                                         // [64][C64_WPITCH]
+  char* ring = smem + 64 * C64_WPITCH;                     // [512][128 B], chunk c of slot q at ((c ^ ((q>>1)&7)) << 4)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  float* cs = reinterpret_cast<float*>(ring + C64_R * 128 + wave * C64_SLAB);
+  {
+    const char* src = reinterpret_cast<const char*>(a.w);
+    for (int i = tid; i < 64 * 72; i += 256) {
+      const int n = i / 72, c = i - n * 72;
+      *reinterpret_cast<f32x4*>(wl + n * C64_WPITCH + c * 16) = *reinterpret_cast<const f32x4*>(src + (size_t)i * 16);
+    }
+  }
+  const int t_begin = blockIdx.x * a.tpw, t_end = min(a.tiles, t_begin + a.tpw);      // 128-position tiles of this workgroup
+  const int nt = t_end - t_begin;                          // uniform over the workgroup (barriers below)
+  const int P0 = t_begin * 128, L0 = P0 - a.W - 1;
+  const int nh = (2 * a.W + 1) >> 7;                       // extra halo blocks a tile reaches into (0 or 1: W <= 127)
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.M * 128, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.M * 128, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)(RESID ? a.resid : a.x), 0, a.M * 128, 0x00020000);
+  // block jb = pixels [L0 + 128 jb, +128): 16 pieces of 8 pixels, this wave issues pieces 4w .. 4w+3.  Pixels before
+  // the tensor (negative -> huge unsigned offset) or past it fall outside the descriptor and arrive as zeros.
+  auto issue_block = [&](int jb) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int q = 128 * jb + 8 * (4 * wave + k);         // ring-relative index of the piece's first pixel
+      const int qi = q + (lane >> 3);
+      const unsigned voff = (unsigned)((L0 + qi) * 128 + (((lane & 7) ^ ((qi >> 1) & 7)) << 4));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)(ring + (q & (C64_R - 1)) * 128), 16,
+                                               (int)voff, 0, 0, 0);
+    }
+  };
+  // (h, w) of this lane's output position inside the tile (fragment row l31 of wave `wave`)
+  const float inv_w = 1.0f / (float)a.W, inv_h = 1.0f / (float)a.H;
+  int ph, pw;
+  {
+    const int m = P0 + 32 * wave + l31, HW = a.H * a.W;
+    const int rem = m % HW;
+    ph = rem / a.W;
+    pw = rem - ph * a.W;
+  }
+  float sc[2], sh[2];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) { sc[cb] = a.scale[32 * cb + l31]; sh[cb] = a.shift[32 * cb + l31]; }
+  const char* b_rd = wl + l31 * C64_WPITCH + lh * 16;
+
+  for (int jb = 0; jb <= 1 + nh; ++jb) issue_block(jb);    // what tile 0 needs
+  for (int T = 0; T < nt; ++T) {
+    const int t = t_begin + T;
+    // own pieces of block T+1+nh have landed (behind them in the queue: only the 4 stores of the previous epilogue)
+    if (T == 0) C64_WAIT(0); else C64_WAIT(4);
+    // raw barrier (a __syncthreads() fence would drain vmcnt to 0, i.e. also wait for the previous tile's stores):
+    // block T+1+nh complete and visible; every wave is done reading for tile T-1
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue_block(T + 2 + nh);                               // overwrites block T-2+nh (4 blocks in the ring): no reader left
+    u32x4 rv[2][2];
+    if constexpr (RESID) {
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int pos = t * 128 + 32 * wave + 16 * i + (lane >> 2);
+          rv[cb][i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, pos * 128 + cb * 64 + (lane & 3) * 16, 0, 0));
+        }
+    }
+    unsigned mask = 0;
+    {
+      const int m = t * 128 + 32 * wave + l31;
+      if (m < a.M) {
+        unsigned colm = 0;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+          if ((unsigned)(pw - 1 + kw) < (unsigned)a.W) colm |= 1u << kw;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+          if ((unsigned)(ph - 1 + kh) < (unsigned)a.H) mask |= colm << (3 * kh);
+      }
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+    const int qb = 128 * T + 32 * wave + l31;              // ring-relative index of tap (0,0) of this lane's position
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int qi = (qb + (tap / 3) * a.W + (tap % 3)) & (C64_R - 1);
+      const char* arow = ring + qi * 128;
+      const unsigned sw = (unsigned)((qi >> 1) & 7);
+      const bool on = (mask >> tap) & 1u;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        f32x4 av = *reinterpret_cast<const f32x4*>(arow + (((2 * s + lh) ^ sw) << 4));
+        if (!on) av = f32x4{0.f, 0.f, 0.f, 0.f};             // halo tap of this position: zero padding
+        const bf16x8 af = __builtin_bit_cast(bf16x8, av);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          const bf16x8 bf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const f32x4*>(b_rd + cb * 32 * C64_WPITCH + tap * 128 + s * 32));
+          acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[cb], 0, 0, 0);
+        }
+      }
+    }
+    // ---- epilogue (as v1): per 32-channel half through the wave's slab, 16 bytes per lane to HBM
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + l31] = acc[cb][r] * sc[cb] + sh[cb];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = 16 * i + (lane >> 2), c8 = (lane & 3) * 8;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(cs + row * 36 + c8);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(cs + row * 36 + c8 + 4);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        if constexpr (RESID) {
+          const bf16x8 rr = __builtin_bit_cast(bf16x8, rv[cb][i]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += (float)rr[e];
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)(a.relu ? fmaxf(v[e], 0.f) : v[e]);
+        const int pos = t * 128 + 32 * wave + row;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsC, pos * 128 + cb * 64 + c8 * 2, 0, 0);
+      }
+    }
+    {                                                      // next tile: + 128 positions (exact float-reciprocal floor, x < 2^16)
+      const int x = pw + 128;
+      const int q1 = (int)(((float)x + 0.5f) * inv_w);
+      pw = x - q1 * a.W;
+      const int y = ph + q1;
+      const int q2 = (int)(((float)y + 0.5f) * inv_h);
+      ph = y - q2 * a.H;
+    }
+  }
+}
+
+// 0 = auto (v2 where it applies), 1 = force v1 (per-wave im2col stages), for A/B runs: CADRE_C64_VARIANT
+static int g_c64_variant = [] { const char* e = getenv("CADRE_C64_VARIANT"); return e ? atoi(e) : 0; }();
+
 extern "C" int cadre_conv3x3_c64_bf16(const void* x, const void* w, const float* scale, const float* shift,
                                       const void* resid, void* out, int32_t F, int32_t H, int32_t W, int32_t relu,
                                       void* stream) {
@@ -216,6 +373,22 @@ extern "C" int cadre_conv3x3_c64_bf16(const void* x, const void* w, const float*
   c64_args a;
   a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.resid = resid; a.out = out;
   a.M = (int)M; a.H = H; a.W = W; a.relu = relu;
+  hipStream_t st = (hipStream_t)stream;
+  if (W <= 127 && W >= 2 && g_c64_variant != 1) {          // v2: shared position ring, each pixel loaded once
+    a.tiles = (int)((M + 127) / 128);
+    int wgs = 256;
+    if (a.tiles < wgs * 2) wgs = (a.tiles + 1) / 2 > 0 ? (a.tiles + 1) / 2 : 1;
+    a.tpw = (a.tiles + wgs - 1) / wgs;
+    const dim3 grid((a.tiles + a.tpw - 1) / a.tpw), block(256);
+    if (resid) {
+      (void)hipFuncSetAttribute((const void*)conv3x3_c64_bf16_v2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL(conv3x3_c64_bf16_v2_kernel<true>, grid, block, C64_V2_LDS, st, a);
+    } else {
+      (void)hipFuncSetAttribute((const void*)conv3x3_c64_bf16_v2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL(conv3x3_c64_bf16_v2_kernel<false>, grid, block, C64_V2_LDS, st, a);
+    }
+    return (int)hipGetLastError();
+  }
   a.tiles = (int)((M + 31) / 32);
   int waves = 1024;                                        // 256 CUs x 4 autonomous waves
   if (a.tiles < waves * 4) waves = (a.tiles + 3) / 4 > 0 ? (a.tiles + 3) / 4 : 1;
@@ -223,7 +396,6 @@ extern "C" int cadre_conv3x3_c64_bf16(const void* x, const void* w, const float*
   const int nwave = (a.tiles + a.tpw - 1) / a.tpw;
   const dim3 grid((nwave + 3) / 4), block(256);
   const size_t lds = 64 * C64_WPITCH + 4 * C64_WAVE_LDS;
-  hipStream_t st = (hipStream_t)stream;
   if (resid) {
     (void)hipFuncSetAttribute((const void*)conv3x3_c64_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(conv3x3_c64_bf16_kernel<true>, grid, block, lds, st, a);
