@@ -18,6 +18,7 @@
 //   float32(rgb / 255.) for all 256 inputs (cadre_div255_selfcheck); bf16: converted once per pixel at staging.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/cadre_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -199,21 +200,34 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(stem_args a) {
 #pragma unroll
             for (int t = 0; t < CH; ++t) px[t] = rp[16 * t];
           };
-          uint32_t pxn[CH];
-          fetch(0, pxn);
-#pragma unroll
-          for (int q = 0; q < NK; ++q) {
-            float af[CH][4];
+          // two-deep software pipeline, pinned with sched_barrier (hipcc otherwise sinks the ring read to its first
+          // use and every k-quad starts with an exposed LDS round trip — 73 % MFMA-busy in profiles/r02 PMC):
+          //   pixels of quad q+2 are requested, then the 4 MFMAs of quad q issue, then quad q+1 is converted.
+          auto conv = [&](const uint32_t* px, float (*af)[4]) {
 #pragma unroll
             for (int t = 0; t < CH; ++t)
 #pragma unroll
-              for (int s = 0; s < 4; ++s) af[t][s] = div255((float)((pxn[t] >> (8 * s)) & 255u));
-            const f32x4 b = *reinterpret_cast<const f32x4*>(wrow + (2 * q + lh) * 4);
-            if (q + 1 < NK) fetch(q + 1, pxn);                     // next quad's pixels fly under this quad's MFMAs
+              for (int s = 0; s < 4; ++s) af[t][s] = div255((float)((px[t] >> (8 * s)) & 255u));
+          };
+          uint32_t pxn[CH];
+          float af[CH][4];
+          fetch(0, pxn);
+          conv(pxn, af);
+          fetch(1, pxn);
+          f32x4 b = *reinterpret_cast<const f32x4*>(wrow + lh * 4);
+#pragma unroll
+          for (int q = 0; q < NK; ++q) {
+            f32x4 bn = b;
+            if (q + 1 < NK) bn = *reinterpret_cast<const f32x4*>(wrow + (2 * (q + 1) + lh) * 4);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
               for (int t = 0; t < CH; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t][s], b[s], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 1 < NK) conv(pxn, af);
+            if (q + 2 < NK) fetch(q + 2, pxn);
+            b = bn;
           }
         } else {
           // k-step q: taps 4q + 2*half + {0,1}: two ring pixels (bf16 x 4 channels each) = the lane's 8 k-values
@@ -343,7 +357,9 @@ extern "C" int cadre_stem_pool(const uint32_t* img, const void* wt, const float*
   hipStream_t st = (hipStream_t)stream;
   const bool ragged = (a.Ws % 16) != 0 || (a.Hs & 1) || a.Wp * 2 != a.Ws;
   // tiles per MFMA chunk (CH): fp32 1 (230 VGPRs, no spill at 2 waves per SIMD), bf16 3 / 2 (B fragment shared by the chunk)
-  if (NT == 9) return ragged ? launch_stem<9, 1, 3, true>(a, bf16 != 0, lds, st) : launch_stem<9, 1, 3, false>(a, bf16 != 0, lds, st);
+  static const int ch9 = [] { const char* e = getenv("CADRE_STEM_CH"); return e ? atoi(e) : 3; }();     // A/B knob
+  if (NT == 9 && ch9 == 1) return ragged ? launch_stem<9, 1, 3, true>(a, bf16 != 0, lds, st) : launch_stem<9, 1, 3, false>(a, bf16 != 0, lds, st);
+  if (NT == 9) return ragged ? launch_stem<9, 3, 3, true>(a, bf16 != 0, lds, st) : launch_stem<9, 3, 3, false>(a, bf16 != 0, lds, st);
   if (NT == 8) return ragged ? launch_stem<8, 1, 2, true>(a, bf16 != 0, lds, st) : launch_stem<8, 1, 2, false>(a, bf16 != 0, lds, st);
   return launch_stem<3, 1, 3, true>(a, bf16 != 0, lds, st);
 }
