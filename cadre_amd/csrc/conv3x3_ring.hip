@@ -1,0 +1,387 @@
+// conv3x3_ring.hip — 3x3 / stride 1 / pad 1 convolution on dense NHWC for gfx950, fp32 (v_mfma_f32_32x32x2_f32,
+// exact fp32 fma chain) and bf16 (v_mfma_f32_32x32x16_bf16), the workhorse of the DANet trunk and head
+// (resnet.py:26-55 BasicBlock conv1/conv2 of layer1-4, danet.py:21-41 conv5a/5c/51/52): 16 of the encoder's 20 3x3
+// convolutions are stride 1.
+//
+// What the implicit-GEMM tile kernels (gemm_f32.hip / gemm_bf16.hip, a_mode 2) pay for on these layers is operand
+// staging: every input pixel is gathered 9 times (once per tap) from L2 into LDS through a VGPR round trip.  Here:
+//   * k is ordered (channel chunk of 128 bytes, tap): for one chunk the workgroup brings the WINDOW of pixels its
+//     256 output positions can touch — positions [P - W - 1, P + 256 + W + 1) of the flattened N*H*W axis, 128 B each
+//     — into LDS ONCE, by LDS-DMA (buffer_load ... lds: no VGPR round trip, hardware zero fill outside the tensor);
+//     the nine taps are nine row offsets (kh*W + kw) into the same resident window; taps that fall outside the frame
+//     are zeroed on the fragment with a per-position 9-bit mask.  A traffic L2 -> LDS drops ~7x;
+//   * the weights [N][chunk][tap][128 B] stream through a 3-stage LDS ring, two k-tiles ahead, also by LDS-DMA;
+//   * the next chunk's window (or the next tile's first window) is loaded in slices during the current chunk's nine
+//     k-tiles — a whole phase of lead time; everything is ordered by each wave's own counted vmcnt plus ONE raw
+//     s_barrier per k-tile (a __syncthreads() fence would drain vmcnt to 0);
+//   * 128-byte rows are XOR-swizzled on the SOURCE address (chunk ^ ((row >> 1) & 7)), LDS stays lane-linear as
+//     LDS-DMA requires, all ds_read_b128 fragment reads are bank-conflict free;
+//   * persistent workgroups (one per CU) walk a contiguous run of (M-tile, N-tile) items, N inner: the epilogue of one
+//     item runs while the loads of the next are already in flight.
+// Same epilogue contract as cadre_gemm_*: y = act(conv * scale[n] + shift[n] (+ resid)) (+ resid after act).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "../../include/cadre_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+int cadre_fail(const char* msg);
+
+#define RG_BM 256                  // output positions per workgroup tile
+#define RG_NSTB 3                  // weight stages
+#define RG_SLAB 4608               // epilogue slab per wave: 32 rows x 36 floats
+
+struct ring_args {
+  const void* x;          // [M][Cin] elements (fp32 or bf16), M = F*H*W
+  const void* w;          // [N][NC][9][128 B]: chunk-major, tap, then the chunk's channels (k contiguous)
+  const float* scale;     // [N] or null
+  const float* shift;     // [N] or null
+  const void* resid;      // [M][N] (fp32 / bf16) or null
+  void* out;              // [M][N] (fp32 / bf16)
+  int M, H, W, Cin, N, NC;
+  int act;                // 0 none, 1 ReLU; |16: resid added after the activation
+  int out_bf16, resid_bf16;
+  int mtiles, ntiles, items, ipw;      // M tiles of 256, N tiles, work items, items per workgroup
+  int WPX;                // window pixels (multiple of 8, >= 288)
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_vm_n(int n) {        // wave-uniform n in [0, 40]
+  switch (n) {
+#define RG_CASE(k) case k: wait_vm<k>(); break;
+    RG_CASE(0) RG_CASE(1) RG_CASE(2) RG_CASE(3) RG_CASE(4) RG_CASE(5) RG_CASE(6) RG_CASE(7) RG_CASE(8) RG_CASE(9)
+    RG_CASE(10) RG_CASE(11) RG_CASE(12) RG_CASE(13) RG_CASE(14) RG_CASE(15) RG_CASE(16) RG_CASE(17) RG_CASE(18) RG_CASE(19)
+    RG_CASE(20) RG_CASE(21) RG_CASE(22) RG_CASE(23) RG_CASE(24) RG_CASE(25) RG_CASE(26) RG_CASE(27) RG_CASE(28) RG_CASE(29)
+    RG_CASE(30) RG_CASE(31) RG_CASE(32) RG_CASE(33) RG_CASE(34) RG_CASE(35) RG_CASE(36) RG_CASE(37) RG_CASE(38) RG_CASE(39)
+#undef RG_CASE
+    default: wait_vm<0>(); break;
+  }
+}
+
+// NTILE: output channels per workgroup tile (64 or 128); 8 waves as 4 (positions) x 2 (channels): a wave owns
+// 64 positions x NTILE/2 channels = 2 x WN MFMA tiles of 32x32.
+// RES: 0 no residual, 1 fp32 residual, 2 bf16 residual; OUTB: output bf16 (else fp32)
+template <bool BF16, int NTILE, int RES, bool OUTB>
+__global__ __launch_bounds__(512, 2) void conv3x3_ring_kernel(ring_args a) {
+  constexpr int WN = NTILE / 64;                           // 32-channel column blocks per wave
+  constexpr int EB = BF16 ? 2 : 4;
+  constexpr int NBPW = NTILE / 64;                         // weight pieces (8 rows x 128 B) per wave per stage
+  constexpr unsigned OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int win_bytes = a.WPX * 128;
+  char* win0 = smem;                                       // two windows, then the weight stages, then a 1 KiB dump
+  char* bst = smem + 2 * win_bytes;
+  char* dump = bst + RG_NSTB * NTILE * 128;
+
+  const int i_begin = blockIdx.x * a.ipw, i_end = min(a.items, i_begin + a.ipw);
+  const int nitems = i_end - i_begin;                      // uniform over the workgroup
+  if (nitems <= 0) return;
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.M * a.Cin * EB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.N * a.NC * 9 * 128, 0x00020000);
+  const int cin_b = a.Cin * EB;
+  const int PA = a.WPX >> 3;                               // window pieces
+
+  // ---- phase bookkeeping: phase ph = (item, chunk); step = (phase, tap)
+  auto item_tiles = [&](int it, int& mt, int& nt) { mt = it / a.ntiles; nt = it - mt * a.ntiles; };
+  // one window piece (8 pixels) of phase (item it, chunk c) into window `wsel`; index j >= PA: dummy into the dump
+  auto issue_a = [&](int it, int c, int wsel, int j, bool live) {
+    int mt, nt;
+    item_tiles(it, mt, nt);
+    const int idx = 8 * j + (lane >> 3);
+    const int xpos = mt * RG_BM - a.W - 1 + idx;           // absolute position (negative / >= M: outside -> zeros)
+    const bool ok = live && j < PA;
+    unsigned voff = OOB;
+    if (ok && xpos >= 0 && xpos < a.M) voff = (unsigned)(xpos * cin_b + c * 128 + (((lane & 7) ^ ((idx >> 1) & 7)) << 4));
+    char* dst = ok ? win0 + wsel * win_bytes + j * 1024 : dump;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)dst, 16, (int)voff, 0, 0, 0);
+  };
+  // this wave's NBPW weight pieces of step (item it, chunk c, tap) into stage `stg`
+  auto issue_b = [&](int it, int c, int tap, int stg, bool live) {
+    int mt, nt;
+    item_tiles(it, mt, nt);
+#pragma unroll
+    for (int k = 0; k < NBPW; ++k) {
+      const int r = (wave * NBPW + k) * 8 + (lane >> 3);   // row of the stage
+      const int n = nt * NTILE + r;
+      unsigned voff = OOB;
+      if (live && n < a.N) voff = (unsigned)(((n * a.NC + c) * 9 + tap) * 128 + (((lane & 7) ^ ((r >> 1) & 7)) << 4));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(bst + stg * (NTILE * 128) + (wave * NBPW + k) * 1024),
+                                               16, (int)voff, 0, 0, 0);
+    }
+  };
+
+  // (h, w) of this lane's two fragment rows (positions 64*wm + 32*rb + l31 of the current M tile)
+  const float inv_w = 1.0f / (float)a.W, inv_h = 1.0f / (float)a.H;
+  int ph[2], pw[2], cur_mt;
+  {
+    int nt0;
+    item_tiles(i_begin, cur_mt, nt0);
+    const int HW = a.H * a.W;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int m = cur_mt * RG_BM + 64 * wm + 32 * rb + l31;
+      const int rem = m % HW;
+      ph[rb] = rem / a.W;
+      pw[rb] = rem - ph[rb] * a.W;
+    }
+  }
+  auto advance_mtile = [&]() {                             // + 256 positions, exact float-reciprocal floors (x < 2^16)
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int x = pw[rb] + RG_BM;
+      const int q1 = (int)(((float)x + 0.5f) * inv_w);
+      pw[rb] = x - q1 * a.W;
+      const int y = ph[rb] + q1;
+      const int q2 = (int)(((float)y + 0.5f) * inv_h);
+      ph[rb] = y - q2 * a.H;
+    }
+  };
+
+  // ---- prologue: window of the first phase (all pieces), weights of steps 0 and 1
+  const int total_ph = nitems * a.NC;
+  for (int j = wave; j < PA; j += 8) issue_a(i_begin, 0, 0, j, true);
+  issue_b(i_begin, 0, 0, 0, true);
+  issue_b(i_begin, 0, 1, 1, true);
+  int extra = 0, extra_steps = 0;                          // epilogue stores still behind the pieces a wait must cover (2 steps)
+  int sg = 0;                                              // global step index (stage = sg % 3)
+  bool first_step = true;
+
+  for (int li = 0; li < nitems; ++li) {
+    const int it = i_begin + li;
+    int mt, nt;
+    item_tiles(it, mt, nt);
+    if (mt != cur_mt) { advance_mtile(); cur_mt = mt; }
+    unsigned mask[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int m = mt * RG_BM + 64 * wm + 32 * rb + l31;
+      unsigned mk = 0;
+      if (m < a.M) {
+        unsigned colm = 0;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+          if ((unsigned)(pw[rb] - 1 + kw) < (unsigned)a.W) colm |= 1u << kw;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+          if ((unsigned)(ph[rb] - 1 + kh) < (unsigned)a.H) mk |= colm << (3 * kh);
+      }
+      mask[rb] = mk;
+    }
+    f32x16 acc[2][WN];
+    float sc[WN], sh[WN];                                  // folded BN of this lane's channels (accumulator layout: lane = channel)
+#pragma unroll
+    for (int cb = 0; cb < WN; ++cb) {
+      const int nch = nt * NTILE + (NTILE / 2) * wn + 32 * cb + l31;
+      sc[cb] = (a.scale && nch < a.N) ? a.scale[nch] : 1.f;
+      sh[cb] = (a.shift && nch < a.N) ? a.shift[nch] : 0.f;
+    }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < WN; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.f;
+
+    for (int c = 0; c < a.NC; ++c) {
+      const int phg = li * a.NC + c;                       // phase index of this workgroup
+      const char* win = win0 + (phg & 1) * win_bytes;
+      // next phase (for the window prefetch)
+      const bool has_next = phg + 1 < total_ph;
+      const int nit = (c + 1 < a.NC) ? it : it + 1, ncx = (c + 1 < a.NC) ? c + 1 : 0;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        // ---- everything issued two steps ago (weights of this step, window slices) has landed; publish
+        if (first_step) { wait_vm<0>(); first_step = false; }
+        else wait_vm_n(NBPW + 1 + (extra_steps > 0 ? extra : 0));
+        if (extra_steps > 0) --extra_steps;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // ---- issue: weights two steps ahead, one window slice of the next phase (slices on taps 0..7 only)
+        {
+          int t2 = tap + 2, c2 = c, it2 = it;
+          if (t2 >= 9) { t2 -= 9; ++c2; if (c2 == a.NC) { c2 = 0; ++it2; } }
+          issue_b(it2, c2, t2, (sg + 2) % RG_NSTB, it2 < i_end);
+          issue_a(nit, ncx, (phg + 1) & 1, tap < 8 ? tap * 8 + wave : PA, has_next);
+        }
+        // ---- compute this step
+        const char* bs = bst + (sg % RG_NSTB) * (NTILE * 128);
+        const int toff = (tap / 3) * a.W + (tap % 3);
+        f32x4 afr[2][4];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          const int idx = 64 * wm + 32 * rb + l31 + toff;
+          const char* arow = win + idx * 128;
+          const unsigned sw = (unsigned)((idx >> 1) & 7);
+          const bool on = (mask[rb] >> tap) & 1u;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(arow + (((2 * s + lh) ^ sw) << 4));
+            if (!on) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            afr[rb][s] = v;
+          }
+        }
+#pragma unroll
+        for (int cb = 0; cb < WN; ++cb) {
+          const int n = (NTILE / 2) * wn + 32 * cb + l31;
+          const char* brow = bs + n * 128;
+          const unsigned sw = (unsigned)((n >> 1) & 7);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(brow + (((2 * s + lh) ^ sw) << 4));
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+              if constexpr (BF16) {
+                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[rb][s]), __builtin_bit_cast(bf16x8, bv),
+                                                                      acc[rb][cb], 0, 0, 0);
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[rb][s][e], bv[e], acc[rb][cb], 0, 0, 0);
+              }
+            }
+          }
+        }
+        ++sg;
+      }
+    }
+    // ---- epilogue of the item: slabs live in the window that was just read (all waves must be done with it).
+    // Straight-line per (RES, OUTB); the residual of block b+1 is requested before block b is processed.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+      const int phl = (li * a.NC + a.NC - 1) & 1;
+      float* cs = reinterpret_cast<float*>(win0 + phl * win_bytes + wave * RG_SLAB);
+      constexpr int ESZ = OUTB ? 2 : 4, RSZ = RES == 2 ? 2 : 4;
+      const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.M * a.N * ESZ, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? a.resid : a.x), 0, RES ? a.M * a.N * RSZ : 0, 0x00020000);
+      const bool relu = (a.act & 15) == 1, post = (a.act & 16) != 0;
+      const int row0 = lane >> 3, c4 = (lane & 7) * 4;     // lane -> (row 8*i + lane/8, channels 4*(lane&7) .. +3)
+      constexpr int NBLK = 2 * WN;                         // 32 x 32 blocks of this wave: b = cb*2 + rb
+      auto eoff = [&](int b, int i) -> unsigned {          // element offset of this lane's 4 outputs, or OOB
+        const int cb = b >> 1, rb = b & 1;
+        const int pos = mt * RG_BM + 64 * wm + 32 * rb + 8 * i + row0;
+        const int ch = nt * NTILE + (NTILE / 2) * wn + 32 * cb + c4;
+        return (pos < a.M && ch < a.N) ? (unsigned)(pos * a.N + ch) : OOB;
+      };
+      u32x4 rq[2][4];
+      auto req = [&](int b, u32x4* dst) {
+        if constexpr (RES != 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const unsigned eo = eoff(b, i);
+            if constexpr (RES == 2) {
+              const u32x2 t = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsR, eo == OOB ? (int)OOB : (int)(eo * 2), 0, 0));
+              dst[i] = u32x4{t[0], t[1], 0u, 0u};
+            } else {
+              dst[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, eo == OOB ? (int)OOB : (int)(eo * 4), 0, 0));
+            }
+          }
+        }
+      };
+      req(0, rq[0]);
+#pragma unroll
+      for (int b = 0; b < NBLK; ++b) {
+        const int cb = b >> 1, rb = b & 1;
+        if (b + 1 < NBLK) req(b + 1, rq[(b + 1) & 1]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + l31] = acc[rb][cb][r] * sc[cb] + sh[cb];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(cs + (8 * i + row0) * 36 + c4);
+          f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (RES == 2) {
+            const bf16x4 t = __builtin_bit_cast(bf16x4, u32x2{rq[b & 1][i][0], rq[b & 1][i][1]});
+            rv = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+          } else if constexpr (RES == 1) {
+            rv = __builtin_bit_cast(f32x4, rq[b & 1][i]);
+          }
+          if constexpr (RES != 0) { if (!post) v += rv; }
+          if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          if constexpr (RES != 0) { if (post) v += rv; }
+          const unsigned eo = eoff(b, i);
+          if constexpr (OUTB) {
+            bf16x4 o;
+            o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rsC, eo == OOB ? (int)OOB : (int)(eo * 2), 0, 0);
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, eo == OOB ? (int)OOB : (int)(eo * 4), 0, 0);
+          }
+        }
+      }
+      extra = NBLK * 4;                                    // these stores sit behind the in-flight pieces in the queue:
+      extra_steps = 2;                                     // the next two waits reach back over them
+    }
+  }
+}
+
+static int g_ring_off = [] { const char* e = getenv("CADRE_RING_CONV"); return e ? (atoi(e) == 0) : 0; }();
+
+// host logic: does cadre_conv3x3_ring take this layer?  (bf16 != 0: bf16 operands)
+extern "C" int cadre_conv3x3_ring_supported(int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t bf16) {
+  if (g_ring_off) return 0;
+  const int eb = bf16 ? 2 : 4;
+  if (F < 1 || H < 1 || W < 2 || W > 95) return 0;
+  if ((Cin * eb) % 128 != 0 || N % 32 != 0) return 0;
+  const long long M = (long long)F * H * W;
+  if (M * Cin * eb >= (1ll << 31) || M * N * 4 >= (1ll << 31) || (long long)N * Cin * 9 * eb >= (1ll << 31)) return 0;
+  return 1;
+}
+
+extern "C" int cadre_conv3x3_ring(const void* x, const void* w, const float* scale, const float* shift, const void* resid,
+                                  void* out, int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t act,
+                                  int32_t flags, void* stream) {
+  const int bf16 = flags & 1, out_bf16 = (flags >> 1) & 1, resid_bf16 = (flags >> 2) & 1;
+  if (!x || !w || !out) return cadre_fail("cadre_conv3x3_ring: null operand");
+  if (!cadre_conv3x3_ring_supported(F, H, W, Cin, N, bf16)) return cadre_fail("cadre_conv3x3_ring: unsupported geometry (see cadre_conv3x3_ring_supported)");
+  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)out | (uintptr_t)resid) & 15) return cadre_fail("cadre_conv3x3_ring: operands must be 16-byte aligned");
+  ring_args a;
+  a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.resid = resid; a.out = out;
+  a.M = F * H * W; a.H = H; a.W = W; a.Cin = Cin; a.N = N; a.NC = Cin * (bf16 ? 2 : 4) / 128;
+  a.act = act; a.out_bf16 = out_bf16; a.resid_bf16 = resid_bf16;
+  const int ntile = N >= 128 ? 128 : 64;
+  a.mtiles = (a.M + RG_BM - 1) / RG_BM;
+  a.ntiles = (N + ntile - 1) / ntile;
+  a.items = a.mtiles * a.ntiles;
+  int wgs = 256;
+  if (a.items < wgs) wgs = a.items;
+  a.ipw = (a.items + wgs - 1) / wgs;
+  const int grid = (a.items + a.ipw - 1) / a.ipw;
+  int wpx = RG_BM + 2 * W + 2;
+  wpx = (wpx + 7) & ~7;
+  if (wpx < 288) wpx = 288;                                // the epilogue slabs (8 x 4608 B) live in a window
+  a.WPX = wpx;
+  const size_t lds = (size_t)2 * wpx * 128 + (size_t)RG_NSTB * ntile * 128 + 1024;
+  if (lds > 160 * 1024) return cadre_fail("cadre_conv3x3_ring: window does not fit LDS");
+  hipStream_t st = (hipStream_t)stream;
+#define RG_LAUNCH(BF, NT_, RS_, OB_)                                                                             \
+  do {                                                                                                           \
+    (void)hipFuncSetAttribute((const void*)conv3x3_ring_kernel<BF, NT_, RS_, OB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL((conv3x3_ring_kernel<BF, NT_, RS_, OB_>), dim3(grid), dim3(512), lds, st, a);               \
+  } while (0)
+#define RG_NT(BF, RS_, OB_) do { if (ntile == 128) RG_LAUNCH(BF, 128, RS_, OB_); else RG_LAUNCH(BF, 64, RS_, OB_); } while (0)
+  if (bf16) {
+    if (resid && !resid_bf16) return cadre_fail("cadre_conv3x3_ring: bf16 operands take a bf16 residual");
+    if (resid) { if (out_bf16) RG_NT(true, 2, true); else RG_NT(true, 2, false); }
+    else { if (out_bf16) RG_NT(true, 0, true); else RG_NT(true, 0, false); }
+  } else {
+    if (out_bf16 || (resid && resid_bf16)) return cadre_fail("cadre_conv3x3_ring: fp32 operands take fp32 residual / output");
+    if (resid) RG_NT(false, 1, false); else RG_NT(false, 0, false);
+  }
+#undef RG_NT
+#undef RG_LAUNCH
+  return (int)hipGetLastError();
+}

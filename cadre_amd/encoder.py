@@ -70,11 +70,21 @@ def _stem_rows_bf16(w):
     return out.reshape(o, nkt * 64).contiguous()
 
 
+def _ring_w(w, cpc):
+    """OIHW 3x3 weights -> [O][Cin/cpc][9][cpc] (channel chunk of 128 bytes, tap, channel): cadre_conv3x3_ring's B."""
+    o, i, kh, kw = w.shape
+    return w.permute(0, 2, 3, 1).reshape(o, kh * kw, i // cpc, cpc).permute(0, 2, 1, 3).contiguous()
+
+
 class _Conv:
-    __slots__ = ("w", "scale", "shift", "cin", "cout", "k", "stride", "pad", "act")
+    __slots__ = ("w", "w_ring", "scale", "shift", "cin", "cout", "k", "stride", "pad", "act")
 
     def __init__(self, w, scale, shift, k, stride, pad, act, dev, wdtype=torch.float32):
         self.w = _khwc(w).to(dev).to(wdtype)
+        cpc = 64 if wdtype == torch.bfloat16 else 32
+        self.w_ring = None
+        if k == 3 and stride == 1 and pad == 1 and w.shape[1] % cpc == 0:
+            self.w_ring = _ring_w(w, cpc).to(dev).to(wdtype)
         self.scale = None if scale is None else scale.contiguous().to(dev)
         self.shift = None if shift is None else shift.contiguous().to(dev)
         self.cout, self.cin = w.shape[0], w.shape[1]
@@ -117,6 +127,7 @@ class DANetEncoderHIP:
         sc, sh = _fold_bn(sd, "backbone.bn1", sd["backbone.conv1.bias"])
         self.stem = _Conv(sd["backbone.conv1.weight"], sc, sh, 7, 2, 3, 1, dev)
         self.c64_kernel = os.environ.get("CADRE_C64_KERNEL", "1") != "0"
+        self.ring_conv = os.environ.get("CADRE_RING_CONV", "1") != "0"
         # fused front (pack -> LUT -> stem conv + BN + ReLU -> max-pool in one kernel, stem_pool.hip)
         self.fused_stem = bool(hip.lib().cadre_stem_pool_supported(H, W)) and os.environ.get("CADRE_FUSED_STEM", "1") != "0"
         if self.fused_stem:
@@ -209,6 +220,10 @@ class DANetEncoderHIP:
                 and M * 128 < 2 ** 31):
             # stage-1 convs of the bf16 encoder: HBM-bound, weights resident in LDS, autonomous LDS-DMA-fed waves
             hip.conv3x3_c64_bf16(x, c.w, c.scale, c.shift, resid, out, F, H, W, 1 if act == 1 else 0)
+        elif (c.w_ring is not None and self.ring_conv and x.dtype == c.w_ring.dtype
+              and hip.lib().cadre_conv3x3_ring_supported(F, H, W, c.cin, c.cout, 1 if wbf else 0)):
+            # stride-1 3x3 convs: each pixel through LDS once per channel chunk, weights streamed (conv3x3_ring.hip)
+            hip.conv3x3_ring(x, c.w_ring, c.scale, c.shift, resid, out, F, H, W, c.cin, c.cout, act)
         elif c.k == 1 and c.stride == 1:
             hip.gemm(x, c.w, out, M, c.cout, K, K, K, c.cout, scale=c.scale, shift=c.shift, resid=resid,
                      ldr=c.cout, act=act, bf16=wbf, flags=flags)

@@ -39,6 +39,8 @@ SYMBOLS = {
     "cadre_gemm_bf16": [C.POINTER(GemmDesc), vp],
     "cadre_gemm_bf16_pick_tile": [C.POINTER(GemmDesc)],
     "cadre_conv3x3_c64_bf16": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "cadre_conv3x3_ring": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "cadre_conv3x3_ring_supported": [i32, i32, i32, i32, i32, i32],
     "cadre_maxpool3x3s2_bf16": [vp, vp, i32, i32, i32, i32, vp],
     "cadre_pam_bf16out": [vp, vp, f32, vp, i32, i32, vp],
     "cadre_cam_bf16out": [vp, f32, vp, i32, i32, vp],
@@ -178,3 +180,23 @@ def conv3x3_c64_bf16(x, w, scale, shift, resid, out, F, H, W, relu):
     M = F * H * W
     nbytes = M * 64 * 2 * (3 if resid is not None else 2) + 64 * 576 * 2
     PROFILE.append((("bf16", 64, 2), 2.0 * M * 64 * 576, e0, e1, (M, 64, 576, 1, 1, 0), nbytes))
+
+
+def conv3x3_ring(x, w_ring, scale, shift, resid, out, F, H, W, Cin, N, act):
+    """cadre_conv3x3_ring (3x3 / s1 / p1, each pixel through LDS once per channel chunk); profiling key
+    ("bf16", 65, 2) / (65, 2, 0) — tile id 65 = the ring kernel."""
+    bf = x.dtype == torch.bfloat16
+    flags = (1 if bf else 0) | (2 if out.dtype == torch.bfloat16 else 0) | (4 if (resid is not None and resid.dtype == torch.bfloat16) else 0)
+    fn = lib().cadre_conv3x3_ring
+    args = (ptr(x), ptr(w_ring), ptr(scale), ptr(shift), ptr(resid), ptr(out), F, H, W, Cin, N, act, flags, stream())
+    if PROFILE is None or torch.cuda.is_current_stream_capturing():
+        check(fn(*args), "cadre_conv3x3_ring")
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(fn(*args), "cadre_conv3x3_ring")
+    e1.record()
+    M, esz = F * H * W, (2 if bf else 4)
+    nbytes = M * Cin * esz + N * 9 * Cin * esz + M * N * out.element_size() + (M * N * resid.element_size() if resid is not None else 0)
+    key = ("bf16", 65, 2) if bf else (65, 2, 0)
+    PROFILE.append((key, 2.0 * M * N * 9 * Cin, e0, e1, (M, N, 9 * Cin, 1, 1, 0), nbytes))

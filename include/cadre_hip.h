@@ -91,6 +91,15 @@ int cadre_gemm_bf16_pick_tile(const cadre_gemm_t* p);
 int cadre_conv3x3_c64_bf16(const void* x, const void* w, const float* scale, const float* shift,
                            const void* resid, void* out, int32_t F, int32_t H, int32_t W, int32_t relu,
                            void* stream);
+/* 3x3 / stride 1 / pad 1 convolution on dense NHWC (resnet.py:26-55 conv1/conv2, danet.py:21-41 conv5a/5c/51/52):
+ * x [F][H][W][Cin], w [N][NC][9][128 B] (NC = Cin*elem/128 channel chunks; chunk-major, tap = kh*3+kw, then the
+ * chunk's channels), y = act(conv*scale[n] + shift[n] (+ resid)) (+ resid after act when act & 16), out [F*H*W][N].
+ * flags bit 0: bf16 operands (else fp32); bit 1: out bf16; bit 2: resid bf16.  Each input pixel goes through LDS once
+ * per channel chunk (conv3x3_ring.hip).  cadre_conv3x3_ring_supported: host logic, no launch. */
+int cadre_conv3x3_ring(const void* x, const void* w, const float* scale, const float* shift, const void* resid,
+                       void* out, int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t act,
+                       int32_t flags, void* stream);
+int cadre_conv3x3_ring_supported(int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t bf16);
 /* C[M][ldc] = act(sum_s slab[s][M][lds] * scale + shift + resid) */
 int cadre_splitk_reduce(const float* slabs, int32_t split_k, int64_t slab_stride, int64_t lds,
                         float* C, int64_t ldc, int32_t M, int32_t N, const float* scale,

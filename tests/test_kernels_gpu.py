@@ -671,3 +671,43 @@ def test_div255_arithmetic_is_the_reference_table(hip):
     bad = torch.full((1,), -1, dtype=torch.int32, device="cuda")
     hip.check(hip.lib().cadre_div255_selfcheck(hip.ptr(lut), hip.ptr(bad), hip.stream()), "cadre_div255_selfcheck")
     assert int(bad.item()) == 0
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("F,H,W,Cin,N,use_resid,act", [
+    (2, 18, 22, 64, 64, False, 1), (1, 72, 72, 64, 64, True, 1), (2, 36, 36, 128, 128, True, 1), (3, 18, 18, 256, 256, True, 1),
+    (5, 9, 9, 512, 512, False, 1), (5, 9, 9, 512, 128, False, 1), (7, 9, 9, 128, 128, True, 1 | 16), (2, 21, 21, 64, 96, True, 0),
+    (40, 9, 9, 128, 256, True, 1)])
+def test_conv3x3_ring(hip, dtype, F, H, W, Cin, N, use_resid, act):
+    """cadre_conv3x3_ring (window of pixels resident in LDS, nine taps as row offsets, weights streamed by LDS-DMA)
+    vs torch fp32 conv2d on the same operands: every trunk / head shape class, residual before and after the ReLU,
+    an N that is not a multiple of the tile, several M tiles and work items per workgroup."""
+    from cadre_amd.encoder import _ring_w
+    bf = dtype == "bf16"
+    td = torch.bfloat16 if bf else torch.float32
+    r = np.random.RandomState(F * 131 + H * 7 + Cin + N)
+    x = torch.from_numpy(r.standard_normal((F, H, W, Cin)).astype(np.float32)).cuda().to(td)
+    w = torch.from_numpy((r.standard_normal((N, Cin, 3, 3)) * (1.5 / np.sqrt(9 * Cin))).astype(np.float32)).to(td)
+    sc = torch.from_numpy((0.5 + r.rand(N)).astype(np.float32)).cuda()
+    sh = torch.from_numpy(r.standard_normal(N).astype(np.float32)).cuda()
+    res = torch.from_numpy(r.standard_normal((F, H, W, N)).astype(np.float32)).cuda().to(td) if use_resid else None
+    out = torch.full((F, H, W, N), 7.0, device="cuda", dtype=td)
+    assert hip.lib().cadre_conv3x3_ring_supported(F, H, W, Cin, N, 1 if bf else 0)
+    wr = _ring_w(w.float(), 64 if bf else 32).to(td).cuda()
+    hip.conv3x3_ring(x, wr, sc, sh, res, out, F, H, W, Cin, N, act)
+    ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2).cpu(), w.float(), padding=1).permute(0, 2, 3, 1) * sc.cpu() + sh.cpu()
+    if use_resid and not (act & 16):
+        ref = ref + res.float().cpu()
+    if act & 1:
+        ref = torch.relu(ref)
+    if use_resid and (act & 16):
+        ref = ref + res.float().cpu()
+    err = float((out.float().cpu() - ref).abs().max() / ref.abs().max())
+    print("conv3x3_ring %s F=%d %dx%d %d->%d: rel-max-err %.2e" % (dtype, F, H, W, Cin, N, err))
+    assert err < (1.5e-2 if bf else 2e-5)
+    if not bf:                                   # fp32 output of the bf16 model's head convs (conv5a / conv5c feed PAM / CAM in fp32)
+        return
+    out32 = torch.empty((F, H, W, N), device="cuda", dtype=torch.float32)
+    if not use_resid:
+        hip.conv3x3_ring(x, wr, sc, sh, None, out32, F, H, W, Cin, N, act)
+        assert float((out32.cpu() - ref).abs().max() / ref.abs().max()) < 1.5e-2

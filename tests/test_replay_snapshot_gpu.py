@@ -66,7 +66,6 @@ def test_recorded_episode_replays_bit_identically(tmp_path):
     torch.manual_seed(9)
     st1, f1 = _run_episode(a1, live, T, rec)
     path = rec.end_episode()
-    out1, p1 = _learner(a1, st1)
 
     ep = replay.load_episode(path)
     assert ep["rgb"].shape[0] == T + 7 and ep["window"].shape == (T, 8)          # distinct frames stored once
@@ -83,6 +82,7 @@ def test_recorded_episode_replays_bit_identically(tmp_path):
         for k in ("action", "action_log_probs", "value_preds", "rewards", "masks", "command"):
             assert torch.equal(getattr(s1, k), getattr(s2, k)), k
         assert ep["action"][:, 0].tolist() == st1[0].action[:T, 0].tolist()      # what was recorded is what was stored
+    out1, p1 = _learner(a1, st1)
     out2, p2 = _learner(a2, st2)
     assert out1 == out2 and torch.equal(p1, p2)                                   # losses and parameters: same bits
     assert float((p1 - make_agent(H, W).arena.params).abs().max()) > 0
