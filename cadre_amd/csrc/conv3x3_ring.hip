@@ -90,46 +90,56 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_kernel(ring_args a) {
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.N * a.NC * 9 * 128, 0x00020000);
   const int cin_b = a.Cin * EB;
   const int PA = a.WPX >> 3;                               // window pieces
+  for (int i = tid; i < 256; i += 512) reinterpret_cast<unsigned*>(dump)[i] = 0u;      // the dump doubles as the ZERO ROW
 
-  // ---- phase bookkeeping: phase ph = (item, chunk); step = (phase, tap)
-  auto item_tiles = [&](int it, int& mt, int& nt) { mt = it / a.ntiles; nt = it - mt * a.ntiles; };
-  // one window piece (8 pixels) of phase (item it, chunk c) into window `wsel`; index j >= PA: dummy into the dump
-  auto issue_a = [&](int it, int c, int wsel, int j, bool live) {
-    int mt, nt;
-    item_tiles(it, mt, nt);
-    const int idx = 8 * j + (lane >> 3);
-    const int xpos = mt * RG_BM - a.W - 1 + idx;           // absolute position (negative / >= M: outside -> zeros)
+  // ---- lane constants of the staging path.  A window piece j (8 pixels): this lane brings pixel 8j + (lane>>3),
+  // LDS chunk (lane&7), i.e. source chunk (lane&7) ^ ((idx>>1)&7) with idx = 8j + (lane>>3): (idx>>1)&7 =
+  // (lane>>4) ^ 4*(j&1), and j = 8*tap + wave has the parity of the wave — a per-lane constant.  Pixels outside the
+  // tensor need no test: a negative position wraps to a huge unsigned offset, one past the end lies beyond
+  // num_records — both arrive as zeros.
+  const int a_lane = (lane >> 3) * cin_b + ((((lane & 7) ^ (lane >> 4) ^ (4 * (wave & 1)))) << 4);
+  int b_lane[NBPW];                                        // weight piece k of this wave: stage row r = (wave*NBPW + k)*8 + lane>>3
+#pragma unroll
+  for (int k = 0; k < NBPW; ++k) {
+    const int r = (wave * NBPW + k) * 8 + (lane >> 3);
+    b_lane[k] = r * a.NC * 9 * 128 + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+  }
+  auto issue_a = [&](int mt_n, int c_n, int wsel, int j, bool live) {      // one window piece of the NEXT phase (or a dummy)
     const bool ok = live && j < PA;
-    unsigned voff = OOB;
-    if (ok && xpos >= 0 && xpos < a.M) voff = (unsigned)(xpos * cin_b + c * 128 + (((lane & 7) ^ ((idx >> 1) & 7)) << 4));
+    const unsigned voff = ok ? (unsigned)((mt_n * RG_BM - a.W - 1 + 8 * j) * cin_b + c_n * 128 + a_lane) : OOB;
     char* dst = ok ? win0 + wsel * win_bytes + j * 1024 : dump;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)dst, 16, (int)voff, 0, 0, 0);
   };
-  // this wave's NBPW weight pieces of step (item it, chunk c, tap) into stage `stg`
-  auto issue_b = [&](int it, int c, int tap, int stg, bool live) {
-    int mt, nt;
-    item_tiles(it, mt, nt);
+  auto issue_b = [&](int nt_b, int c, int tap, int stg, bool live) {       // this wave's weight pieces of one step
 #pragma unroll
     for (int k = 0; k < NBPW; ++k) {
-      const int r = (wave * NBPW + k) * 8 + (lane >> 3);   // row of the stage
-      const int n = nt * NTILE + r;
-      unsigned voff = OOB;
-      if (live && n < a.N) voff = (unsigned)(((n * a.NC + c) * 9 + tap) * 128 + (((lane & 7) ^ ((r >> 1) & 7)) << 4));
+      const unsigned voff = live ? (unsigned)(nt_b * (NTILE * a.NC * 9 * 128) + (c * 9 + tap) * 128 + b_lane[k]) : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(bst + stg * (NTILE * 128) + (wave * NBPW + k) * 1024),
                                                16, (int)voff, 0, 0, 0);
     }
   };
+  // ---- lane constants of the fragment reads
+  const int arow0 = (64 * wm + l31) * 128;                 // window byte offset of fragment row (rb = 0) at tap (0,0)
+  int kc[4];                                               // logical 16-B chunk of k-step s for this lane half
+#pragma unroll
+  for (int s = 0; s < 4; ++s) kc[s] = 2 * s + lh;
+  int boff[WN][4];                                         // weight fragment offsets inside a stage (swizzle is per row: constant)
+#pragma unroll
+  for (int cb = 0; cb < WN; ++cb) {
+    const int n = (NTILE / 2) * wn + 32 * cb + l31;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) boff[cb][s] = n * 128 + (((2 * s + lh) ^ ((n >> 1) & 7)) << 4);
+  }
 
   // (h, w) of this lane's two fragment rows (positions 64*wm + 32*rb + l31 of the current M tile)
   const float inv_w = 1.0f / (float)a.W, inv_h = 1.0f / (float)a.H;
-  int ph[2], pw[2], cur_mt;
+  int ph[2], pw[2];
+  int mt = i_begin / a.ntiles, nt = i_begin - mt * a.ntiles;      // the only divisions of the kernel
   {
-    int nt0;
-    item_tiles(i_begin, cur_mt, nt0);
     const int HW = a.H * a.W;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
-      const int m = cur_mt * RG_BM + 64 * wm + 32 * rb + l31;
+      const int m = mt * RG_BM + 64 * wm + 32 * rb + l31;
       const int rem = m % HW;
       ph[rb] = rem / a.W;
       pw[rb] = rem - ph[rb] * a.W;
@@ -149,18 +159,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_kernel(ring_args a) {
 
   // ---- prologue: window of the first phase (all pieces), weights of steps 0 and 1
   const int total_ph = nitems * a.NC;
-  for (int j = wave; j < PA; j += 8) issue_a(i_begin, 0, 0, j, true);
-  issue_b(i_begin, 0, 0, 0, true);
-  issue_b(i_begin, 0, 1, 1, true);
+  for (int j = wave; j < PA; j += 8) issue_a(mt, 0, 0, j, true);       // (j parity == wave parity: a_lane holds)
+  issue_b(nt, 0, 0, 0, true);
+  issue_b(nt, 0, 1, 1, true);
   int extra = 0, extra_steps = 0;                          // epilogue stores still behind the pieces a wait must cover (2 steps)
-  int sg = 0;                                              // global step index (stage = sg % 3)
+  int stg = 0;                                             // weight stage of the current step
   bool first_step = true;
 
   for (int li = 0; li < nitems; ++li) {
-    const int it = i_begin + li;
-    int mt, nt;
-    item_tiles(it, mt, nt);
-    if (mt != cur_mt) { advance_mtile(); cur_mt = mt; }
+    // next item (N inner): its tiles feed the look-ahead issues
+    int mt1 = mt, nt1 = nt + 1;
+    if (nt1 == a.ntiles) { nt1 = 0; ++mt1; }
+    const bool more = li + 1 < nitems;
     unsigned mask[2];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
@@ -195,50 +205,45 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_kernel(ring_args a) {
     for (int c = 0; c < a.NC; ++c) {
       const int phg = li * a.NC + c;                       // phase index of this workgroup
       const char* win = win0 + (phg & 1) * win_bytes;
-      // next phase (for the window prefetch)
       const bool has_next = phg + 1 < total_ph;
-      const int nit = (c + 1 < a.NC) ? it : it + 1, ncx = (c + 1 < a.NC) ? c + 1 : 0;
+      const bool last_c = c + 1 == a.NC;
+      const int mt_n = last_c ? mt1 : mt, c_n = last_c ? 0 : c + 1;
+      char* const zrow = dump;
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         // ---- everything issued two steps ago (weights of this step, window slices) has landed; publish
         if (first_step) { wait_vm<0>(); first_step = false; }
-        else wait_vm_n(NBPW + 1 + (extra_steps > 0 ? extra : 0));
-        if (extra_steps > 0) --extra_steps;
+        else if (extra_steps > 0) { wait_vm_n(NBPW + 1 + extra); --extra_steps; }
+        else wait_vm<NBPW + 1>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         // ---- issue: weights two steps ahead, one window slice of the next phase (slices on taps 0..7 only)
         {
-          int t2 = tap + 2, c2 = c, it2 = it;
-          if (t2 >= 9) { t2 -= 9; ++c2; if (c2 == a.NC) { c2 = 0; ++it2; } }
-          issue_b(it2, c2, t2, (sg + 2) % RG_NSTB, it2 < i_end);
-          issue_a(nit, ncx, (phg + 1) & 1, tap < 8 ? tap * 8 + wave : PA, has_next);
+          const int s2 = stg + 2 >= RG_NSTB ? stg + 2 - RG_NSTB : stg + 2;
+          if (tap < 7) issue_b(nt, c, tap + 2, s2, true);
+          else if (!last_c) issue_b(nt, c + 1, tap - 7, s2, true);
+          else issue_b(nt1, 0, tap - 7, s2, more);
+          issue_a(mt_n, c_n, (phg + 1) & 1, tap < 8 ? tap * 8 + wave : PA, has_next);
         }
         // ---- compute this step
-        const char* bs = bst + (sg % RG_NSTB) * (NTILE * 128);
+        const char* bs = bst + stg * (NTILE * 128);
         const int toff = (tap / 3) * a.W + (tap % 3);
         f32x4 afr[2][4];
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
           const int idx = 64 * wm + 32 * rb + l31 + toff;
-          const char* arow = win + idx * 128;
           const unsigned sw = (unsigned)((idx >> 1) & 7);
-          const bool on = (mask[rb] >> tap) & 1u;
+          // halo tap of this position: read the zero row instead (one select per row, not per fragment register)
+          const char* arow = ((mask[rb] >> tap) & 1u) ? win + arow0 + (32 * rb + toff) * 128 : zrow;
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(arow + (((2 * s + lh) ^ sw) << 4));
-            if (!on) v = f32x4{0.f, 0.f, 0.f, 0.f};
-            afr[rb][s] = v;
-          }
+          for (int s = 0; s < 4; ++s) afr[rb][s] = *reinterpret_cast<const f32x4*>(arow + ((kc[s] ^ sw) << 4));
         }
 #pragma unroll
         for (int cb = 0; cb < WN; ++cb) {
-          const int n = (NTILE / 2) * wn + 32 * cb + l31;
-          const char* brow = bs + n * 128;
-          const unsigned sw = (unsigned)((n >> 1) & 7);
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(brow + (((2 * s + lh) ^ sw) << 4));
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bs + boff[cb][s]);
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
               if constexpr (BF16) {
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_kernel(ring_args a) {
             }
           }
         }
-        ++sg;
+        stg = stg + 1 == RG_NSTB ? 0 : stg + 1;
       }
     }
     // ---- epilogue of the item: slabs live in the window that was just read (all waves must be done with it).
@@ -325,6 +330,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_kernel(ring_args a) {
       extra = NBLK * 4;                                    // these stores sit behind the in-flight pieces in the queue:
       extra_steps = 2;                                     // the next two waits reach back over them
     }
+    if (mt1 != mt) advance_mtile();
+    mt = mt1; nt = nt1;
   }
 }
 
@@ -352,8 +359,17 @@ extern "C" int cadre_conv3x3_ring(const void* x, const void* w, const float* sca
   a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.resid = resid; a.out = out;
   a.M = F * H * W; a.H = H; a.W = W; a.Cin = Cin; a.N = N; a.NC = Cin * (bf16 ? 2 : 4) / 128;
   a.act = act; a.out_bf16 = out_bf16; a.resid_bf16 = resid_bf16;
-  const int ntile = N >= 128 ? 128 : 64;
+  // channel tile: 128 where it divides the work over 256 persistent workgroups as evenly as 64 does (a step of the
+  // 64-wide tile costs ~0.55 of a 128-wide one); CADRE_RING_NTILE forces one for A/B runs
+  static const int force_nt = [] { const char* e = getenv("CADRE_RING_NTILE"); return e ? atoi(e) : 0; }();
   a.mtiles = (a.M + RG_BM - 1) / RG_BM;
+  int ntile = 64;
+  if (N >= 128) {
+    const long long i128 = (long long)a.mtiles * ((N + 127) / 128), i64 = (long long)a.mtiles * ((N + 63) / 64);
+    const double t128 = (double)((i128 + 255) / 256) * 1.0, t64 = (double)((i64 + 255) / 256) * 0.55;
+    ntile = t128 <= t64 ? 128 : 64;
+  }
+  if (force_nt == 64 || (force_nt == 128 && N >= 128)) ntile = force_nt;
   a.ntiles = (N + ntile - 1) / ntile;
   a.items = a.mtiles * a.ntiles;
   int wgs = 256;
