@@ -335,16 +335,44 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_kernel(ring_args a) {
   }
 }
 
-static int g_ring_off = [] { const char* e = getenv("CADRE_RING_CONV"); return e ? (atoi(e) == 0) : 0; }();
 
-// host logic: does cadre_conv3x3_ring take this layer?  (bf16 != 0: bf16 operands)
+// Channel tile and work split over the persistent workgroups (host logic).  The makespan is ceil(items / 256) item
+// times: 128 wide where that divides as evenly as 64 wide (a step of the 64-wide tile costs ~0.52 (fp32, MFMA-bound)
+// / ~0.6 (bf16) of a 128-wide one); CADRE_RING_NTILE forces one for A/B runs.
+static int ring_plan(long long M, int N, int bf16, int* ntile_out, double* eff_out) {
+  static const int force_nt = [] { const char* e = getenv("CADRE_RING_NTILE"); return e ? atoi(e) : 0; }();
+  const long long mtiles = (M + RG_BM - 1) / RG_BM;
+  int ntile = 64;
+  if (N >= 128) {
+    const long long i128 = mtiles * ((N + 127) / 128), i64 = mtiles * ((N + 63) / 64);
+    const double t128 = (double)((i128 + 255) / 256) * 1.0, t64 = (double)((i64 + 255) / 256) * (bf16 ? 0.6 : 0.52);
+    ntile = t128 <= t64 ? 128 : 64;
+  }
+  if (force_nt == 64 || (force_nt == 128 && N >= 128)) ntile = force_nt;
+  const long long items = mtiles * ((N + ntile - 1) / ntile);
+  const long long rounds = (items + 255) / 256;
+  *ntile_out = ntile;
+  *eff_out = items >= 256 ? (double)items / (double)(rounds * 256) : 1.0;      // small launches: latency, not balance
+  return (int)items;
+}
+
+static int g_ring_mode = [] { const char* e = getenv("CADRE_RING_CONV"); return e ? atoi(e) : 1; }();   // 0 off, 1 auto, 2 wherever supported
+
+// host logic: does cadre_conv3x3_ring take this layer?  (bf16 != 0: bf16 operands).  Auto mode follows the per-layer
+// measurements at 1024 frames x 288x288 (profiles/r02_enc_layers_*.log, TFLOP/s ring vs implicit-GEMM tiles):
+//   fp32  N = 64 (layer1) 126-132 vs 116-118 | N = 128 133-138 vs 136-140 | N = 256 128-132 vs 134-137 | N = 512 ~120 vs 137
+//   bf16  N = 128 (layer2, head) 806-929 vs 703-748, 865 vs 735 | N = 256 866-967 vs 863-938 | N = 512 933-966 vs 979-1033
+// i.e. the window kernel wins where operand staging (not the MFMA pipe) binds: narrow N.  (One workgroup per CU in
+// lockstep exposes its per-k-tile turnover; the tile-per-workgroup kernels hide theirs behind 2-4 co-resident
+// workgroups, which is what wins once N >= 256 gives them enough reuse.)  CADRE_RING_CONV=2 uses it wherever supported.
 extern "C" int cadre_conv3x3_ring_supported(int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t bf16) {
-  if (g_ring_off) return 0;
+  if (g_ring_mode == 0) return 0;
   const int eb = bf16 ? 2 : 4;
   if (F < 1 || H < 1 || W < 2 || W > 95) return 0;
   if ((Cin * eb) % 128 != 0 || N % 32 != 0) return 0;
   const long long M = (long long)F * H * W;
   if (M * Cin * eb >= (1ll << 31) || M * N * 4 >= (1ll << 31) || (long long)N * Cin * 9 * eb >= (1ll << 31)) return 0;
+  if (g_ring_mode == 1 && N > (bf16 ? 128 : 64)) return 0;
   return 1;
 }
 
@@ -359,17 +387,10 @@ extern "C" int cadre_conv3x3_ring(const void* x, const void* w, const float* sca
   a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.resid = resid; a.out = out;
   a.M = F * H * W; a.H = H; a.W = W; a.Cin = Cin; a.N = N; a.NC = Cin * (bf16 ? 2 : 4) / 128;
   a.act = act; a.out_bf16 = out_bf16; a.resid_bf16 = resid_bf16;
-  // channel tile: 128 where it divides the work over 256 persistent workgroups as evenly as 64 does (a step of the
-  // 64-wide tile costs ~0.55 of a 128-wide one); CADRE_RING_NTILE forces one for A/B runs
-  static const int force_nt = [] { const char* e = getenv("CADRE_RING_NTILE"); return e ? atoi(e) : 0; }();
   a.mtiles = (a.M + RG_BM - 1) / RG_BM;
-  int ntile = 64;
-  if (N >= 128) {
-    const long long i128 = (long long)a.mtiles * ((N + 127) / 128), i64 = (long long)a.mtiles * ((N + 63) / 64);
-    const double t128 = (double)((i128 + 255) / 256) * 1.0, t64 = (double)((i64 + 255) / 256) * 0.55;
-    ntile = t128 <= t64 ? 128 : 64;
-  }
-  if (force_nt == 64 || (force_nt == 128 && N >= 128)) ntile = force_nt;
+  int ntile;
+  double eff;
+  ring_plan(a.M, N, bf16, &ntile, &eff);
   a.ntiles = (N + ntile - 1) / ntile;
   a.items = a.mtiles * a.ntiles;
   int wgs = 256;
