@@ -217,23 +217,28 @@ TPL_BF16 = {1: (2, 2, 2, 2, 2), 2: (2, 1, 2, 2, 2), 3: (1, 1, 2, 2, 2), 4: (4, 2
             10: (1, 1, 2, 2, 4), 11: (2, 1, 2, 2, 4)}
 TILE = {1: "128x128", 2: "128x64", 3: "64x64", 4: "256x128", 5: "128x256", 6: "256x64", 7: "256x256 (8 waves)",
         8: "128x128 (8 waves)", 9: "32x128", 10: "128x64 (8 waves)", 11: "256x64 (8 waves)",
-        12: "64x64, 8 M-tiles per workgroup", 64: "32x64 per autonomous wave, weights resident in LDS"}
+        12: "64x64, 8 M-tiles per workgroup", 64: "128 positions x 64, weights resident in LDS, pixel ring",
+        65: "256 positions x 64/128, pixel window resident in LDS"}
 AM = {0: "dense A[M][K]", 1: "dense A[K][M]", 2: "NHWC implicit-GEMM conv", 3: "Cin=4 stem conv",
       4: "Cin=4 stem conv on the zero-padded image"}
 
 
 def kname(k):
     """Exact kernel symbol as rocprofv3 prints it, from a hip.PROFILE key."""
+    if k[0] == "ring":
+        return "conv3x3_ring_kernel<%s, %d, %d, %s>" % ("true" if k[1] else "false", k[2], k[3], "true" if k[4] else "false")
     if k[0] == "bf16":
         _, tile, am = k
         if tile == 12:
             return "conv_stream_bf16_kernel<%d>" % am
         if tile == 64:
-            return "conv3x3_c64_bf16_kernel"
+            return "conv3x3_c64_bf16_v2_kernel"
+
         wm_, wn_, wvn_, ns_, wvm_ = TPL_BF16[tile]
         return "gemm_bf16_kernel<%d, %d, %d, %d, %d, %d>" % (wm_, wn_, am, wvn_, ns_, wvm_)
     if k[0] == 12:
         return "conv_stream_f32_kernel<%d>" % k[1]
+
     wm_, wn_, wvn_, wvm_ = TPL_F32[k[0]]
     return "gemm_f32_kernel<%d, %d, %d, %d, %d, 2, %d>" % (wm_, wn_, k[1], k[2], wvn_, wvm_)
 
@@ -250,10 +255,10 @@ def roofline_of(prof, steps):
         return None, {}
     dom = max(by, key=lambda k: by[k][1])
     fl, t, n, nb = by[dom]
-    bf16 = dom[0] == "bf16"
+    bf16 = dom[0] == "bf16" or (dom[0] == "ring" and dom[1])
     peak_tf = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
     t_mfma, t_hbm = fl / (peak_tf * 1e12), nb / (PEAK_HBM_GBPS * 1e9)
-    tile, am = (dom[1], dom[2]) if bf16 else (dom[0], dom[1])
+    tile, am = (65, 2) if dom[0] == "ring" else ((dom[1], dom[2]) if bf16 else (dom[0], dom[1]))
     r = {"kernel": kname(dom), "kernel_desc": "%s tile, %s%s" % (TILE.get(tile, tile), AM.get(am, am), ", bf16" if bf16 else ""),
          "flops_per_launch": round(fl / n, 1), "bytes_per_launch": round(nb / n, 1), "launches": n,
          "avg_launch_us": round(t / n * 1e6, 2),

@@ -365,15 +365,26 @@ static int g_ring_mode = [] { const char* e = getenv("CADRE_RING_CONV"); return 
 // i.e. the window kernel wins where operand staging (not the MFMA pipe) binds: narrow N.  (One workgroup per CU in
 // lockstep exposes its per-k-tile turnover; the tile-per-workgroup kernels hide theirs behind 2-4 co-resident
 // workgroups, which is what wins once N >= 256 gives them enough reuse.)  CADRE_RING_CONV=2 uses it wherever supported.
-extern "C" int cadre_conv3x3_ring_supported(int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t bf16) {
-  if (g_ring_mode == 0) return 0;
+static int ring_capable(int F, int H, int W, int Cin, int N, int bf16) {      // geometry the kernel can run at all
   const int eb = bf16 ? 2 : 4;
   if (F < 1 || H < 1 || W < 2 || W > 95) return 0;
   if ((Cin * eb) % 128 != 0 || N % 32 != 0) return 0;
   const long long M = (long long)F * H * W;
   if (M * Cin * eb >= (1ll << 31) || M * N * 4 >= (1ll << 31) || (long long)N * Cin * 9 * eb >= (1ll << 31)) return 0;
+  return 1;
+}
+extern "C" int cadre_conv3x3_ring_supported(int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t bf16) {
+  if (g_ring_mode == 0 || !ring_capable(F, H, W, Cin, N, bf16)) return 0;
   if (g_ring_mode == 1 && N > (bf16 ? 128 : 64)) return 0;
   return 1;
+}
+
+// channel tile (64 / 128) cadre_conv3x3_ring would use (host logic; names the kernel instantiation for profiles)
+extern "C" int cadre_conv3x3_ring_ntile(int32_t F, int32_t H, int32_t W, int32_t N, int32_t bf16) {
+  int ntile;
+  double eff;
+  ring_plan((long long)F * H * W, N, bf16, &ntile, &eff);
+  return ntile;
 }
 
 extern "C" int cadre_conv3x3_ring(const void* x, const void* w, const float* scale, const float* shift, const void* resid,
@@ -381,7 +392,7 @@ extern "C" int cadre_conv3x3_ring(const void* x, const void* w, const float* sca
                                   int32_t flags, void* stream) {
   const int bf16 = flags & 1, out_bf16 = (flags >> 1) & 1, resid_bf16 = (flags >> 2) & 1;
   if (!x || !w || !out) return cadre_fail("cadre_conv3x3_ring: null operand");
-  if (!cadre_conv3x3_ring_supported(F, H, W, Cin, N, bf16)) return cadre_fail("cadre_conv3x3_ring: unsupported geometry (see cadre_conv3x3_ring_supported)");
+  if (!ring_capable(F, H, W, Cin, N, bf16)) return cadre_fail("cadre_conv3x3_ring: unsupported geometry (W in 2..95, Cin a multiple of 128 bytes, N % 32 == 0, tensors < 2 GiB)");
   if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)out | (uintptr_t)resid) & 15) return cadre_fail("cadre_conv3x3_ring: operands must be 16-byte aligned");
   ring_args a;
   a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.resid = resid; a.out = out;

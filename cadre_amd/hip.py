@@ -41,6 +41,7 @@ SYMBOLS = {
     "cadre_conv3x3_c64_bf16": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "cadre_conv3x3_ring": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "cadre_conv3x3_ring_supported": [i32, i32, i32, i32, i32, i32],
+    "cadre_conv3x3_ring_ntile": [i32, i32, i32, i32, i32],
     "cadre_maxpool3x3s2_bf16": [vp, vp, i32, i32, i32, i32, vp],
     "cadre_pam_bf16out": [vp, vp, f32, vp, i32, i32, vp],
     "cadre_cam_bf16out": [vp, f32, vp, i32, i32, vp],
@@ -184,7 +185,7 @@ def conv3x3_c64_bf16(x, w, scale, shift, resid, out, F, H, W, relu):
 
 def conv3x3_ring(x, w_ring, scale, shift, resid, out, F, H, W, Cin, N, act):
     """cadre_conv3x3_ring (3x3 / s1 / p1, each pixel through LDS once per channel chunk); profiling key
-    ("bf16", 65, 2) / (65, 2, 0) — tile id 65 = the ring kernel."""
+    ("ring", bf16, ntile, res, out_bf16) = the template arguments of conv3x3_ring_kernel."""
     bf = x.dtype == torch.bfloat16
     flags = (1 if bf else 0) | (2 if out.dtype == torch.bfloat16 else 0) | (4 if (resid is not None and resid.dtype == torch.bfloat16) else 0)
     fn = lib().cadre_conv3x3_ring
@@ -198,5 +199,7 @@ def conv3x3_ring(x, w_ring, scale, shift, resid, out, F, H, W, Cin, N, act):
     e1.record()
     M, esz = F * H * W, (2 if bf else 4)
     nbytes = M * Cin * esz + N * 9 * Cin * esz + M * N * out.element_size() + (M * N * resid.element_size() if resid is not None else 0)
-    key = ("bf16", 65, 2) if bf else (65, 2, 0)
+    ntile = lib().cadre_conv3x3_ring_ntile(F, H, W, N, 1 if bf else 0)
+    res = 0 if resid is None else (2 if resid.dtype == torch.bfloat16 else 1)
+    key = ("ring", bf, ntile, res, out.dtype == torch.bfloat16)
     PROFILE.append((key, 2.0 * M * N * 9 * Cin, e0, e1, (M, N, 9 * Cin, 1, 1, 0), nbytes))

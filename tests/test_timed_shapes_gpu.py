@@ -56,8 +56,8 @@ def test_c2_encoder_goldens_inside_1024_frame_chunk(golden):
         torch.cuda.synchronize()
     finally:
         hip.PROFILE = None
-    tiles = {k[0] for k, *_ in prof}
-    launched = {(k[0], shape[0], shape[1]) for k, _f, _a, _b, shape, _nb in prof}
+    tiles = {(65 if k[0] == "ring" else k[0]) for k, *_ in prof}
+    launched = {((65 if k[0] == "ring" else k[0]), shape[0], shape[1]) for k, _f, _a, _b, shape, _nb in prof}
     # the timed run's kernels: fused front (stem_pool.hip, no GEMM launch for the stem), the stage-1 convs on the full
     # 1024-frame M (64x64 tile 3, or the ring kernel 65 where it is enabled), 8-wave 128x128 tile (8) for layer2.0
     assert enc.fused_stem and 8 in tiles, sorted(tiles)
