@@ -244,15 +244,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_kernel(ring_args a) {
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const f32x4 bv = *reinterpret_cast<const f32x4*>(bs + boff[cb][s]);
+            if constexpr (BF16) {
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
-              if constexpr (BF16) {
+              for (int rb = 0; rb < 2; ++rb)
                 acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[rb][s]), __builtin_bit_cast(bf16x8, bv),
                                                                       acc[rb][cb], 0, 0, 0);
-              } else {
+            } else {                                       // alternate the two accumulators: consecutive MFMAs independent
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[rb][s][e], bv[e], acc[rb][cb], 0, 0, 0);
-              }
+              for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[rb][s][e], bv[e], acc[rb][cb], 0, 0, 0);
             }
           }
         }
