@@ -161,11 +161,14 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(stem_args a) {
   __syncthreads();
 
   const float sc = a.scale[32 * hN + l31], sh = a.shift[32 * hN + l31];
-  float prevH[NT][8];
+  // previous stem row's horizontal maxima.  bf16 build: kept as packed bf16 pairs (half the registers) — rounding is
+  // monotonic, so max(bf16(a), b, c) rounded to bf16 is the same value as bf16(max(a, b, c)).
+  constexpr int PHN = BF16 ? 4 : 8;
+  float prevH[NT][PHN];
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) prevH[t][k] = 0.f;                 // post-ReLU values are >= 0: 0 is the pool's -inf
+    for (int k = 0; k < PHN; ++k) prevH[t][k] = 0.f;               // post-ReLU values are >= 0: 0 is the pool's -inf
 
   const int dy = (l31 >> 2) & 1, dx = (l31 & 3) + 4 * (l31 >> 3);
   char* outp = reinterpret_cast<char*>(a.out);
@@ -282,8 +285,24 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(stem_args a) {
 #pragma unroll
           for (int k = 0; k < 8; ++k) {
             const float lo = lo_to_hi(h[k]);                               // stem row 2p (held by lane half 0)
-            const float o = fmaxf(fmaxf(prevH[T][k], lo), h[k]);           // rows 2p-1, 2p, 2p+1 (lane half 1)
-            prevH[T][k] = h[k];
+            float pv;
+            if constexpr (BF16) {
+              const unsigned w = __builtin_bit_cast(unsigned, prevH[T][k >> 1]);
+              pv = __builtin_bit_cast(float, (k & 1) ? (w & 0xffff0000u) : (w << 16));
+            } else {
+              pv = prevH[T][k];
+            }
+            const float o = fmaxf(fmaxf(pv, lo), h[k]);                    // rows 2p-1, 2p, 2p+1 (lane half 1)
+            if constexpr (BF16) {
+              if (k & 1) {
+                typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+                bf16x2 pk;
+                pk[0] = (__bf16)h[k - 1]; pk[1] = (__bf16)h[k];
+                prevH[T][k >> 1] = __builtin_bit_cast(float, pk);
+              }
+            } else {
+              prevH[T][k] = h[k];
+            }
             const int c = 8 * T + k;
             if (emit && lh == 1 && (!RAGGED || c < a.Wp)) {
               const long long e = a.out_off + (long long)f * a.out_frame + (long long)p * a.out_row + (long long)c * a.out_px + 32 * hN + l31;
