@@ -109,7 +109,7 @@ def encode_worker(agent, wk, cfg, chunk_windows):
     for t0 in range(0, T if not cfg.get("dedup") else 0, chunk_windows):
         t1 = min(T, t0 + chunk_windows)
         ids = wk.win[t0 * SEQ:t1 * SEQ]
-        x = enc.preprocess(wk.rgb.index_select(0, ids), wk.route.index_select(0, ids))
+        x = enc.preprocess(wk.rgb, wk.route, frame_idx=ids)      # window gather rides on the packing pass
         rows = obs_rows[t0 * SEQ:t1 * SEQ]
         enc.forward_nhwc(x, rows)
         hip.check(L.cadre_append_measurements(hip.ptr(wk.meas[t0 * SEQ:t1 * SEQ]), hip.ptr(rows), rows.stride(0),

@@ -40,9 +40,9 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
 // ============================================================================ pre_process
-__global__ void route_max_kernel(const uint8_t* route, uint32_t* frame_max, int per_frame) {
+__global__ void route_max_kernel(const uint8_t* route, uint32_t* frame_max, int per_frame, const int64_t* frame_idx = nullptr) {
   const int f = blockIdx.y;
-  const uint8_t* r = route + (int64_t)f * per_frame;
+  const uint8_t* r = route + (frame_idx ? frame_idx[f] : (int64_t)f) * per_frame;
   uint32_t m = 0;
   const int stride = gridDim.x * blockDim.x, t0 = blockIdx.x * blockDim.x + threadIdx.x;
   if ((((uintptr_t)r) & 15) == 0) {                       // 16 bytes per lane
@@ -166,11 +166,13 @@ extern "C" int cadre_preprocess_bf16pad(const uint8_t* rgb, const uint8_t* route
 // normalised route {0,1} stored as byte 0 / 255, so that EVERY byte goes through the same /255 LUT
 // (LUT[255] = float32(255/255.) = 1.0 exactly).  4x less HBM than the f32 NHWC4 image.
 __global__ __launch_bounds__(256) void pack_obs_kernel(const uint8_t* rgb, const uint8_t* route, const uint32_t* frame_max,
-                                                       uint32_t* out, uint8_t* route_norm, int F, int H, int W) {
+                                                       uint32_t* out, uint8_t* route_norm, int F, int H, int W,
+                                                       const int64_t* frame_idx) {
   __shared__ uint8_t s_r[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int f = blockIdx.z, h0 = blockIdx.y * 32, w0 = blockIdx.x * 32;
-  const uint32_t mx = frame_max[f];
+  const int fo = blockIdx.z, h0 = blockIdx.y * 32, w0 = blockIdx.x * 32;
+  const int64_t f = frame_idx ? frame_idx[fo] : fo;       // source frame (sliding windows repeat frames)
+  const uint32_t mx = frame_max[fo];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int wl = ty + 8 * j, w = w0 + wl, h = h0 + tx;
@@ -188,22 +190,21 @@ __global__ __launch_bounds__(256) void pack_obs_kernel(const uint8_t* rgb, const
   for (int j = 0; j < 4; ++j) {
     const int hl = ty + 8 * j, h = h0 + hl, w = w0 + tx;
     if (h < H && w < W) {
-      const int64_t i = ((int64_t)f * H + h) * W + w;
-      const uint8_t* px = rgb + i * 3;
-      out[i] = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16) | (s_r[tx][hl] ? 0xff000000u : 0u);
+      const uint8_t* px = rgb + (((int64_t)f * H + h) * W + w) * 3;
+      out[((int64_t)fo * H + h) * W + w] = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16) | (s_r[tx][hl] ? 0xff000000u : 0u);
     }
   }
 }
 extern "C" int cadre_pack_obs(const uint8_t* rgb, const uint8_t* route, uint32_t* out, uint8_t* route_norm,
-                              uint32_t* frame_max, int32_t F, int32_t H, int32_t W, void* stream) {
+                              uint32_t* frame_max, int32_t F, int32_t H, int32_t W, const int64_t* frame_idx, void* stream) {
   FAIL_IF(!rgb || !route || !out || !frame_max || F < 1 || H < 1 || W < 1, "cadre_pack_obs: bad argument");
   hipError_t e = hipMemsetAsync(frame_max, 0, sizeof(uint32_t) * F, ST(stream));
   if (e != hipSuccess) return (int)e;
   const int per = H * W;
   dim3 g1(min(64, (per + 255) / 256), F);
-  hipLaunchKernelGGL(route_max_kernel, g1, dim3(256), 0, ST(stream), route, frame_max, per);
+  hipLaunchKernelGGL(route_max_kernel, g1, dim3(256), 0, ST(stream), route, frame_max, per, frame_idx);
   hipLaunchKernelGGL(pack_obs_kernel, dim3((W + 31) / 32, (H + 31) / 32, F), dim3(256), 0, ST(stream), rgb, route,
-                     frame_max, out, route_norm, F, H, W);
+                     frame_max, out, route_norm, F, H, W, frame_idx);
   return (int)hipGetLastError();
 }
 
@@ -721,7 +722,7 @@ extern "C" int cadre_lstm_pointwise_bwd(const float* gates, float* dgates, int64
 
 // ============================================================================ column sums / relu backward
 __global__ void colsum_kernel(const float* X, int64_t ldx, int64_t x_str, float* out, int64_t o_str, int M, int N,
-                              int accumulate) {
+                              int accumulate, float* out2) {
   // 256 threads = 64 columns x 4 row-slices; slices combined through LDS in fixed order
   __shared__ float part[4][64];
   const int z = blockIdx.z;
@@ -746,14 +747,48 @@ __global__ void colsum_kernel(const float* X, int64_t ldx, int64_t x_str, float*
   if (sl == 0 && col < N) {
     const float t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
     float* o = out + z * o_str + col;
-    *o = accumulate ? *o + t : t;
+    const float v = accumulate ? *o + t : t;
+    *o = v;
+    if (out2) out2[z * o_str + col] = v;              // b_ih and b_hh enter the gates as a sum: identical gradients
   }
 }
 extern "C" int cadre_colsum(const float* X, int64_t ldx, int64_t x_str, float* out, int64_t o_str, int32_t M,
                             int32_t N, int32_t batch, int32_t accumulate, void* stream) {
   FAIL_IF(!X || !out || M < 1 || N < 1 || batch < 1, "cadre_colsum: bad argument");
   hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, 1, batch), dim3(256), 0, ST(stream), X, ldx, x_str, out,
-                     o_str, M, N, accumulate);
+                     o_str, M, N, accumulate, (float*)nullptr);
+  return (int)hipGetLastError();
+}
+extern "C" int cadre_colsum2(const float* X, int64_t ldx, int64_t x_str, float* out, float* out2, int64_t o_str, int32_t M,
+                             int32_t N, int32_t batch, void* stream) {
+  FAIL_IF(!X || !out || !out2 || M < 1 || N < 1 || batch < 1, "cadre_colsum2: bad argument");
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, 1, batch), dim3(256), 0, ST(stream), X, ldx, x_str, out,
+                     o_str, M, N, 0, out2);
+  return (int)hipGetLastError();
+}
+
+// LSTM state slots: Hs[z][0] <- h0[z / x_div], Cs[z][0] <- c0[z / x_div] for z < Z (rows of ld floats, n_per = B*ld
+// floats per net and slot), and dC (Z * n_per floats, may be null) <- 0: the initial hidden state of agent.py:166-175
+// for every command net of a head and the zero dL/dc_T of the backward pass, in one launch.
+__global__ void lstm_init_kernel(const float* h0, const float* c0, float* Hs, float* Cs, float* dC, int64_t n_per,
+                                 int64_t z_str, int x_div, int Z) {
+  const int z = blockIdx.y;
+  const float4* h4 = reinterpret_cast<const float4*>(h0 + (int64_t)(z / x_div) * n_per);
+  const float4* c4 = reinterpret_cast<const float4*>(c0 + (int64_t)(z / x_div) * n_per);
+  float4* H4 = reinterpret_cast<float4*>(Hs + (int64_t)z * z_str);
+  float4* C4 = reinterpret_cast<float4*>(Cs + (int64_t)z * z_str);
+  float4* D4 = dC ? reinterpret_cast<float4*>(dC + (int64_t)z * n_per) : nullptr;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n_per >> 2); i += (int64_t)gridDim.x * blockDim.x) {
+    H4[i] = h4[i];
+    C4[i] = c4[i];
+    if (D4) D4[i] = float4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+extern "C" int cadre_lstm_init(const float* h0, const float* c0, float* Hs, float* Cs, float* dC, int64_t n_per,
+                               int64_t z_str, int32_t x_div, int32_t Z, void* stream) {
+  FAIL_IF(!h0 || !c0 || !Hs || !Cs || n_per < 4 || (n_per & 3) || (z_str & 3) || x_div < 1 || Z < 1, "cadre_lstm_init: bad argument");
+  const int bx = (int)std::min<int64_t>(((n_per >> 2) + 255) / 256, 64);
+  hipLaunchKernelGGL(lstm_init_kernel, dim3(bx, Z), dim3(256), 0, ST(stream), h0, c0, Hs, Cs, dC, n_per, z_str, x_div, Z);
   return (int)hipGetLastError();
 }
 

@@ -233,15 +233,18 @@ class DANetEncoderHIP:
                      conv=(H, W, c.cin, Ho, Wo, c.k, c.k, c.stride, c.pad), bf16=wbf, flags=flags)
         return out, Ho, Wo
 
-    def preprocess(self, rgb_d, route_d, route_norm_d=None):
-        """agent.py:43-75 on device: u8 [F,H,W,3] + u8 [F,W,H] -> f32 NHWC [F,H,W,4]."""
-        F = rgb_d.shape[0]
+    def preprocess(self, rgb_d, route_d, route_norm_d=None, frame_idx=None):
+        """agent.py:43-75 on device: u8 [F,H,W,3] + u8 [F,W,H] -> f32 NHWC [F,H,W,4] (or the packed u8 image of the
+        fused front).  frame_idx (i64 device tensor): output frame f is source frame frame_idx[f] (sliding windows)."""
+        if frame_idx is not None and not self.fused_stem:
+            rgb_d, route_d, frame_idx = rgb_d.index_select(0, frame_idx), route_d.index_select(0, frame_idx), None
+        F = rgb_d.shape[0] if frame_idx is None else frame_idx.numel()
         fmax = self._buf("fmax", (F,), torch.int32)
         L = hip.lib()
         if self.fused_stem:  # packed u8 pixels (one dword each): the LUT conversion happens inside the stem kernel
             x = self._buf("packed", (F, self.H, self.W), torch.int32)
             hip.check(L.cadre_pack_obs(hip.ptr(rgb_d), hip.ptr(route_d), hip.ptr(x), hip.ptr(route_norm_d), hip.ptr(fmax),
-                                       F, self.H, self.W, hip.stream()), "cadre_pack_obs")
+                                       F, self.H, self.W, hip.ptr(frame_idx), hip.stream()), "cadre_pack_obs")
             return x
         if self.bf16:       # zero-bordered bf16 image for the bf16 stem; the border is written never
             x = self._buf("pre_pad", (F, self.Hp, self.Wp, 4), torch.bfloat16, zero=True)

@@ -49,7 +49,7 @@ SYMBOLS = {
     "cadre_preprocess": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "cadre_preprocess_bf16pad": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "cadre_maxpool3x3s2": [vp, vp, i32, i32, i32, i32, vp],
-    "cadre_pack_obs": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "cadre_pack_obs": [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp],
     "cadre_stem_pool": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, i64, vp],
     "cadre_div255_selfcheck": [vp, vp, vp],
     "cadre_stem_pool_supported": [i32, i32],
@@ -65,6 +65,8 @@ SYMBOLS = {
     "cadre_lstm_pointwise_bwd": [vp, vp, i64, i64, vp, vp, i64, vp, vp, i64, i32, i64, i64, i32, i32, i32, vp, i32, vp],
     "cadre_colsum": [vp, i64, i64, vp, i64, i32, i32, i32, i32, vp],
     "cadre_relu_bwd": [vp, vp, i64, vp, i32, i32, i32, vp],
+    "cadre_colsum2": [vp, i64, i64, vp, vp, i64, i32, i32, i32, vp],
+    "cadre_lstm_init": [vp, vp, vp, vp, vp, i64, i64, i32, i32, vp],
     "cadre_sort_rows_by_command": [vp, i32, i32, vp, vp, vp],
     "cadre_permute_minibatch": [vp, i32, i32, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "cadre_ppo_loss": [vp, i64, i64, vp, i64, i64, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, f32, vp, vp, vp, vp],

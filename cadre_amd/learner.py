@@ -80,9 +80,9 @@ class PPOLearnerHIP:
         pL = P[g0 * a.size_L:]
         sL = gs * a.size_L
         X, G, Hs, Cs, TC = w["X"], w["G"], w["Hs"], w["Cs"], w["TC"]
-        # h_{-1}, c_{-1} (hidden_state_batch, agent.py:166-175) into slot 0 of every net
-        Hs.view(-1, x_div, S + 1, B, DP)[:, :, 0].copy_(w["h0"][:Z // x_div].unsqueeze(1))
-        Cs.view(-1, x_div, S + 1, B, DP)[:, :, 0].copy_(w["c0"][:Z // x_div].unsqueeze(1))
+        # h_{-1}, c_{-1} (hidden_state_batch, agent.py:166-175) into slot 0 of every net; dC <- 0 for the backward
+        hip.check(L.cadre_lstm_init(hip.ptr(w["h0"]), hip.ptr(w["c0"]), hip.ptr(Hs), hip.ptr(Cs), hip.ptr(w["dC"]),
+                                    B * DP, (S + 1) * B * DP, x_div, Z, st), "cadre_lstm_init")
         # all input projections x_t W_ih^T + b_ih: one GEMM [S*B, DP] x [DP, H4] per net
         sg1 = None if seg is None else (1, seg, B, 1)
         hip.gemm(X, pL[a.o_wih:], G, S * B, H4, DP, DP, DP, H4, shift=pL[a.o_bih:], batch=Z,
@@ -211,7 +211,6 @@ class PPOLearnerHIP:
                      a_z=(1, 0, 2 * B * hid), b_z=(1, 0, a.size_P), c_z=(1, 0, B * DP),
                      resid=dH if tower else None, ldr=DP, r_z=(1, 0, B * DP), seg=sgM1)
         # ---------------- backward through time (autograd of models.py:148-151)
-        dC.zero_()
         G, dG, Cs, TC, X = w["G"], w["dG"], w["Cs"], w["TC"], w["X"]
         pL, gL, sL = a.params, Gr, a.size_L
         for t in range(S - 1, -1, -1):
@@ -229,10 +228,9 @@ class PPOLearnerHIP:
                  a_z=(1, 0, S * B * H4), b_z=(1, 0, (S + 1) * B * DP), c_z=(1, 0, sL), seg=sgK1)
         hip.gemm(dG, X, gL[a.o_wih:], H4, DP, S * B, H4, DP, DP, a_mode=1, b_mode=1, batch=Z,
                  a_z=(1, 0, S * B * H4), b_z=(C, 0, S * B * DP), c_z=(1, 0, sL), seg=sgK1)
-        hip.check(L.cadre_colsum(hip.ptr(dG), H4, S * B * H4, hip.ptr(gL[a.o_bih:]), sL, S * B, H4, Z, 0, st),
-                  "cadre_colsum")
-        # b_ih and b_hh enter the gates as a sum: identical gradients (strided arena views, one copy)
-        Gr.as_strided((Z, H4), (sL, 1), a.o_bhh).copy_(Gr.as_strided((Z, H4), (sL, 1), a.o_bih))
+        # b_ih and b_hh enter the gates as a sum: identical gradients, written by one pass
+        hip.check(L.cadre_colsum2(hip.ptr(dG), H4, S * B * H4, hip.ptr(gL[a.o_bih:]), hip.ptr(gL[a.o_bhh:]), sL, S * B, H4, Z, st),
+                  "cadre_colsum2")
         return w["losses"]
 
     # ------------------------------------------------------------------ optimiser (chief.py:13-21)

@@ -124,9 +124,11 @@ int cadre_preprocess_bf16pad(const uint8_t* rgb, const uint8_t* route, const flo
                              int32_t Hp, int32_t Wp, int32_t pad_t, int32_t pad_l, void* stream);
 /* The same pre_process as ONE packed dword per pixel for the fused front (cadre_stem_pool):
  * out u32 [F][H][W] = R | G<<8 | B<<16 | route<<24, the normalised route {0,1} stored as byte 0 / 255 so
- * that every byte takes the same /255 LUT (LUT[255] == 1.0f exactly).  route_norm / frame_max as above. */
+ * that every byte takes the same /255 conversion (255/255 == 1.0f exactly).  route_norm / frame_max as above.
+ * frame_idx (i64 [F], may be NULL): output frame f is source frame frame_idx[f] — the sliding 8-frame windows of
+ * train.py:50-75 repeat each camera frame 8 times, the gather rides on the packing pass. */
 int cadre_pack_obs(const uint8_t* rgb, const uint8_t* route, uint32_t* out, uint8_t* route_norm,
-                   uint32_t* frame_max, int32_t F, int32_t H, int32_t W, void* stream);
+                   uint32_t* frame_max, int32_t F, int32_t H, int32_t W, const int64_t* frame_idx, void* stream);
 /* Fused encoder front: packed observation -> /255 -> conv1 7x7/s2/p3 (4 -> 64) + folded BN + ReLU ->
  * MaxPool2d(3,2,1)  (agent.py:46, resnet.py:111-115,168-172) in one kernel; the stem map never reaches HBM.
  * wt: tap-major weights [64][taps][4] (tap = ky*7 + kx; fp32: 50 taps, bf16: 52 taps, zero padded).
@@ -261,6 +263,14 @@ int cadre_categorical_eval(const float* logits, int64_t ldl, const int64_t* acti
  * per-row argmax of probs (first maximum, `mode`).  Any of the three outputs may be NULL. */
 int cadre_categorical_dist(const float* raw, int64_t ldl, int32_t R, int32_t n_out, float* logits_out,
                            float* probs_out, int64_t* mode_out, void* stream);
+
+/* db_ih = db_hh = colsum(dG) in one pass (both biases enter the LSTM gates as a sum): out and out2 [batch][o_str] */
+int cadre_colsum2(const float* X, int64_t ldx, int64_t x_str, float* out, float* out2, int64_t o_str, int32_t M,
+                  int32_t N, int32_t batch, void* stream);
+/* Initial LSTM state of every net z < Z: Hs[z*z_str ..] <- h0[(z / x_div)*n_per ..], same for Cs <- c0 (n_per floats
+ * each, agent.py:166-175 hidden_state_batch shared by a head's command nets) and dC (Z*n_per floats, may be NULL) <- 0 */
+int cadre_lstm_init(const float* h0, const float* c0, float* Hs, float* Cs, float* dC, int64_t n_per,
+                    int64_t z_str, int32_t x_div, int32_t Z, void* stream);
 
 /* ---------------------------------------------------------------- optimiser
  * chief.py:13-21 + main.py:55: per-model clip_grad_norm_(max_norm) then Adam (torch defaults)
