@@ -218,7 +218,7 @@ TPL_BF16 = {1: (2, 2, 2, 2, 2), 2: (2, 1, 2, 2, 2), 3: (1, 1, 2, 2, 2), 4: (4, 2
 TILE = {1: "128x128", 2: "128x64", 3: "64x64", 4: "256x128", 5: "128x256", 6: "256x64", 7: "256x256 (8 waves)",
         8: "128x128 (8 waves)", 9: "32x128", 10: "128x64 (8 waves)", 11: "256x64 (8 waves)",
         12: "64x64, 8 M-tiles per workgroup", 64: "128 positions x 64, weights resident in LDS, pixel ring",
-        65: "256 positions x 64/128, pixel window resident in LDS"}
+        65: "128/256 positions x 64/128, pixel window resident in LDS"}
 AM = {0: "dense A[M][K]", 1: "dense A[K][M]", 2: "NHWC implicit-GEMM conv", 3: "Cin=4 stem conv",
       4: "Cin=4 stem conv on the zero-padded image"}
 
@@ -226,7 +226,7 @@ AM = {0: "dense A[M][K]", 1: "dense A[K][M]", 2: "NHWC implicit-GEMM conv", 3: "
 def kname(k):
     """Exact kernel symbol as rocprofv3 prints it, from a hip.PROFILE key."""
     if k[0] == "ring":
-        return "conv3x3_ring_kernel<%s, %d, %d, %s>" % ("true" if k[1] else "false", k[2], k[3], "true" if k[4] else "false")
+        return "conv3x3_ring_kernel<%s, %d, %d, %s, %d>" % ("true" if k[1] else "false", k[2], k[3], "true" if k[4] else "false", k[5])
     if k[0] == "bf16":
         _, tile, am = k
         if tile == 12:

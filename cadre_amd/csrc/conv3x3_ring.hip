@@ -33,8 +33,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 int cadre_fail(const char* msg);
 
-#define RG_BM 256                  // output positions per workgroup tile
-#define RG_NSTB 3                  // weight stages
+#define RG_BM_MAX 256               // output positions per workgroup tile: 64 * WVM
 #define RG_SLAB 4608               // epilogue slab per wave: 32 rows x 36 floats
 
 struct ring_args {
@@ -68,11 +67,17 @@ __device__ __forceinline__ void wait_vm_n(int n) {        // wave-uniform n in [
 // NTILE: output channels per workgroup tile (64 or 128); 8 waves as 4 (positions) x 2 (channels): a wave owns
 // 64 positions x NTILE/2 channels = 2 x WN MFMA tiles of 32x32.
 // RES: 0 no residual, 1 fp32 residual, 2 bf16 residual; OUTB: output bf16 (else fp32)
-template <bool BF16, int NTILE, int RES, bool OUTB>
-__global__ __launch_bounds__(512, 2) void conv3x3_ring_kernel(ring_args a) {
+// WVM: waves along the positions (4: 256-position tile, 8 waves, 3 weight stages two k-tiles ahead, ONE workgroup
+// per CU; 2: 128-position tile, 4 waves, 2 weight stages one k-tile ahead, <= 80 KB of LDS so that TWO workgroups share
+// a CU and each one's per-k-tile turnover runs under the other's MFMAs — for the layers with small maps).
+template <bool BF16, int NTILE, int RES, bool OUTB, int WVM>
+__global__ __launch_bounds__(128 * WVM, 2) void conv3x3_ring_kernel(ring_args a) {
   constexpr int WN = NTILE / 64;                           // 32-channel column blocks per wave
   constexpr int EB = BF16 ? 2 : 4;
-  constexpr int NBPW = NTILE / 64;                         // weight pieces (8 rows x 128 B) per wave per stage
+  constexpr int NWAVES = 2 * WVM, NTHR = 64 * NWAVES;
+  constexpr int RG_BM = 64 * WVM;
+  constexpr int RG_NSTB = WVM == 4 ? 3 : 2, LEAD = RG_NSTB - 1;
+  constexpr int NBPW = (NTILE / 8) / NWAVES;               // weight pieces (8 rows x 128 B) per wave per stage
   constexpr unsigned OOB = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_kernel(ring_args a) {
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.N * a.NC * 9 * 128, 0x00020000);
   const int cin_b = a.Cin * EB;
   const int PA = a.WPX >> 3;                               // window pieces
-  for (int i = tid; i < 256; i += 512) reinterpret_cast<unsigned*>(dump)[i] = 0u;      // the dump doubles as the ZERO ROW
+  for (int i = tid; i < 256; i += NTHR) reinterpret_cast<unsigned*>(dump)[i] = 0u;      // the dump doubles as the ZERO ROW
 
   // ---- lane constants of the staging path.  A window piece j (8 pixels): this lane brings pixel 8j + (lane>>3),
   // LDS chunk (lane&7), i.e. source chunk (lane&7) ^ ((idx>>1)&7) with idx = 8j + (lane>>3): (idx>>1)&7 =
@@ -159,9 +164,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_kernel(ring_args a) {
 
   // ---- prologue: window of the first phase (all pieces), weights of steps 0 and 1
   const int total_ph = nitems * a.NC;
-  for (int j = wave; j < PA; j += 8) issue_a(mt, 0, 0, j, true);       // (j parity == wave parity: a_lane holds)
+  for (int j = wave; j < PA; j += NWAVES) issue_a(mt, 0, 0, j, true);  // (j parity == wave parity: a_lane holds)
   issue_b(nt, 0, 0, 0, true);
-  issue_b(nt, 0, 1, 1, true);
+  if constexpr (LEAD == 2) issue_b(nt, 0, 1, 1, true);
   int extra = 0, extra_steps = 0;                          // epilogue stores still behind the pieces a wait must cover (2 steps)
   int stg = 0;                                             // weight stage of the current step
   bool first_step = true;
@@ -212,19 +217,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_kernel(ring_args a) {
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         // ---- everything issued two steps ago (weights of this step, window slices) has landed; publish
+        // (in-order completion: all but the youngest (LEAD-1) steps' pieces — plus, for LEAD steps after an epilogue,
+        //  its stores — must have completed)
         if (first_step) { wait_vm<0>(); first_step = false; }
-        else if (extra_steps > 0) { wait_vm_n(NBPW + 1 + extra); --extra_steps; }
-        else wait_vm<NBPW + 1>();
+        else if (extra_steps > 0) { wait_vm_n((LEAD - 1) * (NBPW + 1) + extra); --extra_steps; }
+        else wait_vm<(LEAD - 1) * (NBPW + 1)>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         // ---- issue: weights two steps ahead, one window slice of the next phase (slices on taps 0..7 only)
         {
-          const int s2 = stg + 2 >= RG_NSTB ? stg + 2 - RG_NSTB : stg + 2;
-          if (tap < 7) issue_b(nt, c, tap + 2, s2, true);
-          else if (!last_c) issue_b(nt, c + 1, tap - 7, s2, true);
-          else issue_b(nt1, 0, tap - 7, s2, more);
-          issue_a(mt_n, c_n, (phg + 1) & 1, tap < 8 ? tap * 8 + wave : PA, has_next);
+          const int s2 = stg + LEAD >= RG_NSTB ? stg + LEAD - RG_NSTB : stg + LEAD;
+          if (tap + LEAD < 9) issue_b(nt, c, tap + LEAD, s2, true);
+          else if (!last_c) issue_b(nt, c + 1, tap + LEAD - 9, s2, true);
+          else issue_b(nt1, 0, tap + LEAD - 9, s2, more);
+          // window slices of the next phase: on the taps whose pieces the next phase's first wait still covers
+          issue_a(mt_n, c_n, (phg + 1) & 1, tap <= 9 - LEAD ? tap * NWAVES + wave : PA, has_next);
         }
         // ---- compute this step
         const char* bs = bst + stg * (NTILE * 128);
@@ -329,7 +337,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_kernel(ring_args a) {
         }
       }
       extra = NBLK * 4;                                    // these stores sit behind the in-flight pieces in the queue:
-      extra_steps = 2;                                     // the next two waits reach back over them
+      extra_steps = LEAD;                                  // the next LEAD waits reach back over them
     }
     if (mt1 != mt) advance_mtile();
     mt = mt1; nt = nt1;
@@ -337,42 +345,47 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_kernel(ring_args a) {
 }
 
 
-// Channel tile and work split over the persistent workgroups (host logic).  The makespan is ceil(items / 256) item
-// times: 128 wide where that divides as evenly as 64 wide (a step of the 64-wide tile costs ~0.52 (fp32, MFMA-bound)
-// / ~0.6 (bf16) of a 128-wide one); CADRE_RING_NTILE forces one for A/B runs.
-static int ring_plan(long long M, int N, int bf16, int* ntile_out, double* eff_out) {
+// Tile configuration (host logic).  Small maps (W <= 29 with 128 channels per tile, W <= 61 with 64): the 128-position
+// tile on 4 waves with 2 weight stages fits 80 KB of LDS, so TWO workgroups share a CU (CADRE_RING_WVM forces 2 / 4).
+// Channel tile 128 unless N < 128 (CADRE_RING_NTILE forces one for A/B runs).
+struct ring_cfg { int wvm, ntile, bm, wpx, wgs; size_t lds; long long items; };
+static void ring_pick(long long M, int W, int N, ring_cfg* c) {
   static const int force_nt = [] { const char* e = getenv("CADRE_RING_NTILE"); return e ? atoi(e) : 0; }();
-  const long long mtiles = (M + RG_BM - 1) / RG_BM;
-  int ntile = 64;
-  if (N >= 128) {
-    const long long i128 = mtiles * ((N + 127) / 128), i64 = mtiles * ((N + 63) / 64);
-    const double t128 = (double)((i128 + 255) / 256) * 1.0, t64 = (double)((i64 + 255) / 256) * (bf16 ? 0.6 : 0.52);
-    ntile = t128 <= t64 ? 128 : 64;
-  }
+  static const int force_wvm = [] { const char* e = getenv("CADRE_RING_WVM"); return e ? atoi(e) : 0; }();
+  int ntile = N >= 128 ? 128 : 64;
   if (force_nt == 64 || (force_nt == 128 && N >= 128)) ntile = force_nt;
-  const long long items = mtiles * ((N + ntile - 1) / ntile);
-  const long long rounds = (items + 255) / 256;
-  *ntile_out = ntile;
-  *eff_out = items >= 256 ? (double)items / (double)(rounds * 256) : 1.0;      // small launches: latency, not balance
-  return (int)items;
+  auto lds_of = [&](int wvm, int nt, int* wpx_out) {
+    const int bm = 64 * wvm;
+    int wpx = (bm + 2 * W + 2 + 7) & ~7;
+    const int min_wpx = (2 * wvm * RG_SLAB + 127) / 128;           // the epilogue slabs live in a window
+    if (wpx < min_wpx) wpx = (min_wpx + 7) & ~7;
+    *wpx_out = wpx;
+    return (size_t)2 * wpx * 128 + (size_t)(wvm == 4 ? 3 : 2) * nt * 128 + 1024;
+  };
+  int wpx2, wpx4;
+  const size_t l2 = lds_of(2, ntile, &wpx2), l4 = lds_of(4, ntile, &wpx4);
+  int wvm = (l2 <= 80 * 1024 && 9 * 4 >= (wpx2 >> 3)) ? 2 : 4;     // (the window's slices must fit the 9 x 4 issue slots)
+  if (force_wvm == 2 && l2 <= 80 * 1024 && 9 * 4 >= (wpx2 >> 3)) wvm = 2;
+  if (force_wvm == 4) wvm = 4;
+  c->wvm = wvm; c->ntile = ntile; c->bm = 64 * wvm;
+  c->wpx = wvm == 2 ? wpx2 : wpx4;
+  c->lds = wvm == 2 ? l2 : l4;
+  c->items = ((M + c->bm - 1) / c->bm) * ((N + ntile - 1) / ntile);
+  const int slots = wvm == 2 ? 512 : 256;                            // persistent workgroups: 2 or 1 per CU
+  c->wgs = (int)(c->items < slots ? c->items : slots);
 }
 
 static int g_ring_mode = [] { const char* e = getenv("CADRE_RING_CONV"); return e ? atoi(e) : 1; }();   // 0 off, 1 auto, 2 wherever supported
 
-// host logic: does cadre_conv3x3_ring take this layer?  (bf16 != 0: bf16 operands).  Auto mode follows the per-layer
-// measurements at 1024 frames x 288x288 (profiles/r02_enc_layers_*.log, TFLOP/s ring vs implicit-GEMM tiles):
-//   fp32  N = 64 (layer1) 126-132 vs 116-118 | N = 128 133-138 vs 136-140 | N = 256 128-132 vs 134-137 | N = 512 ~120 vs 137
-//   bf16  N = 128 (layer2, head) 806-929 vs 703-748, 865 vs 735 | N = 256 866-967 vs 863-938 | N = 512 933-966 vs 979-1033
-// i.e. the window kernel wins where operand staging (not the MFMA pipe) binds: narrow N.  (One workgroup per CU in
-// lockstep exposes its per-k-tile turnover; the tile-per-workgroup kernels hide theirs behind 2-4 co-resident
-// workgroups, which is what wins once N >= 256 gives them enough reuse.)  CADRE_RING_CONV=2 uses it wherever supported.
 static int ring_capable(int F, int H, int W, int Cin, int N, int bf16) {      // geometry the kernel can run at all
   const int eb = bf16 ? 2 : 4;
   if (F < 1 || H < 1 || W < 2 || W > 95) return 0;
   if ((Cin * eb) % 128 != 0 || N % 32 != 0) return 0;
   const long long M = (long long)F * H * W;
   if (M * Cin * eb >= (1ll << 31) || M * N * 4 >= (1ll << 31) || (long long)N * Cin * 9 * eb >= (1ll << 31)) return 0;
-  return 1;
+  ring_cfg c;
+  ring_pick(M, W, N, &c);
+  return c.lds <= 160 * 1024;
 }
 extern "C" int cadre_conv3x3_ring_supported(int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t bf16) {
   if (g_ring_mode == 0 || !ring_capable(F, H, W, Cin, N, bf16)) return 0;
@@ -380,12 +393,13 @@ extern "C" int cadre_conv3x3_ring_supported(int32_t F, int32_t H, int32_t W, int
   return 1;
 }
 
-// channel tile (64 / 128) cadre_conv3x3_ring would use (host logic; names the kernel instantiation for profiles)
+// tile configuration cadre_conv3x3_ring would use, as ntile (64 / 128) + 1000 * WVM (host logic; names the kernel
+// instantiation conv3x3_ring_kernel<bf16, ntile, res, out_bf16, WVM> for profiles)
 extern "C" int cadre_conv3x3_ring_ntile(int32_t F, int32_t H, int32_t W, int32_t N, int32_t bf16) {
-  int ntile;
-  double eff;
-  ring_plan((long long)F * H * W, N, bf16, &ntile, &eff);
-  return ntile;
+  ring_cfg c;
+  ring_pick((long long)F * H * W, W, N, &c);
+  (void)bf16;
+  return c.ntile + 1000 * c.wvm;
 }
 
 extern "C" int cadre_conv3x3_ring(const void* x, const void* w, const float* scale, const float* shift, const void* resid,
@@ -399,29 +413,28 @@ extern "C" int cadre_conv3x3_ring(const void* x, const void* w, const float* sca
   a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.resid = resid; a.out = out;
   a.M = F * H * W; a.H = H; a.W = W; a.Cin = Cin; a.N = N; a.NC = Cin * (bf16 ? 2 : 4) / 128;
   a.act = act; a.out_bf16 = out_bf16; a.resid_bf16 = resid_bf16;
-  a.mtiles = (a.M + RG_BM - 1) / RG_BM;
-  int ntile;
-  double eff;
-  ring_plan(a.M, N, bf16, &ntile, &eff);
+  ring_cfg cfg;
+  ring_pick(a.M, W, N, &cfg);
+  const int ntile = cfg.ntile;
+  a.mtiles = (a.M + cfg.bm - 1) / cfg.bm;
   a.ntiles = (N + ntile - 1) / ntile;
-  a.items = a.mtiles * a.ntiles;
-  int wgs = 256;
-  if (a.items < wgs) wgs = a.items;
-  a.ipw = (a.items + wgs - 1) / wgs;
+  a.items = (int)cfg.items;
+  a.ipw = (a.items + cfg.wgs - 1) / cfg.wgs;
   const int grid = (a.items + a.ipw - 1) / a.ipw;
-  int wpx = RG_BM + 2 * W + 2;
-  wpx = (wpx + 7) & ~7;
-  if (wpx < 288) wpx = 288;                                // the epilogue slabs (8 x 4608 B) live in a window
-  a.WPX = wpx;
-  const size_t lds = (size_t)2 * wpx * 128 + (size_t)RG_NSTB * ntile * 128 + 1024;
+  a.WPX = cfg.wpx;
+  const size_t lds = cfg.lds;
   if (lds > 160 * 1024) return cadre_fail("cadre_conv3x3_ring: window does not fit LDS");
   hipStream_t st = (hipStream_t)stream;
-#define RG_LAUNCH(BF, NT_, RS_, OB_)                                                                             \
+#define RG_LAUNCH(BF, NT_, RS_, OB_, WV_)                                                                        \
   do {                                                                                                           \
-    (void)hipFuncSetAttribute((const void*)conv3x3_ring_kernel<BF, NT_, RS_, OB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    hipLaunchKernelGGL((conv3x3_ring_kernel<BF, NT_, RS_, OB_>), dim3(grid), dim3(512), lds, st, a);               \
+    (void)hipFuncSetAttribute((const void*)conv3x3_ring_kernel<BF, NT_, RS_, OB_, WV_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL((conv3x3_ring_kernel<BF, NT_, RS_, OB_, WV_>), dim3(grid), dim3(128 * WV_), lds, st, a);    \
   } while (0)
-#define RG_NT(BF, RS_, OB_) do { if (ntile == 128) RG_LAUNCH(BF, 128, RS_, OB_); else RG_LAUNCH(BF, 64, RS_, OB_); } while (0)
+#define RG_NT(BF, RS_, OB_)                                                                                      \
+  do {                                                                                                           \
+    if (cfg.wvm == 4) { if (ntile == 128) RG_LAUNCH(BF, 128, RS_, OB_, 4); else RG_LAUNCH(BF, 64, RS_, OB_, 4); } \
+    else { if (ntile == 128) RG_LAUNCH(BF, 128, RS_, OB_, 2); else RG_LAUNCH(BF, 64, RS_, OB_, 2); }             \
+  } while (0)
   if (bf16) {
     if (resid && !resid_bf16) return cadre_fail("cadre_conv3x3_ring: bf16 operands take a bf16 residual");
     if (resid) { if (out_bf16) RG_NT(true, 2, true); else RG_NT(true, 2, false); }

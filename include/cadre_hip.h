@@ -100,6 +100,8 @@ int cadre_conv3x3_ring(const void* x, const void* w, const float* scale, const f
                        void* out, int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t act,
                        int32_t flags, void* stream);
 int cadre_conv3x3_ring_supported(int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t bf16);
+/* tile configuration as ntile (64 / 128) + 1000 * WVM (waves along the positions: 4 = 256-position tile, one workgroup
+ * per CU; 2 = 128-position tile, two per CU): names the instantiation conv3x3_ring_kernel<bf16, ntile, res, out_bf16, WVM> */
 int cadre_conv3x3_ring_ntile(int32_t F, int32_t H, int32_t W, int32_t N, int32_t bf16);
 /* C[M][ldc] = act(sum_s slab[s][M][lds] * scale + shift + resid) */
 int cadre_splitk_reduce(const float* slabs, int32_t split_k, int64_t slab_stride, int64_t lds,
