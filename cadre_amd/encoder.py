@@ -126,7 +126,7 @@ class DANetEncoderHIP:
         # ---- trunk (resnet.py:111-115, 152-166)
         sc, sh = _fold_bn(sd, "backbone.bn1", sd["backbone.conv1.bias"])
         self.stem = _Conv(sd["backbone.conv1.weight"], sc, sh, 7, 2, 3, 1, dev)
-        self.c64_kernel = os.environ.get("CADRE_C64_KERNEL", "1") != "0"
+        self.c64_kernel = int(os.environ.get("CADRE_C64_KERNEL", "1"))      # 0 off, 1 fallback, 2 preferred
         self.ring_conv = os.environ.get("CADRE_RING_CONV", "1") != "0"
         # fused front (pack -> LUT -> stem conv + BN + ReLU -> max-pool in one kernel, stem_pool.hip)
         self.fused_stem = bool(hip.lib().cadre_stem_pool_supported(H, W)) and os.environ.get("CADRE_FUSED_STEM", "1") != "0"
@@ -215,13 +215,16 @@ class DANetEncoderHIP:
         act = c.act if act is None else act
         wbf = c.w.dtype == torch.bfloat16
         flags = (2 if odt == torch.bfloat16 else 0) | (4 if (resid is not None and resid.dtype == torch.bfloat16) else 0)
-        if (wbf and self.c64_kernel and c.k == 3 and c.stride == 1 and c.pad == 1 and c.cin == 64 and c.cout == 64
-                and odt == torch.bfloat16 and (act & 16) == 0 and (resid is None or resid.dtype == torch.bfloat16)
-                and M * 128 < 2 ** 31):
-            # stage-1 convs of the bf16 encoder: HBM-bound, weights resident in LDS, autonomous LDS-DMA-fed waves
+        use_c64 = (wbf and self.c64_kernel and c.k == 3 and c.stride == 1 and c.pad == 1 and c.cin == 64 and c.cout == 64
+                   and odt == torch.bfloat16 and (act & 16) == 0 and (resid is None or resid.dtype == torch.bfloat16)
+                   and M * 128 < 2 ** 31)
+        use_ring = (c.w_ring is not None and self.ring_conv and x.dtype == c.w_ring.dtype
+                    and bool(hip.lib().cadre_conv3x3_ring_supported(F, H, W, c.cin, c.cout, 1 if wbf else 0)))
+        if use_c64 and (self.c64_kernel == 2 or not use_ring):
+            # stage-1 convs of the bf16 encoder with the weights resident in LDS (bit-identical to cadre_gemm_bf16);
+            # the window kernel below measures 3 % faster on them and takes precedence unless CADRE_C64_KERNEL=2
             hip.conv3x3_c64_bf16(x, c.w, c.scale, c.shift, resid, out, F, H, W, 1 if act == 1 else 0)
-        elif (c.w_ring is not None and self.ring_conv and x.dtype == c.w_ring.dtype
-              and hip.lib().cadre_conv3x3_ring_supported(F, H, W, c.cin, c.cout, 1 if wbf else 0)):
+        elif use_ring:
             # stride-1 3x3 convs: each pixel through LDS once per channel chunk, weights streamed (conv3x3_ring.hip)
             hip.conv3x3_ring(x, c.w_ring, c.scale, c.shift, resid, out, F, H, W, c.cin, c.cout, act)
         elif c.k == 1 and c.stride == 1:
