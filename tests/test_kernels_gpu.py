@@ -710,3 +710,41 @@ def test_conv3x3_ring(hip, dtype, F, H, W, Cin, N, use_resid, act):
     if not use_resid:
         hip.conv3x3_ring(x, wr, sc, sh, None, out32, F, H, W, Cin, N, act)
         assert float((out32.cpu() - ref).abs().max() / ref.abs().max()) < 1.5e-2
+
+
+@pytest.mark.parametrize("dtype,F,H,W,Cin,N", [("bf16", 192, 36, 36, 128, 128), ("bf16", 256, 18, 18, 256, 256),
+                                               ("f32", 48, 72, 72, 64, 64), ("bf16", 48, 72, 72, 64, 64)])
+def test_conv3x3_ring_and_c64_repeatable_under_load(hip, dtype, F, H, W, Cin, N):
+    """The LDS-DMA kernels order their staging with hand-counted s_waitcnt vmcnt(N) and raw barriers: a miscount is a
+    race, and a race shows up as run-to-run differences once every CU is busy with several tiles.  20 launches on the
+    same operands (many persistent items per workgroup, all CUs loaded) must agree bit for bit, and with torch."""
+    from cadre_amd.encoder import _ring_w
+    bf = dtype == "bf16"
+    td = torch.bfloat16 if bf else torch.float32
+    g = torch.Generator(device="cuda").manual_seed(F + Cin)
+    x = torch.randn(F, H, W, Cin, device="cuda", generator=g).to(td)
+    w = (torch.randn(N, Cin, 3, 3, device="cuda", generator=g) * (1.5 / np.sqrt(9 * Cin))).to(td)
+    sc = 0.5 + torch.rand(N, device="cuda", generator=g)
+    sh = torch.randn(N, device="cuda", generator=g)
+    res = torch.randn(F, H, W, N, device="cuda", generator=g).to(td)
+    wr = _ring_w(w.float().cpu(), 64 if bf else 32).to(td).cuda()
+    outs = []
+    for rep in range(20):
+        out = torch.empty(F, H, W, N, device="cuda", dtype=td)
+        hip.conv3x3_ring(x, wr, sc, sh, res, out, F, H, W, Cin, N, 1)
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    ref = torch.nn.functional.conv2d(x[:4].float().permute(0, 3, 1, 2), w.float(), padding=1).permute(0, 2, 3, 1) * sc + sh
+    ref = torch.relu(ref + res[:4].float())
+    assert float((outs[0][:4].float() - ref).abs().max() / ref.abs().max()) < (1.5e-2 if bf else 2e-5)
+    if bf and Cin == 64 and N == 64:
+        w_khwc = w.permute(0, 2, 3, 1).reshape(N, 576).contiguous()
+        outs2 = []
+        for rep in range(20):
+            out = torch.empty(F, H, W, N, device="cuda", dtype=td)
+            hip.conv3x3_c64_bf16(x, w_khwc, sc, sh, res, out, F, H, W, 1)
+            outs2.append(out)
+        torch.cuda.synchronize()
+        assert all(torch.equal(outs2[0], o) for o in outs2[1:])
+        assert float((outs2[0][:4].float() - ref).abs().max() / ref.abs().max()) < 1.5e-2
