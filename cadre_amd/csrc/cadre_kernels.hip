@@ -296,59 +296,88 @@ extern "C" int cadre_maxpool3x3s2(const float* x, float* y, int32_t F, int32_t H
 }
 
 // ============================================================================ PAM (position attention)
-// One workgroup per frame.  qkv [Np][160] = (q 16 | k 16 | v 128) from the merged 1x1-conv GEMM.
+// One workgroup (4 waves) per frame.  qkv [Np][160] = (q 16 | k 16 | v 128) from the merged 1x1-conv GEMM.
+// Both products run on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32 fma chain in k order — the same
+// arithmetic as a scalar k-ascending loop): energy = q k^T (da_att.py:43, 96x96 padded, K = 16) as 3x3 tiles,
+// out = attention v (da_att.py:47, 96x128, K = 96) as 3x4 tiles; the row softmax in between is a wave-shuffle
+// reduction over LDS.  Rows / columns >= Np are zero padding (their energies are -inf before the softmax).
 #define PAM_MAXNP 96
+typedef float pam_f32x16 __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void pam_kernel(const float* qkv, const float* x, float gamma, float* y, int Np,
                                                   int out_bf16) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* q = sm;                    // [Np][17]
-  float* k = q + Np * 17;           // [Np][17]
-  float* v = k + Np * 17;           // [Np][128]
-  float* att = v + Np * 128;        // [Np][Np+1]
+  constexpr int R = PAM_MAXNP, QP = 17, AP = R + 1;
+  float* q = sm;                    // [96][17]
+  float* k = q + R * QP;            // [96][17]
+  float* v = k + R * QP;            // [96][128]
+  float* att = v + R * 128;         // [96][97]
   const int f = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const float* src = qkv + (int64_t)f * Np * 160;
-  for (int i = tid; i < Np * 160; i += 256) {
+  for (int i = tid; i < R * 160; i += 256) {
     const int n = i / 160, c = i % 160;
-    const float val = src[i];
-    if (c < 16) q[n * 17 + c] = val;
-    else if (c < 32) k[n * 17 + c - 16] = val;
+    const float val = n < Np ? src[i] : 0.f;
+    if (c < 16) q[n * QP + c] = val;
+    else if (c < 32) k[n * QP + c - 16] = val;
     else v[n * 128 + c - 32] = val;
   }
   __syncthreads();
-  const int P = Np + 1;
-  for (int i = tid; i < Np * Np; i += 256) {        // energy[n][m] = q[n] . k[m]   (da_att.py:43)
-    const int n = i / Np, m = i % Np;
-    float e = 0.f;
+  // ---- energy[n][m] = q[n] . k[m]: 9 tiles of 32x32 over 4 waves, 8 MFMAs (K = 16) each
+  for (int t = wave; t < 9; t += 4) {
+    const int n0 = (t / 3) * 32, m0 = (t % 3) * 32;
+    pam_f32x16 acc;
 #pragma unroll
-    for (int d = 0; d < 16; ++d) e += q[n * 17 + d] * k[m * 17 + d];
-    att[n * P + m] = e;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q[(n0 + l31) * QP + 2 * kk + lh], k[(m0 + l31) * QP + 2 * kk + lh], acc, 0, 0, 0);
+    const int m = m0 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) att[(n0 + (r & 3) + 8 * (r >> 2) + 4 * lh) * AP + m] = m < Np ? acc[r] : -INFINITY;
   }
   __syncthreads();
-  const int lane = tid & 63, wave = tid >> 6;
-  for (int n = wave; n < Np; n += 4) {               // row softmax (da_att.py:44)
+  for (int n = wave; n < R; n += 4) {                // row softmax (da_att.py:44); padded rows become zeros
+    if (n >= Np) {
+      for (int m = lane; m < R; m += 64) att[n * AP + m] = 0.f;
+      continue;
+    }
     float mx = -INFINITY;
-    for (int m = lane; m < Np; m += 64) mx = fmaxf(mx, att[n * P + m]);
+    for (int m = lane; m < R; m += 64) mx = fmaxf(mx, att[n * AP + m]);
     mx = wave_max(mx);
     float s = 0.f;
-    for (int m = lane; m < Np; m += 64) {
-      const float e = expf(att[n * P + m] - mx);
-      att[n * P + m] = e;
+    for (int m = lane; m < R; m += 64) {
+      const float e = expf(att[n * AP + m] - mx);    // exp(-inf) = 0 for the padded columns
+      att[n * AP + m] = e;
       s += e;
     }
     s = wave_sum(s);
-    for (int m = lane; m < Np; m += 64) att[n * P + m] = att[n * P + m] / s;
+    for (int m = lane; m < R; m += 64) att[n * AP + m] = att[n * AP + m] / s;
   }
   __syncthreads();
-  const int c = tid & 127;
-  const float* xf = x + (int64_t)f * Np * 128;
-  float* yf = y + (int64_t)f * Np * 128;
-  for (int n = tid >> 7; n < Np; n += 2) {           // out[n][c] = sum_m att[n][m] v[m][c]  (:47)
-    float o = 0.f;
-    for (int m = 0; m < Np; ++m) o += att[n * P + m] * v[m * 128 + c];
-    const float r = gamma * o + xf[n * 128 + c];
-    if (out_bf16) reinterpret_cast<__bf16*>(y)[(int64_t)f * Np * 128 + n * 128 + c] = (__bf16)r;
-    else yf[n * 128 + c] = r;
+  // ---- out[n][c] = sum_m att[n][m] v[m][c]: wave w owns channel block w (32 channels), all three row blocks
+  pam_f32x16 o[3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
+  const int c = 32 * wave + l31;
+  for (int kk = 0; kk < R / 2; ++kk) {
+    const float bv = v[(2 * kk + lh) * 128 + c];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) o[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(att[(32 * b + l31) * AP + 2 * kk + lh], bv, o[b], 0, 0, 0);
   }
+  const float* xf = x + (int64_t)f * Np * 128;
+#pragma unroll
+  for (int b = 0; b < 3; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (n < Np) {
+        const float res = gamma * o[b][r] + xf[n * 128 + c];
+        if (out_bf16) reinterpret_cast<__bf16*>(y)[(int64_t)f * Np * 128 + n * 128 + c] = (__bf16)res;
+        else y[(int64_t)f * Np * 128 + n * 128 + c] = res;
+      }
+    }
 }
 
 static int pam_launch(const float* x, const float* qkv, float gamma, void* y, int32_t F, int32_t Np, int out_bf16,
@@ -364,7 +393,7 @@ extern "C" int cadre_pam_bf16out(const float* x, const float* qkv, float gamma, 
 static int pam_launch(const float* x, const float* qkv, float gamma, void* y, int32_t F, int32_t Np, int out_bf16,
                       void* stream) {
   FAIL_IF(!x || !qkv || !y || F < 1 || Np < 1 || Np > PAM_MAXNP, "cadre_pam: bad argument (Np<=96)");
-  const size_t shm = sizeof(float) * ((size_t)Np * 34 + (size_t)Np * 128 + (size_t)Np * (Np + 1));
+  const size_t shm = sizeof(float) * ((size_t)PAM_MAXNP * 34 + (size_t)PAM_MAXNP * 128 + (size_t)PAM_MAXNP * (PAM_MAXNP + 1));
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)pam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
