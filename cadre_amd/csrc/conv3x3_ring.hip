@@ -48,7 +48,15 @@ struct ring_args {
   int out_bf16, resid_bf16;
   int mtiles, ntiles, items, ipw;      // M tiles of 256, N tiles, work items, items per workgroup
   int WPX;                // window pixels (multiple of 8, >= 288)
+#ifdef RING_TRACE
+  long long* trace;       // tools/ring_trace.py: per (workgroup, item) 6 shader-clock stamps of wave 0
+#endif
 };
+#ifdef RING_TRACE
+#define RG_STAMP(k) do { if (a.trace && tid == 0 && li < 64) a.trace[((size_t)blockIdx.x * 64 + li) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define RG_STAMP(k) do { } while (0)
+#endif
 
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -77,7 +85,12 @@ __global__ __launch_bounds__(128 * WVM, 2) void conv3x3_ring_kernel(ring_args a)
   constexpr int NWAVES = 2 * WVM, NTHR = 64 * NWAVES;
   constexpr int RG_BM = 64 * WVM;
   constexpr int RG_NSTB = WVM == 4 ? 3 : 2, LEAD = RG_NSTB - 1;
+  constexpr int STG_B = NTILE * 128;                       // bytes of one weight stage: [NTILE rows][128 B]
   constexpr int NBPW = (NTILE / 8) / NWAVES;               // weight pieces (8 rows x 128 B) per wave per stage
+  // window slices of the NEXT phase, per wave and step: front-loaded, two per step on the first NFL steps (a slice
+  // needs an HBM round trip, 2-4 us under load: issued late in the phase it is waited on at the next phase's first step)
+  constexpr int NFL = WVM == 4 ? 4 : 5;
+  auto sl_of = [](int tap) constexpr -> int { return tap < NFL ? 2 : 0; };
   constexpr unsigned OOB = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -86,20 +99,28 @@ __global__ __launch_bounds__(128 * WVM, 2) void conv3x3_ring_kernel(ring_args a)
   const int win_bytes = a.WPX * 128;
   char* win0 = smem;                                       // two windows, then the weight stages, then a 1 KiB dump
   char* bst = smem + 2 * win_bytes;
-  char* dump = bst + RG_NSTB * NTILE * 128;
+  char* dump = bst + RG_NSTB * STG_B;                      // ... a 1 KiB dump, the folded-BN table
 
   const int i_begin = blockIdx.x * a.ipw, i_end = min(a.items, i_begin + a.ipw);
   const int nitems = i_end - i_begin;                      // uniform over the workgroup
   if (nitems <= 0) return;
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.M * a.Cin * EB, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.N * a.NC * 9 * 128, 0x00020000);
+  constexpr int ESZ = OUTB ? 2 : 4, RSZ = RES == 2 ? 2 : 4;
+  const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.M * a.N * ESZ, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? a.resid : a.x), 0, RES ? a.M * a.N * RSZ : 0, 0x00020000);
   const int cin_b = a.Cin * EB;
   const int PA = a.WPX >> 3;                               // window pieces
   for (int i = tid; i < 256; i += NTHR) reinterpret_cast<unsigned*>(dump)[i] = 0u;      // the dump doubles as the ZERO ROW
+  float* sc_lds = reinterpret_cast<float*>(dump + 1024);   // folded BN of every output channel: [scale | shift], ntiles*NTILE each
+  for (int i = tid; i < a.ntiles * NTILE; i += NTHR) {
+    sc_lds[i] = (a.scale && i < a.N) ? a.scale[i] : 1.f;
+    sc_lds[a.ntiles * NTILE + i] = (a.shift && i < a.N) ? a.shift[i] : 0.f;
+  }
 
   // ---- lane constants of the staging path.  A window piece j (8 pixels): this lane brings pixel 8j + (lane>>3),
   // LDS chunk (lane&7), i.e. source chunk (lane&7) ^ ((idx>>1)&7) with idx = 8j + (lane>>3): (idx>>1)&7 =
-  // (lane>>4) ^ 4*(j&1), and j = 8*tap + wave has the parity of the wave — a per-lane constant.  Pixels outside the
+  // (lane>>4) ^ 4*(j&1), and j = NWAVES*slot + wave has the parity of the wave — a per-lane constant.  Pixels outside the
   // tensor need no test: a negative position wraps to a huge unsigned offset, one past the end lies beyond
   // num_records — both arrive as zeros.
   const int a_lane = (lane >> 3) * cin_b + ((((lane & 7) ^ (lane >> 4) ^ (4 * (wave & 1)))) << 4);
@@ -119,7 +140,7 @@ __global__ __launch_bounds__(128 * WVM, 2) void conv3x3_ring_kernel(ring_args a)
 #pragma unroll
     for (int k = 0; k < NBPW; ++k) {
       const unsigned voff = live ? (unsigned)(nt_b * (NTILE * a.NC * 9 * 128) + (c * 9 + tap) * 128 + b_lane[k]) : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(bst + stg * (NTILE * 128) + (wave * NBPW + k) * 1024),
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(bst + stg * STG_B + (wave * NBPW + k) * 1024),
                                                16, (int)voff, 0, 0, 0);
     }
   };
@@ -176,6 +197,7 @@ __global__ __launch_bounds__(128 * WVM, 2) void conv3x3_ring_kernel(ring_args a)
     int mt1 = mt, nt1 = nt + 1;
     if (nt1 == a.ntiles) { nt1 = 0; ++mt1; }
     const bool more = li + 1 < nitems;
+    RG_STAMP(0);
     unsigned mask[2];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
@@ -193,13 +215,30 @@ __global__ __launch_bounds__(128 * WVM, 2) void conv3x3_ring_kernel(ring_args a)
       mask[rb] = mk;
     }
     f32x16 acc[2][WN];
-    float sc[WN], sh[WN];                                  // folded BN of this lane's channels (accumulator layout: lane = channel)
+    // epilogue addressing (also used by the early residual request inside the k-loop)
+    constexpr int NBLK = 2 * WN;                           // 32 x 32 blocks of this wave: b = cb*2 + rb
+    const int row0 = lane >> 3, c4 = (lane & 7) * 4;       // lane -> (row 8*i + lane/8, channels 4*(lane&7) .. +3)
+    auto eoff = [&](int b, int i) -> unsigned {            // element offset of this lane's 4 outputs, or OOB
+      const int cb = b >> 1, rb = b & 1;
+      const int pos = mt * RG_BM + 64 * wm + 32 * rb + 8 * i + row0;
+      const int ch = nt * NTILE + (NTILE / 2) * wn + 32 * cb + c4;
+      return (pos < a.M && ch < a.N) ? (unsigned)(pos * a.N + ch) : OOB;
+    };
+    u32x4 rq[2][4];
+    auto req = [&](int b, u32x4* dst) {
+      if constexpr (RES != 0) {
 #pragma unroll
-    for (int cb = 0; cb < WN; ++cb) {
-      const int nch = nt * NTILE + (NTILE / 2) * wn + 32 * cb + l31;
-      sc[cb] = (a.scale && nch < a.N) ? a.scale[nch] : 1.f;
-      sh[cb] = (a.shift && nch < a.N) ? a.shift[nch] : 0.f;
-    }
+        for (int i = 0; i < 4; ++i) {
+          const unsigned eo = eoff(b, i);
+          if constexpr (RES == 2) {
+            const u32x2 t = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsR, eo == OOB ? (int)OOB : (int)(eo * 2), 0, 0));
+            dst[i] = u32x4{t[0], t[1], 0u, 0u};
+          } else {
+            dst[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, eo == OOB ? (int)OOB : (int)(eo * 4), 0, 0));
+          }
+        }
+      }
+    };
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -216,52 +255,87 @@ __global__ __launch_bounds__(128 * WVM, 2) void conv3x3_ring_kernel(ring_args a)
       char* const zrow = dump;
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
-        // ---- everything issued two steps ago (weights of this step, window slices) has landed; publish
-        // (in-order completion: all but the youngest (LEAD-1) steps' pieces — plus, for LEAD steps after an epilogue,
-        //  its stores — must have completed)
+        // ---- everything issued LEAD steps ago (weights of this step, window slices) has landed; publish
+        // (in-order completion: all but the youngest (LEAD-1) steps' operations — plus, for LEAD steps after an
+        //  epilogue, its stores — must have completed)
         if (first_step) { wait_vm<0>(); first_step = false; }
-        else if (extra_steps > 0) { wait_vm_n((LEAD - 1) * (NBPW + 1) + extra); --extra_steps; }
-        else wait_vm<(LEAD - 1) * (NBPW + 1)>();
+        else {
+          int allow = (LEAD - 1) * (NBPW + sl_of((tap + 8) % 9));                  // (folds: tap is unrolled)
+          if (RES != 0 && LEAD == 2 && tap == 8 && last_c) allow += 4;               // the early residual request (below)
+          if (extra_steps > 0) { wait_vm_n(allow + extra); --extra_steps; }
+          else wait_vm_n(allow);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (c == 0 && tap == 0) RG_STAMP(1);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        // ---- issue: weights two steps ahead, one window slice of the next phase (slices on taps 0..7 only)
+        if (c == 0 && tap == 0) RG_STAMP(2);
+        // ---- issue: weights LEAD steps ahead, window slices of the next phase
         {
           const int s2 = stg + LEAD >= RG_NSTB ? stg + LEAD - RG_NSTB : stg + LEAD;
           if (tap + LEAD < 9) issue_b(nt, c, tap + LEAD, s2, true);
           else if (!last_c) issue_b(nt, c + 1, tap + LEAD - 9, s2, true);
           else issue_b(nt1, 0, tap + LEAD - 9, s2, more);
-          // window slices of the next phase: on the taps whose pieces the next phase's first wait still covers
-          issue_a(mt_n, c_n, (phg + 1) & 1, tap <= 9 - LEAD ? tap * NWAVES + wave : PA, has_next);
+#pragma unroll
+          for (int i = 0; i < sl_of(tap); ++i)
+            issue_a(mt_n, c_n, (phg + 1) & 1, (2 * tap + i) * NWAVES + wave, has_next);
+          // the residual of the item's first output block: requested two steps before the epilogue needs it
+          if constexpr (RES != 0) { if (tap == 7 && last_c) req(0, rq[0]); }
         }
-        // ---- compute this step
-        const char* bs = bst + stg * (NTILE * 128);
+        // ---- compute this step.  The WEIGHTS are the MFMA's A operand, the pixels its B operand: the accumulator then
+        // holds (lane -> position, register -> channel), four consecutive channels per register quad — the epilogue
+        // stores a quad with one ds_write_b128.
+        const char* bs = bst + stg * STG_B;
         const int toff = (tap / 3) * a.W + (tap % 3);
         f32x4 afr[2][4];
+        const char* arow[2];
+        unsigned sw[2];
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
           const int idx = 64 * wm + 32 * rb + l31 + toff;
-          const unsigned sw = (unsigned)((idx >> 1) & 7);
+          sw[rb] = (unsigned)((idx >> 1) & 7);
           // halo tap of this position: read the zero row instead (one select per row, not per fragment register)
-          const char* arow = ((mask[rb] >> tap) & 1u) ? win + arow0 + (32 * rb + toff) * 128 : zrow;
-#pragma unroll
-          for (int s = 0; s < 4; ++s) afr[rb][s] = *reinterpret_cast<const f32x4*>(arow + ((kc[s] ^ sw) << 4));
+          arow[rb] = ((mask[rb] >> tap) & 1u) ? win + arow0 + (32 * rb + toff) * 128 : zrow;
         }
-#pragma unroll
-        for (int cb = 0; cb < WN; ++cb) {
+        if constexpr (BF16) {
+          // A bf16 k-tile is 8 x WN MFMAs of 32 cycles: left to itself the compiler sinks every fragment read to its
+          // MFMA (read, s_waitcnt, MFMA, read ...), one LDS round trip per pair.  All reads of the step are issued
+          // first, in the order the MFMAs consume them, and pinned there: the waits become counted lgkmcnt(n).
+          f32x4 bfr[WN][4];
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(bs + boff[cb][s]);
-            if constexpr (BF16) {
+            bfr[0][s] = *reinterpret_cast<const f32x4*>(bs + boff[0][s]);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) afr[rb][s] = *reinterpret_cast<const f32x4*>(arow[rb] + ((kc[s] ^ sw[rb]) << 4));
+          }
+#pragma unroll
+          for (int cb = 1; cb < WN; ++cb)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) bfr[cb][s] = *reinterpret_cast<const f32x4*>(bs + boff[cb][s]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int cb = 0; cb < WN; ++cb)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
               for (int rb = 0; rb < 2; ++rb)
-                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, afr[rb][s]), __builtin_bit_cast(bf16x8, bv),
+                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bfr[cb][s]), __builtin_bit_cast(bf16x8, afr[rb][s]),
                                                                       acc[rb][cb], 0, 0, 0);
-            } else {                                       // alternate the two accumulators: consecutive MFMAs independent
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
 #pragma unroll
-              for (int e = 0; e < 4; ++e)
+          for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[rb][s][e], bv[e], acc[rb][cb], 0, 0, 0);
+            for (int s = 0; s < 4; ++s) afr[rb][s] = *reinterpret_cast<const f32x4*>(arow[rb] + ((kc[s] ^ sw[rb]) << 4));
+#pragma unroll
+          for (int cb = 0; cb < WN; ++cb) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              const f32x4 bv = *reinterpret_cast<const f32x4*>(bs + boff[cb][s]);
+#pragma unroll
+              for (int e = 0; e < 4; ++e)                  // alternate the two accumulators: consecutive MFMAs independent
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[e], afr[rb][s][e], acc[rb][cb], 0, 0, 0);
             }
           }
         }
@@ -269,50 +343,37 @@ __global__ __launch_bounds__(128 * WVM, 2) void conv3x3_ring_kernel(ring_args a)
       }
     }
     // ---- epilogue of the item: slabs live in the window that was just read (all waves must be done with it).
-    // Straight-line per (RES, OUTB); the residual of block b+1 is requested before block b is processed.
+    // Per 32 x 32 block: the raw accumulator goes to the slab as [position][channel] (4 ds_write_b128), comes back as
+    // (row 8i + lane/8, channels 4*(lane&7)..+3) for folded BN (this lane's two float4 from LDS), residual, ReLU and a
+    // coalesced store.  The residual of block b+1 is requested before block b is processed (block 0: at tap 7).
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    RG_STAMP(3);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    RG_STAMP(4);
     {
       const int phl = (li * a.NC + a.NC - 1) & 1;
       float* cs = reinterpret_cast<float*>(win0 + phl * win_bytes + wave * RG_SLAB);
-      constexpr int ESZ = OUTB ? 2 : 4, RSZ = RES == 2 ? 2 : 4;
-      const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.M * a.N * ESZ, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? a.resid : a.x), 0, RES ? a.M * a.N * RSZ : 0, 0x00020000);
       const bool relu = (a.act & 15) == 1, post = (a.act & 16) != 0;
-      const int row0 = lane >> 3, c4 = (lane & 7) * 4;     // lane -> (row 8*i + lane/8, channels 4*(lane&7) .. +3)
-      constexpr int NBLK = 2 * WN;                         // 32 x 32 blocks of this wave: b = cb*2 + rb
-      auto eoff = [&](int b, int i) -> unsigned {          // element offset of this lane's 4 outputs, or OOB
-        const int cb = b >> 1, rb = b & 1;
-        const int pos = mt * RG_BM + 64 * wm + 32 * rb + 8 * i + row0;
-        const int ch = nt * NTILE + (NTILE / 2) * wn + 32 * cb + c4;
-        return (pos < a.M && ch < a.N) ? (unsigned)(pos * a.N + ch) : OOB;
-      };
-      u32x4 rq[2][4];
-      auto req = [&](int b, u32x4* dst) {
-        if constexpr (RES != 0) {
+      f32x4 sc4[WN], sh4[WN];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const unsigned eo = eoff(b, i);
-            if constexpr (RES == 2) {
-              const u32x2 t = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsR, eo == OOB ? (int)OOB : (int)(eo * 2), 0, 0));
-              dst[i] = u32x4{t[0], t[1], 0u, 0u};
-            } else {
-              dst[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, eo == OOB ? (int)OOB : (int)(eo * 4), 0, 0));
-            }
-          }
-        }
-      };
-      req(0, rq[0]);
+      for (int cb = 0; cb < WN; ++cb) {
+        const int nl = nt * NTILE + (NTILE / 2) * wn + 32 * cb + c4;
+        sc4[cb] = *reinterpret_cast<const f32x4*>(sc_lds + nl);
+        sh4[cb] = *reinterpret_cast<const f32x4*>(sc_lds + a.ntiles * NTILE + nl);
+      }
 #pragma unroll
       for (int b = 0; b < NBLK; ++b) {
         const int cb = b >> 1, rb = b & 1;
         if (b + 1 < NBLK) req(b + 1, rq[(b + 1) & 1]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) cs[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + l31] = acc[rb][cb][r] * sc[cb] + sh[cb];
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<f32x4*>(cs + l31 * 36 + 8 * g + 4 * lh) =
+              f32x4{acc[rb][cb][4 * g], acc[rb][cb][4 * g + 1], acc[rb][cb][4 * g + 2], acc[rb][cb][4 * g + 3]};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           f32x4 v = *reinterpret_cast<const f32x4*>(cs + (8 * i + row0) * 36 + c4);
+          v = v * sc4[cb] + sh4[cb];
           f32x4 rv = {0.f, 0.f, 0.f, 0.f};
           if constexpr (RES == 2) {
             const bf16x4 t = __builtin_bit_cast(bf16x4, u32x2{rq[b & 1][i][0], rq[b & 1][i][1]});
@@ -336,6 +397,7 @@ __global__ __launch_bounds__(128 * WVM, 2) void conv3x3_ring_kernel(ring_args a)
           }
         }
       }
+      RG_STAMP(5);
       extra = NBLK * 4;                                    // these stores sit behind the in-flight pieces in the queue:
       extra_steps = LEAD;                                  // the next LEAD waits reach back over them
     }
@@ -360,15 +422,16 @@ static void ring_pick(long long M, int W, int N, ring_cfg* c) {
     const int min_wpx = (2 * wvm * RG_SLAB + 127) / 128;           // the epilogue slabs live in a window
     if (wpx < min_wpx) wpx = (min_wpx + 7) & ~7;
     *wpx_out = wpx;
-    return (size_t)2 * wpx * 128 + (size_t)(wvm == 4 ? 3 : 2) * nt * 128 + 1024;
+    const size_t bn_table = (size_t)((N + nt - 1) / nt) * nt * 8;      // folded BN of every channel: scale | shift
+    return (size_t)2 * wpx * 128 + (size_t)(wvm == 4 ? 3 : 2) * nt * 128 + 1024 + bn_table;
   };
   int wpx2, wpx4;
   const size_t l2 = lds_of(2, ntile, &wpx2), l4 = lds_of(4, ntile, &wpx4);
   // two workgroups per CU pay off on long runs of items (layer3/4: +8 % over one 8-wave workgroup); with fewer than
   // four rounds of work (the 9x9 head convs) the larger tile wins (865 vs 752 TFLOP/s bf16)
   const long long items2 = ((M + 127) / 128) * ((N + ntile - 1) / ntile);
-  int wvm = (l2 <= 80 * 1024 && 9 * 4 >= (wpx2 >> 3) && items2 >= 4 * 512) ? 2 : 4;     // (window slices must fit the 9 x 4 issue slots)
-  if (force_wvm == 2 && l2 <= 80 * 1024 && 9 * 4 >= (wpx2 >> 3)) wvm = 2;
+  int wvm = (l2 <= 80 * 1024 && 10 * 4 >= (wpx2 >> 3) && items2 >= 4 * 512) ? 2 : 4;     // (window slices must fit the 10 x 4 issue slots)
+  if (force_wvm == 2 && l2 <= 80 * 1024 && 10 * 4 >= (wpx2 >> 3)) wvm = 2;
   if (force_wvm == 4) wvm = 4;
   c->wvm = wvm; c->ntile = ntile; c->bm = 64 * wvm;
   c->wpx = wvm == 2 ? wpx2 : wpx4;
@@ -400,10 +463,15 @@ extern "C" int cadre_conv3x3_ring_supported(int32_t F, int32_t H, int32_t W, int
 // instantiation conv3x3_ring_kernel<bf16, ntile, res, out_bf16, WVM> for profiles)
 extern "C" int cadre_conv3x3_ring_ntile(int32_t F, int32_t H, int32_t W, int32_t N, int32_t bf16) {
   ring_cfg c;
-  ring_pick((long long)F * H * W, W, N, &c);
   (void)bf16;
+  ring_pick((long long)F * H * W, W, N, &c);
   return c.ntile + 1000 * c.wvm;
 }
+
+#ifdef RING_TRACE
+static long long* g_ring_trace = nullptr;
+extern "C" void cadre_ring_set_trace(void* p) { g_ring_trace = (long long*)p; }
+#endif
 
 extern "C" int cadre_conv3x3_ring(const void* x, const void* w, const float* scale, const float* shift, const void* resid,
                                   void* out, int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t act,
@@ -425,18 +493,23 @@ extern "C" int cadre_conv3x3_ring(const void* x, const void* w, const float* sca
   a.ipw = (a.items + cfg.wgs - 1) / cfg.wgs;
   const int grid = (a.items + a.ipw - 1) / a.ipw;
   a.WPX = cfg.wpx;
+#ifdef RING_TRACE
+  a.trace = g_ring_trace;
+#endif
   const size_t lds = cfg.lds;
   if (lds > 160 * 1024) return cadre_fail("cadre_conv3x3_ring: window does not fit LDS");
   hipStream_t st = (hipStream_t)stream;
 #define RG_LAUNCH(BF, NT_, RS_, OB_, WV_)                                                                        \
   do {                                                                                                           \
     (void)hipFuncSetAttribute((const void*)conv3x3_ring_kernel<BF, NT_, RS_, OB_, WV_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    hipLaunchKernelGGL((conv3x3_ring_kernel<BF, NT_, RS_, OB_, WV_>), dim3(grid), dim3(128 * WV_), lds, st, a);    \
+    hipLaunchKernelGGL((conv3x3_ring_kernel<BF, NT_, RS_, OB_, WV_>), dim3(grid), dim3(128 * WV_), lds, st, a); \
   } while (0)
 #define RG_NT(BF, RS_, OB_)                                                                                      \
   do {                                                                                                           \
-    if (cfg.wvm == 4) { if (ntile == 128) RG_LAUNCH(BF, 128, RS_, OB_, 4); else RG_LAUNCH(BF, 64, RS_, OB_, 4); } \
-    else { if (ntile == 128) RG_LAUNCH(BF, 128, RS_, OB_, 2); else RG_LAUNCH(BF, 64, RS_, OB_, 2); }             \
+    if (cfg.wvm == 4) {                                                                                          \
+      if (ntile == 128) RG_LAUNCH(BF, 128, RS_, OB_, 4);                                                      \
+      else RG_LAUNCH(BF, 64, RS_, OB_, 4);                                                                    \
+    } else { if (ntile == 128) RG_LAUNCH(BF, 128, RS_, OB_, 2); else RG_LAUNCH(BF, 64, RS_, OB_, 2); }     \
   } while (0)
   if (bf16) {
     if (resid && !resid_bf16) return cadre_fail("cadre_conv3x3_ring: bf16 operands take a bf16 residual");
