@@ -226,7 +226,8 @@ AM = {0: "dense A[M][K]", 1: "dense A[K][M]", 2: "NHWC implicit-GEMM conv", 3: "
 def kname(k):
     """Exact kernel symbol as rocprofv3 prints it, from a hip.PROFILE key."""
     if k[0] == "ring":
-        return "conv3x3_ring_kernel<%s, %d, %d, %s, %d>" % ("true" if k[1] else "false", k[2], k[3], "true" if k[4] else "false", k[5])
+        tf = ("true" if k[1] else "false", k[2], k[3], "true" if k[4] else "false")
+        return "conv3x3_ring_pp_kernel<%s, %d, %d, %s>" % tf if k[6] else ("conv3x3_ring_kernel<%s, %d, %d, %s, %%d>" % tf) % k[5]
     if k[0] == "bf16":
         _, tile, am = k
         if tile == 12:

@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "../../include/cadre_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -52,10 +53,16 @@ struct ring_args {
   long long* trace;       // tools/ring_trace.py: per (workgroup, item) 6 shader-clock stamps of wave 0
 #endif
 };
-#ifdef RING_TRACE
-#define RG_STAMP(k) do { if (a.trace && tid == 0 && li < 64) a.trace[((size_t)blockIdx.x * 64 + li) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define RG_STAMP_(k) do { if (a.trace && (tid == 0 || tid == 256) && li < 64 && (tid == 0) == (blockIdx.x % 2 == 0)) a.trace[((size_t)blockIdx.x * 64 + li) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#if defined(RING_TRACE) && RING_TRACE == 1      // sections of an item
+#define RG_STAMP(k) RG_STAMP_(k)
 #else
 #define RG_STAMP(k) do { } while (0)
+#endif
+#if defined(RING_TRACE) && RING_TRACE == 2      // inside k-tiles 4 and 5 of the first chunk
+#define RG_STEP(k) RG_STAMP_(k)
+#else
+#define RG_STEP(k) do { } while (0)
 #endif
 
 template <int N>
@@ -258,6 +265,8 @@ __global__ __launch_bounds__(128 * WVM, 2) void conv3x3_ring_kernel(ring_args a)
         // ---- everything issued LEAD steps ago (weights of this step, window slices) has landed; publish
         // (in-order completion: all but the youngest (LEAD-1) steps' operations — plus, for LEAD steps after an
         //  epilogue, its stores — must have completed)
+        if (c == 0 && tap == 4) RG_STEP(0);
+        if (c == 0 && tap == 5) RG_STEP(4);
         if (first_step) { wait_vm<0>(); first_step = false; }
         else {
           int allow = (LEAD - 1) * (NBPW + sl_of((tap + 8) % 9));                  // (folds: tap is unrolled)
@@ -267,9 +276,13 @@ __global__ __launch_bounds__(128 * WVM, 2) void conv3x3_ring_kernel(ring_args a)
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (c == 0 && tap == 0) RG_STAMP(1);
+        if (c == 0 && tap == 4) RG_STEP(1);
+        if (c == 0 && tap == 5) RG_STEP(5);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (c == 0 && tap == 0) RG_STAMP(2);
+        if (c == 0 && tap == 4) RG_STEP(2);
+        if (c == 0 && tap == 5) RG_STEP(6);
         // ---- issue: weights LEAD steps ahead, window slices of the next phase
         {
           const int s2 = stg + LEAD >= RG_NSTB ? stg + LEAD - RG_NSTB : stg + LEAD;
@@ -282,6 +295,7 @@ __global__ __launch_bounds__(128 * WVM, 2) void conv3x3_ring_kernel(ring_args a)
           // the residual of the item's first output block: requested two steps before the epilogue needs it
           if constexpr (RES != 0) { if (tap == 7 && last_c) req(0, rq[0]); }
         }
+        if (c == 0 && tap == 4) RG_STEP(3);
         // ---- compute this step.  The WEIGHTS are the MFMA's A operand, the pixels its B operand: the accumulator then
         // holds (lane -> position, register -> channel), four consecutive channels per register quad — the epilogue
         // stores a quad with one ds_write_b128.
@@ -407,11 +421,353 @@ __global__ __launch_bounds__(128 * WVM, 2) void conv3x3_ring_kernel(ring_args a)
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------
+// PING-PONG variant (8 waves, 256-position tile).  In the kernel above all eight waves cross one barrier per k-tile
+// together: right after it nobody has an MFMA to issue — every wave is issuing its loads and waiting for its fragment
+// reads — and the matrix pipe idles for that turn, every k-tile (traced with -DRING_TRACE=2: 35-40 % of a bf16
+// k-tile).  Here the waves form two groups of four (waves w and w+4 share a SIMD) that run HALF A STEP APART, two
+// barriers per k-tile:
+//     slot 2t   : group 0  R(t)  = issue the loads of k-tile t+LEAD, read the fragments of k-tile t into registers
+//                 group 1  M(t-1) = its MFMAs of k-tile t-1
+//     slot 2t+1 : group 0  M(t),   group 1  R(t)
+// so that on every SIMD one wave computes while the other stages.  Per-item work (the epilogue of the previous item,
+// masks, accumulator clear) sits in the group's R(0) slot, under the other group's MFMAs.
+//   * weights: stage (t+LEAD) % (LEAD+1) is rewritten from slot 2t on; its last readers (group 1, k-tile t-1) finished
+//     in slot 2t-1.  A wave confirms (counted vmcnt) at the end of R(t) the weights it issued in R(t-1) (k-tile t+1):
+//     one slot before group 0 reads them.
+//   * windows: the slices of the next phase go out on k-tiles 1..NFL (not 0: the epilogue slabs of the previous item
+//     live in that buffer until both groups have passed their R(0)).
+template <bool BF16, int NTILE, int RES, bool OUTB>
+__global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
+  constexpr int WN = NTILE / 64;
+  constexpr int EB = BF16 ? 2 : 4;
+  constexpr int NWAVES = 8, NTHR = 512, RG_BM = 256;
+  constexpr int LEAD = 2, RG_NSTB = 3;
+  constexpr int STG_B = NTILE * 128;
+  constexpr int NBPW = (NTILE / 8) / NWAVES;
+  constexpr int NFL = 4;
+  auto sl_of = [](int tap) constexpr -> int { return (tap >= 1 && tap <= NFL) ? 2 : 0; };
+  constexpr unsigned OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: scalar registers, scalar branches
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int grp = wave >> 2;                               // waves w and w + 4 sit on the same SIMD
+  const int win_bytes = a.WPX * 128;
+  char* win0 = smem;
+  char* bst = smem + 2 * win_bytes;
+  char* dump = bst + RG_NSTB * STG_B;
+
+  const int i_begin = blockIdx.x * a.ipw, i_end = min(a.items, i_begin + a.ipw);
+  const int nitems = i_end - i_begin;
+  if (nitems <= 0) return;
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.M * a.Cin * EB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.N * a.NC * 9 * 128, 0x00020000);
+  constexpr int ESZ = OUTB ? 2 : 4, RSZ = RES == 2 ? 2 : 4;
+  const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.M * a.N * ESZ, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? a.resid : a.x), 0, RES ? a.M * a.N * RSZ : 0, 0x00020000);
+  const int cin_b = a.Cin * EB;
+  const int PA = a.WPX >> 3;
+  for (int i = tid; i < 256; i += NTHR) reinterpret_cast<unsigned*>(dump)[i] = 0u;
+  float* sc_lds = reinterpret_cast<float*>(dump + 1024);
+  for (int i = tid; i < a.ntiles * NTILE; i += NTHR) {
+    sc_lds[i] = (a.scale && i < a.N) ? a.scale[i] : 1.f;
+    sc_lds[a.ntiles * NTILE + i] = (a.shift && i < a.N) ? a.shift[i] : 0.f;
+  }
+  const int a_lane = (lane >> 3) * cin_b + ((((lane & 7) ^ (lane >> 4) ^ (4 * (wave & 1)))) << 4);
+  int b_lane[NBPW];
+#pragma unroll
+  for (int k = 0; k < NBPW; ++k) {
+    const int r = (wave * NBPW + k) * 8 + (lane >> 3);
+    b_lane[k] = r * a.NC * 9 * 128 + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
+  }
+  auto issue_a = [&](int mt_n, int c_n, int wsel, int j, bool live) {
+    const bool ok = live && j < PA;
+    const unsigned voff = ok ? (unsigned)((mt_n * RG_BM - a.W - 1 + 8 * j) * cin_b + c_n * 128 + a_lane) : OOB;
+    char* dst = ok ? win0 + wsel * win_bytes + j * 1024 : dump;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)dst, 16, (int)voff, 0, 0, 0);
+  };
+  auto issue_b = [&](int nt_b, int c, int tap, int stg, bool live) {
+#pragma unroll
+    for (int k = 0; k < NBPW; ++k) {
+      const unsigned voff = live ? (unsigned)(nt_b * (NTILE * a.NC * 9 * 128) + (c * 9 + tap) * 128 + b_lane[k]) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(bst + stg * STG_B + (wave * NBPW + k) * 1024),
+                                               16, (int)voff, 0, 0, 0);
+    }
+  };
+  const int arow0 = (64 * wm + l31) * 128;
+  int kc[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) kc[s] = 2 * s + lh;
+  int boff[WN][4];
+#pragma unroll
+  for (int cb = 0; cb < WN; ++cb) {
+    const int n = (NTILE / 2) * wn + 32 * cb + l31;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) boff[cb][s] = n * 128 + (((2 * s + lh) ^ ((n >> 1) & 7)) << 4);
+  }
+  const float inv_w = 1.0f / (float)a.W, inv_h = 1.0f / (float)a.H;
+  int ph[2], pw[2];
+  int mt = i_begin / a.ntiles, nt = i_begin - mt * a.ntiles;
+  {
+    const int HW = a.H * a.W;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int m = mt * RG_BM + 64 * wm + 32 * rb + l31;
+      const int rem = m % HW;
+      ph[rb] = rem / a.W;
+      pw[rb] = rem - ph[rb] * a.W;
+    }
+  }
+  auto advance_mtile = [&]() {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int x = pw[rb] + RG_BM;
+      const int q1 = (int)(((float)x + 0.5f) * inv_w);
+      pw[rb] = x - q1 * a.W;
+      const int y = ph[rb] + q1;
+      const int q2 = (int)(((float)y + 0.5f) * inv_h);
+      ph[rb] = y - q2 * a.H;
+    }
+  };
+
+  // ---- epilogue of one item (coordinates passed in: it runs in the R(0) slot of the NEXT item)
+  constexpr int NBLK = 2 * WN;
+  const int row0 = lane >> 3, c4 = (lane & 7) * 4;
+  f32x16 acc[2][WN];
+  typedef typename std::conditional<RES == 2, u32x2, u32x4>::type rq_t;
+  rq_t rq[2][4];
+  // Output addressing: element offset = ebase(item) + (32*rb + 8*i) * N + 32*cb, one add per store; a position past
+  // M lies past num_records (dropped by the buffer unit), a channel past N is sent there by hand.
+  auto ebase_of = [&](int mt_e, int nt_e) -> int {
+    return (mt_e * RG_BM + 64 * wm + row0) * a.N + nt_e * NTILE + (NTILE / 2) * wn + c4;
+  };
+  auto req = [&](int eb, unsigned chm, int b, rq_t* dst) {  // residual quads of block b
+    if constexpr (RES != 0) {
+      const int cb = b >> 1, rb = b & 1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int eo = eb + (32 * rb + 8 * i) * a.N + 32 * cb;
+        const int bo = ((chm >> cb) & 1u) ? eo * RSZ : (int)OOB;
+        if constexpr (RES == 2) dst[i] = __builtin_bit_cast(rq_t, __builtin_amdgcn_raw_buffer_load_b64(rsR, bo, 0, 0));
+        else dst[i] = __builtin_bit_cast(rq_t, __builtin_amdgcn_raw_buffer_load_b128(rsR, bo, 0, 0));
+      }
+    }
+  };
+  auto chmask_of = [&](int nt_e) -> unsigned {             // bit cb: this lane's 4 channels of column block cb exist
+    unsigned m = 0;
+#pragma unroll
+    for (int cb = 0; cb < WN; ++cb)
+      if (nt_e * NTILE + (NTILE / 2) * wn + 32 * cb + c4 < a.N) m |= 1u << cb;
+    return m;
+  };
+  const float act_floor = (a.act & 15) == 1 ? 0.f : -__builtin_inff();      // y = max(x, floor): ReLU or identity
+  const bool post = (a.act & 16) != 0;
+  auto epilogue = [&](int mt_e, int nt_e, int phl) {
+    float* cs = reinterpret_cast<float*>(win0 + phl * win_bytes + wave * RG_SLAB);
+    const int eb = ebase_of(mt_e, nt_e);
+    const unsigned chm = chmask_of(nt_e);
+    f32x4 sc4[WN], sh4[WN];
+#pragma unroll
+    for (int cb = 0; cb < WN; ++cb) {
+      const int nl = nt_e * NTILE + (NTILE / 2) * wn + 32 * cb + c4;
+      sc4[cb] = *reinterpret_cast<const f32x4*>(sc_lds + nl);
+      sh4[cb] = *reinterpret_cast<const f32x4*>(sc_lds + a.ntiles * NTILE + nl);
+    }
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+      const int cb = b >> 1, rb = b & 1;
+      if (b + 1 < NBLK) req(eb, chm, b + 1, rq[(b + 1) & 1]);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(cs + l31 * 36 + 8 * g + 4 * lh) =
+            f32x4{acc[rb][cb][4 * g], acc[rb][cb][4 * g + 1], acc[rb][cb][4 * g + 2], acc[rb][cb][4 * g + 3]};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(cs + (8 * i + row0) * 36 + c4);
+        v = v * sc4[cb] + sh4[cb];
+        if constexpr (RES != 0) {
+          f32x4 rv;
+          if constexpr (RES == 2) {
+            const bf16x4 t = __builtin_bit_cast(bf16x4, rq[b & 1][i]);
+            rv = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+          } else {
+            rv = __builtin_bit_cast(f32x4, rq[b & 1][i]);
+          }
+          const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+          v += post ? zero : rv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], act_floor);
+          v += post ? rv : zero;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], act_floor);
+        }
+        const int eo = eb + (32 * rb + 8 * i) * a.N + 32 * cb;
+        const int bo = ((chm >> cb) & 1u) ? eo * ESZ : (int)OOB;
+        if constexpr (OUTB) {
+          bf16x4 o;
+          o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rsC, bo, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, bo, 0, 0);
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // slab reads done before this wave's loads may land in that window
+  };
+
+  // ---- prologue: window of the first phase, weights of k-tiles 0 .. LEAD-1; everything landed and published
+  const int total_ph = nitems * a.NC;
+  for (int j = wave; j < PA; j += NWAVES) issue_a(mt, 0, 0, j, true);
+#pragma unroll
+  for (int s = 0; s < LEAD; ++s) issue_b(nt, 0, s, s, true);                          // (LEAD <= 3 < 9 k-tiles of a chunk)
+  wait_vm<0>();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (grp == 1) __builtin_amdgcn_s_barrier();              // group 1 runs one slot behind
+  int stg = 0;
+  int mt_p = 0, nt_p = 0, phl_p = 0;
+  bool have_prev = false;
+
+  for (int li = 0; li < nitems; ++li) {
+    int mt1 = mt, nt1 = nt + 1;
+    if (nt1 == a.ntiles) { nt1 = 0; ++mt1; }
+    const bool more = li + 1 < nitems;
+    unsigned mask[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int m = mt * RG_BM + 64 * wm + 32 * rb + l31;
+      unsigned mk = 0;
+      if (m < a.M) {
+        unsigned colm = 0;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+          if ((unsigned)(pw[rb] - 1 + kw) < (unsigned)a.W) colm |= 1u << kw;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+          if ((unsigned)(ph[rb] - 1 + kh) < (unsigned)a.H) mk |= colm << (3 * kh);
+      }
+      mask[rb] = mk;
+    }
+    for (int c = 0; c < a.NC; ++c) {
+      const int phg = li * a.NC + c;
+      const char* win = win0 + (phg & 1) * win_bytes;
+      const bool has_next = phg + 1 < total_ph;
+      const bool last_c = c + 1 == a.NC;
+      const int mt_n = last_c ? mt1 : mt, c_n = last_c ? 0 : c + 1;
+      char* const zrow = dump;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        // ================= R slot
+        if (tap == 0 && c == 0) {
+          RG_STAMP(0);
+          // the previous item's epilogue, both groups side by side: group 0 is in its R(0) slot, group 1 — one slot
+          // behind — still in its M(8) slot, whose closing barrier it takes only now
+          if (have_prev) {
+            epilogue(mt_p, nt_p, phl_p);
+            if (grp == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+          }
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < WN; ++cb)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.f;
+          RG_STAMP(1);
+        }
+        if (tap == 4 && c == 0) RG_STAMP(2);
+        // operations this wave issues in this R slot / issued in its previous one (folds: tap is unrolled)
+        const int n_now = NBPW + sl_of(tap) + ((RES != 0 && tap == 7 && last_c) ? 4 : 0);
+        const char* bs = bst + stg * STG_B;
+        const int toff = (tap / 3) * a.W + (tap % 3);
+        f32x4 afr[2][4], bfr[WN][4];
+        {
+          const char* arow[2];
+          unsigned sw[2];
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb) {
+            const int idx = 64 * wm + 32 * rb + l31 + toff;
+            sw[rb] = (unsigned)((idx >> 1) & 7);
+            arow[rb] = ((mask[rb] >> tap) & 1u) ? win + arow0 + (32 * rb + toff) * 128 : zrow;
+          }
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            bfr[0][s] = *reinterpret_cast<const f32x4*>(bs + boff[0][s]);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) afr[rb][s] = *reinterpret_cast<const f32x4*>(arow[rb] + ((kc[s] ^ sw[rb]) << 4));
+          }
+#pragma unroll
+          for (int cb = 1; cb < WN; ++cb)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) bfr[cb][s] = *reinterpret_cast<const f32x4*>(bs + boff[cb][s]);
+        }
+        __builtin_amdgcn_sched_barrier(0);                   // (the reads go out first: their latency runs under the issue below)
+        {
+          const int s2 = stg + LEAD >= RG_NSTB ? stg + LEAD - RG_NSTB : stg + LEAD;
+          if (tap + LEAD < 9) issue_b(nt, c, tap + LEAD, s2, true);
+          else if (!last_c) issue_b(nt, c + 1, tap + LEAD - 9, s2, true);
+          else issue_b(nt1, 0, tap + LEAD - 9, s2, more);
+#pragma unroll
+          for (int i = 0; i < sl_of(tap); ++i)
+            issue_a(mt_n, c_n, (phg + 1) & 1, (2 * (tap - 1) + i) * NWAVES + wave, has_next);
+          if constexpr (RES != 0) {
+            if (tap == 7 && last_c) req(ebase_of(mt, nt), chmask_of(nt), 0, rq[0]);
+          }
+        }
+        // confirm the weights this wave issued in its previous R slot (in-order completion), all fragment reads returned
+        // (a slot issues weights first, then window slices / the early residual: those younger operations of the
+        //  oldest slot still counted may stay in flight too — the slices are HBM reads, not needed before the next phase)
+        const int young = sl_of((tap + 8) % 9) + ((RES != 0 && tap == 8 && last_c) ? 4 : 0);
+        wait_vm_n(n_now + young);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (tap == 4 && c == 0) RG_STAMP(3);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (tap == 4 && c == 0) RG_STAMP(4);
+        __builtin_amdgcn_sched_barrier(0);
+        // ================= M slot
+#pragma unroll
+        for (int cb = 0; cb < WN; ++cb)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            if constexpr (BF16) {
+#pragma unroll
+              for (int rb = 0; rb < 2; ++rb)
+                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bfr[cb][s]), __builtin_bit_cast(bf16x8, afr[rb][s]),
+                                                                      acc[rb][cb], 0, 0, 0);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[cb][s][e], afr[rb][s][e], acc[rb][cb], 0, 0, 0);
+            }
+          }
+        __builtin_amdgcn_sched_barrier(0);
+        if (tap == 4 && c == 0) RG_STAMP(5);
+        if (!(tap == 8 && last_c && grp == 1)) __builtin_amdgcn_s_barrier();      // (group 1, end of an item: after its epilogue)
+        asm volatile("" ::: "memory");
+        if (tap == 4 && c == 0) RG_STAMP(6);
+        stg = stg + 1 == RG_NSTB ? 0 : stg + 1;
+      }
+    }
+    mt_p = mt; nt_p = nt; phl_p = (li * a.NC + a.NC - 1) & 1; have_prev = true;
+    if (mt1 != mt) advance_mtile();
+    mt = mt1; nt = nt1;
+  }
+  // ---- tail: the last item's epilogue, group 0 one slot before group 1
+  epilogue(mt_p, nt_p, phl_p);
+  __builtin_amdgcn_s_barrier();
+}
+
+
 // Tile configuration (host logic).  Small maps (W <= 29 with 128 channels per tile, W <= 61 with 64): the 128-position
 // tile on 4 waves with 2 weight stages fits 80 KB of LDS, so TWO workgroups share a CU (CADRE_RING_WVM forces 2 / 4).
 // Channel tile 128 unless N < 128 (CADRE_RING_NTILE forces one for A/B runs).
-struct ring_cfg { int wvm, ntile, bm, wpx, wgs; size_t lds; long long items; };
-static void ring_pick(long long M, int W, int N, ring_cfg* c) {
+struct ring_cfg { int wvm, ntile, bm, wpx, wgs, pp; size_t lds; long long items; };
+static void ring_pick(long long M, int W, int N, int bf16, ring_cfg* c) {
   static const int force_nt = [] { const char* e = getenv("CADRE_RING_NTILE"); return e ? atoi(e) : 0; }();
   static const int force_wvm = [] { const char* e = getenv("CADRE_RING_WVM"); return e ? atoi(e) : 0; }();
   int ntile = N >= 128 ? 128 : 64;
@@ -431,11 +787,17 @@ static void ring_pick(long long M, int W, int N, ring_cfg* c) {
   // four rounds of work (the 9x9 head convs) the larger tile wins (865 vs 752 TFLOP/s bf16)
   const long long items2 = ((M + 127) / 128) * ((N + ntile - 1) / ntile);
   int wvm = (l2 <= 80 * 1024 && 10 * 4 >= (wpx2 >> 3) && items2 >= 4 * 512) ? 2 : 4;     // (window slices must fit the 10 x 4 issue slots)
+  // bf16: the 8-wave ping-pong kernel beats two 4-wave workgroups per CU on every trunk shape (layer3: 1134 vs 990 TFLOP/s)
+  static const int force_pp = [] { const char* e = getenv("CADRE_RING_PP"); return e ? atoi(e) : 1; }();
+  if (bf16 && force_pp > 0) wvm = 4;
   if (force_wvm == 2 && l2 <= 80 * 1024 && 10 * 4 >= (wpx2 >> 3)) wvm = 2;
   if (force_wvm == 4) wvm = 4;
   c->wvm = wvm; c->ntile = ntile; c->bm = 64 * wvm;
   c->wpx = wvm == 2 ? wpx2 : wpx4;
   c->lds = wvm == 2 ? l2 : l4;
+  // 8-wave tile in bf16: the ping-pong kernel (fp32 k-tiles are 4x longer: the lockstep turn costs them 10 %, and a
+  // single wave per SIMD feeding the pipe costs more — 3.12 vs 3.00 ms on layer1; CADRE_RING_PP=0 / 2 force off / on)
+  c->pp = (wvm == 4 && ((bf16 && force_pp > 0) || force_pp == 2)) ? 1 : 0;
   c->items = ((M + c->bm - 1) / c->bm) * ((N + ntile - 1) / ntile);
   const int slots = wvm == 2 ? 512 : 256;                            // persistent workgroups: 2 or 1 per CU
   c->wgs = (int)(c->items < slots ? c->items : slots);
@@ -450,12 +812,12 @@ static int ring_capable(int F, int H, int W, int Cin, int N, int bf16) {      //
   const long long M = (long long)F * H * W;
   if (M * Cin * eb >= (1ll << 31) || M * N * 4 >= (1ll << 31) || (long long)N * Cin * 9 * eb >= (1ll << 31)) return 0;
   ring_cfg c;
-  ring_pick(M, W, N, &c);
+  ring_pick(M, W, N, bf16, &c);
   return c.lds <= 160 * 1024;
 }
 extern "C" int cadre_conv3x3_ring_supported(int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t bf16) {
   if (g_ring_mode == 0 || !ring_capable(F, H, W, Cin, N, bf16)) return 0;
-  if (g_ring_mode == 1 && N > (bf16 ? 256 : 64)) return 0;
+  if (g_ring_mode == 1 && !bf16 && N > 64) return 0;      // fp32: the tile kernels win from N = 128 on
   return 1;
 }
 
@@ -463,9 +825,8 @@ extern "C" int cadre_conv3x3_ring_supported(int32_t F, int32_t H, int32_t W, int
 // instantiation conv3x3_ring_kernel<bf16, ntile, res, out_bf16, WVM> for profiles)
 extern "C" int cadre_conv3x3_ring_ntile(int32_t F, int32_t H, int32_t W, int32_t N, int32_t bf16) {
   ring_cfg c;
-  (void)bf16;
-  ring_pick((long long)F * H * W, W, N, &c);
-  return c.ntile + 1000 * c.wvm;
+  ring_pick((long long)F * H * W, W, N, bf16, &c);
+  return c.ntile + 1000 * c.wvm + 100000 * c.pp;
 }
 
 #ifdef RING_TRACE
@@ -485,7 +846,7 @@ extern "C" int cadre_conv3x3_ring(const void* x, const void* w, const float* sca
   a.M = F * H * W; a.H = H; a.W = W; a.Cin = Cin; a.N = N; a.NC = Cin * (bf16 ? 2 : 4) / 128;
   a.act = act; a.out_bf16 = out_bf16; a.resid_bf16 = resid_bf16;
   ring_cfg cfg;
-  ring_pick(a.M, W, N, &cfg);
+  ring_pick(a.M, W, N, bf16, &cfg);
   const int ntile = cfg.ntile;
   a.mtiles = (a.M + cfg.bm - 1) / cfg.bm;
   a.ntiles = (N + ntile - 1) / ntile;
@@ -504,9 +865,16 @@ extern "C" int cadre_conv3x3_ring(const void* x, const void* w, const float* sca
     (void)hipFuncSetAttribute((const void*)conv3x3_ring_kernel<BF, NT_, RS_, OB_, WV_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
     hipLaunchKernelGGL((conv3x3_ring_kernel<BF, NT_, RS_, OB_, WV_>), dim3(grid), dim3(128 * WV_), lds, st, a); \
   } while (0)
+#define RG_PP(BF, NT_, RS_, OB_)                                                                                 \
+  do {                                                                                                           \
+    (void)hipFuncSetAttribute((const void*)conv3x3_ring_pp_kernel<BF, NT_, RS_, OB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL((conv3x3_ring_pp_kernel<BF, NT_, RS_, OB_>), dim3(grid), dim3(512), lds, st, a);          \
+  } while (0)
 #define RG_NT(BF, RS_, OB_)                                                                                      \
   do {                                                                                                           \
-    if (cfg.wvm == 4) {                                                                                          \
+    if (cfg.wvm == 4 && cfg.pp) {                                                                                \
+      if (ntile == 128) RG_PP(BF, 128, RS_, OB_); else RG_PP(BF, 64, RS_, OB_);                                  \
+    } else if (cfg.wvm == 4) {                                                                                   \
       if (ntile == 128) RG_LAUNCH(BF, 128, RS_, OB_, 4);                                                      \
       else RG_LAUNCH(BF, 64, RS_, OB_, 4);                                                                    \
     } else { if (ntile == 128) RG_LAUNCH(BF, 128, RS_, OB_, 2); else RG_LAUNCH(BF, 64, RS_, OB_, 2); }     \
@@ -520,6 +888,7 @@ extern "C" int cadre_conv3x3_ring(const void* x, const void* w, const float* sca
     if (resid) RG_NT(false, 1, false); else RG_NT(false, 0, false);
   }
 #undef RG_NT
+#undef RG_PP
 #undef RG_LAUNCH
   return (int)hipGetLastError();
 }

@@ -187,7 +187,8 @@ def conv3x3_c64_bf16(x, w, scale, shift, resid, out, F, H, W, relu):
 
 def conv3x3_ring(x, w_ring, scale, shift, resid, out, F, H, W, Cin, N, act):
     """cadre_conv3x3_ring (3x3 / s1 / p1, each pixel through LDS once per channel chunk); profiling key
-    ("ring", bf16, ntile, res, out_bf16, WVM) = the template arguments of conv3x3_ring_kernel."""
+    ("ring", bf16, ntile, res, out_bf16, WVM, pp): pp 0 = conv3x3_ring_kernel<bf16, ntile, res, out_bf16, WVM>,
+    pp 1 = conv3x3_ring_pp_kernel<bf16, ntile, res, out_bf16> (the 8-wave ping-pong kernel)."""
     bf = x.dtype == torch.bfloat16
     flags = (1 if bf else 0) | (2 if out.dtype == torch.bfloat16 else 0) | (4 if (resid is not None and resid.dtype == torch.bfloat16) else 0)
     fn = lib().cadre_conv3x3_ring
@@ -201,7 +202,7 @@ def conv3x3_ring(x, w_ring, scale, shift, resid, out, F, H, W, Cin, N, act):
     e1.record()
     M, esz = F * H * W, (2 if bf else 4)
     nbytes = M * Cin * esz + N * 9 * Cin * esz + M * N * out.element_size() + (M * N * resid.element_size() if resid is not None else 0)
-    code = lib().cadre_conv3x3_ring_ntile(F, H, W, N, 1 if bf else 0)      # ntile + 1000 * WVM
+    code = lib().cadre_conv3x3_ring_ntile(F, H, W, N, 1 if bf else 0)      # ntile + 1000 * WVM + 100000 * ping-pong
     res = 0 if resid is None else (2 if resid.dtype == torch.bfloat16 else 1)
-    key = ("ring", bf, code % 1000, res, out.dtype == torch.bfloat16, code // 1000)
+    key = ("ring", bf, code % 1000, res, out.dtype == torch.bfloat16, code // 1000 % 100, code // 100000)
     PROFILE.append((key, 2.0 * M * N * 9 * Cin, e0, e1, (M, N, 9 * Cin, 1, 1, 0), nbytes))

@@ -23,12 +23,13 @@ def main():
     ap.add_argument("--shape", type=int, nargs=5, default=(1024, 72, 72, 64, 64), metavar=("F", "H", "W", "CIN", "N"))
     ap.add_argument("--resid", type=int, default=0)
     ap.add_argument("--build-only", action="store_true")
+    ap.add_argument("--mode", type=int, default=1, help="1: sections of an item; 2: inside k-tiles 4 and 5 of the first chunk")
     args = ap.parse_args()
-    so = os.path.join(ROOT, "tools", "_trace", "libcadre_trace.so")       # (git-ignored; build it before gpurun: --build-only)
+    so = os.path.join(ROOT, "tools", "_trace", "libcadre_trace%d.so" % args.mode)    # (git-ignored; build before gpurun: --build-only)
     if args.build_only or not os.path.exists(so):
         os.makedirs(os.path.dirname(so), exist_ok=True)
         srcs = [os.path.join(ROOT, "cadre_amd", "csrc", f) for f in ("conv3x3_ring.hip", "cadre_kernels.hip")]
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DRING_TRACE",
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DRING_TRACE=%d" % args.mode,
                                "-o", so] + srcs)
         if args.build_only:
             return
@@ -60,6 +61,27 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     t = trace.cpu().numpy().reshape(512, 64, 8)
+    if args.mode == 1 and t[:, :, 6].any():                  # ping-pong kernel: wave 0 (group 0) of even workgroups, wave 4 (group 1) of odd
+        for gname, sel in (("group 0 (wave 0)", slice(0, None, 2)), ("group 1 (wave 4)", slice(1, None, 2))):
+            tt = t[sel]
+            live = tt[:, :, 6] != 0
+            live[:, 0] = False
+            d = np.diff(tt[:, :, :7], axis=2)[live]
+            item = (tt[:, 1:, 0] - tt[:, :-1, 0])[live[:, 1:] & (tt[:, :-1, 0] != 0)]
+            print("%s %s F=%d %dx%d %d->%d resid=%d: %.3f ms, %d items" % (gname, args.dtype, F, H, W, Cin, N, args.resid, e0.elapsed_time(e1), d.shape[0]))
+            for i, n in enumerate(["epilogue+clear", "k-tiles 0..3", "R(4): issue+reads+wait", "barrier A", "M(4)", "barrier B"]):
+                print("  %-24s mean %7.0f  median %7.0f  p90 %7.0f" % (n, d[:, i].mean(), np.median(d[:, i]), np.percentile(d[:, i], 90)))
+            print("  %-24s mean %7.0f" % ("item", item.mean()))
+        return
+    if args.mode == 2:
+        live = (t[:, :, 6] != 0)
+        live[:, 0] = False
+        d = np.diff(t[:, :, :7], axis=2)[live]
+        print("%s F=%d %dx%d %d->%d resid=%d: %.3f ms, %d items traced (wave 0, k-tile 4 then 5 of chunk 0)" % (
+            args.dtype, F, H, W, Cin, N, args.resid, e0.elapsed_time(e1), d.shape[0]))
+        for i, n in enumerate(["wait vmcnt", "barrier", "issue DMA", "reads+MFMA", "wait vmcnt'", "barrier'"]):
+            print("  %-12s mean %7.0f  median %7.0f  p90 %7.0f" % (n, d[:, i].mean(), np.median(d[:, i]), np.percentile(d[:, i], 90)))
+        return
     live = t[:, :, 5] != 0
     live[:, 0] = False                                    # first item of a workgroup: cold start
     d = np.diff(t[:, :, :6], axis=2)[live]                # [n, 5]
