@@ -49,6 +49,7 @@ struct ring_args {
   int out_bf16, resid_bf16;
   int mtiles, ntiles, items, ipw;      // M tiles of 256, N tiles, work items, items per workgroup
   int WPX;                // window pixels (multiple of 8, >= 288)
+  int prio;               // ping-pong kernel: raise the wave priority in the staging slots
 #ifdef RING_TRACE
   long long* trace;       // tools/ring_trace.py: per (workgroup, item) 6 shader-clock stamps of wave 0
 #endif
@@ -661,7 +662,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
       char* const zrow = dump;
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
-        // ================= R slot
+        // ================= R slot (at raised priority: its few instructions go between the other group's MFMAs)
+        if (a.prio) __builtin_amdgcn_s_setprio(2);
         if (tap == 0 && c == 0) {
           RG_STAMP(0);
           // the previous item's epilogue, both groups side by side: group 0 is in its R(0) slot, group 1 — one slot
@@ -727,6 +729,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (tap == 4 && c == 0) RG_STAMP(4);
+        if (a.prio) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         // ================= M slot
 #pragma unroll
@@ -795,9 +798,10 @@ static void ring_pick(long long M, int W, int N, int bf16, ring_cfg* c) {
   c->wvm = wvm; c->ntile = ntile; c->bm = 64 * wvm;
   c->wpx = wvm == 2 ? wpx2 : wpx4;
   c->lds = wvm == 2 ? l2 : l4;
-  // 8-wave tile in bf16: the ping-pong kernel (fp32 k-tiles are 4x longer: the lockstep turn costs them 10 %, and a
-  // single wave per SIMD feeding the pipe costs more — 3.12 vs 3.00 ms on layer1; CADRE_RING_PP=0 / 2 force off / on)
-  c->pp = (wvm == 4 && ((bf16 && force_pp > 0) || force_pp == 2)) ? 1 : 0;
+  // 8-wave tile in bf16: the ping-pong kernel.  (fp32 k-tiles are 4x longer, the lockstep turn costs them 10 %; in
+  // ping-pong the staging wave's instructions are starved by the other group's back-to-back 64-cycle MFMAs — its R slot
+  // lasts as long as their M slot, traced — and layer1 takes 3.12 instead of 3.00 ms: fp32 stays on the lockstep kernel.)
+  c->pp = (wvm == 4 && bf16 && force_pp > 0) ? 1 : 0;
   c->items = ((M + c->bm - 1) / c->bm) * ((N + ntile - 1) / ntile);
   const int slots = wvm == 2 ? 512 : 256;                            // persistent workgroups: 2 or 1 per CU
   c->wgs = (int)(c->items < slots ? c->items : slots);
@@ -834,6 +838,14 @@ static long long* g_ring_trace = nullptr;
 extern "C" void cadre_ring_set_trace(void* p) { g_ring_trace = (long long*)p; }
 #endif
 
+template <bool BF, int NT, int RS, bool OB>
+static void ring_launch_pp(const ring_args& a, int grid, size_t lds, hipStream_t st) {
+  if constexpr (BF) {                                      // (bf16 only: see ring_pick)
+    (void)hipFuncSetAttribute((const void*)conv3x3_ring_pp_kernel<true, NT, RS, OB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((conv3x3_ring_pp_kernel<true, NT, RS, OB>), dim3(grid), dim3(512), lds, st, a);
+  }
+}
+
 extern "C" int cadre_conv3x3_ring(const void* x, const void* w, const float* scale, const float* shift, const void* resid,
                                   void* out, int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t act,
                                   int32_t flags, void* stream) {
@@ -854,6 +866,8 @@ extern "C" int cadre_conv3x3_ring(const void* x, const void* w, const float* sca
   a.ipw = (a.items + cfg.wgs - 1) / cfg.wgs;
   const int grid = (a.items + a.ipw - 1) / a.ipw;
   a.WPX = cfg.wpx;
+  static const int prio = [] { const char* e = getenv("CADRE_RING_PRIO"); return e ? atoi(e) : 1; }();   // (+1-3 % on every bf16 shape)
+  a.prio = prio;
 #ifdef RING_TRACE
   a.trace = g_ring_trace;
 #endif
@@ -865,11 +879,7 @@ extern "C" int cadre_conv3x3_ring(const void* x, const void* w, const float* sca
     (void)hipFuncSetAttribute((const void*)conv3x3_ring_kernel<BF, NT_, RS_, OB_, WV_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
     hipLaunchKernelGGL((conv3x3_ring_kernel<BF, NT_, RS_, OB_, WV_>), dim3(grid), dim3(128 * WV_), lds, st, a); \
   } while (0)
-#define RG_PP(BF, NT_, RS_, OB_)                                                                                 \
-  do {                                                                                                           \
-    (void)hipFuncSetAttribute((const void*)conv3x3_ring_pp_kernel<BF, NT_, RS_, OB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    hipLaunchKernelGGL((conv3x3_ring_pp_kernel<BF, NT_, RS_, OB_>), dim3(grid), dim3(512), lds, st, a);          \
-  } while (0)
+#define RG_PP(BF, NT_, RS_, OB_) ring_launch_pp<BF, NT_, RS_, OB_>(a, grid, lds, st)
 #define RG_NT(BF, RS_, OB_)                                                                                      \
   do {                                                                                                           \
     if (cfg.wvm == 4 && cfg.pp) {                                                                                \
