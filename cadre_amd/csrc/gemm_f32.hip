@@ -537,6 +537,8 @@ extern thread_local char g_cadre_err[256];
 int cadre_fail(const char* msg);
 
 int cadre_conv_stream_f32_launch(const cadre_gemm_t& p, void* stream);     // conv_stream_f32.hip (tile 12)
+int cadre_gemm_f32_skinny_ok(const cadre_gemm_t& p);                       // gemm_f32_skinny.hip (tile 11)
+int cadre_gemm_f32_skinny_launch(const cadre_gemm_t& p, void* stream);
 
 #define GEMM_CHECK(cond, msg) \
   if (!(cond)) return cadre_fail("cadre_gemm_f32: " msg)
@@ -562,7 +564,11 @@ static int pick_tile(const cadre_gemm_t& p) {
   if (p.a_mode == 3 && batch == 1 && sk == 1 && !p.seg_mode && p.M >= 64 * 2048 &&
       ((p.N | p.ldc | (p.resid ? p.ldr : 0)) & 3) == 0 && (((uintptr_t)p.C | (uintptr_t)p.resid) & 15) == 0)
     return 12;
-  // row-sorted minibatch (each batch entry owns one run of rows per period): 32-row tiles skip the most
+  // row-sorted minibatch (each batch entry owns one run of rows per period): 32-row tiles skip the most.  The
+  // register-direct kernel (gemm_f32_skinny.hip, tile 11) is opt-in: measured on the update's launches it only wins the
+  // backward at B = 64 (31 vs 39 us with the split-K pass) and loses the forward at B = 256 (39.5 vs 23.8 us)
+  static const int skinny = [] { const char* e = getenv("CADRE_SKINNY_GEMM"); return e ? atoi(e) : 0; }();
+  if (p.seg_mode == 1 && skinny && cadre_gemm_f32_skinny_ok(p)) return 11;
   if (p.seg_mode == 1 && (p.N >= 96 || p.seg_period % 64 != 0)) return 9;
   const Cand* c = p.N <= 64 ? narrow : (p.a_mode >= 2 ? big_conv : big);
   int best = c[0].id;
@@ -638,6 +644,10 @@ extern "C" int cadre_gemm_f32(const cadre_gemm_t* pp, void* stream) {
     GEMM_CHECK(p.batch == 1 && p.split_k == 1 && ((p.N | p.ldc) & 3) == 0 && !p.resid, "bf16 output needs the vector epilogue, no batch/split/resid");
   int tile = p.tile ? p.tile : pick_tile(p);
   if (tile == 12) return cadre_conv_stream_f32_launch(p, stream);      // 64x64 conv, several M-tiles per workgroup
+  if (tile == 11) {                                                    // skinny products of the PPO update
+    if (!cadre_gemm_f32_skinny_ok(p)) return cadre_fail("cadre_gemm_f32: tile 11 (skinny) does not take this descriptor");
+    return cadre_gemm_f32_skinny_launch(p, stream);
+  }
   hipStream_t st = (hipStream_t)stream;
   if (tile < 1 || tile > 10 || tile == 7) return cadre_fail("cadre_gemm_f32: bad tile");
   // 9: 32x128 on 4 waves (1x4) for row-sorted skinny GEMMs; 10: 128x64 on 8 waves (4x2) for N <= 64 convs

@@ -175,6 +175,7 @@ class PPOLearnerHIP:
         sgM2 = None if seg is None else (1, seg, B, 2)  # M tiles, z = 2*net + tower
         sgK1 = None if seg is None else (2, seg, B, 1)  # k tiles (rows), z = net
         sgK2 = None if seg is None else (2, seg, B, 2)
+        skinny = seg is not None and os.environ.get("CADRE_SKINNY_GEMM", "0") != "0"     # (opt-in: cadre_gemm_f32 tile 11, see gemm_f32.hip)
         self._forward(w, B, (0, 1, Z), C, seg=seg)
         O3, dO3 = w["O3"], w["dO3"]
         hip.check(L.cadre_ppo_loss(hip.ptr(O3), NP, 2 * B * NP, hip.ptr(O3[1]), NP, 2 * B * NP,
@@ -218,7 +219,10 @@ class PPOLearnerHIP:
                                                  hip.ptr(dC), B * DP, hip.ptr(TC[:, t + 1]), hip.ptr(Cs[:, t]),
                                                  (S + 1) * B * DP, 1, DP, (S + 1) * B * DP, B, a.D, Z, cmd, C, st),
                       "cadre_lstm_pointwise_bwd")
-            if t > 0:   # dh_{t-1} = dG_t W_hh : tiny output, K = 2120 -> split-K so >500 workgroups stream W_hh
+            if t > 0 and skinny:   # dh_{t-1} = dG_t W_hh, K = 2120: the K slices meet inside the workgroup (tile 11)
+                hip.gemm(dG[:, t], pL[a.o_whh:], dH, B, DP, H4, H4, DP, DP, b_mode=1, batch=Z,
+                         a_z=(1, 0, S * B * H4), b_z=(1, 0, sL), c_z=(1, 0, B * DP), seg=sgM1)
+            elif t > 0:            # tile kernels: split-K so that >500 workgroups stream W_hh, then a reduction pass
                 hip.gemm(dG[:, t], pL[a.o_whh:], w["dHs"], B, DP, H4, H4, DP, DP, b_mode=1, batch=Z,
                          a_z=(1, 0, S * B * H4), b_z=(1, 0, sL), c_z=(1, 0, B * DP), split_k=self.SPLIT_DH, seg=sgM1)
                 hip.check(L.cadre_splitk_reduce(hip.ptr(w["dHs"]), self.SPLIT_DH, Z * B * DP, DP, hip.ptr(dH), DP,

@@ -507,6 +507,7 @@ def test_sort_rows_and_permute(hip):
 
 @pytest.mark.parametrize("P,tile,BM,segs", [(128, 3, 64, [[0, 40], [40, 0], [40, 70], [110, 18]]),
                                             (128, 9, 32, [[0, 40], [40, 0], [40, 70], [110, 18]]),
+                                            (128, 11, 32, [[0, 40], [40, 0], [40, 70], [110, 18]]),
                                             (96, 0, 32, [[0, 10], [10, 30], [40, 0], [40, 56]]),     # 32-row periods: auto -> tile 9
                                             (64, 0, 32, [[0, 16], [16, 16], [32, 31], [63, 1]])])
 def test_gemm_row_segments(hip, P, tile, BM, segs):
@@ -548,6 +549,63 @@ def test_gemm_row_segments(hip, P, tile, BM, segs):
     for z in range(Z):
         if int(seg[z, 1]) == 0:
             assert float(dW[z].abs().max()) == 0.0                                        # empty net: exact zeros
+
+
+@pytest.mark.parametrize("B", [1, 24, 64, 256])
+def test_gemm_skinny_update_shapes(hip, B):
+    """Tile 11 (gemm_f32_skinny.hip: fragments straight from global memory, four K slices per workgroup summed in LDS)
+    on the products of one LSTM step of update_policy (models.py:139-152): the recurrent forward
+    gates = h W_hh^T + b_hh + gates (in place, row segments), the backward dh = dG W_hh (k-major B, K = 2120), and a
+    ReLU tower layer — against float64, and against the tile kernel it replaces."""
+    g = torch.Generator().manual_seed(5 + B)
+    Z, D, H4, hid = 8, 544, 2120, 128
+    # rows sorted by command: net z = head*4 + c owns one run of its head's B rows
+    cuts = sorted(torch.randint(0, B + 1, (3,), generator=g).tolist())
+    run = [(0, cuts[0]), (cuts[0], cuts[1] - cuts[0]), (cuts[1], cuts[2] - cuts[1]), (cuts[2], B - cuts[2])]
+    seg = torch.tensor(run + run, dtype=torch.int32)
+    sd_ = dev(seg)
+    use_seg = B % 32 == 0
+    sg = (1, sd_, B, 1) if use_seg else None
+    h = torch.randn(Z, B, D, generator=g); W = torch.randn(Z, H4, D, generator=g) * 0.05
+    b = torch.randn(Z, H4, generator=g); G0 = torch.randn(Z, B, H4, generator=g)
+    hd, Wd, bd = dev(h), dev(W), dev(b)
+    outs = {}
+    for tile in (11, 9):
+        G = dev(G0)
+        hip.gemm(hd, Wd, G, B, H4, D, D, D, H4, shift=bd, resid=G, ldr=H4, batch=Z, a_z=(1, 0, B * D), b_z=(1, 0, H4 * D),
+                 c_z=(1, 0, B * H4), s_z=(1, 0, H4), r_z=(1, 0, B * H4), seg=sg, tile=tile)
+        outs[tile] = G.cpu()
+    want = (torch.bmm(h.double(), W.double().transpose(1, 2)) + b.double()[:, None] + G0.double()).float()
+    for z in range(Z):
+        b0, c = (int(seg[z, 0]), int(seg[z, 1])) if use_seg else (0, B)
+        rows = slice(b0, b0 + c)
+        if c:
+            assert rel(outs[11][z, rows], want[z, rows]) < 2e-5
+            assert rel(outs[11][z, rows], outs[9][z, rows]) < 2e-5
+        for m0 in range(0, B, 32):                                                  # tiles outside the run: untouched
+            if use_seg and (c == 0 or m0 + 32 <= b0 or m0 >= b0 + c):
+                assert torch.equal(outs[11][z, m0:m0 + 32], G0[z, m0:m0 + 32])
+    # backward: dh = dG W_hh  ([B, 2120] x [2120, 544], k-major B)
+    dG = torch.randn(Z, B, H4, generator=g)
+    dGd = dev(dG)
+    dH = torch.full((Z, B, D), 3.0, device="cuda")
+    hip.gemm(dGd, Wd, dH, B, D, H4, H4, D, D, b_mode=1, batch=Z, a_z=(1, 0, B * H4), b_z=(1, 0, H4 * D), c_z=(1, 0, B * D),
+             seg=sg, tile=11)
+    wantH = torch.bmm(dG.double(), W.double()).float()
+    for z in range(Z):
+        b0, c = (int(seg[z, 0]), int(seg[z, 1])) if use_seg else (0, B)
+        if c:
+            assert rel(dH[z, b0:b0 + c].cpu(), wantH[z, b0:b0 + c]) < 2e-5
+    # a tower layer: relu(x W1^T + b1), 16 towers reading 8 inputs (a_div 2)
+    W1 = torch.randn(2 * Z, hid, D, generator=g) * 0.05; b1 = torch.randn(2 * Z, hid, generator=g)
+    A1 = torch.empty(2 * Z, B, hid, device="cuda")
+    hip.gemm(hd, dev(W1), A1, B, hid, D, D, D, hid, shift=dev(b1), act=1, batch=2 * Z, a_z=(2, 0, B * D), b_z=(1, 0, hid * D),
+             c_z=(1, 0, B * hid), s_z=(1, 0, hid), seg=None if sg is None else (1, sd_, B, 2), tile=11)
+    wantA = torch.relu(torch.bmm(h.double().repeat_interleave(2, 0), W1.double().transpose(1, 2)) + b1.double()[:, None]).float()
+    for z in range(2 * Z):
+        b0, c = (int(seg[z // 2, 0]), int(seg[z // 2, 1])) if use_seg else (0, B)
+        if c:
+            assert rel(A1[z, b0:b0 + c].cpu(), wantA[z, b0:b0 + c]) < 2e-5
 
 
 def test_conv_decode_random_geometries(hip):
