@@ -538,7 +538,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
   const int row0 = lane >> 3, c4 = (lane & 7) * 4;
   f32x16 acc[2][WN];
   typedef typename std::conditional<RES == 2, u32x2, u32x4>::type rq_t;
-  rq_t rq[2][4];
+  rq_t rq[NBLK][4];                                        // residual quads of every block: requested during the last k-tiles
   // Output addressing: element offset = ebase(item) + (32*rb + 8*i) * N + 32*cb, one add per store; a position past
   // M lies past num_records (dropped by the buffer unit), a channel past N is sent there by hand.
   auto ebase_of = [&](int mt_e, int nt_e) -> int {
@@ -577,9 +577,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
       sh4[cb] = *reinterpret_cast<const f32x4*>(sc_lds + a.ntiles * NTILE + nl);
     }
 #pragma unroll
+    for (int b = 2; b < NBLK; ++b) req(eb, chm, b, rq[b]);
+#pragma unroll
     for (int b = 0; b < NBLK; ++b) {
       const int cb = b >> 1, rb = b & 1;
-      if (b + 1 < NBLK) req(eb, chm, b + 1, rq[(b + 1) & 1]);
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         *reinterpret_cast<f32x4*>(cs + l31 * 36 + 8 * g + 4 * lh) =
@@ -591,10 +592,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
         if constexpr (RES != 0) {
           f32x4 rv;
           if constexpr (RES == 2) {
-            const bf16x4 t = __builtin_bit_cast(bf16x4, rq[b & 1][i]);
+            const bf16x4 t = __builtin_bit_cast(bf16x4, rq[b][i]);
             rv = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
           } else {
-            rv = __builtin_bit_cast(f32x4, rq[b & 1][i]);
+            rv = __builtin_bit_cast(f32x4, rq[b][i]);
           }
           const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
           v += post ? zero : rv;
@@ -682,7 +683,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
         }
         if (tap == 4 && c == 0) RG_STAMP(2);
         // operations this wave issues in this R slot / issued in its previous one (folds: tap is unrolled)
-        const int n_now = NBPW + sl_of(tap) + ((RES != 0 && tap == 7 && last_c) ? 4 : 0);
+        // (residual of output blocks 0 and 1: requested at k-tiles 7 and 8 of the item's last chunk — an HBM round trip
+        //  ahead of the epilogue that adds them; the later blocks when the epilogue starts, two blocks ahead)
+        auto n_res = [&](int t) -> int { return (RES != 0 && t >= 7) ? 4 : 0; };
+        const int n_now = NBPW + sl_of(tap) + (last_c ? n_res(tap) : 0);
         const char* bs = bst + stg * STG_B;
         const int toff = (tap / 3) * a.W + (tap % 3);
         f32x4 afr[2][4], bfr[WN][4];
@@ -716,13 +720,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
           for (int i = 0; i < sl_of(tap); ++i)
             issue_a(mt_n, c_n, (phg + 1) & 1, (2 * (tap - 1) + i) * NWAVES + wave, has_next);
           if constexpr (RES != 0) {
-            if (tap == 7 && last_c) req(ebase_of(mt, nt), chmask_of(nt), 0, rq[0]);
+            if (tap >= 7 && last_c) req(ebase_of(mt, nt), chmask_of(nt), tap - 7, rq[tap - 7]);
           }
         }
         // confirm the weights this wave issued in its previous R slot (in-order completion), all fragment reads returned
         // (a slot issues weights first, then window slices / the early residual: those younger operations of the
         //  oldest slot still counted may stay in flight too — the slices are HBM reads, not needed before the next phase)
-        const int young = sl_of((tap + 8) % 9) + ((RES != 0 && tap == 8 && last_c) ? 4 : 0);
+        const int young = sl_of((tap + 8) % 9) + (tap == 0 ? ((c == 0 && have_prev) ? n_res(8) : 0) : (last_c ? n_res(tap - 1) : 0));
         wait_vm_n(n_now + young);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (tap == 4 && c == 0) RG_STAMP(3);
