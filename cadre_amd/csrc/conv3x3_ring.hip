@@ -60,6 +60,11 @@ struct ring_args {
 #else
 #define RG_STAMP(k) do { } while (0)
 #endif
+#if defined(RING_TRACE) && RING_TRACE == 3      // ping-pong kernel: inside the staging slot of k-tile 4
+#define RG_SLOT(k) RG_STAMP_(k)
+#else
+#define RG_SLOT(k) do { } while (0)
+#endif
 #if defined(RING_TRACE) && RING_TRACE == 2      // inside k-tiles 4 and 5 of the first chunk
 #define RG_STEP(k) RG_STAMP_(k)
 #else
@@ -500,7 +505,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
   const int arow0 = (64 * wm + l31) * 128;
   int kc[4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) kc[s] = 2 * s + lh;
+  for (int s = 0; s < 4; ++s) kc[s] = (2 * s + lh) << 4;      // byte offset of the logical 16-B chunk of k-step s
   int boff[WN][4];
 #pragma unroll
   for (int cb = 0; cb < WN; ++cb) {
@@ -630,7 +635,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   if (grp == 1) __builtin_amdgcn_s_barrier();              // group 1 runs one slot behind
-  int stg = 0;
   int mt_p = 0, nt_p = 0, phl_p = 0;
   bool have_prev = false;
 
@@ -656,11 +660,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
     }
     for (int c = 0; c < a.NC; ++c) {
       const int phg = li * a.NC + c;
-      const char* win = win0 + (phg & 1) * win_bytes;
+      const int win_off = (phg & 1) * win_bytes;
       const bool has_next = phg + 1 < total_ph;
       const bool last_c = c + 1 == a.NC;
       const int mt_n = last_c ? mt1 : mt, c_n = last_c ? 0 : c + 1;
-      char* const zrow = dump;
+      const unsigned zrow_off = (unsigned)(dump - smem);
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         // ================= R slot (at raised priority: its few instructions go between the other group's MFMAs)
@@ -682,28 +686,31 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
           RG_STAMP(1);
         }
         if (tap == 4 && c == 0) RG_STAMP(2);
+        if (tap == 4 && c == 0) RG_SLOT(0);
         // operations this wave issues in this R slot / issued in its previous one (folds: tap is unrolled)
         // (residual of output blocks 0 and 1: requested at k-tiles 7 and 8 of the item's last chunk — an HBM round trip
         //  ahead of the epilogue that adds them; the later blocks when the epilogue starts, two blocks ahead)
         auto n_res = [&](int t) -> int { return (RES != 0 && t >= 7) ? 4 : 0; };
         const int n_now = NBPW + sl_of(tap) + (last_c ? n_res(tap) : 0);
-        const char* bs = bst + stg * STG_B;
+        const char* bs = bst + (tap % RG_NSTB) * STG_B;     // 9 k-tiles per chunk, 3 stages: the stage of k-tile `tap` is tap % 3 — static
         const int toff = (tap / 3) * a.W + (tap % 3);
         f32x4 afr[2][4], bfr[WN][4];
         {
-          const char* arow[2];
-          unsigned sw[2];
+          // byte offsets from the LDS base.  Rows start on 128-byte boundaries, so row + (chunk << 4) == row ^ (chunk << 4)
+          // and the swizzle (chunk ^ sw) << 4 folds into two XORs: one per row, one per fragment.
+          unsigned arow_sw[2];
 #pragma unroll
           for (int rb = 0; rb < 2; ++rb) {
             const int idx = 64 * wm + 32 * rb + l31 + toff;
-            sw[rb] = (unsigned)((idx >> 1) & 7);
-            arow[rb] = ((mask[rb] >> tap) & 1u) ? win + arow0 + (32 * rb + toff) * 128 : zrow;
+            const unsigned row = ((mask[rb] >> tap) & 1u) ? (unsigned)(win_off + arow0 + (32 * rb + toff) * 128) : zrow_off;
+            arow_sw[rb] = row ^ (unsigned)(((idx >> 1) & 7) << 4);
           }
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             bfr[0][s] = *reinterpret_cast<const f32x4*>(bs + boff[0][s]);
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) afr[rb][s] = *reinterpret_cast<const f32x4*>(arow[rb] + ((kc[s] ^ sw[rb]) << 4));
+            for (int rb = 0; rb < 2; ++rb)      // (rows are 128-byte aligned LDS offsets: base + x == base ^ x for x < 128)
+              afr[rb][s] = *reinterpret_cast<const f32x4*>(smem + (arow_sw[rb] ^ (unsigned)kc[s]));
           }
 #pragma unroll
           for (int cb = 1; cb < WN; ++cb)
@@ -712,7 +719,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
         }
         __builtin_amdgcn_sched_barrier(0);                   // (the reads go out first: their latency runs under the issue below)
         {
-          const int s2 = stg + LEAD >= RG_NSTB ? stg + LEAD - RG_NSTB : stg + LEAD;
+          const int s2 = (tap + LEAD) % RG_NSTB;
           if (tap + LEAD < 9) issue_b(nt, c, tap + LEAD, s2, true);
           else if (!last_c) issue_b(nt, c + 1, tap + LEAD - 9, s2, true);
           else issue_b(nt1, 0, tap + LEAD - 9, s2, more);
@@ -723,13 +730,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
             if (tap >= 7 && last_c) req(ebase_of(mt, nt), chmask_of(nt), tap - 7, rq[tap - 7]);
           }
         }
+        if (tap == 4 && c == 0) RG_SLOT(1);
         // confirm the weights this wave issued in its previous R slot (in-order completion), all fragment reads returned
         // (a slot issues weights first, then window slices / the early residual: those younger operations of the
         //  oldest slot still counted may stay in flight too — the slices are HBM reads, not needed before the next phase)
         const int young = sl_of((tap + 8) % 9) + (tap == 0 ? ((c == 0 && have_prev) ? n_res(8) : 0) : (last_c ? n_res(tap - 1) : 0));
         wait_vm_n(n_now + young);
+        if (tap == 4 && c == 0) RG_SLOT(2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (tap == 4 && c == 0) RG_STAMP(3);
+        if (tap == 4 && c == 0) RG_SLOT(3);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (tap == 4 && c == 0) RG_STAMP(4);
@@ -757,7 +767,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
         if (!(tap == 8 && last_c && grp == 1)) __builtin_amdgcn_s_barrier();      // (group 1, end of an item: after its epilogue)
         asm volatile("" ::: "memory");
         if (tap == 4 && c == 0) RG_STAMP(6);
-        stg = stg + 1 == RG_NSTB ? 0 : stg + 1;
       }
     }
     mt_p = mt; nt_p = nt; phl_p = (li * a.NC + a.NC - 1) & 1; have_prev = true;

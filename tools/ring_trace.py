@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--shape", type=int, nargs=5, default=(1024, 72, 72, 64, 64), metavar=("F", "H", "W", "CIN", "N"))
     ap.add_argument("--resid", type=int, default=0)
     ap.add_argument("--build-only", action="store_true")
-    ap.add_argument("--mode", type=int, default=1, help="1: sections of an item; 2: inside k-tiles 4 and 5 of the first chunk")
+    ap.add_argument("--mode", type=int, default=1, help="1: sections of an item; 2: inside k-tiles 4 and 5 of the first chunk; 3: inside a ping-pong staging slot")
     args = ap.parse_args()
     so = os.path.join(ROOT, "tools", "_trace", "libcadre_trace%d.so" % args.mode)    # (git-ignored; build before gpurun: --build-only)
     if args.build_only or not os.path.exists(so):
@@ -72,6 +72,16 @@ def main():
             for i, n in enumerate(["epilogue+clear", "k-tiles 0..3", "R(4): issue+reads+wait", "barrier A", "M(4)", "barrier B"]):
                 print("  %-24s mean %7.0f  median %7.0f  p90 %7.0f" % (n, d[:, i].mean(), np.median(d[:, i]), np.percentile(d[:, i], 90)))
             print("  %-24s mean %7.0f" % ("item", item.mean()))
+        return
+    if args.mode == 3:
+        for gname, sel in (("group 0 (wave 0)", slice(0, None, 2)), ("group 1 (wave 4)", slice(1, None, 2))):
+            tt = t[sel]
+            live = tt[:, :, 3] != 0
+            live[:, 0] = False
+            d = np.diff(tt[:, :, :4], axis=2)[live]
+            print("%s %s F=%d %dx%d %d->%d resid=%d: staging slot of k-tile 4, %d items" % (gname, args.dtype, F, H, W, Cin, N, args.resid, d.shape[0]))
+            for i, n in enumerate(["issue reads + DMA", "wait vmcnt", "wait lgkmcnt(0)"]):
+                print("  %-20s mean %7.0f  median %7.0f  p90 %7.0f" % (n, d[:, i].mean(), np.median(d[:, i]), np.percentile(d[:, i], 90)))
         return
     if args.mode == 2:
         live = (t[:, :, 6] != 0)
