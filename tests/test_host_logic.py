@@ -191,6 +191,26 @@ def test_gemm_tile_choice_is_host_logic():
     assert pick(300, 200, 544, tile=2) == 2
 
 
+def test_window_conv_policy_is_host_logic():
+    """cadre_conv3x3_ring_supported / _ntile run on the host: every stride-1 3x3 conv of the bf16 encoder goes to the
+    8-wave ping-pong window kernel, fp32 only the 64-channel stage (lockstep kernel), and geometry the window cannot
+    hold is refused."""
+    from cadre_amd import hip
+    L = hip.lib()
+    F = 1024
+    trunk = [(72, 64, 64), (36, 128, 128), (18, 256, 256), (9, 512, 512), (9, 512, 128), (9, 128, 128)]
+    for hw, cin, n in trunk:
+        assert L.cadre_conv3x3_ring_supported(F, hw, hw, cin, n, 1) == 1
+        code = L.cadre_conv3x3_ring_ntile(F, hw, hw, n, 1)            # ntile + 1000 * waves-along-positions + 100000 * ping-pong
+        assert code == (64 if n < 128 else 128) + 4000 + 100000
+    assert L.cadre_conv3x3_ring_supported(F, 72, 72, 64, 64, 0) == 1
+    assert L.cadre_conv3x3_ring_ntile(F, 72, 72, 64, 0) == 64 + 4000      # fp32: lockstep kernel
+    for hw, cin, n in trunk[1:4]:
+        assert L.cadre_conv3x3_ring_supported(F, hw, hw, cin, n, 0) == 0  # fp32 N >= 128: the tile kernels
+    assert L.cadre_conv3x3_ring_supported(1, 144, 144, 64, 64, 1) == 0    # W > 95: two windows do not fit LDS
+    assert L.cadre_conv3x3_ring_supported(F, 36, 36, 48, 64, 1) == 0      # channel chunk not 128 bytes
+
+
 def test_drop_in_package_keeps_reference_meta_importable(tmp_path):
     """The reference's ppo_agent/ is a namespace package that also holds ppo_agent/meta/ (main.py:4, eval.py:4,
     simple_test.py:2: `from ppo_agent.meta.config import Config`).  With both roots on sys.path — in either
