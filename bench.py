@@ -391,6 +391,7 @@ def main():
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
     ap.add_argument("--chunk-windows", type=int, default=128, help="windows (x8 frames) per encoder launch chain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-peaks", action="store_true", help="skip the measured-peaks microbenchmarks (HBM copy, MFMA chains; ~2 s)")
     ap.add_argument("--no-c3", action="store_true", help="skip the extra C3 section (4 workers/GPU, bf16 encoder) of the line")
     ap.add_argument("--encoder-dtype", default=None, choices=["f32", "bf16"],
                     help="override the config's encoder arithmetic (C2: f32, C3: bf16 storage / fp32 accumulate)")
@@ -430,6 +431,22 @@ def main():
         c3["metric"], c3["unit"], c3["n_gpus"] = "ppo_update_samples_per_sec", "samples/s", world
         out["c3"] = c3
     if rank == 0:
+        if not args.no_peaks and world == 1:
+            # the datasheet peaks re-measured on this box (stream copy, register-operand MFMA chains): the
+            # roofline fractions above use the datasheet figures, `frac_of_measured` restates them against these
+            try:
+                from tools.peaks_bench import measure
+                mp = measure()
+                out["measured_peaks"] = mp
+                for sect in (out, out.get("c3")):
+                    rf = sect.get("roofline") if sect else None
+                    if rf and rf.get("bound") == "mfma":
+                        pk = mp["mfma_bf16_2wave_TFLOPs"] if rf["peak"] > 1000 else mp["mfma_f32_2wave_TFLOPs"]
+                        rf["frac_of_measured"] = round(rf["achieved"] / pk, 4)
+                    elif rf:
+                        rf["frac_of_measured"] = round(rf["achieved"] / mp["hbm_copy_GBps"], 4)
+            except Exception as e:                           # a diagnostic: never fails the bench line
+                log("[bench] measured_peaks skipped: %r" % (e,))
         if not args.no_cpu_baseline and world == 1:          # CPU baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(cfg, enc_state, ppo_state)
         print(json.dumps(out), flush=True)

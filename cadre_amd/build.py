@@ -3,7 +3,7 @@ import os
 import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["gemm_f32.hip", "gemm_f32_skinny.hip", "conv_stream_f32.hip", "gemm_bf16.hip", "conv_stream_bf16.hip", "stem_pool.hip", "conv3x3_c64_bf16.hip", "conv3x3_ring.hip", "cadre_kernels.hip"]
+SOURCES = ["gemm_f32.hip", "gemm_f32_skinny.hip", "conv_stream_f32.hip", "gemm_bf16.hip", "conv_stream_bf16.hip", "stem_pool.hip", "conv3x3_c64_bf16.hip", "conv3x3_ring.hip", "peaks.hip", "cadre_kernels.hip"]
 LIB = os.path.join(CSRC, "libcadre_hip.so")
 
 

@@ -103,6 +103,10 @@ int cadre_conv3x3_ring_supported(int32_t F, int32_t H, int32_t W, int32_t Cin, i
 /* tile configuration as ntile (64 / 128) + 1000 * WVM (waves along the positions: 4 = 256-position tile, one workgroup
  * per CU; 2 = 128-position tile, two per CU): names the instantiation conv3x3_ring_kernel<bf16, ntile, res, out_bf16, WVM> */
 int cadre_conv3x3_ring_ntile(int32_t F, int32_t H, int32_t W, int32_t N, int32_t bf16);
+/* Sustained matrix-pipe rate of this device (peaks.hip; SURVEY.md 8d asks for the measured peak next to the datasheet
+ * one): workgroups x 4 waves, each iters x 8 register-operand MFMAs on independent accumulators (fp32:
+ * v_mfma_f32_32x32x2_f32 = 4096 FLOP, bf16: v_mfma_f32_32x32x16_bf16 = 32768 FLOP).  The caller times the launch. */
+int cadre_mfma_peak(int32_t bf16, int32_t workgroups, int32_t iters, float* sink, void* stream);
 /* C[M][ldc] = act(sum_s slab[s][M][lds] * scale + shift + resid) */
 int cadre_splitk_reduce(const float* slabs, int32_t split_k, int64_t slab_stride, int64_t lds,
                         float* C, int64_t ldc, int32_t M, int32_t N, const float* scale,
