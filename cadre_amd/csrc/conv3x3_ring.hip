@@ -779,45 +779,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
 }
 
 
-// Tile configuration (host logic).  Small maps (W <= 29 with 128 channels per tile, W <= 61 with 64): the 128-position
-// tile on 4 waves with 2 weight stages fits 80 KB of LDS, so TWO workgroups share a CU (CADRE_RING_WVM forces 2 / 4).
-// Channel tile 128 unless N < 128 (CADRE_RING_NTILE forces one for A/B runs).
+// Tile configuration (host logic): 256 positions x 64 / 128 channels on 8 waves, one persistent workgroup per CU.
+// Channel tile 128 unless N < 128 (CADRE_RING_NTILE forces one for A/B runs).  (A 128-position / 4-wave shape with two
+// workgroups per CU existed until the ping-pong kernel beat it on every shape it was picked for: layer3 bf16 1134 vs
+// 990 TFLOP/s; the kernel template still takes WVM = 2.)
 struct ring_cfg { int wvm, ntile, bm, wpx, wgs, pp; size_t lds; long long items; };
 static void ring_pick(long long M, int W, int N, int bf16, ring_cfg* c) {
   static const int force_nt = [] { const char* e = getenv("CADRE_RING_NTILE"); return e ? atoi(e) : 0; }();
-  static const int force_wvm = [] { const char* e = getenv("CADRE_RING_WVM"); return e ? atoi(e) : 0; }();
+  static const int force_pp = [] { const char* e = getenv("CADRE_RING_PP"); return e ? atoi(e) : 1; }();
   int ntile = N >= 128 ? 128 : 64;
   if (force_nt == 64 || (force_nt == 128 && N >= 128)) ntile = force_nt;
-  auto lds_of = [&](int wvm, int nt, int* wpx_out) {
-    const int bm = 64 * wvm;
-    int wpx = (bm + 2 * W + 2 + 7) & ~7;
-    const int min_wpx = (2 * wvm * RG_SLAB + 127) / 128;           // the epilogue slabs live in a window
-    if (wpx < min_wpx) wpx = (min_wpx + 7) & ~7;
-    *wpx_out = wpx;
-    const size_t bn_table = (size_t)((N + nt - 1) / nt) * nt * 8;      // folded BN of every channel: scale | shift
-    return (size_t)2 * wpx * 128 + (size_t)(wvm == 4 ? 3 : 2) * nt * 128 + 1024 + bn_table;
-  };
-  int wpx2, wpx4;
-  const size_t l2 = lds_of(2, ntile, &wpx2), l4 = lds_of(4, ntile, &wpx4);
-  // two workgroups per CU pay off on long runs of items (layer3/4: +8 % over one 8-wave workgroup); with fewer than
-  // four rounds of work (the 9x9 head convs) the larger tile wins (865 vs 752 TFLOP/s bf16)
-  const long long items2 = ((M + 127) / 128) * ((N + ntile - 1) / ntile);
-  int wvm = (l2 <= 80 * 1024 && 10 * 4 >= (wpx2 >> 3) && items2 >= 4 * 512) ? 2 : 4;     // (window slices must fit the 10 x 4 issue slots)
-  // bf16: the 8-wave ping-pong kernel beats two 4-wave workgroups per CU on every trunk shape (layer3: 1134 vs 990 TFLOP/s)
-  static const int force_pp = [] { const char* e = getenv("CADRE_RING_PP"); return e ? atoi(e) : 1; }();
-  if (bf16 && force_pp > 0) wvm = 4;
-  if (force_wvm == 2 && l2 <= 80 * 1024 && 10 * 4 >= (wpx2 >> 3)) wvm = 2;
-  if (force_wvm == 4) wvm = 4;
-  c->wvm = wvm; c->ntile = ntile; c->bm = 64 * wvm;
-  c->wpx = wvm == 2 ? wpx2 : wpx4;
-  c->lds = wvm == 2 ? l2 : l4;
-  // 8-wave tile in bf16: the ping-pong kernel.  (fp32 k-tiles are 4x longer, the lockstep turn costs them 10 %; in
-  // ping-pong the staging wave's instructions are starved by the other group's back-to-back 64-cycle MFMAs — its R slot
-  // lasts as long as their M slot, traced — and layer1 takes 3.12 instead of 3.00 ms: fp32 stays on the lockstep kernel.)
-  c->pp = (wvm == 4 && bf16 && force_pp > 0) ? 1 : 0;
-  c->items = ((M + c->bm - 1) / c->bm) * ((N + ntile - 1) / ntile);
-  const int slots = wvm == 2 ? 512 : 256;                            // persistent workgroups: 2 or 1 per CU
-  c->wgs = (int)(c->items < slots ? c->items : slots);
+  const int wvm = 4, bm = 64 * wvm;
+  int wpx = (bm + 2 * W + 2 + 7) & ~7;
+  const int min_wpx = (2 * wvm * RG_SLAB + 127) / 128;             // the epilogue slabs live in a window
+  if (wpx < min_wpx) wpx = (min_wpx + 7) & ~7;
+  const size_t bn_table = (size_t)((N + ntile - 1) / ntile) * ntile * 8;      // folded BN of every channel: scale | shift
+  c->wvm = wvm; c->ntile = ntile; c->bm = bm; c->wpx = wpx;
+  c->lds = (size_t)2 * wpx * 128 + (size_t)3 * ntile * 128 + 1024 + bn_table;
+  // bf16: the ping-pong kernel.  (fp32 k-tiles are 4x longer, the lockstep turn costs them 10 %; in ping-pong the
+  // staging wave's instructions are starved by the other group's back-to-back 64-cycle MFMAs — its slot lasts as long as
+  // theirs, traced — and layer1 takes 3.12 instead of 3.00 ms: fp32 stays on the lockstep kernel.  CADRE_RING_PP=0: the
+  // lockstep kernel for bf16 too, for A/B runs.)
+  c->pp = (bf16 && force_pp > 0) ? 1 : 0;
+  c->items = ((M + bm - 1) / bm) * ((N + ntile - 1) / ntile);
+  c->wgs = (int)(c->items < 256 ? c->items : 256);                  // persistent workgroups: one per CU
 }
 
 static int g_ring_mode = [] { const char* e = getenv("CADRE_RING_CONV"); return e ? atoi(e) : 1; }();   // 0 off, 1 auto, 2 wherever supported
@@ -895,12 +880,12 @@ extern "C" int cadre_conv3x3_ring(const void* x, const void* w, const float* sca
 #define RG_PP(BF, NT_, RS_, OB_) ring_launch_pp<BF, NT_, RS_, OB_>(a, grid, lds, st)
 #define RG_NT(BF, RS_, OB_)                                                                                      \
   do {                                                                                                           \
-    if (cfg.wvm == 4 && cfg.pp) {                                                                                \
+    if (cfg.pp) {                                                                                \
       if (ntile == 128) RG_PP(BF, 128, RS_, OB_); else RG_PP(BF, 64, RS_, OB_);                                  \
-    } else if (cfg.wvm == 4) {                                                                                   \
+    } else {                                                                                                     \
       if (ntile == 128) RG_LAUNCH(BF, 128, RS_, OB_, 4);                                                      \
       else RG_LAUNCH(BF, 64, RS_, OB_, 4);                                                                    \
-    } else { if (ntile == 128) RG_LAUNCH(BF, 128, RS_, OB_, 2); else RG_LAUNCH(BF, 64, RS_, OB_, 2); }     \
+    }                                                                                                            \
   } while (0)
   if (bf16) {
     if (resid && !resid_bf16) return cadre_fail("cadre_conv3x3_ring: bf16 operands take a bf16 residual");

@@ -100,8 +100,9 @@ int cadre_conv3x3_ring(const void* x, const void* w, const float* scale, const f
                        void* out, int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t act,
                        int32_t flags, void* stream);
 int cadre_conv3x3_ring_supported(int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t bf16);
-/* tile configuration as ntile (64 / 128) + 1000 * WVM (waves along the positions: 4 = 256-position tile, one workgroup
- * per CU; 2 = 128-position tile, two per CU): names the instantiation conv3x3_ring_kernel<bf16, ntile, res, out_bf16, WVM> */
+/* tile configuration as ntile (64 / 128) + 1000 * WVM (waves along the positions: 4 = 256-position tile on 8 waves, one
+ * workgroup per CU) + 100000 when the 8-wave ping-pong kernel runs (bf16): names the instantiation
+ * conv3x3_ring_kernel<bf16, ntile, res, out_bf16, WVM> / conv3x3_ring_pp_kernel<bf16, ntile, res, out_bf16> */
 int cadre_conv3x3_ring_ntile(int32_t F, int32_t H, int32_t W, int32_t N, int32_t bf16);
 /* Sustained matrix-pipe rate of this device (peaks.hip; SURVEY.md 8d asks for the measured peak next to the datasheet
  * one): workgroups x 4 waves, each iters x 8 register-operand MFMAs on independent accumulators (fp32:
