@@ -410,6 +410,11 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     import torch.distributed as dist
+    # stdout carries ONE JSON line: RCCL writes its version banner (and warnings) to the C stdout whenever a communicator
+    # starts, so fd 1 is pointed at stderr for the duration of the run and restored for the line
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or os.environ.get("CADRE_BENCH_FORCE_DIST") == "1"     # force: exercise RCCL init at N=1
     if use_dist:
@@ -449,7 +454,10 @@ def main():
                 log("[bench] measured_peaks skipped: %r" % (e,))
         if not args.no_cpu_baseline and world == 1:          # CPU baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(cfg, enc_state, ppo_state)
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
