@@ -404,14 +404,16 @@ static int pam_launch(const float* x, const float* qkv, float gamma, void* y, in
 }
 
 // ============================================================================ CAM (channel attention)
+#define CAM_XP 132                // row pitch of the staged frame [Np][128] (+4: rows 14 apart land on different banks)
+#define CAM_EP 132                // row pitch of the energy / attention matrix [128][128]
 __global__ __launch_bounds__(256) void cam_kernel(const float* x, float gamma, float* y, int Np, int out_bf16) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* xs = sm;                 // [Np][128]
-  float* E = xs + Np * 128;       // [128][129]
+  float* xs = sm;                 // [Np][CAM_XP]
+  float* E = xs + Np * CAM_XP;    // [128][CAM_EP]
   const int f = blockIdx.x, tid = threadIdx.x;
   const float* xf = x + (int64_t)f * Np * 128;
   for (int i = tid; i < Np * 32; i += 256)
-    reinterpret_cast<float4*>(xs)[i] = reinterpret_cast<const float4*>(xf)[i];
+    *reinterpret_cast<float4*>(xs + (i >> 5) * CAM_XP + (i & 31) * 4) = reinterpret_cast<const float4*>(xf)[i];
   __syncthreads();
   {  // energy[c][d] = sum_n x[n][c] x[n][d]   (da_att.py:74): 8x8 register block per thread
     const int c0 = (tid >> 4) * 8, d0 = (tid & 15) * 8;
@@ -422,10 +424,10 @@ __global__ __launch_bounds__(256) void cam_kernel(const float* x, float gamma, f
       for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
     for (int n = 0; n < Np; ++n) {
       float a[8], b[8];
-      const float4 a0 = *reinterpret_cast<const float4*>(xs + n * 128 + c0);
-      const float4 a1 = *reinterpret_cast<const float4*>(xs + n * 128 + c0 + 4);
-      const float4 b0 = *reinterpret_cast<const float4*>(xs + n * 128 + d0);
-      const float4 b1 = *reinterpret_cast<const float4*>(xs + n * 128 + d0 + 4);
+      const float4 a0 = *reinterpret_cast<const float4*>(xs + n * CAM_XP + c0);
+      const float4 a1 = *reinterpret_cast<const float4*>(xs + n * CAM_XP + c0 + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(xs + n * CAM_XP + d0);
+      const float4 b1 = *reinterpret_cast<const float4*>(xs + n * CAM_XP + d0 + 4);
       a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
       b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
 #pragma unroll
@@ -434,31 +436,65 @@ __global__ __launch_bounds__(256) void cam_kernel(const float* x, float gamma, f
         for (int j = 0; j < 8; ++j) acc[i][j] += a[i] * b[j];
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) E[(c0 + i) * 129 + d0 + j] = acc[i][j];
+    for (int i = 0; i < 8; ++i) {
+      *reinterpret_cast<float4*>(E + (c0 + i) * CAM_EP + d0) = float4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+      *reinterpret_cast<float4*>(E + (c0 + i) * CAM_EP + d0 + 4) = float4{acc[i][4], acc[i][5], acc[i][6], acc[i][7]};
+    }
   }
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
   for (int c = wave; c < 128; c += 4) {               // energy_new = rowmax - energy; softmax (:75-76)
-    const float e0 = E[c * 129 + lane], e1 = E[c * 129 + lane + 64];
+    const float e0 = E[c * CAM_EP + lane], e1 = E[c * CAM_EP + lane + 64];
     const float rmax = wave_max(fmaxf(e0, e1));
     const float n0 = rmax - e0, n1 = rmax - e1;
     const float m2 = wave_max(fmaxf(n0, n1));
     const float p0 = expf(n0 - m2), p1 = expf(n1 - m2);
     const float s = wave_sum(p0 + p1);
-    E[c * 129 + lane] = p0 / s;
-    E[c * 129 + lane + 64] = p1 / s;
+    E[c * CAM_EP + lane] = p0 / s;
+    E[c * CAM_EP + lane + 64] = p1 / s;
   }
   __syncthreads();
-  const int c = tid & 127;
-  float* yf = y + (int64_t)f * Np * 128;
-  for (int n = tid >> 7; n < Np; n += 2) {            // out[c][n] = sum_d att[c][d] x[d][n]  (:79)
-    float o = 0.f;
-    for (int d = 0; d < 128; ++d) o += E[c * 129 + d] * xs[n * 128 + d];
-    const float r = gamma * o + xs[n * 128 + c];
-    if (out_bf16) reinterpret_cast<__bf16*>(y)[(int64_t)f * Np * 128 + n * 128 + c] = (__bf16)r;
-    else yf[n * 128 + c] = r;
+  // out[c][n] = sum_d att[c][d] x[d][n]  (:79), the d sum in order 0..127 per output.  Register block of 8 channels
+  // (c = cg + 16 i: rows of different threads on different banks) x 7 positions (n = ng + 14 j <= 97) per thread, d in steps
+  // of 4: 15 ds_read_b128 per 224 FMAs (one thread per output read two words per FMA: the LDS bound this phase).
+  if (tid < 224) {
+    const int cg = tid / 14, ng = tid % 14;
+    float o[8][7];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 7; ++j) o[i][j] = 0.f;
+    int nrow[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) nrow[j] = min(ng + 14 * j, Np - 1) * CAM_XP;      // (rows past Np: clamped, not stored)
+    for (int d = 0; d < 128; d += 4) {
+      float4 av[8], xv[7];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) av[i] = *reinterpret_cast<const float4*>(E + (cg + 16 * i) * CAM_EP + d);
+#pragma unroll
+      for (int j = 0; j < 7; ++j) xv[j] = *reinterpret_cast<const float4*>(xs + nrow[j] + d);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+          o[i][j] += av[i].x * xv[j].x;
+          o[i][j] += av[i].y * xv[j].y;
+          o[i][j] += av[i].z * xv[j].z;
+          o[i][j] += av[i].w * xv[j].w;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const int n = ng + 14 * j;
+      if (n >= Np) continue;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = cg + 16 * i;
+        const float r = gamma * o[i][j] + xs[n * CAM_XP + c];
+        if (out_bf16) reinterpret_cast<__bf16*>(y)[(int64_t)f * Np * 128 + n * 128 + c] = (__bf16)r;
+        else y[(int64_t)f * Np * 128 + n * 128 + c] = r;
+      }
+    }
   }
 }
 
@@ -471,7 +507,7 @@ extern "C" int cadre_cam_bf16out(const float* x, float gamma, void* y, int32_t F
 }
 static int cam_launch(const float* x, float gamma, void* y, int32_t F, int32_t Np, int out_bf16, void* stream) {
   FAIL_IF(!x || !y || F < 1 || Np < 1 || Np > PAM_MAXNP, "cadre_cam: bad argument (Np<=96)");
-  const size_t shm = sizeof(float) * ((size_t)Np * 128 + 128 * 129);
+  const size_t shm = sizeof(float) * ((size_t)Np * CAM_XP + 128 * CAM_EP);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)cam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

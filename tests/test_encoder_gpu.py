@@ -55,7 +55,7 @@ def test_encoder_batch_invariance_and_chunking(golden):
     assert torch.equal(a, b) and torch.equal(a[3:5], c)
 
 
-@pytest.mark.parametrize("tag", ["84", "288"])
+@pytest.mark.parametrize("tag", ["84", "native", "288"])
 def test_encoder_bf16_close_to_fp32_reference(golden, tag):
     """BASELINE config C3 ("bf16 encoder"): bf16 storage, fp32 accumulation.  Compared with the fp32
     reference goldens; tolerance 3e-2 of the tensor's max (bf16 has 8 significand bits; 20 layers)."""
