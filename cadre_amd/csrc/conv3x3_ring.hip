@@ -449,6 +449,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
   constexpr int EB = BF16 ? 2 : 4;
   constexpr int NWAVES = 8, NTHR = 512, RG_BM = 256;
   constexpr int LEAD = 2, RG_NSTB = 3;
+  constexpr bool AHEAD = NTILE == 64 || !BF16;              // staging-slot address arithmetic done one slot ahead (see the k-loop)
   constexpr int STG_B = NTILE * 128;
   constexpr int NBPW = (NTILE / 8) / NWAVES;
   constexpr int NFL = 4;
@@ -488,19 +489,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
     const int r = (wave * NBPW + k) * 8 + (lane >> 3);
     b_lane[k] = r * a.NC * 9 * 128 + (((lane & 7) ^ ((r >> 1) & 7)) << 4);
   }
-  auto issue_a = [&](int mt_n, int c_n, int wsel, int j, bool live) {
-    const bool ok = live && j < PA;
-    const unsigned voff = ok ? (unsigned)((mt_n * RG_BM - a.W - 1 + 8 * j) * cin_b + c_n * 128 + a_lane) : OOB;
-    char* dst = ok ? win0 + wsel * win_bytes + j * 1024 : dump;
+  // The per-lane source offsets of a slot's loads (vector ALU work) are computed apart from their issue (scalar + VMEM
+  // only): in the k-loop they are prepared one slot ahead, under the wave's own MFMAs.
+  auto voff_a = [&](int mt_n, int c_n, int j, bool live) -> unsigned {
+    return (live && j < PA) ? (unsigned)((mt_n * RG_BM - a.W - 1 + 8 * j) * cin_b + c_n * 128 + a_lane) : OOB;
+  };
+  auto send_a = [&](unsigned voff, int wsel, int j, bool live) {
+    char* dst = (live && j < PA) ? win0 + wsel * win_bytes + j * 1024 : dump;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)dst, 16, (int)voff, 0, 0, 0);
+  };
+  auto issue_a = [&](int mt_n, int c_n, int wsel, int j, bool live) { send_a(voff_a(mt_n, c_n, j, live), wsel, j, live); };
+  auto voff_b = [&](int nt_b, int c, int tap, bool live, int k) -> unsigned {
+    return live ? (unsigned)(nt_b * (NTILE * a.NC * 9 * 128) + (c * 9 + tap) * 128 + b_lane[k]) : OOB;
+  };
+  auto send_b = [&](unsigned voff, int stg, int k) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(bst + stg * STG_B + (wave * NBPW + k) * 1024),
+                                             16, (int)voff, 0, 0, 0);
   };
   auto issue_b = [&](int nt_b, int c, int tap, int stg, bool live) {
 #pragma unroll
-    for (int k = 0; k < NBPW; ++k) {
-      const unsigned voff = live ? (unsigned)(nt_b * (NTILE * a.NC * 9 * 128) + (c * 9 + tap) * 128 + b_lane[k]) : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(bst + stg * STG_B + (wave * NBPW + k) * 1024),
-                                               16, (int)voff, 0, 0, 0);
-    }
+    for (int k = 0; k < NBPW; ++k) send_b(voff_b(nt_b, c, tap, live, k), stg, k);
   };
   const int arow0 = (64 * wm + l31) * 128;
   int kc[4];
@@ -625,6 +633,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // slab reads done before this wave's loads may land in that window
   };
 
+  // byte offsets (from the LDS base) of this lane's pixel fragments of k-tile `tap`.  Rows start on 128-byte boundaries,
+  // so row + (chunk << 4) == row ^ (chunk << 4) and the swizzle (chunk ^ sw) << 4 folds into two XORs.
+  typedef const __attribute__((address_space(3))) char* lds_cptr;
+  lds_cptr a_addr[2][4];
+  const lds_cptr lds0 = (lds_cptr)smem;
+  const unsigned zrow_off = (unsigned)(dump - smem);
+  auto frag_addr = [&](int tap, int win_off, const unsigned* mask, lds_cptr (*out)[4]) {
+    const int toff = (tap / 3) * a.W + (tap % 3);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int idx = 64 * wm + 32 * rb + l31 + toff;
+      const unsigned row = ((mask[rb] >> tap) & 1u) ? (unsigned)(win_off + arow0 + (32 * rb + toff) * 128) : zrow_off;
+      const unsigned rsw = row ^ (unsigned)(((idx >> 1) & 7) << 4);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) out[rb][s] = lds0 + (rsw ^ (unsigned)kc[s]);
+    }
+  };
+
+  unsigned dma_b[NBPW], dma_a[2];                          // source offsets of the next staging slot's loads
+
   // ---- prologue: window of the first phase, weights of k-tiles 0 .. LEAD-1; everything landed and published
   const int total_ph = nitems * a.NC;
   for (int j = wave; j < PA; j += NWAVES) issue_a(mt, 0, 0, j, true);
@@ -664,7 +692,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
       const bool has_next = phg + 1 < total_ph;
       const bool last_c = c + 1 == a.NC;
       const int mt_n = last_c ? mt1 : mt, c_n = last_c ? 0 : c + 1;
-      const unsigned zrow_off = (unsigned)(dump - smem);
+      auto slot_voff = [&](int tap) {                      // source offsets of the loads staging slot `tap` issues
+#pragma unroll
+        for (int k = 0; k < NBPW; ++k)
+          dma_b[k] = tap + LEAD < 9 ? voff_b(nt, c, tap + LEAD, true, k)
+                                    : (!last_c ? voff_b(nt, c + 1, tap + LEAD - 9, true, k) : voff_b(nt1, 0, tap + LEAD - 9, more, k));
+#pragma unroll
+        for (int i = 0; i < sl_of(tap); ++i) dma_a[i] = voff_a(mt_n, c_n, (2 * (tap - 1) + i) * NWAVES + wave, has_next);
+      };
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         // ================= R slot (at raised priority: its few instructions go between the other group's MFMAs)
@@ -693,24 +728,37 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
         auto n_res = [&](int t) -> int { return (RES != 0 && t >= 7) ? 4 : 0; };
         const int n_now = NBPW + sl_of(tap) + (last_c ? n_res(tap) : 0);
         const char* bs = bst + (tap % RG_NSTB) * STG_B;     // 9 k-tiles per chunk, 3 stages: the stage of k-tile `tap` is tap % 3 — static
-        const int toff = (tap / 3) * a.W + (tap % 3);
         f32x4 afr[2][4], bfr[WN][4];
         {
-          // byte offsets from the LDS base.  Rows start on 128-byte boundaries, so row + (chunk << 4) == row ^ (chunk << 4)
-          // and the swizzle (chunk ^ sw) << 4 folds into two XORs: one per row, one per fragment.
-          unsigned arow_sw[2];
+          // AHEAD: the pixel-fragment addresses and load offsets of this k-tile were computed in the wave's previous MFMA
+          // slot (below) — while the OTHER group's MFMAs run back to back the vector ALU port of the SIMD is theirs, and
+          // a staging slot with VALU work in it lasts as long as their MFMA slot (traced: fp32 2430 vs 2100 cycles,
+          // 280 without).  Either way the VALU work takes its time on the shared port: worth it where the staging slot
+          // is the longer one (64-channel tile: 12 reads per 8 MFMAs, layer1 0.50 / 0.55 vs 0.54 / 0.61 ms; fp32), not
+          // where the MFMA slot is (128-channel tile: 0.37 vs 0.34 ms on layer2).
+          if constexpr (AHEAD) {
+            if (tap == 0) frag_addr(0, win_off, mask, a_addr);
 #pragma unroll
-          for (int rb = 0; rb < 2; ++rb) {
-            const int idx = 64 * wm + 32 * rb + l31 + toff;
-            const unsigned row = ((mask[rb] >> tap) & 1u) ? (unsigned)(win_off + arow0 + (32 * rb + toff) * 128) : zrow_off;
-            arow_sw[rb] = row ^ (unsigned)(((idx >> 1) & 7) << 4);
-          }
+            for (int s = 0; s < 4; ++s) {
+              bfr[0][s] = *reinterpret_cast<const f32x4*>(bs + boff[0][s]);
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            bfr[0][s] = *reinterpret_cast<const f32x4*>(bs + boff[0][s]);
+              for (int rb = 0; rb < 2; ++rb) afr[rb][s] = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(a_addr[rb][s]);
+            }
+          } else {
+            const int toff = (tap / 3) * a.W + (tap % 3);
+            unsigned arow_sw[2];
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)      // (rows are 128-byte aligned LDS offsets: base + x == base ^ x for x < 128)
-              afr[rb][s] = *reinterpret_cast<const f32x4*>(smem + (arow_sw[rb] ^ (unsigned)kc[s]));
+            for (int rb = 0; rb < 2; ++rb) {
+              const int idx = 64 * wm + 32 * rb + l31 + toff;
+              const unsigned row = ((mask[rb] >> tap) & 1u) ? (unsigned)(win_off + arow0 + (32 * rb + toff) * 128) : zrow_off;
+              arow_sw[rb] = row ^ (unsigned)(((idx >> 1) & 7) << 4);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              bfr[0][s] = *reinterpret_cast<const f32x4*>(bs + boff[0][s]);
+#pragma unroll
+              for (int rb = 0; rb < 2; ++rb) afr[rb][s] = *reinterpret_cast<const f32x4*>(smem + (arow_sw[rb] ^ (unsigned)kc[s]));
+            }
           }
 #pragma unroll
           for (int cb = 1; cb < WN; ++cb)
@@ -720,12 +768,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
         __builtin_amdgcn_sched_barrier(0);                   // (the reads go out first: their latency runs under the issue below)
         {
           const int s2 = (tap + LEAD) % RG_NSTB;
-          if (tap + LEAD < 9) issue_b(nt, c, tap + LEAD, s2, true);
-          else if (!last_c) issue_b(nt, c + 1, tap + LEAD - 9, s2, true);
-          else issue_b(nt1, 0, tap + LEAD - 9, s2, more);
+          if constexpr (AHEAD) {
+            if (tap == 0) slot_voff(0);                      // (first k-tile of a phase: no previous MFMA slot of this phase)
 #pragma unroll
-          for (int i = 0; i < sl_of(tap); ++i)
-            issue_a(mt_n, c_n, (phg + 1) & 1, (2 * (tap - 1) + i) * NWAVES + wave, has_next);
+            for (int k = 0; k < NBPW; ++k) send_b(dma_b[k], s2, k);
+#pragma unroll
+            for (int i = 0; i < sl_of(tap); ++i)
+              send_a(dma_a[i], (phg + 1) & 1, (2 * (tap - 1) + i) * NWAVES + wave, has_next);
+          } else {                                           // offsets computed as the loads go out
+            if (tap + LEAD < 9) issue_b(nt, c, tap + LEAD, s2, true);
+            else if (!last_c) issue_b(nt, c + 1, tap + LEAD - 9, s2, true);
+            else issue_b(nt1, 0, tap + LEAD - 9, s2, more);
+#pragma unroll
+            for (int i = 0; i < sl_of(tap); ++i)
+              issue_a(mt_n, c_n, (phg + 1) & 1, (2 * (tap - 1) + i) * NWAVES + wave, has_next);
+          }
           if constexpr (RES != 0) {
             if (tap >= 7 && last_c) req(ebase_of(mt, nt), chmask_of(nt), tap - 7, rq[tap - 7]);
           }
@@ -762,6 +819,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
                 for (int rb = 0; rb < 2; ++rb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[cb][s][e], afr[rb][s][e], acc[rb][cb], 0, 0, 0);
             }
           }
+        if (AHEAD && tap < 8) {                              // next k-tile's fragment addresses and load offsets: VALU work under OUR MFMAs
+          frag_addr(tap + 1, win_off, mask, a_addr);
+          slot_voff(tap + 1);
+#pragma unroll
+          for (int k = 0; k < NBPW; ++k) asm volatile("" : "+v"(dma_b[k]));
+#pragma unroll
+          for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(dma_a[i]));
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(a_addr[rb][s]));      // (materialised HERE: not sunk to the reads)
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (tap == 4 && c == 0) RG_STAMP(5);
         if (!(tap == 8 && last_c && grp == 1)) __builtin_amdgcn_s_barrier();      // (group 1, end of an item: after its epilogue)
@@ -796,11 +865,10 @@ static void ring_pick(long long M, int W, int N, int bf16, ring_cfg* c) {
   const size_t bn_table = (size_t)((N + ntile - 1) / ntile) * ntile * 8;      // folded BN of every channel: scale | shift
   c->wvm = wvm; c->ntile = ntile; c->bm = bm; c->wpx = wpx;
   c->lds = (size_t)2 * wpx * 128 + (size_t)3 * ntile * 128 + 1024 + bn_table;
-  // bf16: the ping-pong kernel.  (fp32 k-tiles are 4x longer, the lockstep turn costs them 10 %; in ping-pong the
-  // staging wave's instructions are starved by the other group's back-to-back 64-cycle MFMAs — its slot lasts as long as
-  // theirs, traced — and layer1 takes 3.12 instead of 3.00 ms: fp32 stays on the lockstep kernel.  CADRE_RING_PP=0: the
-  // lockstep kernel for bf16 too, for A/B runs.)
-  c->pp = (bf16 && force_pp > 0) ? 1 : 0;
+  // The ping-pong kernel: every bf16 shape, and the fp32 64-channel tile (layer1: 2.99 vs 3.03 ms once its staging
+  // slots carry no vector-ALU work; fp32 with 128-channel tiles is not instantiated — those layers run on the tile
+  // kernels, and a forced window conv takes the lockstep kernel).  CADRE_RING_PP=0: lockstep everywhere, for A/B runs.
+  c->pp = (force_pp > 0 && (bf16 || ntile == 64)) ? 1 : 0;
   c->items = ((M + bm - 1) / bm) * ((N + ntile - 1) / ntile);
   c->wgs = (int)(c->items < 256 ? c->items : 256);                  // persistent workgroups: one per CU
 }
@@ -838,9 +906,9 @@ extern "C" void cadre_ring_set_trace(void* p) { g_ring_trace = (long long*)p; }
 
 template <bool BF, int NT, int RS, bool OB>
 static void ring_launch_pp(const ring_args& a, int grid, size_t lds, hipStream_t st) {
-  if constexpr (BF) {                                      // (bf16 only: see ring_pick)
-    (void)hipFuncSetAttribute((const void*)conv3x3_ring_pp_kernel<true, NT, RS, OB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((conv3x3_ring_pp_kernel<true, NT, RS, OB>), dim3(grid), dim3(512), lds, st, a);
+  if constexpr (BF || NT == 64) {                          // (fp32: the 64-channel tile only — see ring_pick)
+    (void)hipFuncSetAttribute((const void*)conv3x3_ring_pp_kernel<BF, NT, RS, OB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((conv3x3_ring_pp_kernel<BF, NT, RS, OB>), dim3(grid), dim3(512), lds, st, a);
   }
 }
 

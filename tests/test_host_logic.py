@@ -193,7 +193,7 @@ def test_gemm_tile_choice_is_host_logic():
 
 def test_window_conv_policy_is_host_logic():
     """cadre_conv3x3_ring_supported / _ntile run on the host: every stride-1 3x3 conv of the bf16 encoder goes to the
-    8-wave ping-pong window kernel, fp32 only the 64-channel stage (lockstep kernel), and geometry the window cannot
+    8-wave ping-pong window kernel, fp32 only the 64-channel stage, and geometry the window cannot
     hold is refused."""
     from cadre_amd import hip
     L = hip.lib()
@@ -204,7 +204,8 @@ def test_window_conv_policy_is_host_logic():
         code = L.cadre_conv3x3_ring_ntile(F, hw, hw, n, 1)            # ntile + 1000 * waves-along-positions + 100000 * ping-pong
         assert code == (64 if n < 128 else 128) + 4000 + 100000
     assert L.cadre_conv3x3_ring_supported(F, 72, 72, 64, 64, 0) == 1
-    assert L.cadre_conv3x3_ring_ntile(F, 72, 72, 64, 0) == 64 + 4000      # fp32: lockstep kernel
+    assert L.cadre_conv3x3_ring_ntile(F, 72, 72, 64, 0) == 64 + 4000 + 100000      # fp32 64-channel stage: ping-pong too
+    assert L.cadre_conv3x3_ring_ntile(F, 36, 36, 128, 0) == 128 + 4000             # (a forced fp32 128-channel tile: lockstep)
     for hw, cin, n in trunk[1:4]:
         assert L.cadre_conv3x3_ring_supported(F, hw, hw, cin, n, 0) == 0  # fp32 N >= 128: the tile kernels
     assert L.cadre_conv3x3_ring_supported(1, 144, 144, 64, 64, 1) == 0    # W > 95: two windows do not fit LDS
