@@ -118,11 +118,52 @@ def encode_worker(agent, wk, cfg, chunk_windows):
     wk.stor[1]._obs.copy_(wk.stor[0]._obs)
 
 
-def learner_round(agent, workers, cfg, shared, timers=None):
+class JointFrames:
+    """The W workers of one GPU encoded as ONE stream of windows (configs with several workers per GPU): their frames
+    in one tensor, window ids offset per worker, chunks of `chunk_windows` windows cut across workers — twice the work
+    items per launch of a per-worker chunk, so the persistent conv kernels lose less to the last partial round of items
+    (layer4 at 1024 frames: 5.06 items per CU -> 6 rounds).  Same per-frame results: frames are independent."""
+
+    def __init__(self, workers):
+        self.rgb = torch.cat([w.rgb for w in workers])
+        self.route = torch.cat([w.route for w in workers])
+        base = np.cumsum([0] + [int(w.rgb.shape[0]) for w in workers[:-1]])
+        self.win = torch.cat([w.win + int(b) for w, b in zip(workers, base)])
+        self.meas = torch.cat([w.meas for w in workers])
+        self.lat = None
+
+
+def encode_joint(agent, workers, joint, cfg, chunk_windows):
+    from cadre_amd import hip
+    T = cfg["T"]
+    enc = agent.vae_model
+    L = hip.lib()
+    nwin = T * len(workers)
+    ldo = workers[0].stor[0]._ldo
+    if joint.lat is None:
+        joint.lat = torch.zeros(nwin * SEQ, ldo, device=joint.rgb.device)
+    for t0 in range(0, nwin, chunk_windows):
+        t1 = min(nwin, t0 + chunk_windows)
+        x = enc.preprocess(joint.rgb, joint.route, frame_idx=joint.win[t0 * SEQ:t1 * SEQ])
+        rows = joint.lat[t0 * SEQ:t1 * SEQ]
+        enc.forward_nhwc(x, rows)
+        hip.check(L.cadre_append_measurements(hip.ptr(joint.meas[t0 * SEQ:t1 * SEQ]), hip.ptr(rows), rows.stride(0),
+                                              (t1 - t0) * SEQ, hip.stream()), "cadre_append_measurements")
+    for w, wk in enumerate(workers):
+        obs_rows = wk.stor[0]._obs.view(-1, ldo)
+        obs_rows[:T * SEQ].copy_(joint.lat[w * T * SEQ:(w + 1) * T * SEQ])
+        obs_rows[T * SEQ:].copy_(obs_rows[(T - 1) * SEQ:T * SEQ])
+        wk.stor[1]._obs.copy_(wk.stor[0]._obs)
+
+
+def learner_round(agent, workers, cfg, shared, timers=None, joint=None):
     from ppo_agent.chief import chief_step
     t0 = time.perf_counter()
-    for wk in workers:
-        encode_worker(agent, wk, cfg, cfg["chunk_windows"])
+    if joint is not None:
+        encode_joint(agent, workers, joint, cfg, cfg["chunk_windows"])
+    else:
+        for wk in workers:
+            encode_worker(agent, wk, cfg, cfg["chunk_windows"])
     if timers is not None:
         torch.cuda.synchronize(); t1 = time.perf_counter()
     advs = []
@@ -282,7 +323,12 @@ def run_config(name, args, rank, local_rank, world, use_dist, steps, warmup, epi
     from cadre_amd import hip, synth
     from ppo_agent.agent import CadreAgent
     from ppo_agent.models import Shared_grad_buffers
-    cfg = dict(CONFIGS[name]); cfg["chunk_windows"] = args.chunk_windows; cfg["dedup"] = args.dedup
+    cfg = dict(CONFIGS[name]); cfg["dedup"] = args.dedup
+    # windows per encoder launch chain: 128 (1024 frames) per worker; with several workers per GPU their windows form
+    # one stream cut into chunks of 256 (2048 frames: every activation tensor stays below the 2 GiB buffer window)
+    joint_ok = cfg["workers"] > 1 and not args.dedup and not episodes_dir and not args.no_joint_encode
+    cw = args.chunk_windows if args.chunk_windows else (256 if joint_ok else 128)
+    cfg["chunk_windows"] = cw
     episodes = None
     if episodes_dir:
         from cadre_amd import replay
@@ -299,7 +345,7 @@ def run_config(name, args, rank, local_rank, world, use_dist, steps, warmup, epi
     enc_dtype = args.encoder_dtype or cfg.get("encoder_dtype", "f32")
     mcfg = dict(use_lstm=True, vae_device=local_rank, device_num=local_rank, vae_params="CoPM", measurement_dim=18,
                 num_output=dict(steer=33, throttle=3), command_num=4, obs_hw=(H, W), weights_init="none", vae_state_dict=enc_state,
-                encoder_max_frames=args.chunk_windows * SEQ, encoder_dtype=enc_dtype)
+                encoder_max_frames=cw * SEQ, encoder_dtype=enc_dtype)
     agent = CadreAgent(rank=rank, model_cfg=mcfg, frame=SEQ, STEER_CONTROL={i: (i - 16) / 16.0 for i in range(33)},
                        THROTTLE_CONTROL={0: [0, 0], 1: [0, 1], 2: [0.6, 0]}, ent_coeff=0.01, value_coeff=0.1,
                        clip_coeff=1.0, clip=0.1)
@@ -308,6 +354,7 @@ def run_config(name, args, rank, local_rank, world, use_dist, steps, warmup, epi
         dist.broadcast(agent.arena.params, 0)
     dev = agent.device
     workers = [Worker(cfg, 1234 + 1000 * rank + w, dev, None if episodes is None else episodes[w]) for w in range(nW)]
+    joint = JointFrames(workers) if joint_ok else None
     shared = Shared_grad_buffers(agent.model_dict, dev)
     torch.manual_seed(100 + rank)
 
@@ -319,13 +366,13 @@ def run_config(name, args, rank, local_rank, world, use_dist, steps, warmup, epi
 
     log("[bench] %s setup done, %d worker(s), %.1f s since start" % (name, nW, time.perf_counter() - T_START))
     for _ in range(warmup):
-        learner_round(agent, workers, cfg, shared)
+        learner_round(agent, workers, cfg, shared, joint=joint)
     sync()
     log("[bench] %s warmup done %.1f s" % (name, time.perf_counter() - T_START))
     hip.PROFILE = prof = []
     t0 = time.perf_counter()
     for _ in range(steps):
-        losses = learner_round(agent, workers, cfg, shared)
+        losses = learner_round(agent, workers, cfg, shared, joint=joint)
     sync()
     elapsed = time.perf_counter() - t0
     hip.PROFILE = None
@@ -348,13 +395,13 @@ def run_config(name, args, rank, local_rank, world, use_dist, steps, warmup, epi
         roof["traffic_unit"] = "HBM bytes per launch (rocprofv3 PMC, profiles/hbm_traffic.json)"
     # untimed split pass for t_encode / t_update
     timers = []
-    learner_round(agent, workers, cfg, shared, timers)
+    learner_round(agent, workers, cfg, shared, timers, joint=joint)
     t_enc, t_upd = timers[0]
     ms = elapsed / steps * 1e3
     frames = nW * (T + SEQ - 1 if args.dedup else T * SEQ)
     flops_frame = agent.vae_model.flops_per_frame()
-    enc_bytes = sum(agent.vae_model.algorithmic_bytes(min(args.chunk_windows, T) * SEQ)
-                    for _ in range(nW * -(-T // args.chunk_windows)))
+    nwin = nW * T if joint is not None else T
+    enc_bytes = sum(agent.vae_model.algorithmic_bytes(min(cw, nwin - t0) * SEQ) for t0 in range(0, nwin, cw)) * (1 if joint is not None else nW)
     out = {
         "value": round(world * nW * T / (elapsed / steps), 2), "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup,
         "dtype": "f32" if enc_dtype == "f32" else "bf16 encoder (fp32 accumulate) / f32 PPO update",
@@ -389,7 +436,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
-    ap.add_argument("--chunk-windows", type=int, default=128, help="windows (x8 frames) per encoder launch chain")
+    ap.add_argument("--chunk-windows", type=int, default=0,
+                    help="windows (x8 frames) per encoder launch chain (default: 128, or 256 across the workers of a GPU)")
+    ap.add_argument("--no-joint-encode", action="store_true", help="encode each worker's windows separately (chunks of 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-peaks", action="store_true", help="skip the measured-peaks microbenchmarks (HBM copy, MFMA chains; ~2 s)")
     ap.add_argument("--no-c3", action="store_true", help="skip the extra C3 section (4 workers/GPU, bf16 encoder) of the line")

@@ -880,7 +880,9 @@ static int ring_capable(int F, int H, int W, int Cin, int N, int bf16) {      //
   if (F < 1 || H < 1 || W < 2 || W > 95) return 0;
   if ((Cin * eb) % 128 != 0 || N % 32 != 0) return 0;
   const long long M = (long long)F * H * W;
-  if (M * Cin * eb >= (1ll << 31) || M * N * 4 >= (1ll << 31) || (long long)N * Cin * 9 * eb >= (1ll << 31)) return 0;
+  // 32-bit buffer offsets: input, weights, and the output / residual at the operands' element size (an fp32 output of
+  // bf16 operands is checked again at launch)
+  if (M * Cin * eb >= (1ll << 31) || M * N * eb >= (1ll << 31) || (long long)N * Cin * 9 * eb >= (1ll << 31)) return 0;
   ring_cfg c;
   ring_pick(M, W, N, bf16, &c);
   return c.lds <= 160 * 1024;
@@ -919,6 +921,8 @@ extern "C" int cadre_conv3x3_ring(const void* x, const void* w, const float* sca
   if (!x || !w || !out) return cadre_fail("cadre_conv3x3_ring: null operand");
   if (!ring_capable(F, H, W, Cin, N, bf16)) return cadre_fail("cadre_conv3x3_ring: unsupported geometry (W in 2..95, Cin a multiple of 128 bytes, N % 32 == 0, tensors < 2 GiB)");
   if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)out | (uintptr_t)resid) & 15) return cadre_fail("cadre_conv3x3_ring: operands must be 16-byte aligned");
+  if ((long long)F * H * W * N * (out_bf16 ? 2 : 4) >= (1ll << 31) || (resid && (long long)F * H * W * N * (resid_bf16 ? 2 : 4) >= (1ll << 31)))
+    return cadre_fail("cadre_conv3x3_ring: output / residual spans >= 2 GiB: chunk the batch");
   ring_args a;
   a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.resid = resid; a.out = out;
   a.M = F * H * W; a.H = H; a.W = W; a.Cin = Cin; a.N = N; a.NC = Cin * (bf16 ? 2 : 4) / 128;
