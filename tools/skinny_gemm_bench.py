@@ -24,24 +24,30 @@ def timeit(fn, reps=30, warm=5, inner=20):
     ts.sort()
     return ts[len(ts) // 2]
 
-hip.lib()
-Z, N = 8, 2120
-for B in (64, 256):
-    q = B // 4
-    seg = torch.tensor([[0, q], [q, q], [2 * q, q], [3 * q, q]] * 2, dtype=torch.int32, device="cuda")
-    for K in (32, 128, 544):
-        A = torch.randn(Z, B, K, device="cuda"); W = torch.randn(Z, N, K, device="cuda") * 0.05
-        C = torch.zeros(Z, B, N, device="cuda")
+
+def main():
+    hip.lib()
+    Z, N = 8, 2120
+    for B in (64, 256):
+        q = B // 4
+        seg = torch.tensor([[0, q], [q, q], [2 * q, q], [3 * q, q]] * 2, dtype=torch.int32, device="cuda")
+        for K in (32, 128, 544):
+            A = torch.randn(Z, B, K, device="cuda"); W = torch.randn(Z, N, K, device="cuda") * 0.05
+            C = torch.zeros(Z, B, N, device="cuda")
+            for tile in (9, 11):
+                for sg in (None, (1, seg, B, 1)):
+                    t = timeit(lambda: hip.gemm(A, W, C, B, N, K, K, K, N, batch=Z, a_z=(1, 0, B * K), b_z=(1, 0, N * K), c_z=(1, 0, B * N),
+                                                tile=tile, seg=sg), reps=30, warm=5)
+                    print("fwd B=%d K=%d tile %d %s: %.1f us" % (B, K, tile, "seg " if sg else "full", t * 1e6), flush=True)
+        # backward dh: [B, 2120] x [2120, 544] (b_mode 1)
+        dG = torch.randn(Z, B, N, device="cuda"); W = torch.randn(Z, N, 544, device="cuda") * 0.05
+        C = torch.zeros(Z, B, 544, device="cuda")
         for tile in (9, 11):
             for sg in (None, (1, seg, B, 1)):
-                t = timeit(lambda: hip.gemm(A, W, C, B, N, K, K, K, N, batch=Z, a_z=(1, 0, B * K), b_z=(1, 0, N * K), c_z=(1, 0, B * N),
-                                            tile=tile, seg=sg), reps=30, warm=5)
-                print("fwd B=%d K=%d tile %d %s: %.1f us" % (B, K, tile, "seg " if sg else "full", t * 1e6), flush=True)
-    # backward dh: [B, 2120] x [2120, 544] (b_mode 1)
-    dG = torch.randn(Z, B, N, device="cuda"); W = torch.randn(Z, N, 544, device="cuda") * 0.05
-    C = torch.zeros(Z, B, 544, device="cuda")
-    for tile in (9, 11):
-        for sg in (None, (1, seg, B, 1)):
-            t = timeit(lambda: hip.gemm(dG, W, C, B, 544, N, N, 544, 544, b_mode=1, batch=Z, a_z=(1, 0, B * N), b_z=(1, 0, N * 544),
-                                        c_z=(1, 0, B * 544), tile=tile, seg=sg), reps=30, warm=5)
-            print("bwd B=%d tile %d %s: %.1f us" % (B, tile, "seg " if sg else "full", t * 1e6), flush=True)
+                t = timeit(lambda: hip.gemm(dG, W, C, B, 544, N, N, 544, 544, b_mode=1, batch=Z, a_z=(1, 0, B * N), b_z=(1, 0, N * 544),
+                                            c_z=(1, 0, B * 544), tile=tile, seg=sg), reps=30, warm=5)
+                print("bwd B=%d tile %d %s: %.1f us" % (B, tile, "seg " if sg else "full", t * 1e6), flush=True)
+
+
+if __name__ == "__main__":
+    main()
