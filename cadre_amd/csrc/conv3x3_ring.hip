@@ -11,13 +11,17 @@
 //     the nine taps are nine row offsets (kh*W + kw) into the same resident window; taps that fall outside the frame
 //     are zeroed on the fragment with a per-position 9-bit mask.  A traffic L2 -> LDS drops ~7x;
 //   * the weights [N][chunk][tap][128 B] stream through a 3-stage LDS ring, two k-tiles ahead, also by LDS-DMA;
-//   * the next chunk's window (or the next tile's first window) is loaded in slices during the current chunk's nine
-//     k-tiles — a whole phase of lead time; everything is ordered by each wave's own counted vmcnt plus ONE raw
-//     s_barrier per k-tile (a __syncthreads() fence would drain vmcnt to 0);
+//   * the next chunk's window (or the next tile's first window) is loaded in slices during the current chunk's first
+//     k-tiles — a whole phase of lead time; everything is ordered by each wave's own counted vmcnt plus raw s_barriers
+//     (a __syncthreads() fence would drain vmcnt to 0);
 //   * 128-byte rows are XOR-swizzled on the SOURCE address (chunk ^ ((row >> 1) & 7)), LDS stays lane-linear as
 //     LDS-DMA requires, all ds_read_b128 fragment reads are bank-conflict free;
 //   * persistent workgroups (one per CU) walk a contiguous run of (M-tile, N-tile) items, N inner: the epilogue of one
 //     item runs while the loads of the next are already in flight.
+// Two kernels share this scheme: conv3x3_ring_kernel (all eight waves in lockstep, one barrier per k-tile) and
+// conv3x3_ring_pp_kernel (two groups of four waves half a k-tile apart, one staging while the other computes: every
+// bf16 shape and the fp32 64-channel stage; see the comment above it).  -DRING_TRACE=1/2/3 compiles shader-clock
+// stamps into them (tools/ring_trace.py) — where an item's time goes was measured, not guessed.
 // Same epilogue contract as cadre_gemm_*: y = act(conv * scale[n] + shift[n] (+ resid)) (+ resid after act).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
