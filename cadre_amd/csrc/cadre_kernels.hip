@@ -708,13 +708,23 @@ extern "C" int cadre_gather_minibatch(const float* obs, int64_t ldo, int32_t S, 
 }
 
 // ============================================================================ LSTM cell pointwise
+// Rows sorted by command (row_seg != NULL: net z owns rows [row_seg[2z], +row_seg[2z+1]) of its B): only the rows of
+// the 32-row tiles that intersect the run are touched — the same rows the segment-aware GEMMs read and write; the
+// others belong to other nets (a net owns a quarter of the minibatch: 4x less traffic for these memory-bound passes).
+__device__ __forceinline__ bool lstm_row_outside(const int32_t* row_seg, int z, int b) {
+  if (!row_seg) return false;
+  const int beg = row_seg[2 * z], cnt = row_seg[2 * z + 1];
+  return cnt <= 0 || b < (beg & ~31) || b >= ((beg + cnt + 31) & ~31);
+}
+
 __global__ void lstm_fwd_kernel(float* gates, int64_t ldg, int64_t g_str, const float* c_prev, int64_t c_prev_str,
                                 int c_prev_div, float* c_out, float* h_out, float* tanh_c, int64_t ldh,
-                                int64_t h_str, int B, int Hd) {
+                                int64_t h_str, int B, int Hd, const int32_t* row_seg) {
   const int z = blockIdx.z;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * Hd) return;
   const int b = i / Hd, j = i % Hd;
+  if (lstm_row_outside(row_seg, z, b)) return;
   float* g = gates + z * g_str + (int64_t)b * ldg;
   const float ig = sigmoidf_(g[j]);
   const float fg = sigmoidf_(g[Hd + j]);
@@ -733,23 +743,24 @@ __global__ void lstm_fwd_kernel(float* gates, int64_t ldg, int64_t g_str, const 
 extern "C" int cadre_lstm_pointwise_fwd(float* gates, int64_t ldg, int64_t g_str, const float* c_prev,
                                         int64_t c_prev_str, int32_t c_prev_div, float* c_out, float* h_out,
                                         float* tanh_c, int64_t ldh, int64_t h_str, int32_t B, int32_t Hd,
-                                        int32_t batch, void* stream) {
+                                        int32_t batch, const int32_t* row_seg, void* stream) {
   FAIL_IF(!gates || !c_prev || !c_out || !h_out || !tanh_c || B < 1 || Hd < 1 || batch < 1 || c_prev_div < 1,
           "cadre_lstm_pointwise_fwd: bad argument");
   dim3 grid((B * Hd + 255) / 256, 1, batch);
   hipLaunchKernelGGL(lstm_fwd_kernel, grid, dim3(256), 0, ST(stream), gates, ldg, g_str, c_prev, c_prev_str,
-                     c_prev_div, c_out, h_out, tanh_c, ldh, h_str, B, Hd);
+                     c_prev_div, c_out, h_out, tanh_c, ldh, h_str, B, Hd, row_seg);
   return (int)hipGetLastError();
 }
 
 __global__ void lstm_bwd_kernel(const float* gates, float* dgates, int64_t ldg, int64_t g_str, const float* dh,
                                 float* dc, int64_t d_str, const float* tanh_c, const float* c_prev,
                                 int64_t c_prev_str, int c_prev_div, int64_t ldh, int64_t h_str, int B, int Hd,
-                                const int32_t* commands, int C) {
+                                const int32_t* commands, int C, const int32_t* row_seg) {
   const int z = blockIdx.z;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * Hd) return;
   const int b = i / Hd, j = i % Hd;
+  if (lstm_row_outside(row_seg, z, b)) return;           // (inside the tiles of the run, foreign rows still get their zeros)
   if (commands && commands[(z / C) * B + b] != z % C) {      // row of another command net: exact zeros
     float* dgz = dgates + z * g_str + (int64_t)b * ldg;
     dgz[j] = 0.f; dgz[Hd + j] = 0.f; dgz[2 * Hd + j] = 0.f; dgz[3 * Hd + j] = 0.f;
@@ -776,18 +787,18 @@ extern "C" int cadre_lstm_pointwise_bwd(const float* gates, float* dgates, int64
                                         const float* dh, float* dc, int64_t d_str, const float* tanh_c,
                                         const float* c_prev, int64_t c_prev_str, int32_t c_prev_div, int64_t ldh,
                                         int64_t h_str, int32_t B, int32_t Hd, int32_t batch, const int32_t* commands,
-                                        int32_t C, void* stream) {
+                                        int32_t C, const int32_t* row_seg, void* stream) {
   FAIL_IF(!gates || !dgates || !dh || !dc || !tanh_c || !c_prev || B < 1 || Hd < 1 || batch < 1 || c_prev_div < 1,
           "cadre_lstm_pointwise_bwd: bad argument");
   dim3 grid((B * Hd + 255) / 256, 1, batch);
   hipLaunchKernelGGL(lstm_bwd_kernel, grid, dim3(256), 0, ST(stream), gates, dgates, ldg, g_str, dh, dc, d_str,
-                     tanh_c, c_prev, c_prev_str, c_prev_div, ldh, h_str, B, Hd, commands, C < 1 ? 1 : C);
+                     tanh_c, c_prev, c_prev_str, c_prev_div, ldh, h_str, B, Hd, commands, C < 1 ? 1 : C, row_seg);
   return (int)hipGetLastError();
 }
 
 // ============================================================================ column sums / relu backward
 __global__ void colsum_kernel(const float* X, int64_t ldx, int64_t x_str, float* out, int64_t o_str, int M, int N,
-                              int accumulate, float* out2) {
+                              int accumulate, float* out2, const int32_t* row_seg, int period) {
   // 256 threads = 64 columns x 4 row-slices; slices combined through LDS in fixed order
   __shared__ float part[4][64];
   const int z = blockIdx.z;
@@ -798,6 +809,21 @@ __global__ void colsum_kernel(const float* X, int64_t ldx, int64_t x_str, float*
     // four independent partial sums: the loop is a chain of dependent HBM/L2 loads otherwise (M = 512 rows)
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int m = sl;
+    if (row_seg) {
+      // rows sorted by command, `period` rows per time step: rows outside the 32-row tiles of this net's run are
+      // exact zeros (cadre_lstm_pointwise_bwd) — skipped, every other row added to the partial sum it had before
+      const int beg = row_seg[2 * z], cnt = row_seg[2 * z + 1];
+      const int lo = beg & ~31, hi = cnt > 0 ? ((beg + cnt + 31) & ~31) : lo;
+      for (int t0 = 0; t0 < M; t0 += period)            // (t0, lo, hi are multiples of 32: row sl + 4q -> partial q % 4, as below)
+        for (int b = lo + sl; b < hi; b += 16) {
+          const float* xr = x + (int64_t)(t0 + b) * ldx;
+          s0 += xr[0];
+          s1 += xr[4 * ldx];
+          s2 += xr[8 * ldx];
+          s3 += xr[12 * ldx];
+        }
+      m = M;
+    }
     for (; m + 12 < M; m += 16) {
       s0 += x[(int64_t)m * ldx];
       s1 += x[(int64_t)(m + 4) * ldx];
@@ -821,14 +847,15 @@ extern "C" int cadre_colsum(const float* X, int64_t ldx, int64_t x_str, float* o
                             int32_t N, int32_t batch, int32_t accumulate, void* stream) {
   FAIL_IF(!X || !out || M < 1 || N < 1 || batch < 1, "cadre_colsum: bad argument");
   hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, 1, batch), dim3(256), 0, ST(stream), X, ldx, x_str, out,
-                     o_str, M, N, accumulate, (float*)nullptr);
+                     o_str, M, N, accumulate, (float*)nullptr, (const int32_t*)nullptr, 0);
   return (int)hipGetLastError();
 }
 extern "C" int cadre_colsum2(const float* X, int64_t ldx, int64_t x_str, float* out, float* out2, int64_t o_str, int32_t M,
-                             int32_t N, int32_t batch, void* stream) {
+                             int32_t N, int32_t batch, const int32_t* row_seg, int32_t period, void* stream) {
   FAIL_IF(!X || !out || !out2 || M < 1 || N < 1 || batch < 1, "cadre_colsum2: bad argument");
+  FAIL_IF(row_seg && (period < 32 || period % 32 != 0 || M % period != 0), "cadre_colsum2: row segments need period % 32 == 0, M % period == 0");
   hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, 1, batch), dim3(256), 0, ST(stream), X, ldx, x_str, out,
-                     o_str, M, N, 0, out2);
+                     o_str, M, N, 0, out2, row_seg, period);
   return (int)hipGetLastError();
 }
 

@@ -61,11 +61,11 @@ SYMBOLS = {
     "cadre_gather_obs": [vp, i64, i32, vp, i32, vp, i64, i32, vp],
     "cadre_gather_minibatch": [vp, i64, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32,
                                vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp],
-    "cadre_lstm_pointwise_fwd": [vp, i64, i64, vp, i64, i32, vp, vp, vp, i64, i64, i32, i32, i32, vp],
-    "cadre_lstm_pointwise_bwd": [vp, vp, i64, i64, vp, vp, i64, vp, vp, i64, i32, i64, i64, i32, i32, i32, vp, i32, vp],
+    "cadre_lstm_pointwise_fwd": [vp, i64, i64, vp, i64, i32, vp, vp, vp, i64, i64, i32, i32, i32, vp, vp],
+    "cadre_lstm_pointwise_bwd": [vp, vp, i64, i64, vp, vp, i64, vp, vp, i64, i32, i64, i64, i32, i32, i32, vp, i32, vp, vp],
     "cadre_colsum": [vp, i64, i64, vp, i64, i32, i32, i32, i32, vp],
     "cadre_relu_bwd": [vp, vp, i64, vp, i32, i32, i32, vp],
-    "cadre_colsum2": [vp, i64, i64, vp, vp, i64, i32, i32, i32, vp],
+    "cadre_colsum2": [vp, i64, i64, vp, vp, i64, i32, i32, i32, vp, i32, vp],
     "cadre_lstm_init": [vp, vp, vp, vp, vp, i64, i64, i32, i32, vp],
     "cadre_mfma_peak": [i32, i32, i32, vp, vp],
     "cadre_sort_rows_by_command": [vp, i32, i32, vp, vp, vp],
@@ -96,7 +96,7 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = args
             fn.restype = C.c_char_p if name == "cadre_last_error" else C.c_int
-        if L.cadre_abi_version() != 3:
+        if L.cadre_abi_version() != 4:
             raise CadreHipError("libcadre_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -85,6 +85,7 @@ class PPOLearnerHIP:
                                     B * DP, (S + 1) * B * DP, x_div, Z, st), "cadre_lstm_init")
         # all input projections x_t W_ih^T + b_ih: one GEMM [S*B, DP] x [DP, H4] per net
         sg1 = None if seg is None else (1, seg, B, 1)
+        sgp = None if seg is None else hip.ptr(seg)           # pointwise passes: only the tiles of each net's run of rows
         hip.gemm(X, pL[a.o_wih:], G, S * B, H4, DP, DP, DP, H4, shift=pL[a.o_bih:], batch=Z,
                  a_z=(x_div, 0, S * B * DP), b_z=(1, 0, sL), c_z=(1, 0, S * B * H4), s_z=(1, 0, sL), seg=sg1)
         for t in range(S):                                          # models.py:148-151
@@ -94,7 +95,7 @@ class PPOLearnerHIP:
                      s_z=(1, 0, sL), r_z=(1, 0, S * B * H4), seg=sg1)
             hip.check(L.cadre_lstm_pointwise_fwd(hip.ptr(Gt), H4, S * B * H4, hip.ptr(Cs[:, t]), (S + 1) * B * DP, 1,
                                                  hip.ptr(Cs[:, t + 1]), hip.ptr(Hs[:, t + 1]), hip.ptr(TC[:, t + 1]),
-                                                 DP, (S + 1) * B * DP, B, a.D, Z, st), "cadre_lstm_pointwise_fwd")
+                                                 DP, (S + 1) * B * DP, B, a.D, Z, sgp, st), "cadre_lstm_pointwise_fwd")
         if mlp:
             self._mlp(w, B, nets, Hs[:, S], (S + 1) * B * DP, seg=seg)
 
@@ -217,7 +218,8 @@ class PPOLearnerHIP:
         for t in range(S - 1, -1, -1):
             hip.check(L.cadre_lstm_pointwise_bwd(hip.ptr(G[:, t]), hip.ptr(dG[:, t]), H4, S * B * H4, hip.ptr(dH),
                                                  hip.ptr(dC), B * DP, hip.ptr(TC[:, t + 1]), hip.ptr(Cs[:, t]),
-                                                 (S + 1) * B * DP, 1, DP, (S + 1) * B * DP, B, a.D, Z, cmd, C, st),
+                                                 (S + 1) * B * DP, 1, DP, (S + 1) * B * DP, B, a.D, Z, cmd, C,
+                                                 None if seg is None else hip.ptr(seg), st),
                       "cadre_lstm_pointwise_bwd")
             if t > 0 and skinny:   # dh_{t-1} = dG_t W_hh, K = 2120: the K slices meet inside the workgroup (tile 11)
                 hip.gemm(dG[:, t], pL[a.o_whh:], dH, B, DP, H4, H4, DP, DP, b_mode=1, batch=Z,
@@ -233,7 +235,8 @@ class PPOLearnerHIP:
         hip.gemm(dG, X, gL[a.o_wih:], H4, DP, S * B, H4, DP, DP, a_mode=1, b_mode=1, batch=Z,
                  a_z=(1, 0, S * B * H4), b_z=(C, 0, S * B * DP), c_z=(1, 0, sL), seg=sgK1)
         # b_ih and b_hh enter the gates as a sum: identical gradients, written by one pass
-        hip.check(L.cadre_colsum2(hip.ptr(dG), H4, S * B * H4, hip.ptr(gL[a.o_bih:]), hip.ptr(gL[a.o_bhh:]), sL, S * B, H4, Z, st),
+        hip.check(L.cadre_colsum2(hip.ptr(dG), H4, S * B * H4, hip.ptr(gL[a.o_bih:]), hip.ptr(gL[a.o_bhh:]), sL, S * B, H4, Z,
+                                  None if seg is None else hip.ptr(seg), B, st),
                   "cadre_colsum2")
         return w["losses"]
 

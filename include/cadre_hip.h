@@ -15,7 +15,7 @@
 extern "C" {
 #endif
 
-#define CADRE_ABI_VERSION 3
+#define CADRE_ABI_VERSION 4
 int cadre_abi_version(void);
 /* human-readable last argument error of the calling thread ("" if none) */
 const char* cadre_last_error(void);
@@ -206,7 +206,10 @@ int cadre_gather_minibatch(const float* obs, int64_t ldo, int32_t S, const float
 int cadre_lstm_pointwise_fwd(float* gates, int64_t ldg, int64_t g_str, const float* c_prev,
                              int64_t c_prev_str, int32_t c_prev_div, float* c_out, float* h_out,
                              float* tanh_c, int64_t ldh, int64_t h_str, int32_t B, int32_t Hd,
-                             int32_t batch, void* stream);
+                             int32_t batch, const int32_t* row_seg, void* stream);
+/* row_seg (may be NULL; [batch][2] = (first row, count) of the run of rows net z owns when the minibatch is sorted by
+ * command, cadre_sort_rows_by_command): only rows of the 32-row tiles that intersect the run are touched — the rows the
+ * segment-aware GEMMs (cadre_gemm_t.seg_mode) read and write. */
 /* backward of one step: dh (in: upstream+recurrent grad of h_t), dc (in/out: grad of c_t ->
  * grad of c_{t-1}), both [batch][B][ldh] with net stride d_str; activated gates, tanh_c,
  * c_prev -> dgates [B][ldg] */
@@ -215,7 +218,7 @@ int cadre_lstm_pointwise_bwd(const float* gates, float* dgates, int64_t ldg, int
                              const float* c_prev,
                              int64_t c_prev_str, int32_t c_prev_div, int64_t ldh, int64_t h_str,
                              int32_t B, int32_t Hd, int32_t batch, const int32_t* commands, int32_t C,
-                             void* stream);
+                             const int32_t* row_seg, void* stream);
 /* (commands != NULL: net z = head*C + c only keeps rows whose command is c; the other rows get
  * dgates = 0 and dc = 0 whatever dh holds — see cadre_gemm_t.seg_mode.) */
 /* column sums: out[z][n] (+)= sum_m X[z][m][n]  (bias gradients) */
@@ -273,7 +276,9 @@ int cadre_categorical_dist(const float* raw, int64_t ldl, int32_t R, int32_t n_o
 
 /* db_ih = db_hh = colsum(dG) in one pass (both biases enter the LSTM gates as a sum): out and out2 [batch][o_str] */
 int cadre_colsum2(const float* X, int64_t ldx, int64_t x_str, float* out, float* out2, int64_t o_str, int32_t M,
-                  int32_t N, int32_t batch, void* stream);
+                  int32_t N, int32_t batch, const int32_t* row_seg, int32_t period, void* stream);
+/* (row_seg != NULL: rows sorted by command, `period` rows per time step — rows outside the 32-row tiles of net z's run
+ * are exact zeros by construction and are skipped; the sum is bit-identical to the full one.) */
 /* Initial LSTM state of every net z < Z: Hs[z*z_str ..] <- h0[(z / x_div)*n_per ..], same for Cs <- c0 (n_per floats
  * each, agent.py:166-175 hidden_state_batch shared by a head's command nets) and dC (Z*n_per floats, may be NULL) <- 0 */
 int cadre_lstm_init(const float* h0, const float* c0, float* Hs, float* Cs, float* dC, int64_t n_per,

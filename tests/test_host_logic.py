@@ -20,7 +20,7 @@ def test_cabi_exports_every_declared_symbol():
     L = ctypes.CDLL(hip.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert hip.lib().cadre_abi_version() == 3
+    assert hip.lib().cadre_abi_version() == 4
     assert ctypes.sizeof(hip.GemmDesc) == 264      # static_assert-ed in gemm_f32.hip
 
 

@@ -261,7 +261,7 @@ def test_lstm_pointwise_fwd_bwd(hip):
     cd = torch.zeros(Z, B, ldh, device="cuda"); hd_ = torch.zeros_like(cd); tcd = torch.zeros_like(cd)
     L = hip.lib()
     hip.check(L.cadre_lstm_pointwise_fwd(Gd.data_ptr(), ldg, B * ldg, c0d.data_ptr(), B * ldh, 4, cd.data_ptr(),
-                                         hd_.data_ptr(), tcd.data_ptr(), ldh, B * ldh, B, Hd, Z, hip.stream()), "lf")
+                                         hd_.data_ptr(), tcd.data_ptr(), ldh, B * ldh, B, Hd, Z, None, hip.stream()), "lf")
     assert rel(hd_[:, :, :Hd], h) < 1e-5 and rel(cd[:, :, :Hd], c) < 1e-5
     assert float(hd_[:, :, Hd:].abs().max()) == 0.0
     dhd = torch.zeros(Z, B, ldh, device="cuda"); dhd[:, :, :Hd] = dh.cuda()
@@ -269,7 +269,7 @@ def test_lstm_pointwise_fwd_bwd(hip):
     dG = torch.zeros(Z, B, ldg, device="cuda")
     hip.check(L.cadre_lstm_pointwise_bwd(Gd.data_ptr(), dG.data_ptr(), ldg, B * ldg, dhd.data_ptr(), dcd.data_ptr(),
                                          B * ldh, tcd.data_ptr(), c0d.data_ptr(), B * ldh, 4, ldh, B * ldh, B, Hd, Z,
-                                         None, 4, hip.stream()), "lb")
+                                         None, 4, None, hip.stream()), "lb")
     # Gr.grad accumulated both backward calls: second call's contribution = full; subtract first
     Gr2 = G.clone().requires_grad_(True); c0r2 = c0.clone().requires_grad_(True)
     i, f, gg, o = Gr2.chunk(4, -1)
@@ -279,6 +279,66 @@ def test_lstm_pointwise_fwd_bwd(hip):
     assert rel(dG, Gr2.grad) < 1e-5
     want_dcprev = (dc_in + dh * torch.sigmoid(o) * (1 - torch.tanh(c2) ** 2)) * torch.sigmoid(f)
     assert rel(dcd[:, :, :Hd], want_dcprev.detach()) < 1e-5
+
+
+def test_lstm_pointwise_and_colsum2_row_segments(hip):
+    """Rows sorted by command: the pointwise LSTM passes and the bias-gradient column sum touch only the 32-row tiles
+    that intersect each net's run of rows — same values there as the unrestricted kernels, bit for bit; rows outside
+    untouched; the segment-aware column sum equals the full one when the rows outside hold the zeros the backward
+    writes."""
+    g = torch.Generator().manual_seed(77)
+    Z, B, S, Hd, ldh = 8, 128, 2, 530, 544
+    ldg = 4 * Hd
+    run = [(0, 40), (40, 0), (40, 70), (110, 18)]
+    seg = torch.tensor(run + run, dtype=torch.int32, device="cuda")
+    hull = [(b & ~31, ((b + c + 31) & ~31) if c else (b & ~31)) for b, c in run + run]
+    G = torch.randn(Z, B, ldg, generator=g).cuda()
+    c0 = torch.zeros(Z, B, ldh, device="cuda"); c0[:, :, :Hd] = torch.randn(Z, B, Hd, generator=g).cuda()
+    L = hip.lib()
+    outs = []
+    for sg in (None, seg):
+        Gd = G.clone()
+        cd = torch.full((Z, B, ldh), 5.0, device="cuda"); hd_ = torch.full_like(cd, 5.0); tcd = torch.full_like(cd, 5.0)
+        hip.check(L.cadre_lstm_pointwise_fwd(Gd.data_ptr(), ldg, B * ldg, c0.data_ptr(), B * ldh, 1, cd.data_ptr(), hd_.data_ptr(),
+                                             tcd.data_ptr(), ldh, B * ldh, B, Hd, Z, None if sg is None else sg.data_ptr(),
+                                             hip.stream()), "lf")
+        outs.append((Gd, cd, hd_, tcd))
+    for z in range(Z):
+        lo, hi = hull[z]
+        for full, part in zip(outs[0], outs[1]):
+            assert torch.equal(full[z, lo:hi], part[z, lo:hi])
+        assert torch.equal(outs[1][0][z, :lo], G[z, :lo]) and torch.equal(outs[1][0][z, hi:], G[z, hi:])     # gates untouched
+        assert float((outs[1][2][z, :lo, :Hd] - 5.0).abs().max() if lo else 0.0) == 0.0
+    # backward: foreign rows inside the tiles get exact zeros, rows outside keep what they held
+    cmds = torch.zeros(2, B, dtype=torch.int32)
+    for c, (b0, cnt) in enumerate(run):
+        cmds[:, b0:b0 + cnt] = c
+    cmds = cmds.cuda()
+    dh = torch.zeros(Z, B, ldh, device="cuda"); dh[:, :, :Hd] = torch.randn(Z, B, Hd, generator=g).cuda()
+    Ga, _cd, _hd, tca = outs[0]
+    res = []
+    for sg in (None, seg):
+        dG = torch.full((Z, B, ldg), 9.0, device="cuda"); dc = torch.zeros(Z, B, ldh, device="cuda")
+        hip.check(L.cadre_lstm_pointwise_bwd(Ga.data_ptr(), dG.data_ptr(), ldg, B * ldg, dh.data_ptr(), dc.data_ptr(), B * ldh,
+                                             tca.data_ptr(), c0.data_ptr(), B * ldh, 1, ldh, B * ldh, B, Hd, Z, cmds.data_ptr(), 4,
+                                             None if sg is None else sg.data_ptr(), hip.stream()), "lb")
+        res.append((dG, dc))
+    for z in range(Z):
+        lo, hi = hull[z]
+        assert torch.equal(res[0][0][z, lo:hi], res[1][0][z, lo:hi]) and torch.equal(res[0][1][z, lo:hi], res[1][1][z, lo:hi])
+        outside = torch.cat([res[1][0][z, :lo], res[1][0][z, hi:]])
+        assert outside.numel() == 0 or float((outside - 9.0).abs().max()) == 0.0
+        b0, cnt = (run + run)[z]
+        inside_foreign = torch.cat([res[1][0][z, lo:min(b0, hi)], res[1][0][z, max(b0 + cnt, lo):hi]])
+        assert inside_foreign.numel() == 0 or float(inside_foreign.abs().max()) == 0.0
+    # bias gradients: dG as the unrestricted backward leaves it (zeros on every foreign row), S time steps of B rows
+    dGs = torch.stack([res[0][0], res[0][0].flip(1) * 0 + res[0][0]], 1).contiguous()        # [Z][S][B][ldg]
+    o1 = torch.zeros(Z, ldg, device="cuda"); o2 = torch.zeros_like(o1); p1 = torch.zeros_like(o1); p2 = torch.zeros_like(o1)
+    hip.check(L.cadre_colsum2(dGs.data_ptr(), ldg, S * B * ldg, o1.data_ptr(), o2.data_ptr(), ldg, S * B, ldg, Z, None, 0, hip.stream()), "cs")
+    hip.check(L.cadre_colsum2(dGs.data_ptr(), ldg, S * B * ldg, p1.data_ptr(), p2.data_ptr(), ldg, S * B, ldg, Z, seg.data_ptr(), B,
+                              hip.stream()), "cs")
+    assert torch.equal(o1, p1) and torch.equal(o2, p2) and torch.equal(o1, o2)
+    assert rel(o1, dGs.double().sum((1, 2))) < 1e-5
 
 
 def test_colsum_relu_bwd(hip):
