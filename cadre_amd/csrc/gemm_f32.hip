@@ -519,11 +519,16 @@ __global__ __launch_bounds__(64 * WVM * WVN, ((WVM * WM + WVN * WN) * 2 * 32 * 3
 
 __global__ void splitk_reduce_kernel(const float* slabs, int split_k, int64_t slab_stride, int64_t lds_,
                                      float* C, int64_t ldc, int M, int N, const float* scale,
-                                     const float* shift, int act, float slope) {
+                                     const float* shift, int act, float slope, const int32_t* row_seg, int period) {
   const int64_t total = (int64_t)M * N;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int m = (int)(i / N), n = (int)(i % N);
+    if (row_seg) {       // rows [z][period] sorted by command: only the 32-row tiles of net z's run were written by the GEMM
+      const int z = m / period, b = m - z * period;
+      const int beg = row_seg[2 * z], cnt = row_seg[2 * z + 1];
+      if (cnt <= 0 || b < (beg & ~31) || b >= ((beg + cnt + 31) & ~31)) continue;
+    }
     float v = 0.f;
     for (int s = 0; s < split_k; ++s) v += slabs[s * slab_stride + (int64_t)m * lds_ + n];
     v = v * (scale ? scale[n] : 1.f) + (shift ? shift[n] : 0.f);
@@ -686,11 +691,13 @@ extern "C" int cadre_gemm_f32(const cadre_gemm_t* pp, void* stream) {
 
 extern "C" int cadre_splitk_reduce(const float* slabs, int32_t split_k, int64_t slab_stride, int64_t lds_,
                                    float* C, int64_t ldc, int32_t M, int32_t N, const float* scale,
-                                   const float* shift, int32_t act, float slope, void* stream) {
+                                   const float* shift, int32_t act, float slope, const int32_t* row_seg, int32_t period,
+                                   void* stream) {
   if (!slabs || !C || split_k < 1 || M < 1 || N < 1) return cadre_fail("cadre_splitk_reduce: bad argument");
+  if (row_seg && (period < 32 || period % 32 != 0 || M % period != 0)) return cadre_fail("cadre_splitk_reduce: row segments need period % 32 == 0, M % period == 0");
   const int64_t total = (int64_t)M * N;
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slabs, split_k,
-                     slab_stride, lds_, C, ldc, M, N, scale, shift, act, slope);
+                     slab_stride, lds_, C, ldc, M, N, scale, shift, act, slope, row_seg, period);
   return (int)hipGetLastError();
 }

@@ -344,7 +344,7 @@ class DANetEncoderHIP:
                 hip.gemm(src, self.ita_w1[b], slabs, F, 1536, Kin, Kin, Kin, 1536, split_k=split,
                          tile=3 if F <= 64 else 0, bf16=self.bf16)
                 hip.check(L.cadre_splitk_reduce(hip.ptr(slabs), split, F * 1536, 1536, hid.data_ptr() + 4 * 1536 * b,
-                                                3072, F, 1536, None, hip.ptr(self.ita_b1[b]), 2, 0.01, st),
+                                                3072, F, 1536, None, hip.ptr(self.ita_b1[b]), 2, 0.01, None, 0, st),
                           "cadre_splitk_reduce")
             else:
                 hip.gemm(src, self.ita_w1[b], hid[:, 1536 * b:], F, 1536, Kin, Kin, Kin, 3072, shift=self.ita_b1[b],

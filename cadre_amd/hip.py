@@ -45,7 +45,7 @@ SYMBOLS = {
     "cadre_maxpool3x3s2_bf16": [vp, vp, i32, i32, i32, i32, vp],
     "cadre_pam_bf16out": [vp, vp, f32, vp, i32, i32, vp],
     "cadre_cam_bf16out": [vp, f32, vp, i32, i32, vp],
-    "cadre_splitk_reduce": [vp, i32, i64, i64, vp, i64, i32, i32, vp, vp, i32, f32, vp],
+    "cadre_splitk_reduce": [vp, i32, i64, i64, vp, i64, i32, i32, vp, vp, i32, f32, vp, i32, vp],
     "cadre_preprocess": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "cadre_preprocess_bf16pad": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "cadre_maxpool3x3s2": [vp, vp, i32, i32, i32, i32, vp],

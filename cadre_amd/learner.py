@@ -228,7 +228,8 @@ class PPOLearnerHIP:
                 hip.gemm(dG[:, t], pL[a.o_whh:], w["dHs"], B, DP, H4, H4, DP, DP, b_mode=1, batch=Z,
                          a_z=(1, 0, S * B * H4), b_z=(1, 0, sL), c_z=(1, 0, B * DP), split_k=self.SPLIT_DH, seg=sgM1)
                 hip.check(L.cadre_splitk_reduce(hip.ptr(w["dHs"]), self.SPLIT_DH, Z * B * DP, DP, hip.ptr(dH), DP,
-                                                Z * B, DP, None, None, 0, 0.0, st), "cadre_splitk_reduce")
+                                                Z * B, DP, None, None, 0, 0.0, None if seg is None else hip.ptr(seg), B, st),
+                          "cadre_splitk_reduce")
         # dW_hh = sum_t dG_t^T h_{t-1} ; dW_ih = sum_t dG_t^T x_t ; db_ih = db_hh = colsum(dG)
         hip.gemm(dG, Hs, gL[a.o_whh:], H4, DP, S * B, H4, DP, DP, a_mode=1, b_mode=1, batch=Z,
                  a_z=(1, 0, S * B * H4), b_z=(1, 0, (S + 1) * B * DP), c_z=(1, 0, sL), seg=sgK1)

@@ -111,7 +111,10 @@ int cadre_mfma_peak(int32_t bf16, int32_t workgroups, int32_t iters, float* sink
 /* C[M][ldc] = act(sum_s slab[s][M][lds] * scale + shift + resid) */
 int cadre_splitk_reduce(const float* slabs, int32_t split_k, int64_t slab_stride, int64_t lds,
                         float* C, int64_t ldc, int32_t M, int32_t N, const float* scale,
-                        const float* shift, int32_t act, float slope, void* stream);
+                        const float* shift, int32_t act, float slope, const int32_t* row_seg, int32_t period,
+                        void* stream);
+/* (row_seg != NULL: the M rows are [batch][period] sorted by command, row_seg [batch][2]; only the rows of the 32-row
+ * tiles of each batch entry's run — the ones a seg_mode 1 GEMM wrote — are reduced, the others left as they are.) */
 
 /* ---------------------------------------------------------------- encoder pieces
  * pre_process: ppo_agent/agent.py:43-75.  rgb u8 [F][H][W][3], route u8 [F][W][H] (stored

@@ -76,7 +76,7 @@ def test_gemm_batched_and_splitk(hip):
     out2 = torch.empty(40, 200, device="cuda")
     b2_d = dev(b2)
     hip.check(hip.lib().cadre_splitk_reduce(slabs.data_ptr(), S, 40 * 200, 200, out2.data_ptr(), 200, 40, 200, None,
-                                            b2_d.data_ptr(), 2, 0.01, hip.stream()), "reduce")
+                                            b2_d.data_ptr(), 2, 0.01, None, 0, hip.stream()), "reduce")
     torch.cuda.synchronize()
     assert rel(out2, want2) < 2e-5
 
@@ -94,7 +94,7 @@ def test_gemm_batched_splitk(hip):
              c_z=(1, 0, M * N), split_k=S)
     out = torch.empty(Z, M, N, device="cuda")
     hip.check(hip.lib().cadre_splitk_reduce(slabs.data_ptr(), S, Z * M * N, N, out.data_ptr(), N, Z * M, N, None, None,
-                                            0, 0.0, hip.stream()), "reduce")
+                                            0, 0.0, None, 0, hip.stream()), "reduce")
     assert rel(out, want) < 2e-5
 
 
