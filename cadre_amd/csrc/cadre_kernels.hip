@@ -707,6 +707,58 @@ extern "C" int cadre_gather_minibatch(const float* obs, int64_t ldo, int32_t S, 
   return (int)hipGetLastError();
 }
 
+// The same gather for all workers and both heads in ONE launch: src[(worker*2 + head)] holds the nine storage pointers
+// of that worker's head (stable for the life of the storages: the table is built once), idx [n_src][Bw] the minibatch
+// row ids of every (worker, head); outputs are the [2][...] workspace arrays (head stride given).
+struct gather_src_t {
+  const float* obs; const float* hn; const float* cn; const int64_t* action; const float* value_preds;
+  const float* returns; const float* logp; const int32_t* command; const float* adv;
+};
+__global__ void gather_minibatch_multi_kernel(const gather_src_t* src, int64_t ldo, int S, int64_t ldh, const int64_t* idx,
+                                              int Bw, int D, int Hd, int Bt, float* X, int64_t x_hs, int64_t ldx, float* h0,
+                                              float* c0, int64_t h_hs, int64_t ldho, int64_t* actions_o, int32_t* commands_o,
+                                              float* old_values_o, float* returns_o, float* old_logp_o, float* adv_o) {
+  const int b = blockIdx.x, s = blockIdx.y, zi = blockIdx.z;
+  const int wi = zi >> 1, hd = zi & 1;
+  const gather_src_t g = src[zi];
+  const int64_t t = idx[(int64_t)zi * Bw + b];
+  const int ob = wi * Bw + b;
+  if (s < S) {
+    const float* sp = g.obs + (t * S + s) * ldo;
+    float* dst = X + hd * x_hs + ((int64_t)s * Bt + ob) * ldx;
+    for (int d = threadIdx.x; d < ldx; d += blockDim.x) dst[d] = d < D ? sp[d] : 0.f;
+    return;
+  }
+  const float* hs = g.hn + t * ldh;
+  const float* cs = g.cn + t * ldh;
+  for (int d = threadIdx.x; d < ldho; d += blockDim.x) {
+    h0[hd * h_hs + (int64_t)ob * ldho + d] = d < Hd ? hs[d] : 0.f;
+    c0[hd * h_hs + (int64_t)ob * ldho + d] = d < Hd ? cs[d] : 0.f;
+  }
+  if (threadIdx.x == 0) {
+    const int64_t o = (int64_t)hd * Bt + ob;
+    actions_o[o] = g.action[t];
+    commands_o[o] = g.command[t];
+    old_values_o[o] = g.value_preds[t];
+    returns_o[o] = g.returns[t];
+    old_logp_o[o] = g.logp[t];
+    adv_o[o] = g.adv[t];
+  }
+}
+extern "C" int cadre_gather_minibatch_multi(const void* src_table, int32_t n_src, int64_t ldo, int32_t S, int64_t ldh,
+                                            const int64_t* idx, int32_t Bw, int32_t D, int32_t Hd, int32_t Bt, float* X,
+                                            int64_t x_head_stride, int64_t ldx, float* h0, float* c0, int64_t h_head_stride,
+                                            int64_t ldho, int64_t* actions_o, int32_t* commands_o, float* old_values_o,
+                                            float* returns_o, float* old_logp_o, float* adv_o, void* stream) {
+  FAIL_IF(!src_table || !idx || !X || !h0 || !c0 || !actions_o || !commands_o || !old_values_o || !returns_o || !old_logp_o ||
+              !adv_o || n_src < 2 || (n_src & 1) || S < 1 || Bw < 1 || D < 1 || Hd < 1 || (n_src / 2) * Bw > Bt || ldx < D || ldho < Hd,
+          "cadre_gather_minibatch_multi: bad argument");
+  hipLaunchKernelGGL(gather_minibatch_multi_kernel, dim3(Bw, S + 1, n_src), dim3(128), 0, ST(stream),
+                     (const gather_src_t*)src_table, ldo, S, ldh, idx, Bw, D, Hd, Bt, X, x_head_stride, ldx, h0, c0, h_head_stride,
+                     ldho, actions_o, commands_o, old_values_o, returns_o, old_logp_o, adv_o);
+  return (int)hipGetLastError();
+}
+
 // ============================================================================ LSTM cell pointwise
 // Rows sorted by command (row_seg != NULL: net z owns rows [row_seg[2z], +row_seg[2z+1]) of its B): only the rows of
 // the 32-row tiles that intersect the run are touched — the same rows the segment-aware GEMMs read and write; the

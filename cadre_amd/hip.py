@@ -61,6 +61,8 @@ SYMBOLS = {
     "cadre_gather_obs": [vp, i64, i32, vp, i32, vp, i64, i32, vp],
     "cadre_gather_minibatch": [vp, i64, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32,
                                vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp],
+    "cadre_gather_minibatch_multi": [vp, i32, i64, i32, i64, vp, i32, i32, i32, i32, vp, i64, i64, vp, vp, i64, i64,
+                                     vp, vp, vp, vp, vp, vp, vp],
     "cadre_lstm_pointwise_fwd": [vp, i64, i64, vp, i64, i32, vp, vp, vp, i64, i64, i32, i32, i32, vp, vp],
     "cadre_lstm_pointwise_bwd": [vp, vp, i64, i64, vp, vp, i64, vp, vp, i64, i32, i64, i64, i32, i32, i32, vp, i32, vp, vp],
     "cadre_colsum": [vp, i64, i64, vp, i64, i32, i32, i32, i32, vp],

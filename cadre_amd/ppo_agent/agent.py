@@ -175,17 +175,42 @@ class CadreAgent(object):
         srt = self.learner.sorted_rows(B)
         u = "_u" if srt else ""                       # sorted mode: gather into staging, then sort + permute
         Xk, hk, ck = ("Xu", "h0u", "c0u") if srt else ("X", "h0", "c0")
-        for wi, (ss, si, sa, ts, ti, ta) in enumerate(batches):
-            for hd, (stor, idx, adv) in enumerate(((ss, si, sa), (ts, ti, ta))):
-                idx_d = idx.to(self.device, non_blocking=True)
-                hip.check(L.cadre_gather_minibatch(
-                    hip.ptr(stor._obs), stor._ldo, stor.seq_length, hip.ptr(stor._hn), hip.ptr(stor._cn), stor._ldh,
-                    hip.ptr(stor.action), hip.ptr(stor.value_preds), hip.ptr(stor.returns),
-                    hip.ptr(stor.action_log_probs), hip.ptr(stor.command), hip.ptr(adv), hip.ptr(idx_d), Bw, a.D, a.D,
-                    B, wi * Bw, hip.ptr(w[Xk][hd]), a.DP, hip.ptr(w[hk][hd]), hip.ptr(w[ck][hd]), a.DP,
-                    hip.ptr(w["actions" + u][hd]), hip.ptr(w["commands" + u][hd]), hip.ptr(w["old_values" + u][hd]),
-                    hip.ptr(w["returns" + u][hd]), hip.ptr(w["old_logp" + u][hd]), hip.ptr(w["adv" + u][hd]), st),
-                    "cadre_gather_minibatch")
+        # ONE gather launch for all workers and both heads: a device table of the storages' pointers (built once per set
+        # of storages / advantage tensors) and one host-to-device copy of the 2*nW index vectors
+        pairs = [(stor, adv) for (ss, si, sa, ts, ti, ta) in batches for (stor, adv) in ((ss, sa), (ts, ta))]
+        ptrs = [[hip.ptr(stor._obs), hip.ptr(stor._hn), hip.ptr(stor._cn), hip.ptr(stor.action), hip.ptr(stor.value_preds),
+                 hip.ptr(stor.returns), hip.ptr(stor.action_log_probs), hip.ptr(stor.command), hip.ptr(adv)] for stor, adv in pairs]
+        key = tuple(p for row in ptrs for p in row)
+        cache = self.__dict__.setdefault("_gather_tables", {})
+        table = cache.get(key)
+        if table is None:
+            if len(cache) > 16:
+                cache.clear()
+            table = cache[key] = torch.tensor(ptrs, dtype=torch.int64).to(self.device)
+        # (pinned staging buffers in a ring: a slot is rewritten only after the copy that last read it has completed —
+        #  the caller may enqueue several minibatch steps without a host sync)
+        ring = self.__dict__.get("_gather_idx")
+        if ring is None or ring["shape"] != (2 * nW, Bw):
+            ring = self._gather_idx = dict(shape=(2 * nW, Bw), pos=0, slots=[
+                [torch.empty(2 * nW, Bw, dtype=torch.int64).pin_memory(),
+                 torch.empty(2 * nW, Bw, dtype=torch.int64, device=self.device), None] for _ in range(8)])
+        stage = ring["slots"][ring["pos"]]
+        ring["pos"] = (ring["pos"] + 1) % len(ring["slots"])
+        if stage[2] is not None:
+            stage[2].synchronize()
+        for i, (ss, si, sa, ts, ti, ta) in enumerate(batches):
+            stage[0][2 * i].copy_(si.reshape(-1))
+            stage[0][2 * i + 1].copy_(ti.reshape(-1))
+        stage[1].copy_(stage[0], non_blocking=True)
+        stage[2] = torch.cuda.Event()
+        stage[2].record()
+        s0 = batches[0][0]
+        hip.check(L.cadre_gather_minibatch_multi(
+            hip.ptr(table), 2 * nW, s0._ldo, s0.seq_length, s0._ldh, hip.ptr(stage[1]), Bw, a.D, a.D, B,
+            hip.ptr(w[Xk]), w[Xk].stride(0), a.DP, hip.ptr(w[hk]), hip.ptr(w[ck]), w[hk].stride(0), a.DP,
+            hip.ptr(w["actions" + u]), hip.ptr(w["commands" + u]), hip.ptr(w["old_values" + u]),
+            hip.ptr(w["returns" + u]), hip.ptr(w["old_logp" + u]), hip.ptr(w["adv" + u]), st),
+            "cadre_gather_minibatch_multi")
         if srt:
             hip.check(L.cadre_sort_rows_by_command(hip.ptr(w["commands_u"]), B, a.C, hip.ptr(w["pos"]), hip.ptr(w["seg"]),
                                                    st), "cadre_sort_rows_by_command")

@@ -200,6 +200,17 @@ int cadre_gather_minibatch(const float* obs, int64_t ldo, int32_t S, const float
                            int64_t ldho, int64_t* actions_o, int32_t* commands_o, float* old_values_o,
                            float* returns_o, float* old_logp_o, float* adv_o, void* stream);
 
+/* The same gather for every worker and both heads in one launch (train.py:93-102 iterates workers; each worker's two
+ * feed_forward_generators storage.py:93-120).  src_table: n_src = 2 * workers records of nine device pointers
+ * {obs, hn, cn, action, value_preds, returns, action_log_probs, command, adv} for (worker, head) = (i / 2, i % 2);
+ * idx [n_src][Bw] row ids; worker w fills rows w*Bw .. of the Bt-row batch; outputs are [2][...] arrays of the two
+ * heads (X / h0 / c0 with the given head strides, the scalars [2][Bt]). */
+int cadre_gather_minibatch_multi(const void* src_table, int32_t n_src, int64_t ldo, int32_t S, int64_t ldh,
+                                 const int64_t* idx, int32_t Bw, int32_t D, int32_t Hd, int32_t Bt, float* X,
+                                 int64_t x_head_stride, int64_t ldx, float* h0, float* c0, int64_t h_head_stride,
+                                 int64_t ldho, int64_t* actions_o, int32_t* commands_o, float* old_values_o,
+                                 float* returns_o, float* old_logp_o, float* adv_o, void* stream);
+
 /* ---------------------------------------------------------------- LSTM cell pointwise
  * nn.LSTMCell gate math (models.py:130-152).  gates [B][ldg] pre-activations (i,f,g,o blocks
  * of Hd), batched over `batch` nets with strides; c_prev of net z is read at
