@@ -167,8 +167,11 @@ def learner_round(agent, workers, cfg, shared, timers=None, joint=None):
     if timers is not None:
         torch.cuda.synchronize(); t1 = time.perf_counter()
     advs = []
-    for wk in workers:
-        nv_s, nv_t = agent.get_value(False, wk.stor[0].get_last(), wk.stor[1].get_last())
+    if len(workers) > 1:      # bootstrap values of all workers in one LSTM + critic pass
+        vals = agent.get_values([(wk.stor[0].get_last(), wk.stor[1].get_last()) for wk in workers])
+    else:
+        vals = [agent.get_value(False, wk.stor[0].get_last(), wk.stor[1].get_last()) for wk in workers]
+    for wk, (nv_s, nv_t) in zip(workers, vals):
         advs.append((wk.stor[0].compute_returns(nv_s), wk.stor[1].compute_returns(nv_t)))
     nW = len(workers)
     dev_losses = []

@@ -289,6 +289,18 @@ class PPOLearnerHIP:
         self._forward(w, 1, (g_s, g_t - g_s, 2), 1, S=S)
         return w["O3"], w["Hs"][:, S], w["Cs"][:, S]
 
+    def infer_rows(self, feats):
+        """LSTM + both towers of ALL command nets of both heads on W independent rows in one pass (zero initial
+        state, agent.py:38-40): feats [2][W][S][D] (head, row).  Returns O3 [4*C][W][NP] (tower z = 2*net + t,
+        net = head*C + c) — the caller picks each row's command.  One launch chain instead of W (get_value for every
+        worker of a GPU, train.py:76-80)."""
+        a, W, S = self.a, feats.shape[1], feats.shape[2]
+        w = self.workspace(W, a.Z, S)
+        w["X"].view(2, S, W, a.DP)[:, :, :, :a.D].copy_(feats.permute(0, 2, 1, 3))
+        w["h0"].zero_(); w["c0"].zero_()
+        self._forward(w, W, (0, 1, a.Z), a.C, S=S)
+        return w["O3"]
+
     # ------------------------------------------------------------------ stand-alone module calls
     def lstm_module_forward(self, g, x, h0, c0):
         """`LSTM.forward` (models.py:139-152) of arena net g: x [T*N, D] time-major (or [N, D]), hidden

@@ -129,6 +129,16 @@ class CadreAgent(object):
         O3, _, _ = self.learner.infer(torch.stack([s_obs, t_obs]), (int(s_cmd), int(t_cmd)))
         return O3[1, :, :1].clone(), O3[3, :, :1].clone()
 
+    def get_values(self, batches):
+        """get_value (agent.py:143-164) for several workers at once: batches = [(steer_batch, throttle_batch), ...] as
+        `RolloutStorage.get_last()` returns them (none of them done).  One LSTM + critic pass over all command nets with
+        one row per worker instead of one launch chain per worker; returns [(v_steer [1,1], v_throttle [1,1]), ...]."""
+        feats = torch.stack([torch.stack([sb[0] for sb, _tb in batches]), torch.stack([tb[0] for _sb, tb in batches])])
+        O3 = self.learner.infer_rows(feats).clone()
+        C = self.arena.C
+        return [(O3[2 * int(sb[1]) + 1, i:i + 1, :1], O3[2 * (C + int(tb[1])) + 1, i:i + 1, :1])
+                for i, (sb, tb) in enumerate(batches)]
+
     # ------------------------------------------------------------------ update
     def _pack(self, w, hd, samples):
         obs, act, old_v, ret, _masks, old_lp, adv, hidden, cmd = samples

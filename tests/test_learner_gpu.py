@@ -437,3 +437,22 @@ def test_ensemble_act_equals_per_agent_loop():
     other = make_agent(84, 84, enc_seed=8)
     with pytest.raises(ValueError):
         CadreAgent.ensemble_act([group_b[0], other], obs_of(steps[0]))
+
+
+def test_get_values_equals_per_worker_get_value():
+    """get_value (agent.py:143-164) for the W workers of a GPU in one pass over all command nets equals W separate
+    calls: every command, ragged feature rows, both heads."""
+    agent = make_agent(84, 84, ppo_seed=13)
+    g = torch.Generator().manual_seed(3)
+    W, S, D = 5, 8, 530
+    batches = []
+    for i in range(W):
+        fs = (torch.randn(S, D, generator=g) * 0.5).cuda()
+        ft = (torch.randn(S, D, generator=g) * 0.5).cuda()
+        batches.append(((fs, i % 4), (ft, (i + 2) % 4)))
+    want = [agent.get_value(False, sb, tb) for sb, tb in batches]
+    got = agent.get_values(batches)
+    for (ws, wt), (gs, gt) in zip(want, got):
+        assert gs.shape == ws.shape == (1, 1) and gt.shape == wt.shape
+        assert abs(float(ws) - float(gs)) <= 1e-6 * max(1.0, abs(float(ws)))
+        assert abs(float(wt) - float(gt)) <= 1e-6 * max(1.0, abs(float(wt)))
