@@ -520,13 +520,28 @@ static int cam_launch(const float* x, float gamma, void* y, int32_t F, int32_t N
 // ============================================================================ inter-task attention tail
 __global__ __launch_bounds__(256) void intertask_kernel(const float* qkv, float* out, int64_t ldo, float temp) {
   __shared__ float s[6 * 256];
-  __shared__ float red[8];
+  __shared__ float ext[4][4];                       // per wave: (max, min) of the two key vectors
   const int f = blockIdx.x, i = threadIdx.x;
   const float* src = qkv + (int64_t)f * 1536;
 #pragma unroll
   for (int r = 0; r < 6; ++r) s[r * 256 + i] = src[r * 256 + i];
   __syncthreads();
   const float* vq = s, *vk = s + 256, *vv = s + 512, *bq = s + 768, *bk = s + 1024, *bv = s + 1280;
+  // The row maximum of the rank-one score matrix q_i * k_j is q_i * max(k) or q_i * min(k) (the product with the
+  // extreme of the right sign is the SAME fp32 product the row would have found): two block reductions replace the
+  // per-row max pass, and the softmax numerators are computed once — normaliser and weighted sum in one sweep.
+  {
+    const float a = bk[i], b = vk[i];
+    const float amax = wave_max(a), amin = -wave_max(-a), bmax = wave_max(b), bmin = -wave_max(-b);
+    if ((i & 63) == 0) { ext[i >> 6][0] = amax; ext[i >> 6][1] = amin; ext[i >> 6][2] = bmax; ext[i >> 6][3] = bmin; }
+  }
+  __syncthreads();
+  float kext[2][2];                                 // [direction][max, min] of that direction's keys
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    kext[d][0] = fmaxf(fmaxf(ext[0][2 * d], ext[1][2 * d]), fmaxf(ext[2][2 * d], ext[3][2 * d]));
+    kext[d][1] = fminf(fminf(ext[0][2 * d + 1], ext[1][2 * d + 1]), fminf(ext[2][2 * d + 1], ext[3][2 * d + 1]));
+  }
   // direction 0: visual query x bc key -> bc value  (intertask_att.py:137-157)
   // direction 1: bc query x visual key -> visual value (:160-176)
 #pragma unroll
@@ -535,17 +550,17 @@ __global__ __launch_bounds__(256) void intertask_kernel(const float* qkv, float*
     const float* K = dir == 0 ? bk : vk;
     const float* V = dir == 0 ? bv : vv;
     const float qi = Q[i] / temp;
-    float mx = -INFINITY;
-    for (int j = 0; j < 256; ++j) mx = fmaxf(mx, qi * K[j]);
-    float sum = 0.f;
-    for (int j = 0; j < 256; ++j) sum += expf(qi * K[j] - mx);
-    float o = 0.f;
-    for (int j = 0; j < 256; ++j) o += V[j] * (expf(qi * K[j] - mx) / sum);
-    o += V[i];
+    const float mx = fmaxf(qi * kext[dir][0], qi * kext[dir][1]);
+    float sum = 0.f, o = 0.f;
+    for (int j = 0; j < 256; ++j) {
+      const float e = expf(qi * K[j] - mx);
+      sum += e;
+      o += V[j] * e;
+    }
+    o = o / sum + V[i];
     // cat((att_visual, att_bc)) danet.py:232: visual first
     out[(int64_t)f * ldo + (dir == 0 ? 256 : 0) + i] = o;
   }
-  (void)red;
 }
 
 extern "C" int cadre_intertask_att(const float* qkv, float* out, int64_t ldo, int32_t F, float temperature,
