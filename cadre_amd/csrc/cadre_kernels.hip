@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void pack_obs_kernel(const uint8_t* rgb, const
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int fo = blockIdx.z, h0 = blockIdx.y * 32, w0 = blockIdx.x * 32;
   const int64_t f = frame_idx ? frame_idx[fo] : fo;       // source frame (sliding windows repeat frames)
-  const uint32_t mx = frame_max[fo];
+  const uint32_t mx = frame_max[f];                      // (per source frame: a window repeats each frame 8 times)
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int wl = ty + 8 * j, w = w0 + wl, h = h0 + tx;
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void pack_obs4_kernel(const uint8_t* rgb, cons
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int fo = blockIdx.z, h0 = blockIdx.y * 32, w0 = blockIdx.x * 32;
   const int64_t f = frame_idx ? frame_idx[fo] : fo;
-  const uint32_t mx = frame_max[fo];
+  const uint32_t mx = frame_max[f];                      // (per source frame: a window repeats each frame 8 times)
 #pragma unroll
   for (int j = 0; j < 4; ++j) {                          // route tile [w][h] -> LDS (stored transposed in memory)
     const int wl = ty + 8 * j, w = w0 + wl, h = h0 + tx;
@@ -232,13 +232,15 @@ __global__ __launch_bounds__(256) void pack_obs4_kernel(const uint8_t* rgb, cons
   }
 }
 extern "C" int cadre_pack_obs(const uint8_t* rgb, const uint8_t* route, uint32_t* out, uint8_t* route_norm,
-                              uint32_t* frame_max, int32_t F, int32_t H, int32_t W, const int64_t* frame_idx, void* stream) {
-  FAIL_IF(!rgb || !route || !out || !frame_max || F < 1 || H < 1 || W < 1, "cadre_pack_obs: bad argument");
-  hipError_t e = hipMemsetAsync(frame_max, 0, sizeof(uint32_t) * F, ST(stream));
+                              uint32_t* frame_max, int32_t F, int32_t H, int32_t W, const int64_t* frame_idx, int32_t n_src,
+                              void* stream) {
+  FAIL_IF(!rgb || !route || !out || !frame_max || F < 1 || H < 1 || W < 1 || (frame_idx && n_src < 1), "cadre_pack_obs: bad argument");
+  const int nmax = frame_idx ? n_src : F;                 // route maxima per SOURCE frame (frame_max holds that many)
+  hipError_t e = hipMemsetAsync(frame_max, 0, sizeof(uint32_t) * nmax, ST(stream));
   if (e != hipSuccess) return (int)e;
   const int per = H * W;
-  dim3 g1(min(64, (per + 255) / 256), F);
-  hipLaunchKernelGGL(route_max_kernel, g1, dim3(256), 0, ST(stream), route, frame_max, per, frame_idx);
+  dim3 g1(min(64, (per + 255) / 256), nmax);
+  hipLaunchKernelGGL(route_max_kernel, g1, dim3(256), 0, ST(stream), route, frame_max, per, (const int64_t*)nullptr);
   if (W % 4 == 0 && ((uintptr_t)rgb & 3) == 0 && ((uintptr_t)out & 15) == 0)
     hipLaunchKernelGGL(pack_obs4_kernel, dim3((W + 31) / 32, (H + 31) / 32, F), dim3(256), 0, ST(stream), rgb, route,
                        frame_max, out, route_norm, F, H, W, frame_idx);

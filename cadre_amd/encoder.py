@@ -242,12 +242,13 @@ class DANetEncoderHIP:
         if frame_idx is not None and not self.fused_stem:
             rgb_d, route_d, frame_idx = rgb_d.index_select(0, frame_idx), route_d.index_select(0, frame_idx), None
         F = rgb_d.shape[0] if frame_idx is None else frame_idx.numel()
-        fmax = self._buf("fmax", (F,), torch.int32)
+        n_src = int(rgb_d.shape[0])
+        fmax = self._buf("fmax", (max(F, n_src),), torch.int32)
         L = hip.lib()
         if self.fused_stem:  # packed u8 pixels (one dword each): the LUT conversion happens inside the stem kernel
             x = self._buf("packed", (F, self.H, self.W), torch.int32)
             hip.check(L.cadre_pack_obs(hip.ptr(rgb_d), hip.ptr(route_d), hip.ptr(x), hip.ptr(route_norm_d), hip.ptr(fmax),
-                                       F, self.H, self.W, hip.ptr(frame_idx), hip.stream()), "cadre_pack_obs")
+                                       F, self.H, self.W, hip.ptr(frame_idx), n_src, hip.stream()), "cadre_pack_obs")
             return x
         if self.bf16:       # zero-bordered bf16 image for the bf16 stem; the border is written never
             x = self._buf("pre_pad", (F, self.Hp, self.Wp, 4), torch.bfloat16, zero=True)

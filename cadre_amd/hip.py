@@ -49,7 +49,7 @@ SYMBOLS = {
     "cadre_preprocess": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "cadre_preprocess_bf16pad": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "cadre_maxpool3x3s2": [vp, vp, i32, i32, i32, i32, vp],
-    "cadre_pack_obs": [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp],
+    "cadre_pack_obs": [vp, vp, vp, vp, vp, i32, i32, i32, vp, i32, vp],
     "cadre_stem_pool": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, i64, vp],
     "cadre_div255_selfcheck": [vp, vp, vp],
     "cadre_stem_pool_supported": [i32, i32],

@@ -138,7 +138,10 @@ int cadre_preprocess_bf16pad(const uint8_t* rgb, const uint8_t* route, const flo
  * frame_idx (i64 [F], may be NULL): output frame f is source frame frame_idx[f] — the sliding 8-frame windows of
  * train.py:50-75 repeat each camera frame 8 times, the gather rides on the packing pass. */
 int cadre_pack_obs(const uint8_t* rgb, const uint8_t* route, uint32_t* out, uint8_t* route_norm,
-                   uint32_t* frame_max, int32_t F, int32_t H, int32_t W, const int64_t* frame_idx, void* stream);
+                   uint32_t* frame_max, int32_t F, int32_t H, int32_t W, const int64_t* frame_idx, int32_t n_src,
+                   void* stream);
+/* (with frame_idx the route maxima are taken once per SOURCE frame: n_src = number of frames in rgb / route, frame_max
+ * u32 scratch of n_src entries; without it n_src is ignored and frame_max holds F entries.) */
 /* Fused encoder front: packed observation -> /255 -> conv1 7x7/s2/p3 (4 -> 64) + folded BN + ReLU ->
  * MaxPool2d(3,2,1)  (agent.py:46, resnet.py:111-115,168-172) in one kernel; the stem map never reaches HBM.
  * wt: tap-major weights [64][taps][4] (tap = ky*7 + kx; fp32: 50 taps, bf16: 52 taps, zero padded).
