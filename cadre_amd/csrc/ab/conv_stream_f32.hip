@@ -15,7 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
-#include "../../include/cadre_hip.h"
+#include "../../../include/cadre_hip_ab.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -22,7 +22,7 @@
 // The kernel stays available as tile 11 (CADRE_SKINNY_GEMM=1 makes the row-sorted update launches use it).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "../../include/cadre_hip.h"
+#include "../../../include/cadre_hip_ab.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

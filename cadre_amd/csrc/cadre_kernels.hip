@@ -1293,9 +1293,12 @@ extern "C" int cadre_categorical_dist(const float* raw, int64_t ldl, int32_t R, 
 }
 
 // ============================================================================ per-model clip + Adam
-__global__ void sqnorm_kernel(const float* g, const int64_t* seg_off, double* norms2) {
+// [rlo, rhi): the element range of the arena this call covers (the whole arena, or one rank's shard of the
+// reduce-scattered gradient: every rank then holds partial square norms, summed by a 16-double all-reduce)
+__global__ void sqnorm_kernel(const float* g, const int64_t* seg_off, double* norms2, int64_t rlo, int64_t rhi) {
   const int mdl = blockIdx.y;
-  const int64_t lo = seg_off[mdl], hi = seg_off[mdl + 1];
+  const int64_t lo = seg_off[mdl] > rlo ? seg_off[mdl] : rlo, hi = seg_off[mdl + 1] < rhi ? seg_off[mdl + 1] : rhi;
+  if (hi <= lo) return;
   double s = 0.0;
   if ((lo & 3) == 0) {          // arena segments start on 16-byte boundaries: 16 B per lane
     const int64_t n4 = (hi - lo) >> 2;
@@ -1374,9 +1377,10 @@ __global__ void adam_prep_kernel(double* norms2, int n_models, int32_t* step_dev
 
 __global__ void adam_dev_kernel(float* p, const float* g, float* m, float* v, const int64_t* seg_off,
                                 const double* norms2, int n_models, float max_norm, float w1, float beta2, float w2,
-                                float eps) {
+                                float eps, int64_t rlo, int64_t rhi) {
   const int mdl = blockIdx.y;
-  const int64_t lo = seg_off[mdl], hi = seg_off[mdl + 1];
+  const int64_t lo = seg_off[mdl] > rlo ? seg_off[mdl] : rlo, hi = seg_off[mdl + 1] < rhi ? seg_off[mdl + 1] : rhi;
+  if (hi <= lo) return;
   const float total = (float)sqrt(norms2[mdl]);
   const float coef = fminf(max_norm / (total + 1e-6f), 1.f);
   const float step_size = (float)norms2[n_models], bc2_sqrt = (float)norms2[n_models + 1];
@@ -1419,10 +1423,38 @@ extern "C" int cadre_clip_adam_graph(float* params, const float* grads, float* e
           "cadre_clip_adam_graph: bad argument");
   hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(256), 0, ST(stream), norms2, n_models, step_dev, lr, beta1, beta2);
   dim3 grid(64, n_models), grid2(256, n_models);
-  hipLaunchKernelGGL(sqnorm_kernel, grid, dim3(256), 0, ST(stream), grads, seg_off, norms2);
+  const int64_t all = (int64_t)1 << 62;
+  hipLaunchKernelGGL(sqnorm_kernel, grid, dim3(256), 0, ST(stream), grads, seg_off, norms2, (int64_t)0, all);
   hipLaunchKernelGGL(adam_dev_kernel, grid2, dim3(256), 0, ST(stream), params, grads, exp_avg, exp_avg_sq, seg_off,
                      norms2, n_models, (float)max_norm, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2),
-                     (float)eps);
+                     (float)eps, (int64_t)0, all);
+  return (int)hipGetLastError();
+}
+
+// Sharded optimiser step (data-parallel ranks; the gradient arena was reduce-scattered, this rank owns elements
+// [rlo, rhi)): cadre_clip_adam_norms leaves this rank's partial per-model square norms in norms2[0..n_models) — the
+// caller sums them over the ranks (all-reduce of n_models doubles) — then cadre_clip_adam_apply runs clip + Adam on
+// the shard only.  exp_avg / exp_avg_sq point at the SHARD's state: element i of the arena is exp_avg[i - rlo].
+extern "C" int cadre_clip_adam_norms(const float* grads, const int64_t* seg_off, int32_t n_models, double* norms2,
+                                     double lr, double beta1, double beta2, int32_t* step_dev, int64_t rlo,
+                                     int64_t rhi, void* stream) {
+  FAIL_IF(!grads || !seg_off || !norms2 || !step_dev || n_models < 1 || n_models > 254 || rlo < 0 || rhi <= rlo ||
+              (rlo & 3) || (rhi & 3),
+          "cadre_clip_adam_norms: bad argument (shard bounds must be multiples of 4 elements)");
+  hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(256), 0, ST(stream), norms2, n_models, step_dev, lr, beta1, beta2);
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(64, n_models), dim3(256), 0, ST(stream), grads, seg_off, norms2, rlo, rhi);
+  return (int)hipGetLastError();
+}
+
+extern "C" int cadre_clip_adam_apply(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                                     const int64_t* seg_off, int32_t n_models, const double* norms2, double max_norm,
+                                     double beta1, double beta2, double eps, int64_t rlo, int64_t rhi, void* stream) {
+  FAIL_IF(!params || !grads || !exp_avg || !exp_avg_sq || !seg_off || !norms2 || n_models < 1 || n_models > 254 ||
+              rlo < 0 || rhi <= rlo || (rlo & 3) || (rhi & 3),
+          "cadre_clip_adam_apply: bad argument (shard bounds must be multiples of 4 elements)");
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(256, n_models), dim3(256), 0, ST(stream), params, grads, exp_avg - rlo,
+                     exp_avg_sq - rlo, seg_off, norms2, n_models, (float)max_norm, (float)(1.0 - beta1), (float)beta2,
+                     (float)(1.0 - beta2), (float)eps, rlo, rhi);
   return (int)hipGetLastError();
 }
 
@@ -1434,7 +1466,7 @@ extern "C" int cadre_clip_adam(float* params, const float* grads, float* exp_avg
   hipError_t e = hipMemsetAsync(norms2, 0, sizeof(double) * n_models, ST(stream));
   if (e != hipSuccess) return (int)e;
   dim3 grid(64, n_models);
-  hipLaunchKernelGGL(sqnorm_kernel, grid, dim3(256), 0, ST(stream), grads, seg_off, norms2);
+  hipLaunchKernelGGL(sqnorm_kernel, grid, dim3(256), 0, ST(stream), grads, seg_off, norms2, (int64_t)0, (int64_t)1 << 62);
   const double bc1 = 1.0 - pow(beta1, (double)step);
   const double bc2 = 1.0 - pow(beta2, (double)step);
   hipLaunchKernelGGL(adam_kernel, grid, dim3(256), 0, ST(stream), params, grads, exp_avg, exp_avg_sq, seg_off,

@@ -329,17 +329,22 @@ __global__ __launch_bounds__(64 * WVM * WVN, ((WVM * WM + WVN * WN) * 2 * 32 * 3
 #undef BODY_ACT
 }
 
-int cadre_conv_stream_bf16_launch(const cadre_gemm_t& p, void* stream);     // conv_stream_bf16.hip (tile 12)
+#ifdef CADRE_AB_KERNELS      // A/B build only (csrc/ab/, include/cadre_hip_ab.h)
+int cadre_conv_stream_bf16_launch(const cadre_gemm_t& p, void* stream);     // ab/conv_stream_bf16.hip (tile 12)
+#endif
 
 #define BCHECK(cond, msg) \
   if (!(cond)) return cadre_fail("cadre_gemm_bf16: " msg)
 
-// Tile choice (host logic).  12 = conv_stream_bf16.hip (64x64, several M-tiles per workgroup).
+// Tile choice (host logic).  12 = ab/conv_stream_bf16.hip (64x64, several M-tiles per workgroup; A/B build only).
 static int pick_tile_bf16(const cadre_gemm_t& p) {
   int tile = p.tile;
   const int batch = p.batch < 1 ? 1 : p.batch, sk = p.split_k < 1 ? 1 : p.split_k;
-  // N <= 64 convs (stage-1 convs, padded stem): several M-tiles per workgroup, conv_stream_bf16.hip (444 vs 431)
+#ifdef CADRE_AB_KERNELS
+  // N <= 64 convs (stage-1 convs, padded stem): several M-tiles per workgroup, ab/conv_stream_bf16.hip (444 vs 431);
+  // the product runs these layers on the window kernel (conv3x3_ring.hip) and the fused front (stem_pool.hip)
   if (tile == 0 && p.N <= 64 && p.a_mode >= 2 && batch == 1 && sk == 1 && p.K >= 128 && p.M >= 64 * 2048) tile = 12;
+#endif
   if (tile == 0) {
     // staging-bound regime: shape factor (dense 8192^3: 256x256 on 8 waves 1054, 128x128 826 TFLOP/s;
     // tools/gemm_bf16_bench.py) x wave quantisation over 256 CUs x resident workgroups per CU
@@ -400,7 +405,9 @@ extern "C" int cadre_gemm_bf16(const cadre_gemm_t* pp, void* stream) {
   const int tile = pick_tile_bf16(p);
   // 10: 128x64 on 8 waves (4x2), 11: 256x64 on 8 waves (4x2, each wave 64x32) — the N <= 64 layers are bound by
   // L2 -> LDS staging bytes per FLOP, which only a taller tile lowers
+#ifdef CADRE_AB_KERNELS
   if (tile == 12) return cadre_conv_stream_bf16_launch(p, stream);       // 64x64 conv, several M-tiles per workgroup
+#endif
   static const int BMS[12] = {0, 128, 128, 64, 256, 128, 256, 256, 0, 0, 128, 256}, BNS[12] = {0, 128, 64, 64, 128, 256, 64, 256, 0, 0, 64, 64};
   BCHECK(tile == 1 || tile == 2 || tile == 3 || tile == 4 || tile == 7 || tile == 10 || tile == 11, "bad tile");
   const int bm = BMS[tile], bn = BNS[tile];

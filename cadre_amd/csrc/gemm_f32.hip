@@ -541,9 +541,11 @@ __global__ void splitk_reduce_kernel(const float* slabs, int split_k, int64_t sl
 extern thread_local char g_cadre_err[256];
 int cadre_fail(const char* msg);
 
-int cadre_conv_stream_f32_launch(const cadre_gemm_t& p, void* stream);     // conv_stream_f32.hip (tile 12)
-int cadre_gemm_f32_skinny_ok(const cadre_gemm_t& p);                       // gemm_f32_skinny.hip (tile 11)
+#ifdef CADRE_AB_KERNELS      // A/B build only (csrc/ab/, include/cadre_hip_ab.h): kernels the dispatch superseded
+int cadre_conv_stream_f32_launch(const cadre_gemm_t& p, void* stream);     // ab/conv_stream_f32.hip (tile 12)
+int cadre_gemm_f32_skinny_ok(const cadre_gemm_t& p);                       // ab/gemm_f32_skinny.hip (tile 11)
 int cadre_gemm_f32_skinny_launch(const cadre_gemm_t& p, void* stream);
+#endif
 
 #define GEMM_CHECK(cond, msg) \
   if (!(cond)) return cadre_fail("cadre_gemm_f32: " msg)
@@ -563,17 +565,20 @@ static int pick_tile(const cadre_gemm_t& p) {
   static const Cand conv_wide[2] = {{8, 128, 128, 2, 0.93}, {3, 64, 64, 4, 1.00}};
   static const Cand narrow[2] = {{2, 128, 64, 2, 0.88}, {3, 64, 64, 4, 1.00}};
   const Cand* big_conv = p.N <= 128 ? conv128 : conv_wide;
+#ifdef CADRE_AB_KERNELS
   // Cin = 4 stem (7 k-tiles per 64x64 tile): several M-tiles per workgroup with the prefetch running across
-  // tile boundaries, conv_stream_f32.hip — 101 vs 94 TFLOP/s; on K >= 576 the one-tile kernel's second
-  // register set is worth more than the hidden start-up (121 vs 125, 128 vs 134)
+  // tile boundaries, ab/conv_stream_f32.hip — 101 vs 94 TFLOP/s; on K >= 576 the one-tile kernel's second
+  // register set is worth more than the hidden start-up (121 vs 125, 128 vs 134).  (The product's stem is the fused
+  // front, stem_pool.hip: this only serves geometries that one does not cover.)
   if (p.a_mode == 3 && batch == 1 && sk == 1 && !p.seg_mode && p.M >= 64 * 2048 &&
       ((p.N | p.ldc | (p.resid ? p.ldr : 0)) & 3) == 0 && (((uintptr_t)p.C | (uintptr_t)p.resid) & 15) == 0)
     return 12;
   // row-sorted minibatch (each batch entry owns one run of rows per period): 32-row tiles skip the most.  The
-  // register-direct kernel (gemm_f32_skinny.hip, tile 11) is opt-in: measured on the update's launches it only wins the
-  // backward at B = 64 (31 vs 39 us with the split-K pass) and loses the forward at B = 256 (39.5 vs 23.8 us)
+  // register-direct kernel (ab/gemm_f32_skinny.hip, tile 11) is opt-in: measured on the update's launches it only wins
+  // the backward at B = 64 (31 vs 39 us with the split-K pass) and loses the forward at B = 256 (39.5 vs 23.8 us)
   static const int skinny = [] { const char* e = getenv("CADRE_SKINNY_GEMM"); return e ? atoi(e) : 0; }();
   if (p.seg_mode == 1 && skinny && cadre_gemm_f32_skinny_ok(p)) return 11;
+#endif
   if (p.seg_mode == 1 && (p.N >= 96 || p.seg_period % 64 != 0)) return 9;
   const Cand* c = p.N <= 64 ? narrow : (p.a_mode >= 2 ? big_conv : big);
   int best = c[0].id;
@@ -648,11 +653,15 @@ extern "C" int cadre_gemm_f32(const cadre_gemm_t* pp, void* stream) {
   if (p.flags & 2)
     GEMM_CHECK(p.batch == 1 && p.split_k == 1 && ((p.N | p.ldc) & 3) == 0 && !p.resid, "bf16 output needs the vector epilogue, no batch/split/resid");
   int tile = p.tile ? p.tile : pick_tile(p);
+#ifdef CADRE_AB_KERNELS
   if (tile == 12) return cadre_conv_stream_f32_launch(p, stream);      // 64x64 conv, several M-tiles per workgroup
   if (tile == 11) {                                                    // skinny products of the PPO update
     if (!cadre_gemm_f32_skinny_ok(p)) return cadre_fail("cadre_gemm_f32: tile 11 (skinny) does not take this descriptor");
     return cadre_gemm_f32_skinny_launch(p, stream);
   }
+#else
+  if (tile == 11 || tile == 12) return cadre_fail("cadre_gemm_f32: tiles 11 / 12 exist only in the A/B build (CADRE_BUILD_AB=1)");
+#endif
   hipStream_t st = (hipStream_t)stream;
   if (tile < 1 || tile > 10 || tile == 7) return cadre_fail("cadre_gemm_f32: bad tile");
   // 9: 32x128 on 4 waves (1x4) for row-sorted skinny GEMMs; 10: 128x64 on 8 waves (4x2) for N <= 64 convs

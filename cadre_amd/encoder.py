@@ -126,7 +126,8 @@ class DANetEncoderHIP:
         # ---- trunk (resnet.py:111-115, 152-166)
         sc, sh = _fold_bn(sd, "backbone.bn1", sd["backbone.conv1.bias"])
         self.stem = _Conv(sd["backbone.conv1.weight"], sc, sh, 7, 2, 3, 1, dev)
-        self.c64_kernel = int(os.environ.get("CADRE_C64_KERNEL", "1"))      # 0 off, 1 fallback, 2 preferred
+        # A/B build only (csrc/ab/conv3x3_c64_bf16.hip): 0 off, 1 fallback when the window kernel declines, 2 preferred
+        self.c64_kernel = int(os.environ.get("CADRE_C64_KERNEL", "1")) if hip.has_ab_kernels() else 0
         self.ring_conv = os.environ.get("CADRE_RING_CONV", "1") != "0"
         # fused front (pack -> LUT -> stem conv + BN + ReLU -> max-pool in one kernel, stem_pool.hip)
         self.fused_stem = bool(hip.lib().cadre_stem_pool_supported(H, W)) and os.environ.get("CADRE_FUSED_STEM", "1") != "0"

@@ -38,7 +38,6 @@ SYMBOLS = {
     "cadre_gemm_pick_tile": [C.POINTER(GemmDesc)],
     "cadre_gemm_bf16": [C.POINTER(GemmDesc), vp],
     "cadre_gemm_bf16_pick_tile": [C.POINTER(GemmDesc)],
-    "cadre_conv3x3_c64_bf16": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "cadre_conv3x3_ring": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "cadre_conv3x3_ring_supported": [i32, i32, i32, i32, i32, i32],
     "cadre_conv3x3_ring_ntile": [i32, i32, i32, i32, i32],
@@ -78,11 +77,26 @@ SYMBOLS = {
     "cadre_categorical_dist": [vp, i64, i32, i32, vp, vp, vp, vp],
     "cadre_clip_adam": [vp, vp, vp, vp, vp, i32, vp, f64, f64, f64, f64, f64, i32, vp],
     "cadre_clip_adam_graph": [vp, vp, vp, vp, vp, i32, vp, f64, f64, f64, f64, f64, vp, vp],
+    "cadre_clip_adam_norms": [vp, vp, i32, vp, f64, f64, f64, vp, i64, i64, vp],
+    "cadre_clip_adam_apply": [vp, vp, vp, vp, vp, i32, vp, f64, f64, f64, f64, i64, i64, vp],
 }
+# entry points of the A/B build only (include/cadre_hip_ab.h; CADRE_BUILD_AB=1 python -m cadre_amd.build, then
+# CADRE_HIP_LIB=.../libcadre_hip_ab.so): bound when the loaded library has them
+AB_SYMBOLS = {
+    "cadre_conv3x3_c64_bf16": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+}
+
+
+ABI_VERSION = 5
 
 
 class CadreHipError(RuntimeError):
     pass
+
+
+def has_ab_kernels():
+    """True when the loaded library is the A/B build (superseded kernels of csrc/ab/ present)."""
+    return hasattr(lib(), "cadre_conv3x3_c64_bf16")
 
 
 def lib():
@@ -98,8 +112,14 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = args
             fn.restype = C.c_char_p if name == "cadre_last_error" else C.c_int
-        if L.cadre_abi_version() != 4:
-            raise CadreHipError("libcadre_hip.so ABI version mismatch")
+        if L.cadre_abi_version() != ABI_VERSION:
+            raise CadreHipError("libcadre_hip.so ABI version mismatch (library %d, binding %d): rebuild with "
+                                "`python -m cadre_amd.build`" % (L.cadre_abi_version(), ABI_VERSION))
+        for name, args in AB_SYMBOLS.items():
+            fn = getattr(L, name, None)
+            if fn is not None:
+                fn.argtypes = args
+                fn.restype = C.c_int
         _lib = L
     return _lib
 
@@ -173,7 +193,9 @@ def gemm(A, B, Cout, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, scale=None, shi
 
 
 def conv3x3_c64_bf16(x, w, scale, shift, resid, out, F, H, W, relu):
-    """cadre_conv3x3_c64_bf16 with the same profiling hook as gemm(): key ("bf16", 64, 2)."""
+    """cadre_conv3x3_c64_bf16 (A/B build only) with the same profiling hook as gemm(): key ("bf16", 64, 2)."""
+    if not has_ab_kernels():
+        raise CadreHipError("cadre_conv3x3_c64_bf16 exists only in the A/B build (CADRE_BUILD_AB=1 python -m cadre_amd.build)")
     fn = lib().cadre_conv3x3_c64_bf16
     args = (ptr(x), ptr(w), ptr(scale), ptr(shift), ptr(resid), ptr(out), F, H, W, relu, stream())
     if PROFILE is None or torch.cuda.is_current_stream_capturing():

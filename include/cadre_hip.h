@@ -15,7 +15,7 @@
 extern "C" {
 #endif
 
-#define CADRE_ABI_VERSION 4
+#define CADRE_ABI_VERSION 5
 int cadre_abi_version(void);
 /* human-readable last argument error of the calling thread ("" if none) */
 const char* cadre_last_error(void);
@@ -58,8 +58,8 @@ typedef struct {
                           8 = 128x128 on 8 waves, 9 = 32x128 on 4 waves (row-sorted
                           minibatches: skips in 32-row steps), 10 = 128x64 on 8 waves
                           (8, 9: cadre_gemm_f32 only; 10 also cadre_gemm_bf16, which adds
-                          11 = 256x64 on 8 waves); 12 = 64x64 conv with several M-tiles per
-                          workgroup (plain conv launches only: a_mode 2/3 fp32, 2/4 bf16)   */
+                          11 = 256x64 on 8 waves).  Tiles 11 (fp32) / 12 exist only in the A/B
+                          build (include/cadre_hip_ab.h)                                    */
   int32_t flags;       /* bit 1: C is bf16; bit 2: resid is bf16 (cadre_gemm_bf16; bit 1 also
                           honoured by cadre_gemm_f32's vector epilogue); others must be 0   */
   /* Row segments (cadre_gemm_f32 only; PPO update with the minibatch rows sorted by command,
@@ -84,13 +84,6 @@ int cadre_gemm_pick_tile(const cadre_gemm_t* p);
 int cadre_gemm_bf16(const cadre_gemm_t* p, void* stream);
 /* tile id cadre_gemm_bf16 would launch for this descriptor (host logic, no launch) */
 int cadre_gemm_bf16_pick_tile(const cadre_gemm_t* p);
-/* Stage-1 convolutions of the bf16 encoder (resnet.py:26-55, layer1): 3x3 / stride 1 / pad 1, 64 -> 64 channels
- * on dense NHWC bf16 x [F][H][W][64], w bf16 [64][576] (k = (kh*3 + kw)*64 + ci), y = act(conv * scale + shift
- * (+ resid)), bf16 out.  HBM-bound layer: weights resident in LDS, autonomous waves fed by LDS-DMA rings
- * (conv3x3_c64_bf16.hip).  Same k order, MFMA and epilogue arithmetic as cadre_gemm_bf16 a_mode 2. */
-int cadre_conv3x3_c64_bf16(const void* x, const void* w, const float* scale, const float* shift,
-                           const void* resid, void* out, int32_t F, int32_t H, int32_t W, int32_t relu,
-                           void* stream);
 /* 3x3 / stride 1 / pad 1 convolution on dense NHWC (resnet.py:26-55 conv1/conv2, danet.py:21-41 conv5a/5c/51/52):
  * x [F][H][W][Cin], w [N][NC][9][128 B] (NC = Cin*elem/128 channel chunks; chunk-major, tap = kh*3+kw, then the
  * chunk's channels), y = act(conv*scale[n] + shift[n] (+ resid)) (+ resid after act when act & 16), out [F*H*W][N].
@@ -315,6 +308,20 @@ int cadre_clip_adam_graph(float* params, const float* grads, float* exp_avg, flo
                           const int64_t* seg_off, int32_t n_models, double* norms2, double max_norm,
                           double lr, double beta1, double beta2, double eps, int32_t* step_dev,
                           void* stream);
+
+
+/* Data-parallel ranks with a reduce-scattered gradient arena (reference semantics chief.py:13-21: SUM
+ * over workers, per-model clip, Adam): this rank owns arena elements [rlo, rhi) (multiples of 4).
+ * cadre_clip_adam_norms: increments *step_dev, stores the step's bias-correction scalars in norms2[n_models..+2) and
+ * leaves the PARTIAL per-model square norms of grads[rlo..rhi) in norms2[0..n_models) — the caller all-reduces those
+ * n_models doubles (SUM) over the ranks.  cadre_clip_adam_apply: clip + Adam on the shard; exp_avg / exp_avg_sq hold
+ * the shard's state only (rhi - rlo floats each, element i of the arena at [i - rlo]); params / grads are the full
+ * arenas.  The caller then all-gathers the parameter shards.  With [0, total) the pair equals cadre_clip_adam_graph. */
+int cadre_clip_adam_norms(const float* grads, const int64_t* seg_off, int32_t n_models, double* norms2, double lr,
+                          double beta1, double beta2, int32_t* step_dev, int64_t rlo, int64_t rhi, void* stream);
+int cadre_clip_adam_apply(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                          const int64_t* seg_off, int32_t n_models, const double* norms2, double max_norm,
+                          double beta1, double beta2, double eps, int64_t rlo, int64_t rhi, void* stream);
 
 #ifdef __cplusplus
 }
