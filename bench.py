@@ -9,6 +9,7 @@ One "step" = one learner ROUND over one batch of synthetic rollouts (SURVEY.md Â
 value = (n_gpus * W * T) / t_round  [samples/s], inputs resident in HBM before timing.
 
     python bench.py                       # N=1, config C2: 1 worker x 128 steps, 288x288, fp32
+    python bench.py --gpus N              # N ranks: the parent (no GPU call) starts one child per GPU and relays the line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 """
@@ -157,6 +158,8 @@ def encode_joint(agent, workers, joint, cfg, chunk_windows):
 
 
 def learner_round(agent, workers, cfg, shared, timers=None, joint=None):
+    """One learner round.  timers (list, untimed split pass only): receives (t_encode, t_update, step_ms) with step_ms the
+    HIP-event time of each of the 8 minibatch steps (gather + update_policy + gradient exchange + clip + Adam)."""
     from ppo_agent.chief import chief_step
     t0 = time.perf_counter()
     if joint is not None:
@@ -175,18 +178,27 @@ def learner_round(agent, workers, cfg, shared, timers=None, joint=None):
         advs.append((wk.stor[0].compute_returns(nv_s), wk.stor[1].compute_returns(nv_t)))
     nW = len(workers)
     dev_losses = []
+    hook = None
+    if cfg.get("grad_buckets") and shared.dist_world():       # MLP-tower gradients out beside the LSTM backward
+        P0 = agent.arena.P0
+        hook = lambda: shared.reduce_bucket_async(P0)
+    evs = []
     for _ in range(PPO_EPOCH):
         idx = [(wk.stor[0].sample_indices(), wk.stor[1].sample_indices()) for wk in workers]
         for b in range(len(idx[0][0])):
             batches = [(wk.stor[0], idx[i][0][b], advs[i][0], wk.stor[1], idx[i][1][b], advs[i][1])
                        for i, wk in enumerate(workers)]
-            dev_losses.append(agent.update_policy_from_storages(batches, sync=False))
-            shared.add_gradient(agent.model_dict)                 # hand-off; chief_step runs the RCCL all-reduce(SUM)
+            if timers is not None:
+                evs.append(torch.cuda.Event(enable_timing=True)); evs[-1].record()
+            dev_losses.append(agent.update_policy_from_storages(batches, sync=False, mlp_grads_ready=hook))
+            shared.add_gradient(agent.model_dict)                 # hand-off; chief_step runs the cross-rank exchange (SUM)
             chief_step(shared, None, 250.0)
+    if timers is not None:
+        evs.append(torch.cuda.Event(enable_timing=True)); evs[-1].record()
     losses = torch.stack(dev_losses).tolist()                     # the round's single host sync
     if timers is not None:
         torch.cuda.synchronize(); t2 = time.perf_counter()
-        timers.append((t1 - t0, t2 - t1))
+        timers.append((t1 - t0, t2 - t1, [evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1)]))
     return losses
 
 
@@ -327,6 +339,7 @@ def run_config(name, args, rank, local_rank, world, use_dist, steps, warmup, epi
     from ppo_agent.agent import CadreAgent
     from ppo_agent.models import Shared_grad_buffers
     cfg = dict(CONFIGS[name]); cfg["dedup"] = args.dedup
+    cfg["grad_buckets"] = args.grad_buckets
     # windows per encoder launch chain: 128 (1024 frames) per worker; with several workers per GPU their windows form
     # one stream cut into chunks of 256 (2048 frames: every activation tensor stays below the 2 GiB buffer window)
     joint_ok = cfg["workers"] > 1 and not args.dedup and not episodes_dir and not args.no_joint_encode
@@ -372,13 +385,19 @@ def run_config(name, args, rank, local_rank, world, use_dist, steps, warmup, epi
         learner_round(agent, workers, cfg, shared, joint=joint)
     sync()
     log("[bench] %s warmup done %.1f s" % (name, time.perf_counter() - T_START))
+    n_ex0 = shared.n_allreduce
     hip.PROFILE = prof = []
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for i in range(steps):
+        marks[i].record()
         losses = learner_round(agent, workers, cfg, shared, joint=joint)
+    marks[steps].record()
     sync()
     elapsed = time.perf_counter() - t0
     hip.PROFILE = None
+    n_ex = shared.n_allreduce - n_ex0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
     log("[bench] %s timed region %.3f s for %d steps" % (name, elapsed, steps))
     if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -399,8 +418,29 @@ def run_config(name, args, rank, local_rank, world, use_dist, steps, warmup, epi
     # untimed split pass for t_encode / t_update
     timers = []
     learner_round(agent, workers, cfg, shared, timers, joint=joint)
-    t_enc, t_upd = timers[0]
+    t_enc, t_upd, step_ms = timers[0]
     ms = elapsed / steps * 1e3
+    # ---- update step against its HBM roof: parameters P read by forward and backward (8P bytes),
+    # gradients written (4P), [all-reduce buffer 4P,] clip read (4P), Adam p/g/m/v in + p/m/v out (28P) = 48P bytes,
+    # plus the activations of the 8 nets x 8 steps
+    P = sum(p.numel() for m in agent.model_dict.values() for p in m.parameters())      # 19 382 808 (arena padding not counted)
+    B_gpu = nW * T // MINI_BATCH_NUM
+    act_bytes = B_gpu * 8 * SEQ * (530 * 2 + 2120 * 2) * 4
+    upd_bytes = 48 * P + act_bytes
+    step_ms_s = sorted(step_ms)
+    med = step_ms_s[len(step_ms_s) // 2]
+    lrn = agent.learner
+    n_launch = sum(v for (part, b), v in lrn.launches.items() if b == B_gpu and part == "all") or \
+        sum(v for (part, b), v in lrn.launches.items() if b == B_gpu)
+    update_roofline = {
+        "bound": "hbm", "bytes_per_step": upd_bytes, "ms_per_step": round(med, 4), "ms_per_step_min": round(step_ms_s[0], 4),
+        "ms_per_step_max": round(step_ms_s[-1], 4), "achieved": round(upd_bytes / (med * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS,
+        "unit": "GB/s", "hbm_frac": round(upd_bytes / (med * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), "minibatch_rows": B_gpu,
+        "kernels_per_update": n_launch, "kernels_note": "C-ABI launches of update_policy (forward, loss, backward) per "
+        "minibatch step; + 3-4 for gather/sort/permute and 3 for clip + Adam; one hipGraph replay each",
+        "flops_per_step": round(3 * 2 * 0.144e9 * B_gpu, 1),
+        "note": "one minibatch step = gather + update_policy + gradient exchange + per-model clip + Adam, HIP events in an "
+                "untimed pass; bytes = 48 x %d parameters + %d activation bytes (SURVEY.md 8d)" % (P, act_bytes)}
     frames = nW * (T + SEQ - 1 if args.dedup else T * SEQ)
     flops_frame = agent.vae_model.flops_per_frame()
     nwin = nW * T if joint is not None else T
@@ -426,11 +466,60 @@ def run_config(name, args, rank, local_rank, world, use_dist, steps, warmup, epi
         "encoder_fwd_GBps_note": "algorithmic bytes (SURVEY 8d layer model, weights once per chunk) / t_encode vs HBM peak "
                                  "8000 GB/s; the fp32 conv stack is MFMA-bound (see roofline)",
         "roofline": roof,
+        "update_roofline": update_roofline,
+        "ms_per_step_min_median_max": [round(per_step[0], 3), round(per_step[len(per_step) // 2], 3), round(per_step[-1], 3)],
         "last_losses": [round(x, 6) for x in losses[-1]],
     }
+    if use_dist:
+        # gradient exchange alone: the collective(s) of one optimiser step on the arena, timed back to back after the run
+        import torch.distributed as dist
+        g = agent.arena.grads
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        mode = shared.exchange_mode()
+        reps = 10
+        sync()
+        e0.record()
+        for _ in range(reps):
+            if mode == "sharded":
+                lo, hi = shared.shard()
+                dist.reduce_scatter_tensor(g[lo:hi], g, op=dist.ReduceOp.SUM)
+                dist.all_gather_into_tensor(agent.arena.params, agent.arena.params[lo:hi])
+            else:
+                dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        e1.record()
+        sync()
+        g.zero_()
+        out["rccl_ranks"] = world
+        out["grad_exchange"] = mode + (" + MLP bucket beside the LSTM backward" if cfg.get("grad_buckets") and mode == "allreduce" else "")
+        out["allreduce_ms_per_step"] = round(e0.elapsed_time(e1) / reps, 4)
+        out["allreduce_bytes"] = int(g.numel() * 4)
+        out["exchanges_in_timed_region"] = n_ex          # one per optimiser step: 8 per round
     del workers, shared, agent
     torch.cuda.empty_cache()
     return out, cfg, enc_state, ppo_state
+
+
+def spawn_ranks(n):
+    """One process per GPU, started from a parent that never initialises HIP (a process that has touched the GPU must
+    not exec or fork GPU work on this pool): children get RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* like
+    torch.distributed.run would set them; rank 0's stdout (the JSON line) is relayed, every stderr goes through."""
+    import socket
+    import subprocess
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0]
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        log("[bench] ranks failed: %s" % bad)
+    return 0 if not bad else (bad[0][1] if 0 < bad[0][1] < 256 else 1)
 
 
 def main():
@@ -450,17 +539,37 @@ def main():
     ap.add_argument("--replay", default=None, metavar="DIR",
                     help="replay recorded rollouts (cadre_amd/replay.py .npz episodes) instead of synthetic ones; "
                          "T/H/W come from the records (BASELINE config C5)")
+    ap.add_argument("--grad-exchange", default=None, choices=["allreduce", "sharded"],
+                    help="N > 1: one all-reduce(SUM) of the gradient arena + replicated clip/Adam (default), or reduce-scatter + "
+                         "clip/Adam on the rank's shard + all-gather of the parameters (same wire bytes, 1/N optimiser traffic)")
+    ap.add_argument("--grad-buckets", action="store_true",
+                    help="N > 1, all-reduce mode: the MLP-tower gradients (6 MB) go out as their own bucket beside the LSTM backward")
+    ap.add_argument("--spawn-selftest", action="store_true",
+                    help="launcher check (no GPU): every rank prints its RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* and exits")
+    ap.add_argument("--c3-steps", type=int, default=10, help="timed rounds of the C3 section (>= 10 by default)")
     ap.add_argument("--dedup", action="store_true",
                     help="encode each distinct frame once (sliding-window latent cache) instead of the "
                          "reference's 8 frames per transition; NOT the default metric convention")
     args = ap.parse_args()
 
+    if args.grad_exchange:
+        os.environ["CADRE_GRAD_EXCHANGE"] = args.grad_exchange
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: this process has not touched the GPU (and never will) â€” it
+        # starts N fresh children, one per LOCAL_RANK, relays rank 0's JSON line and exits with their status
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.spawn_selftest:
+        line = json.dumps({"rank": rank, "local_rank": local_rank, "world": world, "master": "%s:%s" % (
+            os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")), "gpus": args.gpus})
+        log("[bench] selftest " + line)
+        if rank == 0:
+            print(line, flush=True)
+        return
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        log("[bench] --gpus %d but WORLD_SIZE=%d: running with the launcher's world size" % (args.gpus, world))
     import torch.distributed as dist
     # stdout carries ONE JSON line: RCCL writes its version banner (and warnings) to the C stdout whenever a communicator
     # starts, so fd 1 is pointed at stderr for the duration of the run and restored for the line
@@ -484,7 +593,7 @@ def main():
     # BASELINE configs C3 / C4 (num_processes = 4 per GPU, minibatch 256, bf16 encoder / fp32 losses) in the same line:
     # the 1 -> 8 GPU scaling target is defined on this shape (C4 = C3 on every GPU + the gradient all-reduce)
     if args.config == "C2" and not args.no_c3 and not args.replay and not args.dedup and args.encoder_dtype is None:
-        c3, _c, _e, _p = run_config("C3", args, rank, local_rank, world, use_dist, max(2, min(args.steps, 3)), 1)
+        c3, _c, _e, _p = run_config("C3", args, rank, local_rank, world, use_dist, max(2, args.c3_steps), 2)
         c3["metric"], c3["unit"], c3["n_gpus"] = "ppo_update_samples_per_sec", "samples/s", world
         out["c3"] = c3
     if rank == 0:
@@ -501,7 +610,10 @@ def main():
                         pk = mp["mfma_bf16_2wave_TFLOPs"] if rf["peak"] > 1000 else mp["mfma_f32_2wave_TFLOPs"]
                         rf["frac_of_measured"] = round(rf["achieved"] / pk, 4)
                     elif rf:
-                        rf["frac_of_measured"] = round(rf["achieved"] / mp["hbm_copy_GBps"], 4)
+                        rf["frac_of_measured"] = round(rf["achieved"] / max(mp["hbm_copy_GBps"], mp["hbm_read_GBps"]), 4)
+                    ur = sect.get("update_roofline") if sect else None
+                    if ur:
+                        ur["frac_of_measured"] = round(ur["achieved"] / max(mp["hbm_copy_GBps"], mp["hbm_read_GBps"]), 4)
             except Exception as e:                           # a diagnostic: never fails the bench line
                 log("[bench] measured_peaks skipped: %r" % (e,))
         if not args.no_cpu_baseline and world == 1:          # CPU baseline: rank 0 at N=1 only

@@ -152,6 +152,9 @@ class PPOArena:
                     v[k].copy_(torch.as_tensor(arr).to(self.device))
 
     def ensure_adam(self):
+        if getattr(self, "_shard", None) is not None:
+            raise RuntimeError("this arena's Adam state is sharded over the data-parallel ranks (elements [%d, %d)); "
+                               "the replicated optimiser step cannot follow sharded ones" % self._shard)
         if self.exp_avg is None:
             self.exp_avg = torch.zeros_like(self.params)
             self.exp_avg_sq = torch.zeros_like(self.params)

@@ -44,3 +44,52 @@ extern "C" int cadre_mfma_peak(int32_t bf16, int32_t workgroups, int32_t iters, 
   else hipLaunchKernelGGL((mfma_peak_kernel<false>), dim3(workgroups), dim3(256), 0, (hipStream_t)stream, iters, sink);
   return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// HBM stream peaks: what a kernel that only moves bytes reaches on this device (the denominator for the HBM-bound
+// kernels' `frac_of_measured`).  16 B per lane, 8 independent loads in flight per lane, grid-stride over 2048 workgroups
+// (8 per CU); the read kernel folds what it loads into one word per lane so nothing is stored.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void hbm_read_kernel(const f32x4* __restrict__ src, int64_t n16, float* sink) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (; i + 7 * stride < n16; i += 8 * stride) {
+    f32x4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(src + i + j * stride);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += v[j];
+  }
+  for (; i < n16; i += stride) acc += __builtin_nontemporal_load(src + i);
+  const float s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  if (s == 12345.678f) sink[0] = s;                          // data-dependent, practically never taken
+}
+
+__global__ __launch_bounds__(256) void hbm_copy_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, int64_t n16) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    f32x4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = __builtin_nontemporal_load(src + i + j * stride);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(v[j], dst + i + j * stride);
+  }
+  for (; i < n16; i += stride) dst[i] = src[i];
+}
+
+// mode 0: read `bytes` from src (dst unused, may be NULL; sink receives nothing in practice); mode 1: copy src -> dst.
+// bytes % 16 == 0, both pointers 16-byte aligned.  The caller times the launch: read = bytes / t, copy = 2 * bytes / t.
+extern "C" int cadre_hbm_stream(int32_t mode, const void* src, void* dst, int64_t bytes, float* sink, void* stream) {
+  if (!src || bytes < 16 || (bytes & 15) || ((uintptr_t)src & 15) || (mode == 1 && (!dst || ((uintptr_t)dst & 15))) ||
+      (mode == 0 && !sink) || mode < 0 || mode > 1)
+    return cadre_fail("cadre_hbm_stream: bad argument");
+  const int64_t n16 = bytes >> 4;
+  if (mode == 0)
+    hipLaunchKernelGGL(hbm_read_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const f32x4*)src, n16, sink);
+  else
+    hipLaunchKernelGGL(hbm_copy_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const f32x4*)src, (f32x4*)dst, n16);
+  return (int)hipGetLastError();
+}

@@ -69,6 +69,7 @@ SYMBOLS = {
     "cadre_colsum2": [vp, i64, i64, vp, vp, i64, i32, i32, i32, vp, i32, vp],
     "cadre_lstm_init": [vp, vp, vp, vp, vp, i64, i64, i32, i32, vp],
     "cadre_mfma_peak": [i32, i32, i32, vp, vp],
+    "cadre_hbm_stream": [i32, vp, vp, i64, vp, vp],
     "cadre_sort_rows_by_command": [vp, i32, i32, vp, vp, vp],
     "cadre_permute_minibatch": [vp, i32, i32, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "cadre_ppo_loss": [vp, i64, i64, vp, i64, i64, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, f32, vp, vp, vp, vp],
@@ -124,7 +125,12 @@ def lib():
     return _lib
 
 
+N_CALLS = 0          # C-ABI calls checked so far (one kernel launch each, cadre_clip_adam_graph three): launch census
+
+
 def check(rc, what):
+    global N_CALLS
+    N_CALLS += 1
     if rc != 0:
         msg = lib().cadre_last_error().decode() if rc < 0 else "hipError_t %d" % rc
         raise CadreHipError("%s failed: %s" % (what, msg))

@@ -34,6 +34,7 @@ class PPOLearnerHIP:
         self.S = seq_length
         self._ws = {}
         self._graphs = {}
+        self.launches = {}
         self.use_graphs = os.environ.get("CADRE_HIP_GRAPHS", "1") != "0"
         self.use_sorted = os.environ.get("CADRE_SORTED_UPDATE", "1") != "0"
         hip.lib()
@@ -123,27 +124,38 @@ class PPOLearnerHIP:
                      a_z=(1, 0, cs * B * hid), b_z=(1, 0, zs), c_z=(1, 0, cs * B * NP), s_z=(1, 0, zs), seg=sg)
 
     # ------------------------------------------------------------------ update_policy
-    def update(self, B, inv_b, sorted_rows=False):
+    def update(self, B, inv_b, sorted_rows=False, mlp_grads_ready=None):
         """Forward + loss + backward for the packed minibatch in workspace(B).  Gradients of all 16
         nets are written (not accumulated) into arena.grads.  Returns the device tensor
         losses[3] = (value_loss*vc, action_loss*cc, ent_loss*ec) (agent.py:226-237).
-        The ~60-launch sequence has fixed shapes and pointers, so after one eager run it is captured
-        into a hipGraph per (B, inv_b) and replayed (launch-bound otherwise: ~2 ms of host time)."""
+        The launch sequence has fixed shapes and pointers, so after one eager run it is captured
+        into a hipGraph per (B, inv_b) and replayed (launch-bound otherwise: ~2 ms of host time).
+        With `mlp_grads_ready` the sequence is cut in two graphs where the gradients of the MLP towers
+        (arena[P0:]) are final — before the backward through time — and the callable runs in between
+        (the data-parallel exchange starts that bucket's all-reduce beside the LSTM backward)."""
+        parts = ("front", "back") if mlp_grads_ready is not None else ("all",)
+        for part in parts:
+            self._run(part, B, inv_b, sorted_rows)
+            if part == "front":
+                mlp_grads_ready()
+        return self.workspace(B)["losses"]
+
+    def _run(self, part, B, inv_b, sorted_rows):
         if not self.use_graphs:
-            return self._update_body(B, inv_b, sorted_rows)
-        key = (B, inv_b, sorted_rows)
+            return self._update_body(B, inv_b, sorted_rows, part)
+        key = (part, B, inv_b, sorted_rows)
         g = self._graphs.get(key)
         if g is None:
-            out = self._update_body(B, inv_b, sorted_rows)  # eager warm-up (func attributes, lazy init)
+            n0 = hip.N_CALLS
+            self._update_body(B, inv_b, sorted_rows, part)          # eager warm-up (func attributes, lazy init)
+            self.launches[(part, B)] = hip.N_CALLS - n0             # kernel launches of this part of the step
             if self._graphs.get(("warm",) + key):
                 torch.cuda.synchronize()
-                g = self._capture(lambda: self._update_body(B, inv_b, sorted_rows))
-                self._graphs[key] = g
+                self._graphs[key] = self._capture(lambda: self._update_body(B, inv_b, sorted_rows, part))
             else:
                 self._graphs[("warm",) + key] = True
-            return out
+            return
         g.replay()
-        return self.workspace(B)["losses"]
 
     @staticmethod
     def _capture(fn):
@@ -164,7 +176,9 @@ class PPOLearnerHIP:
                 gc.enable()
         return g
 
-    def _update_body(self, B, inv_b, sorted_rows=False):
+    def _update_body(self, B, inv_b, sorted_rows=False, part="all"):
+        """part: "all", or "front" (forward, loss, MLP-tower backward, dh_S) / "back" (backward through time and the
+        LSTM weight gradients) — the two halves of the same launch sequence."""
         a, S = self.a, self.S
         w = self.workspace(B)
         Z, C = a.Z, a.C
@@ -176,14 +190,17 @@ class PPOLearnerHIP:
         sgM2 = None if seg is None else (1, seg, B, 2)  # M tiles, z = 2*net + tower
         sgK1 = None if seg is None else (2, seg, B, 1)  # k tiles (rows), z = net
         sgK2 = None if seg is None else (2, seg, B, 2)
-        skinny = seg is not None and os.environ.get("CADRE_SKINNY_GEMM", "0") != "0"     # (opt-in: cadre_gemm_f32 tile 11, see gemm_f32.hip)
-        self._forward(w, B, (0, 1, Z), C, seg=seg)
+        # (opt-in, A/B build only: cadre_gemm_f32 tile 11, csrc/ab/gemm_f32_skinny.hip)
+        skinny = seg is not None and os.environ.get("CADRE_SKINNY_GEMM", "0") != "0" and hip.has_ab_kernels()
+        front, back = part in ("all", "front"), part in ("all", "back")
         O3, dO3 = w["O3"], w["dO3"]
-        hip.check(L.cadre_ppo_loss(hip.ptr(O3), NP, 2 * B * NP, hip.ptr(O3[1]), NP, 2 * B * NP,
-                                   hip.ptr(w["actions"]), hip.ptr(w["commands"]), hip.ptr(w["old_values"]),
-                                   hip.ptr(w["returns"]), hip.ptr(w["old_logp"]), hip.ptr(w["adv"]), B,
-                                   a.n_out[0], a.n_out[1], self.clip, self.vc, self.cc, self.ec, inv_b,
-                                   hip.ptr(w["losses"]), hip.ptr(dO3), hip.ptr(dO3[1]), st), "cadre_ppo_loss")
+        if front:
+            self._forward(w, B, (0, 1, Z), C, seg=seg)
+            hip.check(L.cadre_ppo_loss(hip.ptr(O3), NP, 2 * B * NP, hip.ptr(O3[1]), NP, 2 * B * NP,
+                                       hip.ptr(w["actions"]), hip.ptr(w["commands"]), hip.ptr(w["old_values"]),
+                                       hip.ptr(w["returns"]), hip.ptr(w["old_logp"]), hip.ptr(w["adv"]), B,
+                                       a.n_out[0], a.n_out[1], self.clip, self.vc, self.cc, self.ec, inv_b,
+                                       hip.ptr(w["losses"]), hip.ptr(dO3), hip.ptr(dO3[1]), st), "cadre_ppo_loss")
         # ---------------- backward: MLP towers (16 = 2Z batched)
         Gr = a.grads
         pP, gP = a.params[a.P0:], Gr[a.P0:]
@@ -201,17 +218,20 @@ class PPOLearnerHIP:
                 hip.gemm(dY, pP[o_w:], dX, B, n_x, n_y, n_y, n_x, n_x, b_mode=1, batch=nb,
                          a_z=(1, 0, B * n_y), b_z=zT, c_z=(1, 0, B * n_x), seg=sgM2)
 
-        layer_bwd(dO3, NP, A2, hid, hid, (1, 0, B * hid), a.t_w3, a.t_b3, dA2)
-        hip.check(L.cadre_relu_bwd(hip.ptr(A2), hip.ptr(dA2), nb * B * hid, cmd, B, hid, C, st), "cadre_relu_bwd")
-        layer_bwd(dA2, hid, A1, hid, hid, (1, 0, B * hid), a.t_w2, a.t_b2, dA1)
-        hip.check(L.cadre_relu_bwd(hip.ptr(A1), hip.ptr(dA1), nb * B * hid, cmd, B, hid, C, st), "cadre_relu_bwd")
-        layer_bwd(dA1, hid, Hs[:, S], DP, DP, (2, 0, (S + 1) * B * DP), a.t_w1, a.t_b1, None)
-        # dh_S = dZ1_actor W1_actor + dZ1_critic W1_critic   (two launches, second accumulates)
         dH, dC = w["dH"], w["dC"]
-        for tower in (0, 1):
-            hip.gemm(dA1[tower:], pP[tower * sT + a.t_w1:], dH, B, DP, hid, hid, DP, DP, b_mode=1, batch=Z,
-                     a_z=(1, 0, 2 * B * hid), b_z=(1, 0, a.size_P), c_z=(1, 0, B * DP),
-                     resid=dH if tower else None, ldr=DP, r_z=(1, 0, B * DP), seg=sgM1)
+        if front:
+            layer_bwd(dO3, NP, A2, hid, hid, (1, 0, B * hid), a.t_w3, a.t_b3, dA2)
+            hip.check(L.cadre_relu_bwd(hip.ptr(A2), hip.ptr(dA2), nb * B * hid, cmd, B, hid, C, st), "cadre_relu_bwd")
+            layer_bwd(dA2, hid, A1, hid, hid, (1, 0, B * hid), a.t_w2, a.t_b2, dA1)
+            hip.check(L.cadre_relu_bwd(hip.ptr(A1), hip.ptr(dA1), nb * B * hid, cmd, B, hid, C, st), "cadre_relu_bwd")
+            layer_bwd(dA1, hid, Hs[:, S], DP, DP, (2, 0, (S + 1) * B * DP), a.t_w1, a.t_b1, None)
+            # dh_S = dZ1_actor W1_actor + dZ1_critic W1_critic   (two launches, second accumulates)
+            for tower in (0, 1):
+                hip.gemm(dA1[tower:], pP[tower * sT + a.t_w1:], dH, B, DP, hid, hid, DP, DP, b_mode=1, batch=Z,
+                         a_z=(1, 0, 2 * B * hid), b_z=(1, 0, a.size_P), c_z=(1, 0, B * DP),
+                         resid=dH if tower else None, ldr=DP, r_z=(1, 0, B * DP), seg=sgM1)
+        if not back:
+            return w["losses"]
         # ---------------- backward through time (autograd of models.py:148-151)
         G, dG, Cs, TC, X = w["G"], w["dG"], w["Cs"], w["TC"], w["X"]
         pL, gL, sL = a.params, Gr, a.size_L
@@ -268,6 +288,29 @@ class PPOLearnerHIP:
             self._graphs[("warm",) + key] = True
             return body()
         g.replay()
+
+    def clip_adam_sharded(self, lo, hi, all_reduce_norms, lr=3e-4, max_grad_norm=250.0, betas=(0.9, 0.999), eps=1e-8):
+        """The same step on arena elements [lo, hi) only (data-parallel ranks after a reduce-scatter of the
+        gradient arena, chief.py:13-21 semantics): partial per-model square norms of the shard ->
+        `all_reduce_norms(norms2[:n_models])` (SUM of 16 doubles over the ranks) -> clip + Adam on the shard.
+        The Adam moments exist for the shard only (1/N of the state and of the pass's HBM traffic)."""
+        a = self.a
+        if getattr(a, "_shard", None) != (lo, hi):
+            if a.step:
+                raise hip.CadreHipError("the optimiser shard changed after %d steps (Adam state is per shard)" % a.step)
+            a._shard = (lo, hi)
+            a.exp_avg = torch.zeros(hi - lo, device=a.device)
+            a.exp_avg_sq = torch.zeros(hi - lo, device=a.device)
+        a.step += 1
+        L, st, nm = hip.lib(), hip.stream(), 2 * a.Z
+        hip.check(L.cadre_clip_adam_norms(hip.ptr(a.grads), hip.ptr(a.seg_off), nm, hip.ptr(a.norms2), float(lr),
+                                          float(betas[0]), float(betas[1]), hip.ptr(a.step_dev), lo, hi, st),
+                  "cadre_clip_adam_norms")
+        all_reduce_norms(a.norms2[:nm])
+        hip.check(L.cadre_clip_adam_apply(hip.ptr(a.params), hip.ptr(a.grads), hip.ptr(a.exp_avg), hip.ptr(a.exp_avg_sq),
+                                          hip.ptr(a.seg_off), nm, hip.ptr(a.norms2), float(max_grad_norm),
+                                          float(betas[0]), float(betas[1]), float(eps), lo, hi, st),
+                  "cadre_clip_adam_apply")
 
     # ------------------------------------------------------------------ inference (act / get_value)
     def infer(self, feats, commands, h0=None, c0=None):

@@ -129,15 +129,21 @@ class CadreAgent(object):
         O3, _, _ = self.learner.infer(torch.stack([s_obs, t_obs]), (int(s_cmd), int(t_cmd)))
         return O3[1, :, :1].clone(), O3[3, :, :1].clone()
 
-    def get_values(self, batches):
+    def get_values(self, batches, dones=None):
         """get_value (agent.py:143-164) for several workers at once: batches = [(steer_batch, throttle_batch), ...] as
-        `RolloutStorage.get_last()` returns them (none of them done).  One LSTM + critic pass over all command nets with
-        one row per worker instead of one launch chain per worker; returns [(v_steer [1,1], v_throttle [1,1]), ...]."""
+        `RolloutStorage.get_last()` returns them; dones[i] (default: none) is worker i's `done` flag — a finished
+        episode bootstraps from zeros (agent.py:144-146).  One LSTM + critic pass over all command nets with one row
+        per worker instead of one launch chain per worker; returns [(v_steer [1,1], v_throttle [1,1]), ...]."""
         feats = torch.stack([torch.stack([sb[0] for sb, _tb in batches]), torch.stack([tb[0] for _sb, tb in batches])])
         O3 = self.learner.infer_rows(feats).clone()
         C = self.arena.C
-        return [(O3[2 * int(sb[1]) + 1, i:i + 1, :1], O3[2 * (C + int(tb[1])) + 1, i:i + 1, :1])
-                for i, (sb, tb) in enumerate(batches)]
+        out = []
+        for i, (sb, tb) in enumerate(batches):
+            if dones is not None and dones[i]:
+                out.append((torch.zeros(1), torch.zeros(1)))
+            else:
+                out.append((O3[2 * int(sb[1]) + 1, i:i + 1, :1], O3[2 * (C + int(tb[1])) + 1, i:i + 1, :1]))
+        return out
 
     # ------------------------------------------------------------------ update
     def _pack(self, w, hd, samples):
@@ -170,12 +176,15 @@ class CadreAgent(object):
         v, a, e = losses.tolist()
         return v, a, e
 
-    def update_policy_from_storages(self, batches, sync=True):
+    def update_policy_from_storages(self, batches, sync=True, mlp_grads_ready=None):
         """Fast path of the learner section: `batches` = [(steer_storage, steer_idx, steer_adv,
         throttle_storage, throttle_idx, throttle_adv), ...] one entry per worker (equal sizes).
         Same math as feed_forward_generator -> update_policy, but the minibatch gather writes
         straight into the update workspace (cadre_gather_minibatch) and the losses stay on the device
-        unless `sync` (one host sync per round instead of one per minibatch)."""
+        unless `sync` (one host sync per round instead of one per minibatch).  `mlp_grads_ready`
+        (callable, optional) is invoked between the MLP-tower backward and the LSTM backward, when the
+        gradients of arena[P0:] are final (Shared_grad_buffers.reduce_bucket_async starts their all-reduce
+        there, beside the LSTM backward)."""
         nW = len(batches)
         Bw = batches[0][1].numel()
         B = nW * Bw
@@ -185,6 +194,26 @@ class CadreAgent(object):
         srt = self.learner.sorted_rows(B)
         u = "_u" if srt else ""                       # sorted mode: gather into staging, then sort + permute
         Xk, hk, ck = ("Xu", "h0u", "c0u") if srt else ("X", "h0", "c0")
+        if any(b[1].numel() != Bw or b[4].numel() != Bw for b in batches):
+            raise ValueError("update_policy_from_storages: every worker's steer and throttle minibatch must have the same "
+                             "number of rows (the losses are the sum of per-worker means over equal minibatches)")
+        s0 = batches[0][0]
+        geo = (s0._ldo, s0.seq_length, s0._ldh)
+        if any((st_._ldo, st_.seq_length, st_._ldh) != geo for b in batches for st_ in (b[0], b[3])):
+            # storages of different geometry (feature pitch / window length): one gather launch per storage with its
+            # own strides (cadre_gather_minibatch) — the one-launch table below assumes a single geometry
+            for i, (ss, si, sa, ts, ti, ta) in enumerate(batches):
+                for hd, (stor, idx, adv) in enumerate(((ss, si, sa), (ts, ti, ta))):
+                    idx_d = idx.reshape(-1).to(self.device)
+                    hip.check(L.cadre_gather_minibatch(
+                        hip.ptr(stor._obs), stor._ldo, stor.seq_length, hip.ptr(stor._hn), hip.ptr(stor._cn), stor._ldh,
+                        hip.ptr(stor.action), hip.ptr(stor.value_preds), hip.ptr(stor.returns),
+                        hip.ptr(stor.action_log_probs), hip.ptr(stor.command), hip.ptr(adv), hip.ptr(idx_d), Bw, a.D, a.D,
+                        B, i * Bw, hip.ptr(w[Xk][hd]), a.DP, hip.ptr(w[hk][hd]), hip.ptr(w[ck][hd]), a.DP,
+                        hip.ptr(w["actions" + u][hd]), hip.ptr(w["commands" + u][hd]), hip.ptr(w["old_values" + u][hd]),
+                        hip.ptr(w["returns" + u][hd]), hip.ptr(w["old_logp" + u][hd]), hip.ptr(w["adv" + u][hd]), st),
+                        "cadre_gather_minibatch")
+            return self._finish_update(w, B, nW, srt, sync, mlp_grads_ready)
         # ONE gather launch for all workers and both heads: a device table of the storages' pointers (built once per set
         # of storages / advantage tensors) and one host-to-device copy of the 2*nW index vectors
         pairs = [(stor, adv) for (ss, si, sa, ts, ti, ta) in batches for (stor, adv) in ((ss, sa), (ts, ta))]
@@ -196,7 +225,12 @@ class CadreAgent(object):
         if table is None:
             if len(cache) > 16:
                 cache.clear()
-            table = cache[key] = torch.tensor(ptrs, dtype=torch.int64).to(self.device)
+            host = torch.tensor(ptrs, dtype=torch.int64).pin_memory()      # pinned: the copy does not stall the host
+            table = torch.empty_like(host, device=self.device)
+            table.copy_(host, non_blocking=True)
+            cache[key] = table
+            self.__dict__.setdefault("_gather_tables_host", []).append(host)   # alive until the copy has run
+            del self._gather_tables_host[:-16]
         # (pinned staging buffers in a ring: a slot is rewritten only after the copy that last read it has completed —
         #  the caller may enqueue several minibatch steps without a host sync)
         ring = self.__dict__.get("_gather_idx")
@@ -214,13 +248,17 @@ class CadreAgent(object):
         stage[1].copy_(stage[0], non_blocking=True)
         stage[2] = torch.cuda.Event()
         stage[2].record()
-        s0 = batches[0][0]
         hip.check(L.cadre_gather_minibatch_multi(
             hip.ptr(table), 2 * nW, s0._ldo, s0.seq_length, s0._ldh, hip.ptr(stage[1]), Bw, a.D, a.D, B,
             hip.ptr(w[Xk]), w[Xk].stride(0), a.DP, hip.ptr(w[hk]), hip.ptr(w[ck]), w[hk].stride(0), a.DP,
             hip.ptr(w["actions" + u]), hip.ptr(w["commands" + u]), hip.ptr(w["old_values" + u]),
             hip.ptr(w["returns" + u]), hip.ptr(w["old_logp" + u]), hip.ptr(w["adv" + u]), st),
             "cadre_gather_minibatch_multi")
+        return self._finish_update(w, B, nW, srt, sync, mlp_grads_ready)
+
+    def _finish_update(self, w, B, nW, srt, sync, mlp_grads_ready=None):
+        """Row sort by command (sorted mode), the fused update and the loss hand-back."""
+        L, st, a = hip.lib(), hip.stream(), self.arena
         if srt:
             hip.check(L.cadre_sort_rows_by_command(hip.ptr(w["commands_u"]), B, a.C, hip.ptr(w["pos"]), hip.ptr(w["seg"]),
                                                    st), "cadre_sort_rows_by_command")
@@ -233,7 +271,7 @@ class CadreAgent(object):
                     hip.ptr(w["actions"][hd]), hip.ptr(w["commands"][hd]), hip.ptr(w["old_values"][hd]),
                     hip.ptr(w["returns"][hd]), hip.ptr(w["old_logp"][hd]), hip.ptr(w["adv"][hd]), st),
                     "cadre_permute_minibatch")
-        losses = self.learner.update(B, float(nW) / B, sorted_rows=srt)
+        losses = self.learner.update(B, float(nW) / B, sorted_rows=srt, mlp_grads_ready=mlp_grads_ready)
         self.arena.attach_grads(self.model_dict)
         if sync:
             return tuple(losses.tolist())

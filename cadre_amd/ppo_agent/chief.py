@@ -16,12 +16,13 @@ def _hyper(optimizer):
 
 def chief_step(shared_grad_buffers, optimizer, max_grad_norm, lr=None):
     """One optimiser step (chief.py:13-23) on the arena behind `shared_grad_buffers`: the pending
-    cross-rank SUM of the gradient arena (one RCCL all-reduce per optimiser step, however many worker
-    agents of this process handed gradients in), then per-model clip + Adam, then clear the buffers.
+    cross-rank SUM of the gradients (ONE exchange per optimiser step, however many worker agents of this
+    process handed gradients in), then per-model clip + Adam, then clear the buffers.  Two forms of the
+    exchange (Shared_grad_buffers.exchange_mode): all-reduce + replicated optimiser, or reduce-scatter +
+    optimiser on this rank's shard + all-gather of the parameters — identical parameters either way.
     Hyper-parameters come from `optimizer` (the reference's optim.Adam, main.py:52) or, without one,
     from `lr` (train_cfg.lr) with Adam's defaults."""
     arena = shared_grad_buffers.arena
-    shared_grad_buffers.all_reduce()
     if optimizer is not None:
         lr, betas, eps = _hyper(optimizer)
     else:
@@ -29,7 +30,17 @@ def chief_step(shared_grad_buffers, optimizer, max_grad_norm, lr=None):
     step = getattr(arena, "_learner", None)
     if step is None:
         arena._learner = step = PPOLearnerHIP(arena)
-    step.clip_adam(lr=lr, max_grad_norm=max_grad_norm, betas=betas, eps=eps)
+    if shared_grad_buffers.exchange_mode() == "sharded":
+        rng = shared_grad_buffers.reduce_scatter()
+        if rng is None:                                    # nothing handed in: plain local step
+            step.clip_adam(lr=lr, max_grad_norm=max_grad_norm, betas=betas, eps=eps)
+        else:
+            step.clip_adam_sharded(rng[0], rng[1], shared_grad_buffers.all_reduce_norms, lr=lr,
+                                   max_grad_norm=max_grad_norm, betas=betas, eps=eps)
+            shared_grad_buffers.all_gather_params()
+    else:
+        shared_grad_buffers.all_reduce()
+        step.clip_adam(lr=lr, max_grad_norm=max_grad_norm, betas=betas, eps=eps)
     shared_grad_buffers.reset()
 
 

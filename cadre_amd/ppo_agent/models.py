@@ -219,15 +219,24 @@ def arena_of(model_dict):
 
 class Shared_grad_buffers(object):
     """models.py:219-258.  `.grads` keeps the reference's key scheme ('<model>_<param>_grad') as
-    views of the flat gradient arena of `model_list`.  `add_gradient` is the gradient hand-off:
-    SUM (never mean — chief.py:18, models.py:237) over every rank with one RCCL all-reduce of
-    the arena when torch.distributed is initialised; nets living in a different arena (separate
-    worker agents in one process) are accumulated first."""
+    views of the flat gradient arena of `model_list`.  `add_gradient` is the gradient hand-off of ONE
+    worker: it accumulates (SUM, never mean — chief.py:18, models.py:237) a foreign arena and counts the
+    hand-in; the cross-rank exchange is a separate step run ONCE per optimiser step by `chief_step`:
+
+      * `all_reduce()`            one RCCL all-reduce(SUM) of the 80 MB gradient arena (default), or
+      * `reduce_scatter()` + sharded clip/Adam + `all_gather_params()`   (`CADRE_GRAD_EXCHANGE=sharded`):
+        the same bytes on the wire, 1/N of the optimiser's HBM traffic per rank.
+
+    Whether an exchange is due is derived from SHARED state (`counter` against `_reduced_at`, both
+    mp.Value): in the reference's topology (main.py:57-70) workers and chief are separate processes, each
+    with its own pickled copy of this object — a plain attribute set by a worker never reaches the chief."""
 
     def __init__(self, model_list, device):
         self.arena = arena_of(model_list)
         self.device = device
         self.counter = Counter()
+        self._reduced_at = Counter()                       # value of `counter` covered by the last exchange
+        self._n_exchange = Counter()                       # exchanges run (any process holding this object)
         self.lock = torch.multiprocessing.Lock()          # reference models.py:223,232
         self.grads = {}
         for model_name, model in model_list.items():
@@ -239,35 +248,115 @@ class Shared_grad_buffers(object):
     def add_gradient(self, model_list):
         """models.py:231-239: accumulate one worker's gradients (SUM).  Nets bound to this arena already
         wrote their gradients into it (update_policy writes, it does not accumulate), so only a foreign
-        arena is added.  The cross-rank reduction is a separate step (`all_reduce`, run once per
-        optimiser step by `chief_step`) — several worker agents of one process feeding this buffer must
-        not be all-reduced once each."""
+        arena is added.  No collective here: several worker agents of one process feeding this buffer must
+        not be reduced over the ranks once each."""
         src = arena_of(model_list)
         with self.lock:
             if src is not self.arena:                     # a worker agent with its own nets (reference topology)
                 self.arena.grads.add_(src.grads)
                 if self.arena.grads.is_cuda:              # the worker overwrites src.grads in its next update
                     torch.cuda.current_stream().synchronize()
-            self._pending = True
             self.counter.increment()
 
-    def all_reduce(self):
-        """One RCCL all-reduce(SUM) of the flat gradient arena over all ranks (chief.py:18 sums, never
-        averages); a no-op outside torch.distributed, at world_size 1, or when nothing was handed in
-        since the last reduction."""
+    # ------------------------------------------------------------------ cross-rank exchange (SURVEY.md 8e)
+    @property
+    def n_allreduce(self):
+        return self._n_exchange.get()
+
+    @staticmethod
+    def dist_world():
+        """World size of the gradient exchange: 0 when no exchange runs (no process group, or one rank
+        without CADRE_BENCH_FORCE_DIST=1, which exercises the collectives at world size 1)."""
         import torch.distributed as dist
-        if not getattr(self, "_pending", False):
+        if not (dist.is_available() and dist.is_initialized()):
+            return 0
+        w = dist.get_world_size()
+        return w if (w > 1 or os.environ.get("CADRE_BENCH_FORCE_DIST") == "1") else 0
+
+    def exchange_mode(self):
+        """'allreduce' (default) or 'sharded' (CADRE_GRAD_EXCHANGE=sharded; needs an arena divisible into
+        16-byte-aligned equal shards, else falls back)."""
+        w = self.dist_world()
+        if w and os.environ.get("CADRE_GRAD_EXCHANGE", "allreduce") == "sharded" and self.arena.total % (4 * w) == 0:
+            return "sharded"
+        return "allreduce"
+
+    def pending(self):
+        return self.counter.get() != self._reduced_at.get()
+
+    def _mark(self):
+        self._reduced_at.val.value = self.counter.get()
+
+    def shard(self):
+        import torch.distributed as dist
+        w, r = dist.get_world_size(), dist.get_rank()
+        n = self.arena.total // w
+        return r * n, (r + 1) * n
+
+    def all_reduce(self):
+        """One all-reduce(SUM) of the flat gradient arena over all ranks (chief.py:18 sums, never averages);
+        a no-op outside torch.distributed, at world_size 1, or when nothing was handed in since the last
+        exchange.  Buckets already reduced on the side stream (`reduce_bucket_async`) are only waited for."""
+        import torch.distributed as dist
+        if not self.pending():
             return
-        self._pending = False
-        if dist.is_available() and dist.is_initialized() and (
-                dist.get_world_size() > 1 or os.environ.get("CADRE_BENCH_FORCE_DIST") == "1"):
+        self._mark()
+        if not self.dist_world():
+            return
+        done = getattr(self, "_bucket_done", None)
+        if done is not None:                               # MLP bucket went out while the LSTM backward ran
+            lo, work = done
+            self._bucket_done = None
+            dist.all_reduce(self.arena.grads[:lo], op=dist.ReduceOp.SUM)
+            work.wait()
+        else:
             dist.all_reduce(self.arena.grads, op=dist.ReduceOp.SUM)
-            self.n_allreduce = getattr(self, "n_allreduce", 0) + 1
+        self._n_exchange.increment()
+
+    def reduce_bucket_async(self, lo):
+        """Start the all-reduce of grads[lo:] (the MLP towers, final before the LSTM backward starts) as an
+        async collective; `all_reduce` later reduces grads[:lo] and waits for this one."""
+        import torch.distributed as dist
+        if not self.dist_world() or self.exchange_mode() != "allreduce":
+            return
+        self._bucket_done = (lo, dist.all_reduce(self.arena.grads[lo:], op=dist.ReduceOp.SUM, async_op=True))
+
+    def reduce_scatter(self):
+        """Sharded exchange, step 1: this rank's shard of the gradient arena receives the SUM over ranks
+        (in place: the shard is a view of the arena).  Returns the shard bounds, or None when nothing is due."""
+        import torch.distributed as dist
+        if not self.pending():
+            return None
+        self._mark()
+        lo, hi = self.shard()
+        g = self.arena.grads
+        try:
+            dist.reduce_scatter_tensor(g[lo:hi], g, op=dist.ReduceOp.SUM)
+        except RuntimeError:        # a backend without reduce-scatter on device tensors (gloo): same sums by all-reduce
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        self._n_exchange.increment()
+        return lo, hi
+
+    def all_reduce_norms(self, norms2):
+        """Sharded exchange, step 2: the per-model partial square norms (f64) of the shards -> global norms."""
+        import torch.distributed as dist
+        dist.all_reduce(norms2, op=dist.ReduceOp.SUM)
+
+    def all_gather_params(self):
+        """Sharded exchange, step 3: every rank's updated parameter shard to every rank."""
+        import torch.distributed as dist
+        lo, hi = self.shard()
+        p = self.arena.params
+        try:
+            dist.all_gather_into_tensor(p, p[lo:hi])
+        except RuntimeError:        # backend without all-gather on device tensors: x + 0 + ... + 0 is x
+            p[:lo].zero_(); p[hi:].zero_()
+            dist.all_reduce(p, op=dist.ReduceOp.SUM)
 
     def average_gradient(self):
         self.arena.grads.div_(max(1, self.counter.get()))
 
     def reset(self):
         self.counter.reset()
-        self._pending = False
+        self._reduced_at.reset()
         self.arena.grads.zero_()

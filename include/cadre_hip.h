@@ -101,6 +101,9 @@ int cadre_conv3x3_ring_ntile(int32_t F, int32_t H, int32_t W, int32_t N, int32_t
  * one): workgroups x 4 waves, each iters x 8 register-operand MFMAs on independent accumulators (fp32:
  * v_mfma_f32_32x32x2_f32 = 4096 FLOP, bf16: v_mfma_f32_32x32x16_bf16 = 32768 FLOP).  The caller times the launch. */
 int cadre_mfma_peak(int32_t bf16, int32_t workgroups, int32_t iters, float* sink, void* stream);
+/* HBM stream peaks of this device (peaks.hip): mode 0 reads `bytes` from src with 16-B loads, 8 in flight per lane
+ * (nothing stored), mode 1 copies src -> dst.  The caller times the launch (read: bytes / t, copy: 2 * bytes / t). */
+int cadre_hbm_stream(int32_t mode, const void* src, void* dst, int64_t bytes, float* sink, void* stream);
 /* C[M][ldc] = act(sum_s slab[s][M][lds] * scale + shift + resid) */
 int cadre_splitk_reduce(const float* slabs, int32_t split_k, int64_t slab_stride, int64_t lds,
                         float* C, int64_t ldc, int32_t M, int32_t N, const float* scale,

@@ -18,6 +18,24 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def chief_in_process_group(*args):
+    """The chief process of main.py:57-60 as a member of a (world-size-1, forced) process group: its `chief_step` must
+    run the cross-rank gradient exchange although the hand-ins happened in OTHER processes (the workers' pickled copies
+    of Shared_grad_buffers) — the exchange is due by shared state, not by a process-local flag."""
+    import torch
+    import torch.distributed as dist
+    from ppo_agent.chief import chief
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29547")
+    os.environ["CADRE_BENCH_FORCE_DIST"] = "1"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        chief(*args)
+    finally:
+        dist.destroy_process_group()
+
+
 def main(out_dir):
     import torch
     import torch.multiprocessing as mp
@@ -34,7 +52,7 @@ def main(out_dir):
         pass
     res = {}
     snaps = {}
-    for mode in ("spawned", "in_process"):
+    for mode in ("spawned", "spawned_dist", "in_process"):
         work = os.path.join(out_dir, mode)
         os.makedirs(work, exist_ok=True)
         train_cfg, agent_cfg, env_cfg, rollout_cfg = topology_cfgs(work)
@@ -46,11 +64,11 @@ def main(out_dir):
             plist += list(shared[name].parameters())
         device = torch.device("cuda:" + str(agent_cfg.model_cfg.device_num))
         bufs = Shared_grad_buffers(shared, device)
-        if mode == "spawned":
+        if mode in ("spawned", "spawned_dist"):
             light, counter, sons = TrafficLight(), Counter(), Counter()
             opt = optim.Adam(plist, lr=train_cfg.lr)
-            procs = [mp.Process(target=chief, args=(1, light, counter, shared, bufs, opt, sons,
-                                                     train_cfg.max_grad_norm, 1))]
+            procs = [mp.Process(target=chief if mode == "spawned" else chief_in_process_group,
+                                args=(1, light, counter, shared, bufs, opt, sons, train_cfg.max_grad_norm, 1))]
             procs.append(mp.Process(target=functools.partial(train, env_cls=SyntheticEnv), args=(
                 0, train_cfg, copy.deepcopy(agent_cfg), copy.deepcopy(env_cfg), rollout_cfg, light, counter, shared,
                 bufs, sons)))
@@ -58,11 +76,11 @@ def main(out_dir):
                 p.start()
             for p in procs:
                 p.join(540)
-            res["exitcodes"] = [p.exitcode for p in procs]
+            res["exitcodes" if mode == "spawned" else "exitcodes_dist"] = [p.exitcode for p in procs]
             for p in procs:
                 if p.is_alive():
                     p.terminate()
-            res["steps_by_chief"] = None
+            res[mode + "_exchanges"] = bufs.n_allreduce          # shared counter: exchanges the chief process ran
         else:
             sons = Counter()
             train(0, train_cfg, copy.deepcopy(agent_cfg), copy.deepcopy(env_cfg), rollout_cfg, None, None, shared,
@@ -73,15 +91,16 @@ def main(out_dir):
         if os.path.exists(snap):
             snaps[mode] = torch.load(snap, map_location="cpu", weights_only=False)
         res[mode + "_shared_param_sum"] = float(arena_of(shared).params.double().sum())
-    if len(snaps) == 2:
-        worst, n = 0.0, 0
-        for name in snaps["spawned"]:
-            a, b = snaps["spawned"][name].state_dict(), snaps["in_process"][name].state_dict()
-            for k in a:
-                worst = max(worst, float((a[k] - b[k]).abs().max()))
-                n += 1
-        res["tensors_compared"] = n
-        res["max_abs_param_diff"] = worst
+    if len(snaps) == 3:
+        for tag, key in (("spawned", "max_abs_param_diff"), ("spawned_dist", "max_abs_param_diff_dist")):
+            worst, n = 0.0, 0
+            for name in snaps[tag]:
+                a, b = snaps[tag][name].state_dict(), snaps["in_process"][name].state_dict()
+                for k in a:
+                    worst = max(worst, float((a[k] - b[k]).abs().max()))
+                    n += 1
+            res["tensors_compared"] = n
+            res[key] = worst
         init = synth.ppo_state(11)
         moved = max(float((snaps["spawned"][m].state_dict()[k] - torch.from_numpy(init[m][k])).abs().max())
                     for m in snaps["spawned"] for k in snaps["spawned"][m].state_dict())

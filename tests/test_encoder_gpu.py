@@ -9,6 +9,7 @@ import torch
 from cadre_amd import synth
 
 pytestmark = pytest.mark.gpu
+BF16_TOL = 1.5e-2         # bf16 encoder (C3) vs the fp32 reference goldens, relative to the tensor's max
 TOL = 2e-4
 
 
@@ -58,7 +59,8 @@ def test_encoder_batch_invariance_and_chunking(golden):
 @pytest.mark.parametrize("tag", ["84", "native", "288"])
 def test_encoder_bf16_close_to_fp32_reference(golden, tag):
     """BASELINE config C3 ("bf16 encoder"): bf16 storage, fp32 accumulation.  Compared with the fp32
-    reference goldens; tolerance 3e-2 of the tensor's max (bf16 has 8 significand bits; 20 layers)."""
+    reference goldens; tolerance 1.5e-2 of the tensor's max (bf16 has 8 significand bits, 20 layers; measured 8e-3 —
+    twice the measured error, a 2x regression fails)."""
     from cadre_amd.encoder import DANetEncoderHIP
     g = golden("enc_" + tag)
     H, W, n = int(g["H"]), int(g["W"]), int(g["n"])
@@ -72,4 +74,4 @@ def test_encoder_bf16_close_to_fp32_reference(golden, tag):
     l4 = taps["layer4"].float().permute(0, 3, 1, 2).cpu().numpy()
     e = (rel(l4, g["layer4"]), rel(lat.cpu().numpy(), g["latent"]))
     print("bf16 encoder %s rel-max-err layer4 %.2e latent %.2e" % ((tag,) + e))
-    assert e[0] < 3e-2 and e[1] < 3e-2
+    assert e[0] < BF16_TOL and e[1] < BF16_TOL

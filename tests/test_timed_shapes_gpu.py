@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 ENC_TOL = 2e-4            # fp32 encoder vs reference goldens (same bar as tests/test_encoder_gpu.py)
 # ---- C3 contract ("bf16 encoder / fp32 losses"): bf16 storage of activations and conv weights (8
 # significand bits, ~4e-3 per rounding, 20 layers deep), fp32 accumulation, fp32 heads and losses.
-C3_FEAT_TOL = 2e-2        # max |feat_bf16 - feat_fp32| / max |feat_fp32|   (measured 8e-3)
+C3_FEAT_TOL = 1.5e-2      # max |feat_bf16 - feat_fp32| / max |feat_fp32|   (measured 8e-3)
 C3_LOSS_TOL = 2e-2        # each of the three update_policy losses, relative, vs oracle-on-fp32 (measured 3e-3)
 C3_VALUE_TOL = 2e-2       # critic values / log-probs of act(): abs error relative to max(1, |ref|) (measured 3e-3)
 C3_MARGIN = 0.25          # action indices must agree wherever the fp32 top-2 gap of log(p/q) exceeds this
@@ -68,6 +68,62 @@ def test_c2_encoder_goldens_inside_1024_frame_chunk(golden):
     assert e < ENC_TOL
     assert torch.equal(got, lat2), "per-frame results must not depend on the batch they were computed in"
     assert bool(torch.isfinite(lat).all())
+
+
+def test_c3_bf16_goldens_inside_2048_frame_joint_chunk(golden):
+    """BASELINE C3 at the shape bench.py times: bf16 encoder, ONE 2048-frame chunk of 288x288 windows assembled the way
+    `bench.encode_joint` does (window ids into the concatenated frames of the workers of a GPU, the chunk straddling two
+    workers; the sliding-window gather rides on the packing pass).  The two reference golden frames
+    (tests/golden/enc_288.npz, danet.py:216-238) sit at positions 0 and 2047: latent within the bf16 bar of the
+    golden AND bit-identical to the 2-frame bf16 run; every stride-1 3x3 conv must have run on the ping-pong window
+    kernel conv3x3_ring_pp_kernel<true, ...> (asserted from the launch profile) — 1.36 GB bf16 activations per
+    layer-1 tensor, next to the 2 GiB buffer window, 5-6 persistent items per CU."""
+    from cadre_amd import hip
+    from cadre_amd.encoder import DANetEncoderHIP
+    g = golden("enc_288")
+    H, W, n = int(g["H"]), int(g["W"]), int(g["n"])
+    assert (H, W, n) == (288, 288, 2)
+    sd = synth.encoder_state(*synth.feat_hw(H, W), int(g["seed"]))
+    r = np.random.RandomState(int(g["frame_seed"]))
+    rgb2 = torch.from_numpy(r.randint(0, 256, (n, H, W, 3)).astype(np.uint8)).cuda()
+    route2 = torch.from_numpy(((r.rand(n, W, H) < 0.15) * 255).astype(np.uint8)).cuda()
+    small = DANetEncoderHIP(sd, H, W, "cuda:0", max_frames=2, dtype="bf16")
+    lat2 = small.latent(rgb2, route2).clone()
+    del small
+    # two workers of T = 128 steps: T + 7 source frames each, windows t .. t+7 (bench.Worker / JointFrames)
+    T, S, nW = 128, 8, 2
+    nf = T + S - 1
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    rgb = torch.randint(0, 256, (nW * nf, H, W, 3), dtype=torch.uint8, device="cuda", generator=gen)
+    route = ((torch.rand(nW * nf, W, H, device="cuda", generator=gen) < 0.15) * 255).to(torch.uint8)
+    win = (torch.arange(T).view(T, 1) + torch.arange(S).view(1, S)).reshape(-1)
+    ids = torch.cat([win + w * nf for w in range(nW)]).cuda()            # 2048 window-frame ids across both workers
+    F = ids.numel()
+    assert F == 2048 and int(ids[0]) == 0 and int(ids[F - 1]) == nW * nf - 1
+    rgb[0], route[0] = rgb2[0], route2[0]                                # first frame of worker 0's first window
+    rgb[nW * nf - 1], route[nW * nf - 1] = rgb2[1], route2[1]            # last frame of worker 1's last window
+    enc = DANetEncoderHIP(sd, H, W, "cuda:0", max_frames=F, dtype="bf16")
+    lat = torch.zeros(F, 544, device="cuda")
+    hip.PROFILE = prof = []
+    try:
+        x = enc.preprocess(rgb, route, frame_idx=ids)
+        enc.forward_nhwc(x, lat, ldo=544)
+        torch.cuda.synchronize()
+    finally:
+        hip.PROFILE = None
+    ring = [k for k, *_ in prof if k[0] == "ring"]
+    # 4 (layer1) + 3 + 3 + 3 (layer2-4: the first conv of each is stride 2) + conv5a/5c/51/52 = 17 stride-1 3x3 convs
+    assert len(ring) == 17 and all(k[1] and k[6] == 1 for k in ring), ring
+    conv3 = [(k, shp) for k, _f, _a, _b, shp, _nb in prof if k[0] == "bf16" and k[2] == 2]
+    assert len(conv3) == 3 + 3, conv3                                      # only the stride-2 3x3 and 1x1-s2 convs stay on tiles
+    got = torch.stack([lat[0, :512], lat[F - 1, :512]])
+    e = rel(got.cpu().numpy(), g["latent"])
+    print("C3 joint chunk (2048 frames, bf16): latent rel-max-err vs reference golden %.2e" % e)
+    assert e < C3_FEAT_TOL
+    assert torch.equal(got, lat2), "per-frame bf16 results must not depend on the chunk they were computed in"
+    assert bool(torch.isfinite(lat).all())
+    # windows repeat frames: the 8 copies of one source frame inside the chunk carry identical latents
+    assert torch.equal(lat[7, :512], lat[8 + 6, :512])                   # frame 7 = window 0 slot 7 = window 1 slot 6
 
 
 def _worker_storages(nW, T, seed0, device):

@@ -1,6 +1,7 @@
 """GPU: the two launch topologies that cannot be tested inside the pytest process.
 
-  * reference main.py:57-70 — one `chief` process + `train` workers started with the `spawn` method, the
+  * reference main.py:57-70 — one `chief` process + `train` workers started with the `spawn` method (also with the
+    chief inside an RCCL process group: the gradient exchange is due by SHARED state, whoever handed in), the
     shared nets / `Shared_grad_buffers` / optimizer handed over by pickling (HIP-IPC handles of views into the
     parameter arena).  Two episodes (two worker<->chief barrier rounds each); the worker's final snapshot must
     equal the one the in-process hand-off produces, bit for bit.
@@ -38,6 +39,11 @@ def test_spawned_chief_and_worker_match_in_process_handoff(tmp_path):
     assert res["tensors_compared"] >= 12 * 4 and res["max_abs_update"] > 0.0      # the optimiser really stepped
     assert res["max_abs_param_diff"] == 0.0
     assert res["spawned_shared_param_sum"] == res["in_process_shared_param_sum"]
+    # the same topology with the chief inside a process group (RCCL, world size 1 forced): the hand-ins happen in the
+    # WORKER process, the exchange must still run in the chief — once per optimiser step (2 episodes x 2 minibatches)
+    assert res["exitcodes_dist"] == [0, 0]
+    assert res["spawned_exchanges"] == 0 and res["spawned_dist_exchanges"] == 4
+    assert res["max_abs_param_diff_dist"] == 0.0
 
 
 def test_rccl_allreduce_on_device_world1():

@@ -24,13 +24,16 @@ def measure():
     out = {}
     n = 1 << 30                                              # 4 GiB of fp32 each
     a = torch.empty(n, device="cuda").normal_(); b = torch.empty_like(a)
-    t = timed(lambda: b.copy_(a))
-    out["hbm_copy_GBps"] = round(2 * 4 * n / t / 1e9, 1)     # read + write
-    t = timed(lambda: a.sum())
-    out["hbm_read_GBps"] = round(4 * n / t / 1e9, 1)
-    del a, b
     sink = torch.zeros(4, device="cuda")
     L = hip.lib()
+    t = timed(lambda: b.copy_(a))
+    out["hbm_copy_GBps_torch"] = round(2 * 4 * n / t / 1e9, 1)     # read + write (torch's copy kernel)
+    # own streaming kernels (peaks.hip): 16 B per lane, 8 loads in flight per lane, nothing but the stream
+    t = timed(lambda: hip.check(L.cadre_hbm_stream(1, hip.ptr(a), hip.ptr(b), 4 * n, hip.ptr(sink), hip.stream()), "cadre_hbm_stream"))
+    out["hbm_copy_GBps"] = round(2 * 4 * n / t / 1e9, 1)
+    t = timed(lambda: hip.check(L.cadre_hbm_stream(0, hip.ptr(a), None, 4 * n, hip.ptr(sink), hip.stream()), "cadre_hbm_stream"))
+    out["hbm_read_GBps"] = round(4 * n / t / 1e9, 1)
+    del a, b
     for name, bf, flop, per_clk in (("f32", 0, 4096.0, 64.0), ("bf16", 1, 32768.0, 1024.0)):
         for wps in (1, 2):                                   # waves per SIMD
             wgs, iters = 256 * wps, 20000 if bf else 10000
