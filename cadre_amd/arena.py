@@ -29,6 +29,7 @@ class PPOArena:
         self.D = obs_dim
         self.DP = _rup(obs_dim, 32)
         self.H4 = 4 * obs_dim
+        self.H4P = 4 * self.DP                # pitch of the gate rows in the update workspace: 4 x 34 k-blocks of 16
         self.C = command_num
         self.Z = 2 * command_num
         self.hid = hid

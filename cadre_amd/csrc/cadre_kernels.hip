@@ -1090,6 +1090,9 @@ extern "C" int cadre_permute_minibatch(const int32_t* pos, int32_t B, int32_t S,
 
 // ============================================================================ policy head + PPO loss (fwd+bwd)
 #define MAX_NOUT 64
+// One wave per row (lane = action index): the log-softmax / entropy reductions are wave shuffles, 16 rows per
+// workgroup, B/16 x 2 workgroups.  The three loss sums stay deterministic: every workgroup publishes its partial sums
+// (agent-scope stores), takes a ticket, and the workgroup that arrives last adds all partials in index order.
 __global__ __launch_bounds__(256) void ppo_loss_kernel(const float* logits, int64_t ldl, int64_t l_ns,
                                                        const float* values, int64_t ldv, int64_t v_ns,
                                                        const int64_t* actions, const int32_t* commands,
@@ -1097,39 +1100,39 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const float* logits, int6
                                                        const float* old_logp, const float* adv, int B, int n_steer,
                                                        int n_throttle, float clip, float value_coeff,
                                                        float clip_coeff, float ent_coeff, float inv_b,
-                                                       float* losses, float* dlogits, float* dvalues) {
-  const int hd = blockIdx.x;                       // 0 steer, 1 throttle
+                                                       float* losses, float* dlogits, float* dvalues, float* scratch) {
+  const int hd = blockIdx.y;                       // 0 steer, 1 throttle
   const int K = hd == 0 ? n_steer : n_throttle;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __shared__ float red[3][4];
-  float s_act = 0.f, s_val = 0.f, s_ent = 0.f;
-  // zero the gradients of the masked-out command nets (agent.py:178-182 multiply by 0): the whole [B][ldl]
-  // block of each of this head's four nets, coalesced; the owning net's entries are overwritten below
-  for (int cc = 0; cc < 4; ++cc) {
-    float* dl = dlogits + (int64_t)(hd * 4 + cc) * l_ns;
-    for (int64_t i = threadIdx.x; i < (int64_t)B * ldl; i += 256) dl[i] = 0.f;
-    for (int b = threadIdx.x; b < B; b += 256) dvalues[(int64_t)(hd * 4 + cc) * v_ns + (int64_t)b * ldv] = 0.f;
-  }
-  __syncthreads();
-  for (int b = threadIdx.x; b < B; b += 256) {
+  float s_act = 0.f, s_val = 0.f, s_ent = 0.f;     // lane 0 of each wave
+  for (int i = 0; i < 4; ++i) {
+    const int b = blockIdx.x * 16 + wave * 4 + i;
+    if (b >= B) break;
     const int row = hd * B + b;                    // per-head sample arrays are [2][B]
     const int c = commands[row];
+    const bool own_ok = c >= 0 && c <= 3;
+    // the masked-out command nets (agent.py:178-182 multiply by 0) get exact zeros: whole rows of ldl columns
+    for (int cc = 0; cc < 4; ++cc) {
+      if (own_ok && cc == c) continue;
+      if (lane < ldl) dlogits[(int64_t)(hd * 4 + cc) * l_ns + (int64_t)b * ldl + lane] = 0.f;
+      if (lane == 0) dvalues[(int64_t)(hd * 4 + cc) * v_ns + (int64_t)b * ldv] = 0.f;
+    }
+    if (!own_ok) continue;
     const int a = (int)actions[row];
-    if (c < 0 || c > 3) continue;
     const int net = hd * 4 + c;
-    const float* x = logits + (int64_t)net * l_ns + (int64_t)b * ldl;
-    float lg[MAX_NOUT];
-    float mx = -INFINITY;
-    for (int k = 0; k < K; ++k) mx = fmaxf(mx, x[k]);
-    float se = 0.f;
-    for (int k = 0; k < K; ++k) se += expf(x[k] - mx);
+    const bool on = lane < K;
+    const float x = on ? logits[(int64_t)net * l_ns + (int64_t)b * ldl + lane] : -INFINITY;
+    const float mx = wave_max(x);
+    const float se = wave_sum(on ? expf(x - mx) : 0.f);
     const float lse = mx + logf(se);               // Categorical(logits=x).logits  distributions.py:80-81
-    float mx2 = -INFINITY;
-    for (int k = 0; k < K; ++k) { lg[k] = x[k] - lse; mx2 = fmaxf(mx2, lg[k]); }
-    float se2 = 0.f;
-    for (int k = 0; k < K; ++k) se2 += expf(lg[k] - mx2);
-    float H = 0.f;                                 // entropy = -sum p*logp  distributions.py:104
-    for (int k = 0; k < K; ++k) { const float pk = expf(lg[k] - mx2) / se2; H -= pk * lg[k]; }
-    const float lp = lg[a];
+    const float lg = x - lse;
+    const float mx2 = wave_max(on ? lg : -INFINITY);
+    const float e2 = on ? expf(lg - mx2) : 0.f;
+    const float se2 = wave_sum(e2);
+    const float pk = e2 / se2;
+    const float H = -wave_sum(on ? pk * lg : 0.f); // entropy = -sum p*logp  distributions.py:104
+    const float lp = __shfl(lg, a, 64);
     const float v = values[(int64_t)net * v_ns + (int64_t)b * ldv];
     const float A = adv[row], ov = old_values[row], R = returns[row];
     // agent.py:184-187 / 215-218
@@ -1137,12 +1140,12 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const float* logits, int6
     const float s1 = ratio * A;
     const float rc = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
     const float s2 = rc * A;
-    s_act += -fminf(s1, s2);
     // agent.py:189-192 / 220-223
     const float dv = v - ov;
     const float dvc = fminf(fmaxf(dv, -clip), clip);
     const float vpc = ov + dvc;
     const float vl = (v - R) * (v - R), vlc = (vpc - R) * (vpc - R);
+    s_act += -fminf(s1, s2);
     s_val += fmaxf(vl, vlc);
     s_ent += H;
     // ---- backward of total = vc*0.5*mean(max) + cc*mean(-min) - ec*mean(H)
@@ -1158,25 +1161,36 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const float* logits, int6
     if (vl > vlc) dmax_dv = g1;
     else if (vl < vlc) dmax_dv = g2;
     else dmax_dv = 0.5f * g1 + 0.5f * g2;
-    dvalues[(int64_t)net * v_ns + (int64_t)b * ldv] = value_coeff * inv_b * 0.5f * dmax_dv;
+    if (lane == 0) dvalues[(int64_t)net * v_ns + (int64_t)b * ldv] = value_coeff * inv_b * 0.5f * dmax_dv;
     const float dH = -ent_coeff * inv_b;
-    float* dl = dlogits + (int64_t)net * l_ns + (int64_t)b * ldl;
-    for (int k = 0; k < K; ++k) {
-      const float pk = expf(lg[k] - mx2) / se2;
-      dl[k] = dlp * ((k == a ? 1.f : 0.f) - pk) + dH * (-pk * (lg[k] + H));
-    }
+    if (lane < ldl)
+      dlogits[(int64_t)net * l_ns + (int64_t)b * ldl + lane] =
+          on ? dlp * ((lane == a ? 1.f : 0.f) - pk) + dH * (-pk * (lg + H)) : 0.f;
   }
-  s_act = wave_sum(s_act); s_val = wave_sum(s_val); s_ent = wave_sum(s_ent);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) { red[0][wave] = s_val; red[1][wave] = s_act; red[2][wave] = s_ent; }
   __syncthreads();
   if (threadIdx.x == 0) {
+    const int nblk = gridDim.x, me = hd * nblk + blockIdx.x, total = 2 * nblk;
+    float* part = scratch + 4;                      // [total][3]; scratch[0] is the arrival counter (zeroed per call)
     const float tv = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
     const float ta = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     const float te = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
-    atomicAdd(losses + 0, value_coeff * 0.5f * tv * inv_b);
-    atomicAdd(losses + 1, clip_coeff * ta * inv_b);
-    atomicAdd(losses + 2, ent_coeff * te * inv_b);
+    __hip_atomic_store(part + 3 * me + 0, tv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(part + 3 * me + 1, ta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(part + 3 * me + 2, te, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned ticket = __hip_atomic_fetch_add(reinterpret_cast<unsigned*>(scratch), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ticket == (unsigned)(total - 1)) {          // last arriver: every partial has been published
+      float sv = 0.f, sa = 0.f, sn = 0.f;
+      for (int w = 0; w < total; ++w) {
+        sv += __hip_atomic_load(part + 3 * w + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sa += __hip_atomic_load(part + 3 * w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sn += __hip_atomic_load(part + 3 * w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      losses[0] = value_coeff * 0.5f * sv * inv_b;
+      losses[1] = clip_coeff * sa * inv_b;
+      losses[2] = ent_coeff * sn * inv_b;
+    }
   }
 }
 
@@ -1189,18 +1203,18 @@ extern "C" int cadre_ppo_loss(const float* logits, int64_t ldl, int64_t l_ns, co
                               const float* old_logp, const float* adv, int32_t B, int32_t n_out_steer,
                               int32_t n_out_throttle, float clip, float value_coeff, float clip_coeff,
                               float ent_coeff, float inv_b, float* losses, float* dlogits, float* dvalues,
-                              void* stream) {
+                              float* scratch, void* stream) {
   FAIL_IF(!logits || !values || !actions || !commands || !old_values || !returns || !old_logp || !adv || !losses ||
-              !dlogits || !dvalues || B < 1 || n_out_steer < 1 || n_out_steer > MAX_NOUT || n_out_throttle < 1 ||
-              n_out_throttle > MAX_NOUT || ldl < n_out_steer || ldl < n_out_throttle,
+              !dlogits || !dvalues || !scratch || B < 1 || n_out_steer < 1 || n_out_steer > MAX_NOUT || n_out_throttle < 1 ||
+              n_out_throttle > MAX_NOUT || ldl < n_out_steer || ldl < n_out_throttle || ldl > 64,
           "cadre_ppo_loss: bad argument");
   // zeroed by a kernel, not hipMemsetAsync: a memset node captured into a hipGraph was observed to
   // replay a 0xD3 byte pattern instead of 0 on ROCm 7.2 (second replay of the update graph)
-  hipLaunchKernelGGL(zero_f32_kernel, dim3(1), dim3(64), 0, ST(stream), losses, 3);
-  hipLaunchKernelGGL(ppo_loss_kernel, dim3(2), dim3(256), 0, ST(stream), logits, ldl, l_ns, values, ldv, v_ns,
+  hipLaunchKernelGGL(zero_f32_kernel, dim3(1), dim3(64), 0, ST(stream), scratch, 1);
+  hipLaunchKernelGGL(ppo_loss_kernel, dim3((B + 15) / 16, 2), dim3(256), 0, ST(stream), logits, ldl, l_ns, values, ldv, v_ns,
                      actions, commands,
                      old_values, returns, old_logp, adv, B, n_out_steer, n_out_throttle, clip, value_coeff,
-                     clip_coeff, ent_coeff, inv_b, losses, dlogits, dvalues);
+                     clip_coeff, ent_coeff, inv_b, losses, dlogits, dvalues, scratch);
   return (int)hipGetLastError();
 }
 

@@ -1,0 +1,494 @@
+// ppo_update.hip — fused kernels of the PPO minibatch update (reference ppo_agent/agent.py:166-237 through
+// ppo_agent/models.py:139-152 nn.LSTMCell and models.py:171-177 / distributions.py:34-40 MLP towers).
+//
+// The update's recurrent products are SKINNY: a command net owns 16 (minibatch 64) to ~64 (minibatch 256) rows of the
+// row-sorted minibatch, against 2120 x 544 weights.  On the general tile kernel (gemm_f32.hip) such a product is one
+// 272-deep chain of v_mfma_f32_32x32x2_f32 per wave (17-45 us per launch) followed by a pointwise pass and, backward, a
+// split-K reduction pass: 3 x 8 launches each way.  Here one launch per time step does the product AND the cell math:
+//
+//   * v_mfma_f32_16x16x4_f32: 16 rows x 16 columns x 4 k per instruction at 32 cycles — for <= 16-row tiles twice the
+//     useful rate of the 32x32x2 form, and a K = 544 chain is 136 instructions;
+//   * the weights go from L2 / Infinity Cache STRAIGHT into MFMA fragments: lane (c = lane & 15, q = lane >> 4) loads
+//     16 bytes = k 16j + 4q .. +3 of column c, i.e. the operand of the four MFMAs of k-block j — the k order inside a
+//     block is permuted identically on A and B, so the products pair correctly.  A weight is used by exactly one wave
+//     (nothing to share through LDS); what bounds a step is how many weight bytes a CU keeps in flight (about 33 GB/s
+//     per CU from the Infinity Cache at 72 KiB in flight), so half of a wave's K is requested before its first MFMA;
+//   * forward: workgroup = (net, 16 hidden units, chunk of 16*RT rows), wave g = gate g (i, f, g, o) of those units over
+//     the full K; the four gate tiles meet in LDS and the workgroup finishes c_t, h_t, tanh(c_t) and the activated gates;
+//   * backward: workgroup = (net, 16 hidden units, chunk of rows), wave w = quarter w of K = 4 x 530 gate columns of
+//     dG_t against the TRANSPOSED recurrent weights (cadre_transpose_batched keeps a [k][n] copy per update: the
+//     reduction index must be the contiguous one); the four partial tiles meet in LDS = dh_{t-1}, and the same
+//     workgroup turns it into dG_{t-1} and dc_{t-2} — no split-K slabs, no reduction pass, no pointwise pass.
+//
+// Rows sorted by command (row_seg): a net touches the 32-row tiles that intersect its run of rows — the rows the
+// segment-aware GEMMs (cadre_gemm_t.seg_mode) read and write; rows of other nets inside those tiles are computed forward
+// (finite, never used: the loss reads each row's own command net) and get exact zeros backward.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "../../include/cadre_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+int cadre_fail(const char* msg);
+#define ST(s) ((hipStream_t)(s))
+#define FAIL_IF(cond, msg) \
+  if (cond) return cadre_fail(msg)
+
+namespace {
+
+__device__ __forceinline__ float sigmoid_(float x) { return 1.f / (1.f + expf(-x)); }
+
+struct fwd_args {
+  const float* W;       // recurrent weights [H4][ldw] of net 0 (k contiguous), net stride w_str
+  const float* bias;    // [H4] of net 0, net stride w_str (may be null)
+  float* G;             // this step's gates [B][ldg] of net 0, net stride g_str: in = x-projection, out = activated gates
+  const float* Hprev;   // h_{t-1} [B][ldh], net stride h_str
+  const float* Cprev;   // c_{t-1}
+  float* Hout;          // h_t
+  float* Cout;          // c_t
+  float* TCout;         // tanh(c_t)
+  const int32_t* row_seg;
+  int64_t w_str, g_str, h_str;
+  int ldw, ldg, ldh, B, D, Z, NS, rev;
+};
+
+// Work item = (net, 16 hidden units, chunk of 16*RT rows), from a 1-D grid with the NET as the fastest index: workgroups
+// are dealt round-robin over the 8 XCDs, so net z's workgroups share one XCD and its 4.6 MB of recurrent weights live
+// in that XCD's 4 MB L2 between time steps instead of coming from the Infinity Cache every step; `rev` walks the unit
+// slices in the opposite order on alternate steps (the most recently used weights are re-used first: an LRU cache
+// slightly smaller than the set it cycles through would otherwise miss every time).  Placement only affects speed.
+__device__ __forceinline__ bool step_item(int Z, int NS, int rev, const int32_t* row_seg, int B, int rows, int& z, int& slice,
+                                          int& row0, int& r_hi) {
+  const int id = blockIdx.x;
+  z = id % Z;
+  const int rest = id / Z;
+  slice = rest % NS;
+  if (rev) slice = NS - 1 - slice;
+  int r_lo = 0;
+  r_hi = B;
+  if (row_seg) {             // the 32-row tiles that intersect the net's run: the rows the segment-aware GEMMs read and write
+    const int beg = row_seg[2 * z], cnt = row_seg[2 * z + 1];
+    if (cnt <= 0) return false;
+    r_lo = beg & ~31;
+    r_hi = min(B, (beg + cnt + 31) & ~31);
+  }
+  row0 = r_lo + (rest / NS) * rows;
+  return row0 < r_hi;
+}
+
+// 16*RT rows x 16 units x 4 gates per workgroup; NB = K / 16 k-blocks (K = ldh, zero padded past D).
+// LDS: the h_{t-1} rows of the chunk (shared by the four gate waves), pitch 552 floats = 138 16-byte slots:
+// conflict-free for the fragment reads (lane (c, q) reads slot 138*row + 4j + q: 16 distinct slots mod 16 per lane group).
+template <int RT, int NB>
+__global__ __launch_bounds__(256) void lstm_step_fwd_kernel(fwd_args p) {
+  constexpr int PD = NB / 2;                              // k-blocks of weights in flight per wave (17 KiB)
+  constexpr int AP = 552;                                 // LDS row pitch of the activation rows (floats)
+  constexpr int ROWS = 16 * RT, K = 16 * NB, NCH = ROWS * (K / 4), NLD = (NCH + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float ah[ROWS * AP];
+  __shared__ float xg[4][ROWS][16];
+  const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  int z, slice, row0, r_hi;
+  if (!step_item(p.Z, p.NS, p.rev, p.row_seg, p.B, ROWS, z, slice, row0, r_hi)) return;
+  const int D = p.D, u = slice * 16 + c;
+  const int uc = u < D ? u : D - 1;                       // units past D: a valid row of W, result discarded
+  const float* wp = p.W + (int64_t)z * p.w_str + (int64_t)(g * D + uc) * p.ldw + 4 * q;
+  f32x4 bq[PD];
+#pragma unroll
+  for (int j = 0; j < PD; ++j) bq[j] = *reinterpret_cast<const f32x4*>(wp + 16 * j);
+  // activation rows -> LDS (every thread 16-byte chunks, coalesced along the rows; rows past the chunk repeat the last)
+  const float* hp = p.Hprev + (int64_t)z * p.h_str;
+  f32x4 st[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int idx = min(tid + 256 * i, NCH - 1), r = idx / (K / 4), ch = idx - r * (K / 4);
+    st[i] = *reinterpret_cast<const f32x4*>(hp + (int64_t)min(row0 + r, r_hi - 1) * p.ldh + 4 * ch);
+  }
+  // accumulators start from the x-projection (+ b_ih, folded there) and b_hh: D[row = 4q + r][col = c]
+  // (loaded unconditionally from clamped addresses: a load under a per-element condition is a branch + vmcnt(0) each)
+  float* gz = p.G + (int64_t)z * p.g_str;
+  const float bv = p.bias ? p.bias[(int64_t)z * p.w_str + g * D + uc] : 0.f;
+  // (two accumulators per row tile, even / odd k-steps: a single chain of this MFMA is latency- not issue-paced)
+  f32x4 acc[RT][2];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    acc[rt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      acc[rt][0][r] = gz[(int64_t)min(row0 + 16 * rt + 4 * q + r, r_hi - 1) * p.ldg + g * D + uc] + bv;
+  }
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int idx = tid + 256 * i, r = idx / (K / 4), ch = idx - r * (K / 4);
+    if (idx < NCH) *reinterpret_cast<f32x4*>(ah + r * AP + 4 * ch) = st[i];
+  }
+  __syncthreads();
+  const float* arow = ah + c * AP + 4 * q;
+  // (the scheduler sinks loads towards their use to save registers; the order is pinned so that PD blocks of weights
+  //  stay in flight: one wave per SIMD has only its own loads to hide the L2 / Infinity Cache latency)
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int s = j % PD;
+    const f32x4 b = bq[s];
+    f32x4 a[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const f32x4*>(arow + 16 * rt * AP + 16 * j);
+    if (j + PD < NB) bq[s] = *reinterpret_cast<const f32x4*>(wp + 16 * (j + PD));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+        acc[rt][i & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][i], b[i], acc[rt][i & 1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // the four gate tiles meet in LDS
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xg[g][16 * rt + 4 * q + r][c] = acc[rt][0][r] + acc[rt][1][r];
+  __syncthreads();
+  const int64_t hz = (int64_t)z * p.h_str;
+#pragma unroll
+  for (int e = 0; e < RT; ++e) {
+    const int pr = tid + 256 * e, rl = pr >> 4, uu = pr & 15;
+    const int row = row0 + rl, un = slice * 16 + uu;
+    if (row >= r_hi || un >= D) continue;
+    const float ig = sigmoid_(xg[0][rl][uu]);
+    const float fg = sigmoid_(xg[1][rl][uu]);
+    const float gg = tanhf(xg[2][rl][uu]);
+    const float og = sigmoid_(xg[3][rl][uu]);
+    const int64_t o = hz + (int64_t)row * p.ldh + un;
+    const float cn = fg * p.Cprev[o] + ig * gg;
+    const float tc = tanhf(cn);
+    float* gr = gz + (int64_t)row * p.ldg + un;
+    gr[0] = ig; gr[D] = fg; gr[2 * D] = gg; gr[3 * D] = og;
+    p.Cout[o] = cn;
+    p.TCout[o] = tc;
+    p.Hout[o] = og * tc;
+  }
+}
+
+struct bwd_args {
+  const float* WT;      // transposed recurrent weights [ldh rows k][ldt] (n contiguous, zero padded to NB*64), net stride wt_str
+  const float* dG_in;   // dG_t [B][ldg] of net 0 (null: no product, dh = dh_in only), net stride g_str
+  float* dG_out;        // dG_{t-1}
+  const float* G_act;   // activated gates of step t-1
+  const float* dh_in;   // upstream dL/dh_{t-1} [B][ldh] added to the product (may be null), net stride d_str
+  float* dC;            // in: dL/dc_{t-1}; out: dL/dc_{t-2}; [B][ldh], net stride d_str
+  const float* TC;      // tanh(c_{t-1})
+  const float* Cprev;   // c_{t-2}
+  const int32_t* commands;   // [2][B] (null: no ownership mask)
+  const int32_t* row_seg;
+  int64_t wt_str, g_str, h_str, d_str;
+  int ldt, ldg, ldh, B, D, C, Z, NS, rev;
+};
+
+// wave w multiplies k-blocks [w*NB, (w+1)*NB) of the 4*NB blocks of the (zero padded) gate axis
+template <int RT, int NB, bool GEMM>
+__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(bwd_args p) {
+  constexpr int PD = RT == 1 ? 16 : (RT == 2 ? 11 : 7);    // k-blocks ((1 + RT) KiB each) in flight per wave
+  constexpr int ROWS = 16 * RT;
+  __shared__ float xs[4][ROWS][16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  int z, slice, row0, r_hi;
+  if (!step_item(p.Z, p.NS, p.rev, p.row_seg, p.B, ROWS, z, slice, row0, r_hi)) return;
+  const int D = p.D;
+  if constexpr (GEMM) {
+    const int u = slice * 16 + c;
+    const int uc = u < D ? u : D - 1;
+    const float* wp = p.WT + (int64_t)z * p.wt_str + (int64_t)uc * p.ldt + 16 * NB * w + 4 * q;
+    const float* gp = p.dG_in + (int64_t)z * p.g_str + 16 * NB * w + 4 * q;
+    const float* ap[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) ap[rt] = gp + (int64_t)min(row0 + 16 * rt + c, r_hi - 1) * p.ldg;
+    // two accumulators per row tile (even / odd k-blocks): a single chain of this MFMA is latency- not issue-paced
+    f32x4 acc[RT][2];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[rt][0] = acc[rt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bq[PD], aq[PD][RT];
+#pragma unroll
+    for (int j = 0; j < PD; ++j) {
+      bq[j] = *reinterpret_cast<const f32x4*>(wp + 16 * j);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) aq[j][rt] = *reinterpret_cast<const f32x4*>(ap[rt] + 16 * j);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int s = j % PD;
+      const f32x4 b = bq[s];
+      f32x4 a[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) a[rt] = aq[s][rt];
+      if (j + PD < NB) {
+        bq[s] = *reinterpret_cast<const f32x4*>(wp + 16 * (j + PD));
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) aq[s][rt] = *reinterpret_cast<const f32x4*>(ap[rt] + 16 * (j + PD));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          acc[rt][i & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][i], b[i], acc[rt][i & 1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xs[w][16 * rt + 4 * q + r][c] = acc[rt][0][r] + acc[rt][1][r];
+    __syncthreads();
+  }
+  const int64_t gzo = (int64_t)z * p.g_str, hz = (int64_t)z * p.h_str, dz = (int64_t)z * p.d_str;
+#pragma unroll
+  for (int e = 0; e < RT; ++e) {
+    const int pr = tid + 256 * e, rl = pr >> 4, uu = pr & 15;
+    const int row = row0 + rl, un = slice * 16 + uu;
+    if (row >= r_hi || un >= D) continue;
+    float* dg = p.dG_out + gzo + (int64_t)row * p.ldg + un;
+    const int64_t od = dz + (int64_t)row * p.ldh + un;
+    if (p.commands && p.commands[(z / p.C) * p.B + row] != z % p.C) {      // row of another command net: exact zeros
+      dg[0] = 0.f; dg[D] = 0.f; dg[2 * D] = 0.f; dg[3 * D] = 0.f;
+      p.dC[od] = 0.f;
+      continue;
+    }
+    float dht = p.dh_in ? p.dh_in[od] : 0.f;
+    if constexpr (GEMM) dht += (xs[0][rl][uu] + xs[1][rl][uu]) + (xs[2][rl][uu] + xs[3][rl][uu]);
+    const float* ga = p.G_act + gzo + (int64_t)row * p.ldg + un;
+    const float ig = ga[0], fg = ga[D], gg = ga[2 * D], og = ga[3 * D];
+    const int64_t o = hz + (int64_t)row * p.ldh + un;
+    const float tc = p.TC[o];
+    const float dct = p.dC[od] + dht * og * (1.f - tc * tc);
+    const float cp = p.Cprev[o];
+    dg[0] = dct * gg * ig * (1.f - ig);
+    dg[D] = dct * cp * fg * (1.f - fg);
+    dg[2 * D] = dct * ig * (1.f - gg * gg);
+    dg[3 * D] = dht * tc * og * (1.f - og);
+    p.dC[od] = dct * fg;
+  }
+}
+
+struct dw_args {
+  const float* dG;      // [S][B][ldg] gate gradients of net 0, net stride g_str
+  const float* Hs;      // h_{t-1} of step t at Hs + t*B*ldh: [S+1][B][ldh], net stride h_str
+  const float* X;       // x_t: [S][B][ldh] of input slot 0; net z reads slot z / x_div, slot stride x_str
+  float* dWhh;          // [H4][ldw] of net 0, net stride w_str (gradient arena)
+  float* dWih;
+  float* dbih;          // [H4]
+  float* dbhh;
+  const int32_t* row_seg;
+  int64_t g_str, h_str, x_str, w_str;
+  int ldg, ldh, ldw, B, S, H4, N, Z, x_div, MG, NG;
+};
+
+// dW_hh = sum_t dG_t^T h_{t-1}, dW_ih = sum_t dG_t^T x_t, db_ih = db_hh = column sums of dG (autograd of
+// models.py:139-152 over the S steps) in ONE launch.  Both operands are "k-major" — the reduction index is the row
+// (sample) index, rows are contiguous in the output index — so an MFMA fragment is a plain coalesced load: lane
+// (c = lane & 15, q = lane >> 4) of k-step s loads 16 bytes of row 4s + q: dG[row][m0 + 4c ..+3] feeds the A operand of
+// FOUR row tiles (output rows m0 + 4c + i, i = 0..3, interleaved), Y[row][n0 + 4c ..+3] the B operand of four column
+// tiles: a wave owns a 64 x 64 output tile = 16 v_mfma_f32_16x16x4_f32 per two 1-KiB loads, no LDS, and its results
+// are 16 (m) x 4 (n) blocks per lane: 16-byte stores, 256 B per output row.  Only a net's own run of rows is
+// multiplied (4-row granularity; the rows of other nets hold exact zeros).  Work item = wave tile; the net is the
+// fastest index of the 1-D grid (one XCD per net: its dG / h / x rows stay in that XCD's L2).
+__global__ __launch_bounds__(256) void lstm_dw_kernel(dw_args p) {
+  constexpr int PD = 8;                                   // k-steps (2 KiB per wave) in flight
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int z = blockIdx.x % p.Z;
+  const int tile = (blockIdx.x / p.Z) * 4 + wave;         // 0 .. 2*MG*NG: (kind, m-group, n-group), n fastest
+  const int per_kind = p.MG * p.NG;
+  if (tile >= 2 * per_kind) return;
+  const int kind = tile / per_kind, tk = tile - kind * per_kind;
+  const int mg = tk / p.NG, ng = tk - mg * p.NG;
+  int lo = 0, hi = p.B;
+  if (p.row_seg) {
+    const int beg = p.row_seg[2 * z], cnt = p.row_seg[2 * z + 1];
+    lo = beg & ~3;
+    hi = cnt > 0 ? beg + cnt : lo;
+  }
+  const int nb = (hi - lo + 3) >> 2;                      // k-steps per time step
+  const int KT = nb * p.S;
+  const int m0 = 64 * mg, n0 = 64 * ng;
+  const int nc = (n0 + 4 * c < p.N) ? c : 0;              // column chunk past the row pitch: a valid one, discarded
+  const float* ga = p.dG + (int64_t)z * p.g_str + m0 + 4 * c;
+  const float* yb = (kind == 0 ? p.Hs + (int64_t)z * p.h_str : p.X + (int64_t)(z / p.x_div) * p.x_str) + n0 + 4 * nc;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};                      // column sums of dG (this lane's rows 4s + q)
+  // k-step ks -> rows t*B + lo + 4*(ks % nb) + q, walked incrementally (state of the next k-step to request).  The loop
+  // body is branch-free: requests past the end repeat the last k-step, whose operand is zeroed where it is consumed.
+  int t_n = 0, b_n = 0, ks_n = 0;
+  f32x4 aq[PD], yq[PD];
+  auto request = [&](int slot) {
+    const int row = min(lo + 4 * b_n + q, p.B - 1);
+    const int64_t r = (int64_t)t_n * p.B + row;
+    aq[slot] = *reinterpret_cast<const f32x4*>(ga + r * p.ldg);
+    yq[slot] = *reinterpret_cast<const f32x4*>(yb + r * p.ldh);
+    const int adv = ks_n + 1 < KT ? 1 : 0;
+    ks_n += adv;
+    const int b1 = b_n + adv;
+    const int wrap = b1 == nb ? 1 : 0;
+    b_n = wrap ? 0 : b1;
+    t_n += wrap;
+  };
+  if (KT > 0) {
+#pragma unroll
+    for (int s = 0; s < PD; ++s) request(s);
+    __builtin_amdgcn_sched_barrier(0);                   // (PD k-steps stay in flight: the loads are not sunk to their use)
+    int b_c = 0;                                          // k-step inside its time step, consumer side
+    for (int ks = 0; ks < KT; ks += PD) {
+#pragma unroll
+      for (int s = 0; s < PD; ++s) {
+        f32x4 av = aq[s];
+        const f32x4 yv = yq[s];
+        request(s);
+        __builtin_amdgcn_sched_barrier(0);
+        // rows past the run (tail of a 4-row step) and k-steps past the end contribute nothing
+        const bool dead = (lo + 4 * b_c + q >= hi) | (ks + s >= KT);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) av[i] = dead ? 0.f : av[i];
+        const int b1 = b_c + 1;
+        b_c = b1 == nb ? 0 : b1;
+        bsum += av;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], yv[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  // ---- store: lane (c, q) holds rows m0 + 16q + 4r + i, columns n0 + 4c .. +3
+  float* out = (kind == 0 ? p.dWhh : p.dWih) + (int64_t)z * p.w_str;
+  if (n0 + 4 * c < p.N) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + 16 * q + 4 * r + i;
+        if (m < p.H4)
+          *reinterpret_cast<f32x4*>(out + (int64_t)m * p.ldw + n0 + 4 * c) = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+      }
+  }
+  if (kind == 0 && ng == 0) {                              // bias gradients: sum the four row quarters (q) of the wave
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = bsum[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      bsum[i] = v;
+    }
+    if (q == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + 4 * c + i;
+        if (m < p.H4) {
+          p.dbih[(int64_t)z * p.w_str + m] = bsum[i];
+          p.dbhh[(int64_t)z * p.w_str + m] = bsum[i];
+        }
+      }
+    }
+  }
+}
+
+// dst[z][c][r] = src[z][r][c] through a padded 32 x 32 LDS tile (both sides coalesced)
+__global__ __launch_bounds__(256) void transpose_kernel(const float* src, int64_t ld_src, int64_t src_str, float* dst,
+                                                        int64_t ld_dst, int64_t dst_str, int rows, int cols) {
+  __shared__ float t[32][33];
+  const int z = blockIdx.z, r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
+  const float* s = src + (int64_t)z * src_str;
+  float* d = dst + (int64_t)z * dst_str;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + y + 8 * i, cc = c0 + x;
+    t[y + 8 * i][x] = (r < rows && cc < cols) ? s[(int64_t)r * ld_src + cc] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int cc = c0 + y + 8 * i, r = r0 + x;
+    if (cc < cols && r < rows) d[(int64_t)cc * ld_dst + r] = t[x][y + 8 * i];
+  }
+}
+
+int rt_for(int B) {
+  static const int forced = [] { const char* e = getenv("CADRE_LSTM_RT"); return e ? atoi(e) : 0; }();
+  if (forced == 1 || forced == 2) return forced;
+  return B <= 16 ? 1 : 2;                                 // chunk = one 32-row tile of the row-sorted minibatch
+}
+
+}  // namespace
+
+extern "C" int cadre_lstm_step_fwd(const float* W, int64_t w_str, int32_t ldw, const float* bias, float* G, int32_t ldg,
+                                   int64_t g_str, const float* Hprev, const float* Cprev, float* Hout, float* Cout,
+                                   float* TCout, int32_t ldh, int64_t h_str, int32_t B, int32_t D, int32_t Z,
+                                   const int32_t* row_seg, int32_t rev, void* stream) {
+  FAIL_IF(!W || !G || !Hprev || !Cprev || !Hout || !Cout || !TCout || B < 1 || D < 1 || Z < 1, "cadre_lstm_step_fwd: bad argument");
+  FAIL_IF(ldh != 544 || ldw != ldh || D > ldh || ldg < 4 * D, "cadre_lstm_step_fwd: built for K = ldh = ldw = 544 (hidden 530 zero padded), ldg >= 4*D");
+  FAIL_IF((((uintptr_t)W | (uintptr_t)Hprev) & 15) || (w_str & 3) || (h_str & 3), "cadre_lstm_step_fwd: operands must be 16-byte aligned");
+  const int rt = rt_for(B), rows = 16 * rt, NS = (D + 15) / 16;
+  fwd_args a{W, bias, G, Hprev, Cprev, Hout, Cout, TCout, row_seg, w_str, g_str, h_str, ldw, ldg, ldh, B, D, Z, NS, rev & 1};
+  dim3 grid(Z * NS * ((B + rows - 1) / rows));          // row chunks: workgroups past a net's cover of rows return at once
+  if (rt == 1) hipLaunchKernelGGL((lstm_step_fwd_kernel<1, 34>), grid, dim3(256), 0, ST(stream), a);
+  else hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 34>), grid, dim3(256), 0, ST(stream), a);
+  return (int)hipGetLastError();
+}
+
+extern "C" int cadre_lstm_step_bwd(const float* WT, int64_t wt_str, int32_t ldt, const float* dG_in, float* dG_out,
+                                   const float* G_act, int32_t ldg, int64_t g_str, const float* dh_in, float* dC,
+                                   int64_t d_str, const float* TC, const float* Cprev, int32_t ldh, int64_t h_str,
+                                   int32_t B, int32_t D, int32_t Z, const int32_t* commands, int32_t C,
+                                   const int32_t* row_seg, int32_t rev, void* stream) {
+  FAIL_IF(!dG_out || !G_act || !dC || !TC || !Cprev || B < 1 || D < 1 || Z < 1 || (!dG_in && !dh_in) || (commands && C < 1),
+          "cadre_lstm_step_bwd: bad argument");
+  FAIL_IF(ldh != 544 || D > ldh || ldg < 4 * D, "cadre_lstm_step_bwd: built for ldh = 544 (hidden 530 zero padded), ldg >= 4*D");
+  if (dG_in) {
+    FAIL_IF(!WT || ldt != 2176 || ldg != 2176, "cadre_lstm_step_bwd: the product needs the transposed weights with ldt = ldg = 2176 (4 x 34 k-blocks, zero padded)");
+    FAIL_IF((((uintptr_t)WT | (uintptr_t)dG_in) & 15) || (wt_str & 3) || (g_str & 3), "cadre_lstm_step_bwd: operands must be 16-byte aligned");
+  }
+  const int rt = rt_for(B), rows = 16 * rt, NS = (D + 15) / 16;
+  bwd_args a{WT, dG_in, dG_out, G_act, dh_in, dC, TC, Cprev, commands, row_seg, wt_str, g_str, h_str, d_str, ldt, ldg, ldh, B, D,
+             C < 1 ? 1 : C, Z, NS, rev & 1};
+  dim3 grid(Z * NS * ((B + rows - 1) / rows));
+#define LB(RT_)                                                                                                  \
+  do {                                                                                                           \
+    if (dG_in) hipLaunchKernelGGL((lstm_step_bwd_kernel<RT_, 34, true>), grid, dim3(256), 0, ST(stream), a);    \
+    else hipLaunchKernelGGL((lstm_step_bwd_kernel<RT_, 34, false>), grid, dim3(256), 0, ST(stream), a);         \
+  } while (0)
+  if (rt == 1) LB(1); else LB(2);
+#undef LB
+  return (int)hipGetLastError();
+}
+
+extern "C" int cadre_transpose_batched(const float* src, int64_t ld_src, int64_t src_str, float* dst, int64_t ld_dst,
+                                       int64_t dst_str, int32_t rows, int32_t cols, int32_t batch, void* stream) {
+  FAIL_IF(!src || !dst || rows < 1 || cols < 1 || batch < 1 || ld_src < cols || ld_dst < rows, "cadre_transpose_batched: bad argument");
+  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, batch), dim3(256), 0, ST(stream), src, ld_src,
+                     src_str, dst, ld_dst, dst_str, rows, cols);
+  return (int)hipGetLastError();
+}
+
+extern "C" int cadre_lstm_dw(const float* dG, int32_t ldg, int64_t g_str, const float* Hs, const float* X, int32_t ldh,
+                             int64_t h_str, int64_t x_str, int32_t x_div, float* dWhh, float* dWih, float* dbih,
+                             float* dbhh, int32_t ldw, int64_t w_str, int32_t B, int32_t S, int32_t H4, int32_t N,
+                             int32_t Z, const int32_t* row_seg, void* stream) {
+  FAIL_IF(!dG || !Hs || !X || !dWhh || !dWih || !dbih || !dbhh || B < 1 || S < 1 || H4 < 1 || N < 1 || Z < 1 || x_div < 1,
+          "cadre_lstm_dw: bad argument");
+  FAIL_IF((ldg & 3) || (ldh & 3) || (ldw & 3) || (N & 3) || N > ldh || N > ldw || ldg < ((H4 + 63) & ~63) ||
+              (((uintptr_t)dG | (uintptr_t)Hs | (uintptr_t)X | (uintptr_t)dWhh | (uintptr_t)dWih) & 15) ||
+              ((g_str | h_str | x_str | w_str) & 3),
+          "cadre_lstm_dw: 16-byte aligned operands, N % 4 == 0, N <= ldh / ldw, ldg >= H4 rounded up to 64 (zero padded)");
+  const int MG = (H4 + 63) / 64, NG = (N + 63) / 64;
+  dw_args a{dG, Hs, X, dWhh, dWih, dbih, dbhh, row_seg, g_str, h_str, x_str, w_str, ldg, ldh, ldw, B, S, H4, N, Z, x_div, MG, NG};
+  const int wgs = (2 * MG * NG + 3) / 4;
+  hipLaunchKernelGGL(lstm_dw_kernel, dim3(Z * wgs), dim3(256), 0, ST(stream), a);
+  return (int)hipGetLastError();
+}

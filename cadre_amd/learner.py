@@ -18,7 +18,6 @@ from . import hip
 
 
 class PPOLearnerHIP:
-    SPLIT_DH = 8
     SORT_MIN_B = 64
 
     def sorted_rows(self, B):
@@ -34,6 +33,7 @@ class PPOLearnerHIP:
         self.S = seq_length
         self._ws = {}
         self._graphs = {}
+        self._wt = None
         self.launches = {}
         self.use_graphs = os.environ.get("CADRE_HIP_GRAPHS", "1") != "0"
         self.use_sorted = os.environ.get("CADRE_SORTED_UPDATE", "1") != "0"
@@ -51,14 +51,14 @@ class PPOLearnerHIP:
             z = lambda *shape, dtype=torch.float32: torch.zeros(*shape, dtype=dtype, device=dev)
             w = dict(
                 X=z(2, S, B, a.DP), h0=z(2, B, a.DP), c0=z(2, B, a.DP),
-                G=z(Z, S, B, a.H4), dG=z(Z, S, B, a.H4),
+                G=z(Z, S, B, a.H4P), dG=z(Z, S, B, a.H4P),         # gate rows [i f g o] x D, zero padded to 4 x 34 k-blocks
                 Hs=z(Z, S + 1, B, a.DP), Cs=z(Z, S + 1, B, a.DP), TC=z(Z, S + 1, B, a.DP),
                 A1=z(2 * Z, B, a.hid), A2=z(2 * Z, B, a.hid), O3=z(2 * Z, B, a.NP),
                 dO3=z(2 * Z, B, a.NP), dA2=z(2 * Z, B, a.hid), dA1=z(2 * Z, B, a.hid),
-                dH=z(Z, B, a.DP), dC=z(Z, B, a.DP), dHs=z(self.SPLIT_DH, Z, B, a.DP),
+                dH=z(Z, B, a.DP), dC=z(Z, B, a.DP),
                 actions=z(2, B, dtype=torch.int64), commands=z(2, B, dtype=torch.int32),
                 old_values=z(2, B), returns=z(2, B), old_logp=z(2, B), adv=z(2, B),
-                losses=z(3),
+                losses=z(3), loss_scratch=z(4 + 6 * ((B + 15) // 16)),
                 pos=z(2, B, dtype=torch.int32), seg=z(2 * a.C, 2, dtype=torch.int32),
             )
             if self.sorted_rows(B) and Z == a.Z:      # unsorted staging for gather -> sort -> permute
@@ -77,7 +77,7 @@ class PPOLearnerHIP:
         g0, gs, Z = nets
         P, st = a.params, hip.stream()
         L = hip.lib()
-        DP, H4, hid, NP = a.DP, a.H4, a.hid, a.NP
+        DP, H4, H4P, hid, NP = a.DP, a.H4, a.H4P, a.hid, a.NP
         pL = P[g0 * a.size_L:]
         sL = gs * a.size_L
         X, G, Hs, Cs, TC = w["X"], w["G"], w["Hs"], w["Cs"], w["TC"]
@@ -86,17 +86,15 @@ class PPOLearnerHIP:
                                     B * DP, (S + 1) * B * DP, x_div, Z, st), "cadre_lstm_init")
         # all input projections x_t W_ih^T + b_ih: one GEMM [S*B, DP] x [DP, H4] per net
         sg1 = None if seg is None else (1, seg, B, 1)
-        sgp = None if seg is None else hip.ptr(seg)           # pointwise passes: only the tiles of each net's run of rows
-        hip.gemm(X, pL[a.o_wih:], G, S * B, H4, DP, DP, DP, H4, shift=pL[a.o_bih:], batch=Z,
-                 a_z=(x_div, 0, S * B * DP), b_z=(1, 0, sL), c_z=(1, 0, S * B * H4), s_z=(1, 0, sL), seg=sg1)
+        sgp = None if seg is None else hip.ptr(seg)           # fused steps: only the 32-row tiles of each net's run of rows
+        hip.gemm(X, pL[a.o_wih:], G, S * B, H4, DP, DP, DP, H4P, shift=pL[a.o_bih:], batch=Z,
+                 a_z=(x_div, 0, S * B * DP), b_z=(1, 0, sL), c_z=(1, 0, S * B * H4P), s_z=(1, 0, sL), seg=sg1)
         for t in range(S):                                          # models.py:148-151
-            Gt = G[:, t]
-            hip.gemm(Hs[:, t], pL[a.o_whh:], Gt, B, H4, DP, DP, DP, H4, shift=pL[a.o_bhh:], resid=Gt, ldr=H4,
-                     batch=Z, a_z=(1, 0, (S + 1) * B * DP), b_z=(1, 0, sL), c_z=(1, 0, S * B * H4),
-                     s_z=(1, 0, sL), r_z=(1, 0, S * B * H4), seg=sg1)
-            hip.check(L.cadre_lstm_pointwise_fwd(hip.ptr(Gt), H4, S * B * H4, hip.ptr(Cs[:, t]), (S + 1) * B * DP, 1,
-                                                 hip.ptr(Cs[:, t + 1]), hip.ptr(Hs[:, t + 1]), hip.ptr(TC[:, t + 1]),
-                                                 DP, (S + 1) * B * DP, B, a.D, Z, sgp, st), "cadre_lstm_pointwise_fwd")
+            # gates = x-projection + h_{t-1} W_hh^T + b_hh, cell math, h_t / c_t / tanh(c_t): one launch for all nets
+            hip.check(L.cadre_lstm_step_fwd(hip.ptr(pL[a.o_whh:]), sL, DP, hip.ptr(pL[a.o_bhh:]), hip.ptr(G[:, t]), H4P,
+                                            S * B * H4P, hip.ptr(Hs[:, t]), hip.ptr(Cs[:, t]), hip.ptr(Hs[:, t + 1]),
+                                            hip.ptr(Cs[:, t + 1]), hip.ptr(TC[:, t + 1]), DP, (S + 1) * B * DP, B, a.D, Z,
+                                            sgp, t & 1, st), "cadre_lstm_step_fwd")
         if mlp:
             self._mlp(w, B, nets, Hs[:, S], (S + 1) * B * DP, seg=seg)
 
@@ -190,8 +188,6 @@ class PPOLearnerHIP:
         sgM2 = None if seg is None else (1, seg, B, 2)  # M tiles, z = 2*net + tower
         sgK1 = None if seg is None else (2, seg, B, 1)  # k tiles (rows), z = net
         sgK2 = None if seg is None else (2, seg, B, 2)
-        # (opt-in, A/B build only: cadre_gemm_f32 tile 11, csrc/ab/gemm_f32_skinny.hip)
-        skinny = seg is not None and os.environ.get("CADRE_SKINNY_GEMM", "0") != "0" and hip.has_ab_kernels()
         front, back = part in ("all", "front"), part in ("all", "back")
         O3, dO3 = w["O3"], w["dO3"]
         if front:
@@ -200,7 +196,8 @@ class PPOLearnerHIP:
                                        hip.ptr(w["actions"]), hip.ptr(w["commands"]), hip.ptr(w["old_values"]),
                                        hip.ptr(w["returns"]), hip.ptr(w["old_logp"]), hip.ptr(w["adv"]), B,
                                        a.n_out[0], a.n_out[1], self.clip, self.vc, self.cc, self.ec, inv_b,
-                                       hip.ptr(w["losses"]), hip.ptr(dO3), hip.ptr(dO3[1]), st), "cadre_ppo_loss")
+                                       hip.ptr(w["losses"]), hip.ptr(dO3), hip.ptr(dO3[1]), hip.ptr(w["loss_scratch"]), st),
+                      "cadre_ppo_loss")
         # ---------------- backward: MLP towers (16 = 2Z batched)
         Gr = a.grads
         pP, gP = a.params[a.P0:], Gr[a.P0:]
@@ -235,30 +232,26 @@ class PPOLearnerHIP:
         # ---------------- backward through time (autograd of models.py:148-151)
         G, dG, Cs, TC, X = w["G"], w["dG"], w["Cs"], w["TC"], w["X"]
         pL, gL, sL = a.params, Gr, a.size_L
-        for t in range(S - 1, -1, -1):
-            hip.check(L.cadre_lstm_pointwise_bwd(hip.ptr(G[:, t]), hip.ptr(dG[:, t]), H4, S * B * H4, hip.ptr(dH),
-                                                 hip.ptr(dC), B * DP, hip.ptr(TC[:, t + 1]), hip.ptr(Cs[:, t]),
-                                                 (S + 1) * B * DP, 1, DP, (S + 1) * B * DP, B, a.D, Z, cmd, C,
-                                                 None if seg is None else hip.ptr(seg), st),
-                      "cadre_lstm_pointwise_bwd")
-            if t > 0 and skinny:   # dh_{t-1} = dG_t W_hh, K = 2120: the K slices meet inside the workgroup (tile 11)
-                hip.gemm(dG[:, t], pL[a.o_whh:], dH, B, DP, H4, H4, DP, DP, b_mode=1, batch=Z,
-                         a_z=(1, 0, S * B * H4), b_z=(1, 0, sL), c_z=(1, 0, B * DP), seg=sgM1)
-            elif t > 0:            # tile kernels: split-K so that >500 workgroups stream W_hh, then a reduction pass
-                hip.gemm(dG[:, t], pL[a.o_whh:], w["dHs"], B, DP, H4, H4, DP, DP, b_mode=1, batch=Z,
-                         a_z=(1, 0, S * B * H4), b_z=(1, 0, sL), c_z=(1, 0, B * DP), split_k=self.SPLIT_DH, seg=sgM1)
-                hip.check(L.cadre_splitk_reduce(hip.ptr(w["dHs"]), self.SPLIT_DH, Z * B * DP, DP, hip.ptr(dH), DP,
-                                                Z * B, DP, None, None, 0, 0.0, None if seg is None else hip.ptr(seg), B, st),
-                          "cadre_splitk_reduce")
-        # dW_hh = sum_t dG_t^T h_{t-1} ; dW_ih = sum_t dG_t^T x_t ; db_ih = db_hh = colsum(dG)
-        hip.gemm(dG, Hs, gL[a.o_whh:], H4, DP, S * B, H4, DP, DP, a_mode=1, b_mode=1, batch=Z,
-                 a_z=(1, 0, S * B * H4), b_z=(1, 0, (S + 1) * B * DP), c_z=(1, 0, sL), seg=sgK1)
-        hip.gemm(dG, X, gL[a.o_wih:], H4, DP, S * B, H4, DP, DP, a_mode=1, b_mode=1, batch=Z,
-                 a_z=(1, 0, S * B * H4), b_z=(C, 0, S * B * DP), c_z=(1, 0, sL), seg=sgK1)
-        # b_ih and b_hh enter the gates as a sum: identical gradients, written by one pass
-        hip.check(L.cadre_colsum2(hip.ptr(dG), H4, S * B * H4, hip.ptr(gL[a.o_bih:]), hip.ptr(gL[a.o_bhh:]), sL, S * B, H4, Z,
-                                  None if seg is None else hip.ptr(seg), B, st),
-                  "cadre_colsum2")
+        H4P = a.H4P
+        sgp = None if seg is None else hip.ptr(seg)
+        # transposed recurrent weights [k][n] for dh = dG W_hh (the reduction index must be the contiguous one)
+        WT = self._wt
+        if WT is None:
+            WT = self._wt = torch.zeros(Z, DP, H4P, device=a.device)
+        hip.check(L.cadre_transpose_batched(hip.ptr(pL[a.o_whh:]), DP, sL, hip.ptr(WT), H4P, DP * H4P, H4, DP, Z, st),
+                  "cadre_transpose_batched")
+        for t in range(S, 0, -1):
+            # t == S: dh_{S-1} = dH (MLP towers), no product; else dh_{t-1} = dG_t W_hh.  Then the cell backward of step
+            # t-1 in the same launch: dG_{t-1}, dc_{t-2}
+            src = None if t == S else hip.ptr(dG[:, t])
+            hip.check(L.cadre_lstm_step_bwd(hip.ptr(WT), DP * H4P, H4P, src, hip.ptr(dG[:, t - 1]), hip.ptr(G[:, t - 1]), H4P,
+                                            S * B * H4P, hip.ptr(dH) if t == S else None, hip.ptr(dC), B * DP,
+                                            hip.ptr(TC[:, t]), hip.ptr(Cs[:, t - 1]), DP, (S + 1) * B * DP, B, a.D, Z, cmd, C,
+                                            sgp, t & 1, st), "cadre_lstm_step_bwd")
+        # dW_hh = sum_t dG_t^T h_{t-1} ; dW_ih = sum_t dG_t^T x_t ; db_ih = db_hh = colsum(dG): one launch for all nets
+        hip.check(L.cadre_lstm_dw(hip.ptr(dG), H4P, S * B * H4P, hip.ptr(Hs), hip.ptr(X), DP, (S + 1) * B * DP, S * B * DP, C,
+                                  hip.ptr(gL[a.o_whh:]), hip.ptr(gL[a.o_wih:]), hip.ptr(gL[a.o_bih:]), hip.ptr(gL[a.o_bhh:]),
+                                  DP, sL, B, S, H4, DP, Z, sgp, st), "cadre_lstm_dw")
         return w["losses"]
 
     # ------------------------------------------------------------------ optimiser (chief.py:13-21)

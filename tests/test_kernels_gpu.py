@@ -295,6 +295,177 @@ def test_lstm_pointwise_fwd_bwd(hip):
     assert rel(dcd[:, :, :Hd], want_dcprev.detach()) < 1e-5
 
 
+def _lstm_step_case(Z, B, seed, sorted_rows):
+    """Operands of one fused LSTM step (ppo_update.hip) in the update workspace's layout: hidden 530 padded to 544,
+    gate rows [i f g o] x 530 at pitch 2176, optional row segments (one run of rows per net of a head)."""
+    g = torch.Generator().manual_seed(seed)
+    D, DP, H4, H4P = 530, 544, 2120, 2176
+    W = torch.zeros(Z, H4, DP); W[:, :, :D] = torch.randn(Z, H4, D, generator=g) * 0.04
+    b = torch.randn(Z, H4, generator=g) * 0.1
+    Gx = torch.randn(Z, B, H4, generator=g) * 0.5
+    hp = torch.zeros(Z, B, DP); hp[:, :, :D] = torch.randn(Z, B, D, generator=g) * 0.5
+    cp = torch.zeros(Z, B, DP); cp[:, :, :D] = torch.randn(Z, B, D, generator=g)
+    seg = None
+    if sorted_rows:
+        cuts = sorted(torch.randint(0, B + 1, (3,), generator=g).tolist())
+        run = [(0, cuts[0]), (cuts[0], cuts[1] - cuts[0]), (cuts[1], cuts[2] - cuts[1]), (cuts[2], B - cuts[2])]
+        seg = torch.tensor((run + run)[:Z], dtype=torch.int32)
+    return D, DP, H4, H4P, W, b, Gx, hp, cp, seg
+
+
+@pytest.mark.parametrize("Z,B,sorted_rows", [(8, 64, True), (8, 256, True), (8, 24, False), (2, 1, False), (8, 96, True)])
+def test_lstm_step_fwd_fused(hip, Z, B, sorted_rows):
+    """cadre_lstm_step_fwd: gates = x-projection + h W_hh^T + b_hh, nn.LSTMCell cell math (models.py:139-152), in one
+    launch, against float64 torch; rows outside a net's 32-row tiles untouched, padding columns never written."""
+    D, DP, H4, H4P, W, b, Gx, hp, cp, seg = _lstm_step_case(Z, B, 100 + B, sorted_rows)
+    pre = Gx.double() + torch.bmm(hp[:, :, :D].double(), W[:, :, :D].double().transpose(1, 2)) + b.double()[:, None]
+    i, f, gg, o = pre.chunk(4, -1)
+    c = torch.sigmoid(f) * cp[:, :, :D].double() + torch.sigmoid(i) * torch.tanh(gg)
+    h = torch.sigmoid(o) * torch.tanh(c)
+    act = torch.cat([torch.sigmoid(i), torch.sigmoid(f), torch.tanh(gg), torch.sigmoid(o)], -1)
+    # arena-like strides: W and bias of net z at z * w_str inside one buffer
+    w_str = H4 * DP + H4
+    buf = torch.zeros(Z * w_str)
+    for z in range(Z):
+        buf[z * w_str: z * w_str + H4 * DP] = W[z].reshape(-1)
+        buf[z * w_str + H4 * DP: (z + 1) * w_str] = b[z]
+    bufd = dev(buf)
+    Gd = torch.full((Z, B, H4P), 7.0, device="cuda"); Gd[:, :, :H4] = Gx.cuda()
+    hpd, cpd = dev(hp), dev(cp)
+    ho = torch.full((Z, B, DP), 7.0, device="cuda"); co = torch.full_like(ho, 7.0); tco = torch.full_like(ho, 7.0)
+    segd = None if seg is None else dev(seg)
+    L = hip.lib()
+    hip.check(L.cadre_lstm_step_fwd(bufd.data_ptr(), w_str, DP, bufd.data_ptr() + 4 * H4 * DP, Gd.data_ptr(), H4P, B * H4P,
+                                    hpd.data_ptr(), cpd.data_ptr(), ho.data_ptr(), co.data_ptr(), tco.data_ptr(), DP, B * DP,
+                                    B, D, Z, None if segd is None else segd.data_ptr(), B & 1, hip.stream()), "cadre_lstm_step_fwd")
+    torch.cuda.synchronize()
+    worst = 0.0
+    for z in range(Z):
+        lo, hi = (0, B) if seg is None else (int(seg[z, 0]) & ~31, min(B, (int(seg[z, 0]) + int(seg[z, 1]) + 31) & ~31) if int(seg[z, 1]) else int(seg[z, 0]) & ~31)
+        if hi > lo:
+            worst = max(worst, rel(ho[z, lo:hi, :D], h[z, lo:hi]), rel(co[z, lo:hi, :D], c[z, lo:hi]),
+                        rel(tco[z, lo:hi, :D], torch.tanh(c[z, lo:hi])), rel(Gd[z, lo:hi, :H4], act[z, lo:hi]))
+        rows_out = torch.ones(B, dtype=torch.bool); rows_out[lo:hi] = False
+        assert bool((ho[z][rows_out.cuda()] == 7.0).all()) and bool((Gd[z][rows_out.cuda()][:, :H4] == Gx[z][rows_out].cuda()).all())
+        assert bool((ho[z, :, D:] == 7.0).all()) and bool((Gd[z, :, H4:] == 7.0).all())        # padding never written
+    print("lstm_step_fwd Z=%d B=%d sorted=%s: rel-max-err %.2e" % (Z, B, sorted_rows, worst))
+    assert worst < 1e-5
+
+
+@pytest.mark.parametrize("Z,B,sorted_rows", [(8, 64, True), (8, 256, True), (8, 24, False), (8, 96, True)])
+def test_lstm_step_bwd_fused(hip, Z, B, sorted_rows):
+    """cadre_lstm_step_bwd: dh_{t-1} = dG_t W_hh (+ dh_in) on the transposed weights, then the cell backward of step t-1
+    in the same launch — against the autograd of the cell; ownership mask (rows of other command nets: exact zeros);
+    the product-free first step; cadre_transpose_batched."""
+    D, DP, H4, H4P, W, b, Gx, hp, cp, seg = _lstm_step_case(Z, B, 300 + B, sorted_rows)
+    g = torch.Generator().manual_seed(B)
+    C = 4
+    L = hip.lib()
+    # transposed weights through the kernel under test
+    Wd = dev(W)
+    WT = torch.zeros(Z, DP, H4P, device="cuda")
+    hip.check(L.cadre_transpose_batched(Wd.data_ptr(), DP, H4 * DP, WT.data_ptr(), H4P, DP * H4P, H4, DP, Z, hip.stream()), "tr")
+    assert torch.equal(WT[:, :, :H4], Wd.transpose(1, 2)) and float(WT[:, :, H4:].abs().max()) == 0.0
+    # cell of step t-1 (activated gates, tanh c, c_prev) and incoming gradients
+    pre = torch.randn(Z, B, H4, generator=g)
+    i, f, gg, o = pre.chunk(4, -1)
+    act = torch.cat([torch.sigmoid(i), torch.sigmoid(f), torch.tanh(gg), torch.sigmoid(o)], -1)
+    cprev = torch.randn(Z, B, D, generator=g)
+    cn = torch.sigmoid(f) * cprev + torch.sigmoid(i) * torch.tanh(gg)
+    dG_t = torch.randn(Z, B, H4, generator=g) * 0.3
+    dh_up = torch.randn(Z, B, D, generator=g) * 0.3
+    dc_in = torch.randn(Z, B, D, generator=g) * 0.3
+    cmds = torch.randint(0, C, (2, B), generator=g, dtype=torch.int32)
+    if seg is not None:                                   # rows sorted by command: consistent with the runs
+        for hd in range(2):
+            for c in range(C):
+                b0, n = int(seg[hd * C + c, 0]), int(seg[hd * C + c, 1])
+                cmds[hd, b0:b0 + n] = c
+    pad = lambda t, w: torch.cat([t, torch.zeros(*t.shape[:-1], w - t.shape[-1])], -1)
+    for with_product in (True, False):
+        dh = (torch.bmm(dG_t.double(), W[:, :, :D].double()) if with_product else 0) + dh_up.double()
+        tc = torch.tanh(cn.double())
+        si, sf, tg, so = (t.double() for t in act.chunk(4, -1))
+        dct = dc_in.double() + dh * so * (1 - tc * tc)
+        want = torch.cat([dct * tg * si * (1 - si), dct * cprev.double() * sf * (1 - sf), dct * si * (1 - tg * tg),
+                          dh * tc * so * (1 - so)], -1)
+        want_dc = dct * sf
+        own = torch.stack([cmds[z // C] == z % C for z in range(Z)])          # [Z][B]
+        want = want * own[:, :, None]; want_dc = want_dc * own[:, :, None]
+        dGt_d = dev(pad(dG_t, H4P)); act_d = dev(pad(act, H4P))
+        dGo = torch.full((Z, B, H4P), 7.0, device="cuda")
+        dCd = dev(pad(dc_in, DP)); dhd = dev(pad(dh_up, DP))
+        tcd = dev(pad(torch.tanh(cn), DP)); cpd = dev(pad(cprev, DP))
+        segd = None if seg is None else dev(seg)
+        cm = dev(cmds)
+        hip.check(L.cadre_lstm_step_bwd(WT.data_ptr(), DP * H4P, H4P, dGt_d.data_ptr() if with_product else None, dGo.data_ptr(),
+                                        act_d.data_ptr(), H4P, B * H4P, dhd.data_ptr(), dCd.data_ptr(), B * DP, tcd.data_ptr(),
+                                        cpd.data_ptr(), DP, B * DP, B, D, Z, cm.data_ptr(), C,
+                                        None if segd is None else segd.data_ptr(), int(with_product), hip.stream()), "cadre_lstm_step_bwd")
+        torch.cuda.synchronize()
+        worst = 0.0
+        for z in range(Z):
+            lo, hi = (0, B) if seg is None else (int(seg[z, 0]) & ~31, min(B, (int(seg[z, 0]) + int(seg[z, 1]) + 31) & ~31) if int(seg[z, 1]) else int(seg[z, 0]) & ~31)
+            if hi > lo:
+                scale = float(want[z].abs().max()) or 1.0
+                worst = max(worst, float((dGo[z, lo:hi, :H4].double().cpu() - want[z, lo:hi]).abs().max()) / scale,
+                            float((dCd[z, lo:hi, :D].double().cpu() - want_dc[z, lo:hi]).abs().max()) / max(float(want_dc[z].abs().max()), 1e-30))
+                foreign = ~own[z, lo:hi]
+                if bool(foreign.any()):
+                    assert float(dGo[z, lo:hi, :H4][foreign.cuda()].abs().max()) == 0.0          # exact zeros
+            rows_out = torch.ones(B, dtype=torch.bool); rows_out[lo:hi] = False
+            assert bool((dGo[z][rows_out.cuda()] == 7.0).all())
+            assert bool((dGo[z, :, H4:] == 7.0).all())
+        print("lstm_step_bwd Z=%d B=%d sorted=%s product=%s: rel-max-err %.2e" % (Z, B, sorted_rows, with_product, worst))
+        assert worst < 2e-5
+
+
+@pytest.mark.parametrize("B,sorted_rows", [(64, True), (256, True), (24, False), (6, False), (96, True)])
+def test_lstm_dw_fused(hip, B, sorted_rows):
+    """cadre_lstm_dw: dW_hh = sum_t dG_t^T h_{t-1}, dW_ih = sum_t dG_t^T x_t, db = column sums of dG for 8 nets in one
+    launch (autograd of models.py:139-152) against float64; only a net's run of rows is multiplied (the others hold the
+    exact zeros the backward writes); padding columns of the gradient rows come out zero; bit-identical on repeat."""
+    g = torch.Generator().manual_seed(900 + B)
+    Z, S, C, D, DP, H4, H4P = 8, 8, 4, 530, 544, 2120, 2176
+    seg = None
+    own = torch.ones(Z, B, dtype=torch.bool)
+    if sorted_rows:
+        cuts = sorted(torch.randint(0, B + 1, (3,), generator=g).tolist())
+        run = [(0, cuts[0]), (cuts[0], cuts[1] - cuts[0]), (cuts[1], cuts[2] - cuts[1]), (cuts[2], B - cuts[2])]
+        seg = torch.tensor(run + run, dtype=torch.int32)
+        own = torch.zeros(Z, B, dtype=torch.bool)
+        for z in range(Z):
+            own[z, int(seg[z, 0]):int(seg[z, 0]) + int(seg[z, 1])] = True
+    dG = torch.zeros(Z, S, B, H4P); dG[..., :H4] = torch.randn(Z, S, B, H4, generator=g) * own[:, None, :, None]
+    Hs = torch.zeros(Z, S + 1, B, DP); Hs[..., :D] = torch.randn(Z, S + 1, B, D, generator=g)
+    X = torch.zeros(2, S, B, DP); X[..., :D] = torch.randn(2, S, B, D, generator=g)
+    want_hh = torch.einsum("zsbm,zsbn->zmn", dG[..., :H4].double(), Hs[:, :S].double())
+    want_ih = torch.einsum("zsbm,zsbn->zmn", dG[..., :H4].double(), X[torch.arange(Z) // C].double())
+    want_b = dG[..., :H4].double().sum((1, 2))
+    sL = 2 * H4 * DP + 2 * H4
+    grads = torch.full((Z * sL,), 7.0, device="cuda")
+    dGd, Hsd, Xd = dev(dG), dev(Hs), dev(X)
+    segd = None if seg is None else dev(seg)
+    L = hip.lib()
+
+    def run():
+        hip.check(L.cadre_lstm_dw(dGd.data_ptr(), H4P, S * B * H4P, Hsd.data_ptr(), Xd.data_ptr(), DP, (S + 1) * B * DP,
+                                  S * B * DP, C, grads.data_ptr() + 4 * H4 * DP, grads.data_ptr(), grads.data_ptr() + 4 * 2 * H4 * DP,
+                                  grads.data_ptr() + 4 * (2 * H4 * DP + H4), DP, sL, B, S, H4, DP, Z,
+                                  None if segd is None else segd.data_ptr(), hip.stream()), "cadre_lstm_dw")
+        torch.cuda.synchronize()
+        return grads.clone()
+    out = run().view(Z, sL)
+    ih = out[:, :H4 * DP].view(Z, H4, DP); hh = out[:, H4 * DP:2 * H4 * DP].view(Z, H4, DP)
+    b_ih = out[:, 2 * H4 * DP:2 * H4 * DP + H4]; b_hh = out[:, 2 * H4 * DP + H4:]
+    e = (rel(hh, want_hh), rel(ih, want_ih), rel(b_ih, want_b))
+    print("lstm_dw B=%d sorted=%s: rel-max-err dWhh %.2e dWih %.2e db %.2e" % ((B, sorted_rows) + e))
+    assert max(e) < 2e-5
+    assert torch.equal(b_ih, b_hh)
+    assert float(hh[:, :, D:].abs().max()) == 0.0 and float(ih[:, :, D:].abs().max()) == 0.0
+    assert torch.equal(run(), out.view(-1))
+
+
 def test_lstm_pointwise_and_colsum2_row_segments(hip):
     """Rows sorted by command: the pointwise LSTM passes and the bias-gradient column sum touch only the 32-row tiles
     that intersect each net's run of rows — same values there as the unrestricted kernels, bit for bit; rows outside
@@ -369,7 +540,7 @@ def test_colsum_relu_bwd(hip):
 
 
 # ----------------------------------------------------------------------------- PPO loss
-@pytest.mark.parametrize("B,scale", [(16, 1.0), (64, 4.0)])
+@pytest.mark.parametrize("B,scale", [(16, 1.0), (64, 4.0), (200, 1.0), (7, 2.0)])
 def test_ppo_loss_fwd_bwd(hip, B, scale):
     """vs autograd through the oracle formulas (agent.py:166-229); `scale` widens ratios so
     both clip branches and both value branches are exercised."""
@@ -408,13 +579,24 @@ def test_ppo_loss_fwd_bwd(hip, B, scale):
     total.backward()
     losses = torch.zeros(3, device="cuda"); dl = torch.full((8, B, ldl), 9.0, device="cuda")
     dv = torch.full((8, B), 9.0, device="cuda")
+    scratch = torch.full((4 + 6 * ((B + 15) // 16),), 3.0, device="cuda")     # counter zeroed by the call itself
     d_ = [dev(t) for t in (logits, values, actions, cmds, old_v, rets, old_lp, adv)]
     hip.check(hip.lib().cadre_ppo_loss(d_[0].data_ptr(), ldl, B * ldl, d_[1].data_ptr(), 1, B, d_[2].data_ptr(),
                                        d_[3].data_ptr(), d_[4].data_ptr(), d_[5].data_ptr(),
                                        d_[6].data_ptr(), d_[7].data_ptr(), B, nS, nT, clip, vc, cc, ec,
-                                       1.0 / B, losses.data_ptr(), dl.data_ptr(), dv.data_ptr(), hip.stream()), "loss")
+                                       1.0 / B, losses.data_ptr(), dl.data_ptr(), dv.data_ptr(), scratch.data_ptr(),
+                                       hip.stream()), "loss")
     want = torch.tensor([float(tot_v * vc), float(tot_a * cc), float(tot_e * ec)])
     assert rel(losses, want) < 1e-5
+    # the loss sums are combined in a fixed order (last-arriving workgroup): bit-identical over repeated launches
+    first = losses.clone()
+    for _ in range(5):
+        hip.check(hip.lib().cadre_ppo_loss(d_[0].data_ptr(), ldl, B * ldl, d_[1].data_ptr(), 1, B, d_[2].data_ptr(),
+                                           d_[3].data_ptr(), d_[4].data_ptr(), d_[5].data_ptr(),
+                                           d_[6].data_ptr(), d_[7].data_ptr(), B, nS, nT, clip, vc, cc, ec,
+                                           1.0 / B, losses.data_ptr(), dl.data_ptr(), dv.data_ptr(), scratch.data_ptr(),
+                                           hip.stream()), "loss")
+        assert torch.equal(losses, first)
     assert rel(dv, vv.grad) < 1e-5
     assert rel(dl, lg.grad) < 2e-5
 
@@ -506,7 +688,7 @@ def test_conv_bf16(hip, Cin, Cout, H, W, k, s, p, tile):
     assert rel(out.permute(0, 3, 1, 2), want) < 2e-5
 
 
-@pytest.mark.parametrize("tile", [3, 10, 12])
+@pytest.mark.parametrize("tile", [3, 10, ab(12)])
 def test_bf16_padded_stem(hip, tile):
     """cadre_gemm_bf16 a_mode 4: 7x7/s2 stem on the zero-padded bf16 NHWC4 image (encoder C3 path), every tile
     that serves N = 64 incl. the streamed kernel (several M-tiles per workgroup)."""
@@ -581,7 +763,7 @@ def test_sort_rows_and_permute(hip):
 
 @pytest.mark.parametrize("P,tile,BM,segs", [(128, 3, 64, [[0, 40], [40, 0], [40, 70], [110, 18]]),
                                             (128, 9, 32, [[0, 40], [40, 0], [40, 70], [110, 18]]),
-                                            (128, 11, 32, [[0, 40], [40, 0], [40, 70], [110, 18]]),
+                                            ab(128, 11, 32, [[0, 40], [40, 0], [40, 70], [110, 18]]),
                                             (96, 0, 32, [[0, 10], [10, 30], [40, 0], [40, 56]]),     # 32-row periods: auto -> tile 9
                                             (64, 0, 32, [[0, 16], [16, 16], [32, 31], [63, 1]])])
 def test_gemm_row_segments(hip, P, tile, BM, segs):

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Timing of the fused LSTM step kernels (ppo_update.hip) alone, in the update's layout: 8 nets, rows sorted by command
+(B = 64: ~16 rows per net, B = 256: ~64), 20 launches back to back per kernel (HIP events on the launch stream)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cadre_amd import hip  # noqa: E402
+
+
+def timeit(fn, reps=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+def main():
+    L = hip.lib()
+    Z, S, C, D, DP, H4, H4P = 8, 8, 4, 530, 544, 2120, 2176
+    g = torch.Generator(device="cuda").manual_seed(1)
+    sL = 2 * H4 * DP + 2 * H4
+    params = torch.randn(Z * sL, device="cuda", generator=g) * 0.04
+    grads = torch.zeros(Z * sL, device="cuda")
+    WT = torch.zeros(Z, DP, H4P, device="cuda")
+    st = hip.stream()
+    for B in (64, 256):
+        per = B // 4
+        seg = torch.tensor([[c * per, per] for c in range(4)] * 2, dtype=torch.int32, device="cuda")
+        cmds = torch.arange(B, device="cuda", dtype=torch.int32).div(per, rounding_mode="floor").repeat(2, 1).contiguous()
+        G = torch.randn(Z, S, B, H4P, device="cuda", generator=g) * 0.3
+        dG = torch.randn(Z, S, B, H4P, device="cuda", generator=g) * 0.3
+        Hs = torch.randn(Z, S + 1, B, DP, device="cuda", generator=g) * 0.3
+        Cs = torch.randn(Z, S + 1, B, DP, device="cuda", generator=g) * 0.3
+        TC = torch.tanh(Cs)
+        X = torch.randn(2, S, B, DP, device="cuda", generator=g)
+        dC = torch.zeros(Z, B, DP, device="cuda")
+        t = [0]
+
+        def fwd():
+            k = t[0] % S; t[0] += 1
+            hip.check(L.cadre_lstm_step_fwd(params.data_ptr() + 4 * H4 * DP, sL, DP, params.data_ptr() + 4 * (2 * H4 * DP + H4),
+                                            G[:, k].data_ptr(), H4P, S * B * H4P, Hs[:, k].data_ptr(), Cs[:, k].data_ptr(),
+                                            Hs[:, k + 1].data_ptr(), Cs[:, k + 1].data_ptr(), TC[:, k + 1].data_ptr(), DP,
+                                            (S + 1) * B * DP, B, D, Z, seg.data_ptr(), k & 1, st), "f")
+
+        def bwd():
+            k = 1 + t[0] % (S - 1); t[0] += 1
+            hip.check(L.cadre_lstm_step_bwd(WT.data_ptr(), DP * H4P, H4P, dG[:, k].data_ptr(), dG[:, k - 1].data_ptr(),
+                                            G[:, k - 1].data_ptr(), H4P, S * B * H4P, None, dC.data_ptr(), B * DP, TC[:, k].data_ptr(),
+                                            Cs[:, k - 1].data_ptr(), DP, (S + 1) * B * DP, B, D, Z, cmds.data_ptr(), C,
+                                            seg.data_ptr(), k & 1, st), "b")
+
+        def dw():
+            hip.check(L.cadre_lstm_dw(dG.data_ptr(), H4P, S * B * H4P, Hs.data_ptr(), X.data_ptr(), DP, (S + 1) * B * DP, S * B * DP,
+                                      C, grads.data_ptr() + 4 * H4 * DP, grads.data_ptr(), grads.data_ptr() + 4 * 2 * H4 * DP,
+                                      grads.data_ptr() + 4 * (2 * H4 * DP + H4), DP, sL, B, S, H4, DP, Z, seg.data_ptr(), st), "d")
+
+        def tr():
+            hip.check(L.cadre_transpose_batched(params.data_ptr() + 4 * H4 * DP, DP, sL, WT.data_ptr(), H4P, DP * H4P, H4, DP, Z, st), "t")
+        tr()
+        print("B=%d: lstm_step_fwd %.1f us, lstm_step_bwd %.1f us, lstm_dw %.1f us, transpose %.1f us" % (
+            B, timeit(fwd), timeit(bwd), timeit(dw, 10), timeit(tr, 10)), flush=True)
+
+
+if __name__ == "__main__":
+    main()
