@@ -8,17 +8,20 @@
 //
 //   * v_mfma_f32_16x16x4_f32: 16 rows x 16 columns x 4 k per instruction at 32 cycles — for <= 16-row tiles twice the
 //     useful rate of the 32x32x2 form, and a K = 544 chain is 136 instructions;
-//   * the weights go from L2 / Infinity Cache STRAIGHT into MFMA fragments: lane (c = lane & 15, q = lane >> 4) loads
-//     16 bytes = k 16j + 4q .. +3 of column c, i.e. the operand of the four MFMAs of k-block j — the k order inside a
-//     block is permuted identically on A and B, so the products pair correctly.  A weight is used by exactly one wave
-//     (nothing to share through LDS); what bounds a step is how many weight bytes a CU keeps in flight (about 33 GB/s
-//     per CU from the Infinity Cache at 72 KiB in flight), so half of a wave's K is requested before its first MFMA;
+//   * the weights go from L2 / Infinity Cache STRAIGHT into MFMA fragments: lane (c = lane & 15, q = lane >> 4) holds
+//     k 16j + 4q .. +3 of column c = the operand of the four MFMAs of k-block j (the k order inside a block is permuted
+//     identically on A and B, so the products pair correctly).  A weight is used by exactly one wave — nothing to share
+//     through LDS.  Read from the row-major matrices such a fragment is 16 rows x 64 bytes per wave instruction, and the
+//     texture addresser serves scattered 64-byte pieces at a quarter of its streaming rate (measured: 76 % of the wave
+//     cycles stalled on instruction issue, 20 GB/s per CU) — so once per update cadre_pack_lstm_weights lays the
+//     recurrent weights out in FRAGMENT ORDER for both directions (the backward needs the transpose anyway: its
+//     reduction index is the gate axis): every weight load is then one contiguous KiB;
 //   * forward: workgroup = (net, 16 hidden units, chunk of 16*RT rows), wave g = gate g (i, f, g, o) of those units over
 //     the full K; the four gate tiles meet in LDS and the workgroup finishes c_t, h_t, tanh(c_t) and the activated gates;
-//   * backward: workgroup = (net, 16 hidden units, chunk of rows), wave w = quarter w of K = 4 x 530 gate columns of
-//     dG_t against the TRANSPOSED recurrent weights (cadre_transpose_batched keeps a [k][n] copy per update: the
-//     reduction index must be the contiguous one); the four partial tiles meet in LDS = dh_{t-1}, and the same
-//     workgroup turns it into dG_{t-1} and dc_{t-2} — no split-K slabs, no reduction pass, no pointwise pass.
+//   * backward: workgroup = (net, 16 hidden units, chunk of rows), wave w = quarter w of the (zero padded) gate axis of
+//     dG_t; the four partial tiles meet in LDS = dh_{t-1}, and the same workgroup turns it into dG_{t-1} and dc_{t-2} —
+//     no split-K slabs, no reduction pass, no pointwise pass.  dG_{t-1} is written twice: row-major (the weight-gradient
+//     kernel reads whole rows) and in fragment order for the next step's A operand (contiguous KiB loads again).
 //
 // Rows sorted by command (row_seg): a net touches the 32-row tiles that intersect its run of rows — the rows the
 // segment-aware GEMMs (cadre_gemm_t.seg_mode) read and write; rows of other nets inside those tiles are computed forward
@@ -40,8 +43,8 @@ namespace {
 __device__ __forceinline__ float sigmoid_(float x) { return 1.f / (1.f + expf(-x)); }
 
 struct fwd_args {
-  const float* W;       // recurrent weights [H4][ldw] of net 0 (k contiguous), net stride w_str
-  const float* bias;    // [H4] of net 0, net stride w_str (may be null)
+  const float* Wp;      // recurrent weights in fragment order (cadre_pack_lstm_weights), net stride wp_str
+  const float* bias;    // [H4] of net 0, net stride b_str (may be null)
   float* G;             // this step's gates [B][ldg] of net 0, net stride g_str: in = x-projection, out = activated gates
   const float* Hprev;   // h_{t-1} [B][ldh], net stride h_str
   const float* Cprev;   // c_{t-1}
@@ -49,8 +52,8 @@ struct fwd_args {
   float* Cout;          // c_t
   float* TCout;         // tanh(c_t)
   const int32_t* row_seg;
-  int64_t w_str, g_str, h_str;
-  int ldw, ldg, ldh, B, D, Z, NS, rev;
+  int64_t wp_str, b_str, g_str, h_str;
+  int ldg, ldh, B, D, Z, NS, rev;
 };
 
 // Work item = (net, 16 hidden units, chunk of 16*RT rows), from a 1-D grid with the NET as the fastest index: workgroups
@@ -92,11 +95,12 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(fwd_args p) {
   int z, slice, row0, r_hi;
   if (!step_item(p.Z, p.NS, p.rev, p.row_seg, p.B, ROWS, z, slice, row0, r_hi)) return;
   const int D = p.D, u = slice * 16 + c;
-  const int uc = u < D ? u : D - 1;                       // units past D: a valid row of W, result discarded
-  const float* wp = p.W + (int64_t)z * p.w_str + (int64_t)(g * D + uc) * p.ldw + 4 * q;
+  const int uc = u < D ? u : D - 1;                       // units past D: zero weights, result discarded
+  // fragment order: [slice][gate][k-block][lane][4] — one contiguous KiB per wave and k-block
+  const float* wp = p.Wp + (int64_t)z * p.wp_str + ((int64_t)(slice * 4 + g) * NB * 64 + lane) * 4;
   f32x4 bq[PD];
 #pragma unroll
-  for (int j = 0; j < PD; ++j) bq[j] = *reinterpret_cast<const f32x4*>(wp + 16 * j);
+  for (int j = 0; j < PD; ++j) bq[j] = *reinterpret_cast<const f32x4*>(wp + 256 * j);
   // activation rows -> LDS (every thread 16-byte chunks, coalesced along the rows; rows past the chunk repeat the last)
   const float* hp = p.Hprev + (int64_t)z * p.h_str;
   f32x4 st[NLD];
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(fwd_args p) {
   // accumulators start from the x-projection (+ b_ih, folded there) and b_hh: D[row = 4q + r][col = c]
   // (loaded unconditionally from clamped addresses: a load under a per-element condition is a branch + vmcnt(0) each)
   float* gz = p.G + (int64_t)z * p.g_str;
-  const float bv = p.bias ? p.bias[(int64_t)z * p.w_str + g * D + uc] : 0.f;
+  const float bv = p.bias ? p.bias[(int64_t)z * p.b_str + g * D + uc] : 0.f;
   // (two accumulators per row tile, even / odd k-steps: a single chain of this MFMA is latency- not issue-paced)
   f32x4 acc[RT][2];
 #pragma unroll
@@ -126,7 +130,11 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(fwd_args p) {
   __syncthreads();
   const float* arow = ah + c * AP + 4 * q;
   // (the scheduler sinks loads towards their use to save registers; the order is pinned so that PD blocks of weights
-  //  stay in flight: one wave per SIMD has only its own loads to hide the L2 / Infinity Cache latency)
+  //  stay in flight — one wave per SIMD has only its own loads to hide the L2 / Infinity Cache latency — and the
+  //  activation fragments are read from LDS one k-block ahead of the MFMAs that use them)
+  f32x4 an[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) an[rt] = *reinterpret_cast<const f32x4*>(arow + 16 * rt * AP);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
@@ -134,8 +142,12 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(fwd_args p) {
     const f32x4 b = bq[s];
     f32x4 a[RT];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) a[rt] = *reinterpret_cast<const f32x4*>(arow + 16 * rt * AP + 16 * j);
-    if (j + PD < NB) bq[s] = *reinterpret_cast<const f32x4*>(wp + 16 * (j + PD));
+    for (int rt = 0; rt < RT; ++rt) a[rt] = an[rt];
+    if (j + 1 < NB) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) an[rt] = *reinterpret_cast<const f32x4*>(arow + 16 * rt * AP + 16 * (j + 1));
+    }
+    if (j + PD < NB) bq[s] = *reinterpret_cast<const f32x4*>(wp + 256 * (j + PD));
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -172,9 +184,10 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(fwd_args p) {
 }
 
 struct bwd_args {
-  const float* WT;      // transposed recurrent weights [ldh rows k][ldt] (n contiguous, zero padded to NB*64), net stride wt_str
-  const float* dG_in;   // dG_t [B][ldg] of net 0 (null: no product, dh = dh_in only), net stride g_str
-  float* dG_out;        // dG_{t-1}
+  const float* Wp;      // transposed recurrent weights in fragment order (cadre_pack_lstm_weights), net stride wp_str
+  const float* dGp_in;  // dG_t in fragment order (null: no product, dh = dh_in only), net stride gp_str
+  float* dGp_out;       // dG_{t-1} in fragment order: [16-row tile][k-block][lane][4], for the next step
+  float* dG_out;        // dG_{t-1} row-major [B][ldg] of net 0, net stride g_str
   const float* G_act;   // activated gates of step t-1
   const float* dh_in;   // upstream dL/dh_{t-1} [B][ldh] added to the product (may be null), net stride d_str
   float* dC;            // in: dL/dc_{t-1}; out: dL/dc_{t-2}; [B][ldh], net stride d_str
@@ -182,8 +195,8 @@ struct bwd_args {
   const float* Cprev;   // c_{t-2}
   const int32_t* commands;   // [2][B] (null: no ownership mask)
   const int32_t* row_seg;
-  int64_t wt_str, g_str, h_str, d_str;
-  int ldt, ldg, ldh, B, D, C, Z, NS, rev;
+  int64_t wp_str, gp_str, g_str, h_str, d_str;
+  int ldg, ldh, B, D, C, Z, NS, rev;
 };
 
 // wave w multiplies k-blocks [w*NB, (w+1)*NB) of the 4*NB blocks of the (zero padded) gate axis
@@ -198,13 +211,12 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(bwd_args p) {
   if (!step_item(p.Z, p.NS, p.rev, p.row_seg, p.B, ROWS, z, slice, row0, r_hi)) return;
   const int D = p.D;
   if constexpr (GEMM) {
-    const int u = slice * 16 + c;
-    const int uc = u < D ? u : D - 1;
-    const float* wp = p.WT + (int64_t)z * p.wt_str + (int64_t)uc * p.ldt + 16 * NB * w + 4 * q;
-    const float* gp = p.dG_in + (int64_t)z * p.g_str + 16 * NB * w + 4 * q;
+    // fragment order: weights [slice][K quarter][k-block][lane][4], dG_t [16-row tile][k-block of the whole gate axis][lane][4]
+    const float* wp = p.Wp + (int64_t)z * p.wp_str + ((int64_t)(slice * 4 + w) * NB * 64 + lane) * 4;
     const float* ap[RT];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) ap[rt] = gp + (int64_t)min(row0 + 16 * rt + c, r_hi - 1) * p.ldg;
+    for (int rt = 0; rt < RT; ++rt)
+      ap[rt] = p.dGp_in + (int64_t)z * p.gp_str + (((int64_t)(row0 / 16 + rt) * 4 + w) * NB * 64 + lane) * 4;
     // two accumulators per row tile (even / odd k-blocks): a single chain of this MFMA is latency- not issue-paced
     f32x4 acc[RT][2];
 #pragma unroll
@@ -212,9 +224,9 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(bwd_args p) {
     f32x4 bq[PD], aq[PD][RT];
 #pragma unroll
     for (int j = 0; j < PD; ++j) {
-      bq[j] = *reinterpret_cast<const f32x4*>(wp + 16 * j);
+      bq[j] = *reinterpret_cast<const f32x4*>(wp + 256 * j);
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) aq[j][rt] = *reinterpret_cast<const f32x4*>(ap[rt] + 16 * j);
+      for (int rt = 0; rt < RT; ++rt) aq[j][rt] = *reinterpret_cast<const f32x4*>(ap[rt] + 256 * j);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -225,9 +237,9 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(bwd_args p) {
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) a[rt] = aq[s][rt];
       if (j + PD < NB) {
-        bq[s] = *reinterpret_cast<const f32x4*>(wp + 16 * (j + PD));
+        bq[s] = *reinterpret_cast<const f32x4*>(wp + 256 * (j + PD));
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) aq[s][rt] = *reinterpret_cast<const f32x4*>(ap[rt] + 16 * (j + PD));
+        for (int rt = 0; rt < RT; ++rt) aq[s][rt] = *reinterpret_cast<const f32x4*>(ap[rt] + 256 * (j + PD));
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -251,8 +263,15 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(bwd_args p) {
     if (row >= r_hi || un >= D) continue;
     float* dg = p.dG_out + gzo + (int64_t)row * p.ldg + un;
     const int64_t od = dz + (int64_t)row * p.ldh + un;
+    // fragment-order copy: element (row, n) at [(row / 16) * 4*NB + n / 16][((n % 16) / 4) * 16 + row % 16][n % 4]
+    float* dgp = p.dGp_out + (int64_t)z * p.gp_str + ((int64_t)(row >> 4) * 4 * NB * 64 + (row & 15)) * 4;
+    auto put = [&](int gate, float v) {
+      const int n = gate * D + un;
+      dg[gate * D] = v;
+      dgp[(n >> 4) * 256 + ((n >> 2) & 3) * 64 + (n & 3)] = v;
+    };
     if (p.commands && p.commands[(z / p.C) * p.B + row] != z % p.C) {      // row of another command net: exact zeros
-      dg[0] = 0.f; dg[D] = 0.f; dg[2 * D] = 0.f; dg[3 * D] = 0.f;
+      put(0, 0.f); put(1, 0.f); put(2, 0.f); put(3, 0.f);
       p.dC[od] = 0.f;
       continue;
     }
@@ -264,10 +283,10 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(bwd_args p) {
     const float tc = p.TC[o];
     const float dct = p.dC[od] + dht * og * (1.f - tc * tc);
     const float cp = p.Cprev[o];
-    dg[0] = dct * gg * ig * (1.f - ig);
-    dg[D] = dct * cp * fg * (1.f - fg);
-    dg[2 * D] = dct * ig * (1.f - gg * gg);
-    dg[3 * D] = dht * tc * og * (1.f - og);
+    put(0, dct * gg * ig * (1.f - ig));
+    put(1, dct * cp * fg * (1.f - fg));
+    put(2, dct * ig * (1.f - gg * gg));
+    put(3, dht * tc * og * (1.f - og));
     p.dC[od] = dct * fg;
   }
 }
@@ -398,24 +417,29 @@ __global__ __launch_bounds__(256) void lstm_dw_kernel(dw_args p) {
   }
 }
 
-// dst[z][c][r] = src[z][r][c] through a padded 32 x 32 LDS tile (both sides coalesced)
-__global__ __launch_bounds__(256) void transpose_kernel(const float* src, int64_t ld_src, int64_t src_str, float* dst,
-                                                        int64_t ld_dst, int64_t dst_str, int rows, int cols) {
-  __shared__ float t[32][33];
-  const int z = blockIdx.z, r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
-  const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
-  const float* s = src + (int64_t)z * src_str;
-  float* d = dst + (int64_t)z * dst_str;
+// Recurrent weights W [4*D][ldw] (k contiguous) of `Z` nets -> fragment order for both directions, NB = ldw / 16:
+//   fwd[z][slice][gate g][k-block j][lane (q, c)][i] = W[g*D + 16*slice + c][16j + 4q + i]          (0 past unit D)
+//   bwd[z][slice][quarter w][k-block j][lane (q, c)][i] = W[n = 16*(NB*w + j) + 4q + i][16*slice + c]  (0 past 4*D / D)
+// one workgroup per (slice, gate | quarter, net) and direction, one KiB per wave and k-block.
+__global__ __launch_bounds__(256) void pack_lstm_weights_kernel(const float* W, int64_t w_str, int ldw, int D, int NB, float* fwd,
+                                                                float* bwd, int64_t p_str) {
+  const int slice = blockIdx.x, gw = blockIdx.y >> 1, dir = blockIdx.y & 1, z = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
+  const float* w = W + (int64_t)z * w_str;
+  const int u = 16 * slice + c;
+  const int64_t blk = (int64_t)(slice * 4 + gw) * NB;
+  for (int j = wave; j < NB; j += 4) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (dir == 0) {
+      if (u < D) v = *reinterpret_cast<const f32x4*>(w + (int64_t)(gw * D + u) * ldw + 16 * j + 4 * q);
+      *reinterpret_cast<f32x4*>(fwd + (int64_t)z * p_str + ((blk + j) * 64 + lane) * 4) = v;
+    } else {
+      const int n = 16 * (NB * gw + j) + 4 * q;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = r0 + y + 8 * i, cc = c0 + x;
-    t[y + 8 * i][x] = (r < rows && cc < cols) ? s[(int64_t)r * ld_src + cc] : 0.f;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int cc = c0 + y + 8 * i, r = r0 + x;
-    if (cc < cols && r < rows) d[(int64_t)cc * ld_dst + r] = t[x][y + 8 * i];
+      for (int i = 0; i < 4; ++i)
+        if (n + i < 4 * D && u < D) v[i] = w[(int64_t)(n + i) * ldw + u];
+      *reinterpret_cast<f32x4*>(bwd + (int64_t)z * p_str + ((blk + j) * 64 + lane) * 4) = v;
+    }
   }
 }
 
@@ -427,40 +451,39 @@ int rt_for(int B) {
 
 }  // namespace
 
-extern "C" int cadre_lstm_step_fwd(const float* W, int64_t w_str, int32_t ldw, const float* bias, float* G, int32_t ldg,
+extern "C" int cadre_lstm_step_fwd(const float* Wp, int64_t wp_str, const float* bias, int64_t b_str, float* G, int32_t ldg,
                                    int64_t g_str, const float* Hprev, const float* Cprev, float* Hout, float* Cout,
                                    float* TCout, int32_t ldh, int64_t h_str, int32_t B, int32_t D, int32_t Z,
                                    const int32_t* row_seg, int32_t rev, void* stream) {
-  FAIL_IF(!W || !G || !Hprev || !Cprev || !Hout || !Cout || !TCout || B < 1 || D < 1 || Z < 1, "cadre_lstm_step_fwd: bad argument");
-  FAIL_IF(ldh != 544 || ldw != ldh || D > ldh || ldg < 4 * D, "cadre_lstm_step_fwd: built for K = ldh = ldw = 544 (hidden 530 zero padded), ldg >= 4*D");
-  FAIL_IF((((uintptr_t)W | (uintptr_t)Hprev) & 15) || (w_str & 3) || (h_str & 3), "cadre_lstm_step_fwd: operands must be 16-byte aligned");
+  FAIL_IF(!Wp || !G || !Hprev || !Cprev || !Hout || !Cout || !TCout || B < 1 || D < 1 || Z < 1, "cadre_lstm_step_fwd: bad argument");
+  FAIL_IF(ldh != 544 || D > ldh || ldg < 4 * D, "cadre_lstm_step_fwd: built for K = ldh = 544 (hidden 530 zero padded), ldg >= 4*D");
+  FAIL_IF((((uintptr_t)Wp | (uintptr_t)Hprev) & 15) || (wp_str & 3) || (h_str & 3), "cadre_lstm_step_fwd: operands must be 16-byte aligned");
   const int rt = rt_for(B), rows = 16 * rt, NS = (D + 15) / 16;
-  fwd_args a{W, bias, G, Hprev, Cprev, Hout, Cout, TCout, row_seg, w_str, g_str, h_str, ldw, ldg, ldh, B, D, Z, NS, rev & 1};
+  fwd_args a{Wp, bias, G, Hprev, Cprev, Hout, Cout, TCout, row_seg, wp_str, b_str, g_str, h_str, ldg, ldh, B, D, Z, NS, rev & 1};
   dim3 grid(Z * NS * ((B + rows - 1) / rows));          // row chunks: workgroups past a net's cover of rows return at once
   if (rt == 1) hipLaunchKernelGGL((lstm_step_fwd_kernel<1, 34>), grid, dim3(256), 0, ST(stream), a);
   else hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 34>), grid, dim3(256), 0, ST(stream), a);
   return (int)hipGetLastError();
 }
 
-extern "C" int cadre_lstm_step_bwd(const float* WT, int64_t wt_str, int32_t ldt, const float* dG_in, float* dG_out,
-                                   const float* G_act, int32_t ldg, int64_t g_str, const float* dh_in, float* dC,
-                                   int64_t d_str, const float* TC, const float* Cprev, int32_t ldh, int64_t h_str,
+extern "C" int cadre_lstm_step_bwd(const float* Wp, int64_t wp_str, const float* dGp_in, float* dGp_out, int64_t gp_str,
+                                   float* dG_out, const float* G_act, int32_t ldg, int64_t g_str, const float* dh_in,
+                                   float* dC, int64_t d_str, const float* TC, const float* Cprev, int32_t ldh, int64_t h_str,
                                    int32_t B, int32_t D, int32_t Z, const int32_t* commands, int32_t C,
                                    const int32_t* row_seg, int32_t rev, void* stream) {
-  FAIL_IF(!dG_out || !G_act || !dC || !TC || !Cprev || B < 1 || D < 1 || Z < 1 || (!dG_in && !dh_in) || (commands && C < 1),
+  FAIL_IF(!dG_out || !dGp_out || !G_act || !dC || !TC || !Cprev || B < 1 || D < 1 || Z < 1 || (!dGp_in && !dh_in) || (commands && C < 1),
           "cadre_lstm_step_bwd: bad argument");
-  FAIL_IF(ldh != 544 || D > ldh || ldg < 4 * D, "cadre_lstm_step_bwd: built for ldh = 544 (hidden 530 zero padded), ldg >= 4*D");
-  if (dG_in) {
-    FAIL_IF(!WT || ldt != 2176 || ldg != 2176, "cadre_lstm_step_bwd: the product needs the transposed weights with ldt = ldg = 2176 (4 x 34 k-blocks, zero padded)");
-    FAIL_IF((((uintptr_t)WT | (uintptr_t)dG_in) & 15) || (wt_str & 3) || (g_str & 3), "cadre_lstm_step_bwd: operands must be 16-byte aligned");
-  }
+  FAIL_IF(ldh != 544 || D > ldh || ldg < 4 * D || 4 * D > 2176, "cadre_lstm_step_bwd: built for ldh = 544 (hidden 530 zero padded), ldg >= 4*D");
+  FAIL_IF(gp_str < (int64_t)((B + 15) / 16) * 2176 * 16 || (gp_str & 3) || ((uintptr_t)dGp_out & 15),
+          "cadre_lstm_step_bwd: the fragment-order copies hold ceil(B / 16) tiles of 16 x 2176 floats per net");
+  if (dGp_in) FAIL_IF(!Wp || (((uintptr_t)Wp | (uintptr_t)dGp_in) & 15) || (wp_str & 3), "cadre_lstm_step_bwd: operands must be 16-byte aligned");
   const int rt = rt_for(B), rows = 16 * rt, NS = (D + 15) / 16;
-  bwd_args a{WT, dG_in, dG_out, G_act, dh_in, dC, TC, Cprev, commands, row_seg, wt_str, g_str, h_str, d_str, ldt, ldg, ldh, B, D,
-             C < 1 ? 1 : C, Z, NS, rev & 1};
+  bwd_args a{Wp, dGp_in, dGp_out, dG_out, G_act, dh_in, dC, TC, Cprev, commands, row_seg, wp_str, gp_str, g_str, h_str, d_str,
+             ldg, ldh, B, D, C < 1 ? 1 : C, Z, NS, rev & 1};
   dim3 grid(Z * NS * ((B + rows - 1) / rows));
 #define LB(RT_)                                                                                                  \
   do {                                                                                                           \
-    if (dG_in) hipLaunchKernelGGL((lstm_step_bwd_kernel<RT_, 34, true>), grid, dim3(256), 0, ST(stream), a);    \
+    if (dGp_in) hipLaunchKernelGGL((lstm_step_bwd_kernel<RT_, 34, true>), grid, dim3(256), 0, ST(stream), a);   \
     else hipLaunchKernelGGL((lstm_step_bwd_kernel<RT_, 34, false>), grid, dim3(256), 0, ST(stream), a);         \
   } while (0)
   if (rt == 1) LB(1); else LB(2);
@@ -468,11 +491,13 @@ extern "C" int cadre_lstm_step_bwd(const float* WT, int64_t wt_str, int32_t ldt,
   return (int)hipGetLastError();
 }
 
-extern "C" int cadre_transpose_batched(const float* src, int64_t ld_src, int64_t src_str, float* dst, int64_t ld_dst,
-                                       int64_t dst_str, int32_t rows, int32_t cols, int32_t batch, void* stream) {
-  FAIL_IF(!src || !dst || rows < 1 || cols < 1 || batch < 1 || ld_src < cols || ld_dst < rows, "cadre_transpose_batched: bad argument");
-  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, batch), dim3(256), 0, ST(stream), src, ld_src,
-                     src_str, dst, ld_dst, dst_str, rows, cols);
+extern "C" int cadre_pack_lstm_weights(const float* W, int64_t w_str, int32_t ldw, int32_t D, int32_t Z, float* fwd, float* bwd,
+                                       int64_t p_str, void* stream) {
+  FAIL_IF(!W || !fwd || !bwd || D < 1 || Z < 1 || ldw != 544 || D > ldw || (w_str & 3) || (p_str & 3) ||
+              (((uintptr_t)W | (uintptr_t)fwd | (uintptr_t)bwd) & 15) || p_str < (int64_t)((D + 15) / 16) * 4 * 34 * 256,
+          "cadre_pack_lstm_weights: bad argument (ldw = 544, 16-byte aligned, p_str >= ceil(D/16) * 4 * 34 * 256 floats)");
+  hipLaunchKernelGGL(pack_lstm_weights_kernel, dim3((D + 15) / 16, 8, Z), dim3(256), 0, ST(stream), W, w_str, ldw, D, ldw / 16,
+                     fwd, bwd, p_str);
   return (int)hipGetLastError();
 }
 

@@ -64,9 +64,9 @@ SYMBOLS = {
                                      vp, vp, vp, vp, vp, vp, vp],
     "cadre_lstm_pointwise_fwd": [vp, i64, i64, vp, i64, i32, vp, vp, vp, i64, i64, i32, i32, i32, vp, vp],
     "cadre_lstm_pointwise_bwd": [vp, vp, i64, i64, vp, vp, i64, vp, vp, i64, i32, i64, i64, i32, i32, i32, vp, i32, vp, vp],
-    "cadre_lstm_step_fwd": [vp, i64, i32, vp, vp, i32, i64, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, vp, i32, vp],
-    "cadre_lstm_step_bwd": [vp, i64, i32, vp, vp, vp, i32, i64, vp, vp, i64, vp, vp, i32, i64, i32, i32, i32, vp, i32, vp, i32, vp],
-    "cadre_transpose_batched": [vp, i64, i64, vp, i64, i64, i32, i32, i32, vp],
+    "cadre_pack_lstm_weights": [vp, i64, i32, i32, i32, vp, vp, i64, vp],
+    "cadre_lstm_step_fwd": [vp, i64, vp, i64, vp, i32, i64, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, vp, i32, vp],
+    "cadre_lstm_step_bwd": [vp, i64, vp, vp, i64, vp, vp, i32, i64, vp, vp, i64, vp, vp, i32, i64, i32, i32, i32, vp, i32, vp, i32, vp],
     "cadre_lstm_dw": [vp, i32, i64, vp, vp, i32, i64, i64, i32, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, vp, vp],
     "cadre_colsum": [vp, i64, i64, vp, i64, i32, i32, i32, i32, vp],
     "cadre_relu_bwd": [vp, vp, i64, vp, i32, i32, i32, vp],

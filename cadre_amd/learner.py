@@ -33,7 +33,8 @@ class PPOLearnerHIP:
         self.S = seq_length
         self._ws = {}
         self._graphs = {}
-        self._wt = None
+        self._wp = None            # recurrent weights in MFMA fragment order (forward, backward), re-packed per optimiser step
+        self._wp_key = None
         self.launches = {}
         self.use_graphs = os.environ.get("CADRE_HIP_GRAPHS", "1") != "0"
         self.use_sorted = os.environ.get("CADRE_SORTED_UPDATE", "1") != "0"
@@ -55,7 +56,7 @@ class PPOLearnerHIP:
                 Hs=z(Z, S + 1, B, a.DP), Cs=z(Z, S + 1, B, a.DP), TC=z(Z, S + 1, B, a.DP),
                 A1=z(2 * Z, B, a.hid), A2=z(2 * Z, B, a.hid), O3=z(2 * Z, B, a.NP),
                 dO3=z(2 * Z, B, a.NP), dA2=z(2 * Z, B, a.hid), dA1=z(2 * Z, B, a.hid),
-                dH=z(Z, B, a.DP), dC=z(Z, B, a.DP),
+                dH=z(Z, B, a.DP), dC=z(Z, B, a.DP), dGp=z(2, Z, (B + 15) // 16, 16 * a.H4P),
                 actions=z(2, B, dtype=torch.int64), commands=z(2, B, dtype=torch.int32),
                 old_values=z(2, B), returns=z(2, B), old_logp=z(2, B), adv=z(2, B),
                 losses=z(3), loss_scratch=z(4 + 6 * ((B + 15) // 16)),
@@ -67,6 +68,23 @@ class PPOLearnerHIP:
                          old_values_u=z(2, B), returns_u=z(2, B), old_logp_u=z(2, B), adv_u=z(2, B))
             self._ws[key] = w
         return w
+
+    # ------------------------------------------------------------------ packed weights
+    def packed_weights(self, g0, gs, Z):
+        """Fragment-order copies of the recurrent weights of all 8 nets (cadre_pack_lstm_weights), refreshed when the
+        parameters changed: the optimiser step count and `params._version` (in-place loads) key the copy.  Returns
+        (forward copy of net g0, net stride gs nets)."""
+        a = self.a
+        key = (a.step, a.params._version, a.params.data_ptr())
+        if self._wp is None:
+            n = ((a.D + 15) // 16) * 4 * (a.DP // 16) * 256
+            self._wp = torch.zeros(2, a.Z, n, device=a.device)
+        if key != self._wp_key or torch.cuda.is_current_stream_capturing():
+            hip.check(hip.lib().cadre_pack_lstm_weights(hip.ptr(a.params[a.o_whh:]), a.size_L, a.DP, a.D, a.Z, hip.ptr(self._wp[0]),
+                                                        hip.ptr(self._wp[1]), self._wp.stride(1), hip.stream()),
+                      "cadre_pack_lstm_weights")
+            self._wp_key = None if torch.cuda.is_current_stream_capturing() else key
+        return self._wp[0, g0:], gs * self._wp.stride(1)
 
     # ------------------------------------------------------------------ forward
     def _forward(self, w, B, nets, x_div, S=None, mlp=True, seg=None):
@@ -89,9 +107,10 @@ class PPOLearnerHIP:
         sgp = None if seg is None else hip.ptr(seg)           # fused steps: only the 32-row tiles of each net's run of rows
         hip.gemm(X, pL[a.o_wih:], G, S * B, H4, DP, DP, DP, H4P, shift=pL[a.o_bih:], batch=Z,
                  a_z=(x_div, 0, S * B * DP), b_z=(1, 0, sL), c_z=(1, 0, S * B * H4P), s_z=(1, 0, sL), seg=sg1)
+        wpf, wps = self.packed_weights(g0, gs, Z)
         for t in range(S):                                          # models.py:148-151
             # gates = x-projection + h_{t-1} W_hh^T + b_hh, cell math, h_t / c_t / tanh(c_t): one launch for all nets
-            hip.check(L.cadre_lstm_step_fwd(hip.ptr(pL[a.o_whh:]), sL, DP, hip.ptr(pL[a.o_bhh:]), hip.ptr(G[:, t]), H4P,
+            hip.check(L.cadre_lstm_step_fwd(hip.ptr(wpf), wps, hip.ptr(pL[a.o_bhh:]), sL, hip.ptr(G[:, t]), H4P,
                                             S * B * H4P, hip.ptr(Hs[:, t]), hip.ptr(Cs[:, t]), hip.ptr(Hs[:, t + 1]),
                                             hip.ptr(Cs[:, t + 1]), hip.ptr(TC[:, t + 1]), DP, (S + 1) * B * DP, B, a.D, Z,
                                             sgp, t & 1, st), "cadre_lstm_step_fwd")
@@ -234,20 +253,17 @@ class PPOLearnerHIP:
         pL, gL, sL = a.params, Gr, a.size_L
         H4P = a.H4P
         sgp = None if seg is None else hip.ptr(seg)
-        # transposed recurrent weights [k][n] for dh = dG W_hh (the reduction index must be the contiguous one)
-        WT = self._wt
-        if WT is None:
-            WT = self._wt = torch.zeros(Z, DP, H4P, device=a.device)
-        hip.check(L.cadre_transpose_batched(hip.ptr(pL[a.o_whh:]), DP, sL, hip.ptr(WT), H4P, DP * H4P, H4, DP, Z, st),
-                  "cadre_transpose_batched")
+        dGp = w["dGp"]                                      # dG of a step in fragment order: ping-pong pair
+        gps = dGp.stride(1)
         for t in range(S, 0, -1):
             # t == S: dh_{S-1} = dH (MLP towers), no product; else dh_{t-1} = dG_t W_hh.  Then the cell backward of step
-            # t-1 in the same launch: dG_{t-1}, dc_{t-2}
-            src = None if t == S else hip.ptr(dG[:, t])
-            hip.check(L.cadre_lstm_step_bwd(hip.ptr(WT), DP * H4P, H4P, src, hip.ptr(dG[:, t - 1]), hip.ptr(G[:, t - 1]), H4P,
-                                            S * B * H4P, hip.ptr(dH) if t == S else None, hip.ptr(dC), B * DP,
-                                            hip.ptr(TC[:, t]), hip.ptr(Cs[:, t - 1]), DP, (S + 1) * B * DP, B, a.D, Z, cmd, C,
-                                            sgp, t & 1, st), "cadre_lstm_step_bwd")
+            # t-1 in the same launch: dG_{t-1} (row-major for the weight gradients, fragment order for the next step), dc_{t-2}
+            src = None if t == S else hip.ptr(dGp[t & 1])
+            hip.check(L.cadre_lstm_step_bwd(hip.ptr(self._wp[1]), self._wp[1].stride(0), src, hip.ptr(dGp[(t - 1) & 1]), gps,
+                                            hip.ptr(dG[:, t - 1]), hip.ptr(G[:, t - 1]), H4P, S * B * H4P,
+                                            hip.ptr(dH) if t == S else None, hip.ptr(dC), B * DP, hip.ptr(TC[:, t]),
+                                            hip.ptr(Cs[:, t - 1]), DP, (S + 1) * B * DP, B, a.D, Z, cmd, C, sgp, t & 1, st),
+                      "cadre_lstm_step_bwd")
         # dW_hh = sum_t dG_t^T h_{t-1} ; dW_ih = sum_t dG_t^T x_t ; db_ih = db_hh = colsum(dG): one launch for all nets
         hip.check(L.cadre_lstm_dw(hip.ptr(dG), H4P, S * B * H4P, hip.ptr(Hs), hip.ptr(X), DP, (S + 1) * B * DP, S * B * DP, C,
                                   hip.ptr(gL[a.o_whh:]), hip.ptr(gL[a.o_wih:]), hip.ptr(gL[a.o_bih:]), hip.ptr(gL[a.o_bhh:]),

@@ -282,6 +282,8 @@ class CadreAgent(object):
         src = arena_of(shared_model_list)
         if src is not self.arena:
             self.arena.params.copy_(src.params)
+        # shared arena (HIP-IPC): another process (the chief) has stepped the parameters — re-derive what is cached from them
+        self.learner._wp_key = None
 
     # ------------------------------------------------------------------ controls
     def convert_action(self, discrete_action):

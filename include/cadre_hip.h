@@ -234,25 +234,33 @@ int cadre_lstm_pointwise_bwd(const float* gates, float* dgates, int64_t ldg, int
                              const int32_t* row_seg, void* stream);
 /* (commands != NULL: net z = head*C + c only keeps rows whose command is c; the other rows get
  * dgates = 0 and dc = 0 whatever dh holds — see cadre_gemm_t.seg_mode.) */
+/* Recurrent weights W [4*D][ldw = 544] of `Z` nets (net z at + z * w_str) -> MFMA FRAGMENT ORDER for the fused LSTM
+ * steps, both directions (ppo_update.hip): `fwd` for cadre_lstm_step_fwd, `bwd` (the transpose: the backward reduces
+ * over the gate axis) for cadre_lstm_step_bwd; ceil(D / 16) * 4 * 34 * 256 floats per net each, net stride p_str.
+ * Once per optimiser step — a fragment read from the row-major matrix is 16 rows x 64 bytes per wave instruction, from
+ * these copies one contiguous KiB. */
+int cadre_pack_lstm_weights(const float* W, int64_t w_str, int32_t ldw, int32_t D, int32_t Z, float* fwd, float* bwd,
+                            int64_t p_str, void* stream);
 /* One LSTM time step of `Z` nets, product AND cell math in one launch (ppo_update.hip; models.py:139-152 nn.LSTMCell):
  * gates = G (x-projection + b_ih, [B][ldg] per net) + h_{t-1} W^T + bias; G <- (i, f, g, o) activated; c_t, h_t,
- * tanh(c_t) written.  W [4*D][ldw] k-contiguous, K = ldh = ldw = 544 (hidden D zero padded); net z at + z * *_str.
- * row_seg as in cadre_lstm_pointwise_fwd (the 32-row tiles that intersect net z's run of rows).  `rev` (0/1): order in
- * which the unit slices are walked — alternate it from step to step so that each XCD's L2 re-uses the most recently read
- * weights first (speed only). */
-int cadre_lstm_step_fwd(const float* W, int64_t w_str, int32_t ldw, const float* bias, float* G, int32_t ldg,
+ * tanh(c_t) written.  Wp: the packed weights (`fwd` of cadre_pack_lstm_weights); K = ldh = 544 (hidden D zero padded);
+ * net z at + z * *_str.  row_seg as in cadre_lstm_pointwise_fwd (the 32-row tiles that intersect net z's run of rows).
+ * `rev` (0/1): order in which the unit slices are walked — alternate it from step to step so that each XCD's L2
+ * re-uses the most recently read weights first (speed only). */
+int cadre_lstm_step_fwd(const float* Wp, int64_t wp_str, const float* bias, int64_t b_str, float* G, int32_t ldg,
                         int64_t g_str, const float* Hprev, const float* Cprev, float* Hout, float* Cout, float* TCout,
                         int32_t ldh, int64_t h_str, int32_t B, int32_t D, int32_t Z, const int32_t* row_seg,
                         int32_t rev, void* stream);
-/* One backward time step: dh_{t-1} = dG_t W (+ dh_in) against the TRANSPOSED weights WT [ldh][ldt] (n contiguous,
- * ldt = ldg = 2176: the 4*D gate axis zero padded; cadre_transpose_batched), then the cell backward of step t-1 in the
- * same launch: dG_out = dG_{t-1} from the activated gates G_act, tanh(c_{t-1}), c_{t-2}; dC in/out.  dG_in == NULL:
- * no product (first step: dh = dh_in, the gradient of the MLP towers).  commands / row_seg as in
- * cadre_lstm_pointwise_bwd. */
-int cadre_lstm_step_bwd(const float* WT, int64_t wt_str, int32_t ldt, const float* dG_in, float* dG_out,
-                        const float* G_act, int32_t ldg, int64_t g_str, const float* dh_in, float* dC, int64_t d_str,
-                        const float* TC, const float* Cprev, int32_t ldh, int64_t h_str, int32_t B, int32_t D, int32_t Z,
-                        const int32_t* commands, int32_t C, const int32_t* row_seg, int32_t rev, void* stream);
+/* One backward time step: dh_{t-1} = dG_t W (+ dh_in) on the packed transposed weights (`bwd` of
+ * cadre_pack_lstm_weights) and dG_t in fragment order (dGp_in: what the previous call left in its dGp_out), then the
+ * cell backward of step t-1 in the same launch: dG_{t-1} from the activated gates G_act, tanh(c_{t-1}), c_{t-2}, written
+ * row-major (dG_out, [B][ldg]) AND in fragment order (dGp_out: ceil(B / 16) tiles of 16 x 2176 floats per net, net stride
+ * gp_str; zero-initialised by the caller, pad never written); dC in/out.  dGp_in == NULL: no product (first step:
+ * dh = dh_in, the gradient of the MLP towers).  commands / row_seg as in cadre_lstm_pointwise_bwd. */
+int cadre_lstm_step_bwd(const float* Wp, int64_t wp_str, const float* dGp_in, float* dGp_out, int64_t gp_str,
+                        float* dG_out, const float* G_act, int32_t ldg, int64_t g_str, const float* dh_in, float* dC,
+                        int64_t d_str, const float* TC, const float* Cprev, int32_t ldh, int64_t h_str, int32_t B, int32_t D,
+                        int32_t Z, const int32_t* commands, int32_t C, const int32_t* row_seg, int32_t rev, void* stream);
 /* The LSTM weight gradients of `Z` nets in one launch (ppo_update.hip): dWhh = sum_t dG_t^T h_{t-1}, dWih = sum_t
  * dG_t^T x_t ([H4][ldw] each, columns 0..N-1 written), dbih = dbhh = column sums of dG.  dG [S][B][ldg] (gate axis zero
  * padded to a multiple of 64), Hs [S+1][B][ldh] (slot t = h_{t-1}), X [S][B][ldh] (net z reads input slot z / x_div).
@@ -261,9 +269,6 @@ int cadre_lstm_dw(const float* dG, int32_t ldg, int64_t g_str, const float* Hs, 
                   int64_t h_str, int64_t x_str, int32_t x_div, float* dWhh, float* dWih, float* dbih, float* dbhh,
                   int32_t ldw, int64_t w_str, int32_t B, int32_t S, int32_t H4, int32_t N, int32_t Z,
                   const int32_t* row_seg, void* stream);
-/* dst[z][c][r] = src[z][r][c] for r < rows, c < cols (pad elements of dst are left as they are) */
-int cadre_transpose_batched(const float* src, int64_t ld_src, int64_t src_str, float* dst, int64_t ld_dst,
-                            int64_t dst_str, int32_t rows, int32_t cols, int32_t batch, void* stream);
 /* column sums: out[z][n] (+)= sum_m X[z][m][n]  (bias gradients) */
 int cadre_colsum(const float* X, int64_t ldx, int64_t x_str, float* out, int64_t o_str,
                  int32_t M, int32_t N, int32_t batch, int32_t accumulate, void* stream);

@@ -330,12 +330,24 @@ def test_lstm_step_fwd_fused(hip, Z, B, sorted_rows):
         buf[z * w_str: z * w_str + H4 * DP] = W[z].reshape(-1)
         buf[z * w_str + H4 * DP: (z + 1) * w_str] = b[z]
     bufd = dev(buf)
+    L = hip.lib()
+    NP = 34 * 4 * 34 * 256                                 # floats of one net's packed copy
+    packed = torch.full((2, Z, NP), 7.0, device="cuda")
+    hip.check(L.cadre_pack_lstm_weights(bufd.data_ptr(), w_str, DP, D, Z, packed[0].data_ptr(), packed[1].data_ptr(), NP,
+                                        hip.stream()), "cadre_pack_lstm_weights")
+    # fragment order, forward: [slice][gate][k-block][q][c][i] = W[g*D + 16*slice + c][16j + 4q + i]
+    Wz = torch.zeros(Z, 4, 34 * 16, DP); Wz[:, :, :D] = W.view(Z, 4, D, DP)
+    want_f = Wz.view(Z, 4, 34, 16, 34, 4, 4).permute(0, 2, 1, 4, 5, 3, 6).reshape(Z, NP)
+    assert torch.equal(packed[0].cpu(), want_f)
+    # backward: [slice][quarter w][k-block j][q][c][i] = W[n = 16*(34w + j) + 4q + i][16*slice + c]
+    Wn = torch.zeros(Z, 2176, 34 * 16); Wn[:, :H4, :D] = W[:, :, :D]
+    want_b = Wn.view(Z, 4, 34, 4, 4, 34, 16).permute(0, 5, 1, 2, 3, 6, 4).reshape(Z, NP)
+    assert torch.equal(packed[1].cpu(), want_b)
     Gd = torch.full((Z, B, H4P), 7.0, device="cuda"); Gd[:, :, :H4] = Gx.cuda()
     hpd, cpd = dev(hp), dev(cp)
     ho = torch.full((Z, B, DP), 7.0, device="cuda"); co = torch.full_like(ho, 7.0); tco = torch.full_like(ho, 7.0)
     segd = None if seg is None else dev(seg)
-    L = hip.lib()
-    hip.check(L.cadre_lstm_step_fwd(bufd.data_ptr(), w_str, DP, bufd.data_ptr() + 4 * H4 * DP, Gd.data_ptr(), H4P, B * H4P,
+    hip.check(L.cadre_lstm_step_fwd(packed[0].data_ptr(), NP, bufd.data_ptr() + 4 * H4 * DP, w_str, Gd.data_ptr(), H4P, B * H4P,
                                     hpd.data_ptr(), cpd.data_ptr(), ho.data_ptr(), co.data_ptr(), tco.data_ptr(), DP, B * DP,
                                     B, D, Z, None if segd is None else segd.data_ptr(), B & 1, hip.stream()), "cadre_lstm_step_fwd")
     torch.cuda.synchronize()
@@ -356,16 +368,21 @@ def test_lstm_step_fwd_fused(hip, Z, B, sorted_rows):
 def test_lstm_step_bwd_fused(hip, Z, B, sorted_rows):
     """cadre_lstm_step_bwd: dh_{t-1} = dG_t W_hh (+ dh_in) on the transposed weights, then the cell backward of step t-1
     in the same launch — against the autograd of the cell; ownership mask (rows of other command nets: exact zeros);
-    the product-free first step; cadre_transpose_batched."""
+    the product-free first step; the fragment-order copy of dG_{t-1} for the next step."""
     D, DP, H4, H4P, W, b, Gx, hp, cp, seg = _lstm_step_case(Z, B, 300 + B, sorted_rows)
     g = torch.Generator().manual_seed(B)
     C = 4
     L = hip.lib()
-    # transposed weights through the kernel under test
+    NP = 34 * 4 * 34 * 256
     Wd = dev(W)
-    WT = torch.zeros(Z, DP, H4P, device="cuda")
-    hip.check(L.cadre_transpose_batched(Wd.data_ptr(), DP, H4 * DP, WT.data_ptr(), H4P, DP * H4P, H4, DP, Z, hip.stream()), "tr")
-    assert torch.equal(WT[:, :, :H4], Wd.transpose(1, 2)) and float(WT[:, :, H4:].abs().max()) == 0.0
+    packed = torch.zeros(2, Z, NP, device="cuda")
+    hip.check(L.cadre_pack_lstm_weights(Wd.data_ptr(), H4 * DP, DP, D, Z, packed[0].data_ptr(), packed[1].data_ptr(), NP,
+                                        hip.stream()), "cadre_pack_lstm_weights")
+
+    def frag(t):                                          # [Z][B][H4] -> fragment order [Z][tile][k-block][q][r16][i], B padded to 16
+        Bp = (B + 15) // 16 * 16
+        full = torch.zeros(Z, Bp, H4P); full[:, :B, :H4] = t
+        return full.view(Z, Bp // 16, 16, 136, 4, 4).permute(0, 1, 3, 4, 2, 5).contiguous()
     # cell of step t-1 (activated gates, tanh c, c_prev) and incoming gradients
     pre = torch.randn(Z, B, H4, generator=g)
     i, f, gg, o = pre.chunk(4, -1)
@@ -392,14 +409,16 @@ def test_lstm_step_bwd_fused(hip, Z, B, sorted_rows):
         want_dc = dct * sf
         own = torch.stack([cmds[z // C] == z % C for z in range(Z)])          # [Z][B]
         want = want * own[:, :, None]; want_dc = want_dc * own[:, :, None]
-        dGt_d = dev(pad(dG_t, H4P)); act_d = dev(pad(act, H4P))
+        dGt_d = dev(frag(dG_t)); act_d = dev(pad(act, H4P))
+        gps = dGt_d[0].numel()
         dGo = torch.full((Z, B, H4P), 7.0, device="cuda")
+        dGpo = torch.full_like(dGt_d, 7.0)
         dCd = dev(pad(dc_in, DP)); dhd = dev(pad(dh_up, DP))
         tcd = dev(pad(torch.tanh(cn), DP)); cpd = dev(pad(cprev, DP))
         segd = None if seg is None else dev(seg)
         cm = dev(cmds)
-        hip.check(L.cadre_lstm_step_bwd(WT.data_ptr(), DP * H4P, H4P, dGt_d.data_ptr() if with_product else None, dGo.data_ptr(),
-                                        act_d.data_ptr(), H4P, B * H4P, dhd.data_ptr(), dCd.data_ptr(), B * DP, tcd.data_ptr(),
+        hip.check(L.cadre_lstm_step_bwd(packed[1].data_ptr(), NP, dGt_d.data_ptr() if with_product else None, dGpo.data_ptr(), gps,
+                                        dGo.data_ptr(), act_d.data_ptr(), H4P, B * H4P, dhd.data_ptr(), dCd.data_ptr(), B * DP, tcd.data_ptr(),
                                         cpd.data_ptr(), DP, B * DP, B, D, Z, cm.data_ptr(), C,
                                         None if segd is None else segd.data_ptr(), int(with_product), hip.stream()), "cadre_lstm_step_bwd")
         torch.cuda.synchronize()
@@ -416,6 +435,11 @@ def test_lstm_step_bwd_fused(hip, Z, B, sorted_rows):
             rows_out = torch.ones(B, dtype=torch.bool); rows_out[lo:hi] = False
             assert bool((dGo[z][rows_out.cuda()] == 7.0).all())
             assert bool((dGo[z, :, H4:] == 7.0).all())
+            # the fragment-order copy holds the same values as the row-major one (rows written), 7.0 elsewhere
+            got_p = dGpo[z].permute(0, 3, 1, 2, 4).reshape(-1, H4P)[:B]
+            if hi > lo:
+                assert torch.equal(got_p[lo:hi, :H4], dGo[z, lo:hi, :H4])
+            assert bool((got_p[rows_out.cuda()] == 7.0).all()) and bool((got_p[:, H4:] == 7.0).all())
         print("lstm_step_bwd Z=%d B=%d sorted=%s product=%s: rel-max-err %.2e" % (Z, B, sorted_rows, with_product, worst))
         assert worst < 2e-5
 

@@ -30,7 +30,8 @@ def main():
     sL = 2 * H4 * DP + 2 * H4
     params = torch.randn(Z * sL, device="cuda", generator=g) * 0.04
     grads = torch.zeros(Z * sL, device="cuda")
-    WT = torch.zeros(Z, DP, H4P, device="cuda")
+    NP = 34 * 4 * 34 * 256
+    packed = torch.zeros(2, Z, NP, device="cuda")
     st = hip.stream()
     for B in (64, 256):
         per = B // 4
@@ -43,19 +44,20 @@ def main():
         TC = torch.tanh(Cs)
         X = torch.randn(2, S, B, DP, device="cuda", generator=g)
         dC = torch.zeros(Z, B, DP, device="cuda")
+        dGp = torch.randn(2, Z, (B + 15) // 16, 16 * H4P, device="cuda", generator=g) * 0.3
         t = [0]
 
         def fwd():
             k = t[0] % S; t[0] += 1
-            hip.check(L.cadre_lstm_step_fwd(params.data_ptr() + 4 * H4 * DP, sL, DP, params.data_ptr() + 4 * (2 * H4 * DP + H4),
+            hip.check(L.cadre_lstm_step_fwd(packed[0].data_ptr(), NP, params.data_ptr() + 4 * (2 * H4 * DP + H4), sL,
                                             G[:, k].data_ptr(), H4P, S * B * H4P, Hs[:, k].data_ptr(), Cs[:, k].data_ptr(),
                                             Hs[:, k + 1].data_ptr(), Cs[:, k + 1].data_ptr(), TC[:, k + 1].data_ptr(), DP,
                                             (S + 1) * B * DP, B, D, Z, seg.data_ptr(), k & 1, st), "f")
 
         def bwd():
             k = 1 + t[0] % (S - 1); t[0] += 1
-            hip.check(L.cadre_lstm_step_bwd(WT.data_ptr(), DP * H4P, H4P, dG[:, k].data_ptr(), dG[:, k - 1].data_ptr(),
-                                            G[:, k - 1].data_ptr(), H4P, S * B * H4P, None, dC.data_ptr(), B * DP, TC[:, k].data_ptr(),
+            hip.check(L.cadre_lstm_step_bwd(packed[1].data_ptr(), NP, dGp[k & 1].data_ptr(), dGp[(k - 1) & 1].data_ptr(), dGp.stride(1),
+                                            dG[:, k - 1].data_ptr(), G[:, k - 1].data_ptr(), H4P, S * B * H4P, None, dC.data_ptr(), B * DP, TC[:, k].data_ptr(),
                                             Cs[:, k - 1].data_ptr(), DP, (S + 1) * B * DP, B, D, Z, cmds.data_ptr(), C,
                                             seg.data_ptr(), k & 1, st), "b")
 
@@ -65,9 +67,9 @@ def main():
                                       grads.data_ptr() + 4 * (2 * H4 * DP + H4), DP, sL, B, S, H4, DP, Z, seg.data_ptr(), st), "d")
 
         def tr():
-            hip.check(L.cadre_transpose_batched(params.data_ptr() + 4 * H4 * DP, DP, sL, WT.data_ptr(), H4P, DP * H4P, H4, DP, Z, st), "t")
+            hip.check(L.cadre_pack_lstm_weights(params.data_ptr() + 4 * H4 * DP, sL, DP, D, Z, packed[0].data_ptr(), packed[1].data_ptr(), NP, st), "t")
         tr()
-        print("B=%d: lstm_step_fwd %.1f us, lstm_step_bwd %.1f us, lstm_dw %.1f us, transpose %.1f us" % (
+        print("B=%d: lstm_step_fwd %.1f us, lstm_step_bwd %.1f us, lstm_dw %.1f us, pack_weights %.1f us" % (
             B, timeit(fwd), timeit(bwd), timeit(dw, 10), timeit(tr, 10)), flush=True)
 
 
