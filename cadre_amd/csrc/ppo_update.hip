@@ -309,13 +309,16 @@ struct dw_args {
 // (sample) index, rows are contiguous in the output index — so an MFMA fragment is a plain coalesced load: lane
 // (c = lane & 15, q = lane >> 4) of k-step s loads 16 bytes of row 4s + q: dG[row][m0 + 4c ..+3] feeds the A operand of
 // FOUR row tiles (output rows m0 + 4c + i, i = 0..3, interleaved), Y[row][n0 + 4c ..+3] the B operand of four column
-// tiles: a wave owns a 64 x 64 output tile = 16 v_mfma_f32_16x16x4_f32 per two 1-KiB loads, no LDS, and its results
+// tiles: a wave owns a 64*TM x 64 output tile = 16*TM v_mfma_f32_16x16x4_f32 per 1 + TM KiB loads, no LDS, and its results
 // are 16 (m) x 4 (n) blocks per lane: 16-byte stores, 256 B per output row.  Only a net's own run of rows is
 // multiplied (4-row granularity; the rows of other nets hold exact zeros).  Work item = wave tile; the net is the
 // fastest index of the 1-D grid (one XCD per net: its dG / h / x rows stay in that XCD's L2).
-__global__ __launch_bounds__(256) void lstm_dw_kernel(dw_args p) {
-  constexpr int PD = 8;                                   // k-steps (2 KiB per wave) in flight
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+template <int TM>
+__global__ __launch_bounds__(256, TM == 1 ? 2 : 1) void lstm_dw_kernel(dw_args p) {
+  constexpr int PD = TM == 1 ? 8 : 6;                     // k-steps ((1 + TM) KiB per wave) in flight
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: the buffer descriptors built from it
+                                                                 // stay in scalar registers (no waterfall loop per load)
   const int c = lane & 15, q = lane >> 4;
   const int z = blockIdx.x % p.Z;
   const int tile = (blockIdx.x / p.Z) * 4 + wave;         // 0 .. 2*MG*NG: (kind, m-group, n-group), n fastest
@@ -331,86 +334,117 @@ __global__ __launch_bounds__(256) void lstm_dw_kernel(dw_args p) {
   }
   const int nb = (hi - lo + 3) >> 2;                      // k-steps per time step
   const int KT = nb * p.S;
-  const int m0 = 64 * mg, n0 = 64 * ng;
+  const int m0 = 64 * TM * mg, n0 = 64 * ng;
   const int nc = (n0 + 4 * c < p.N) ? c : 0;              // column chunk past the row pitch: a valid one, discarded
-  const float* ga = p.dG + (int64_t)z * p.g_str + m0 + 4 * c;
-  const float* yb = (kind == 0 ? p.Hs + (int64_t)z * p.h_str : p.X + (int64_t)(z / p.x_div) * p.x_str) + n0 + 4 * nc;
-  f32x4 acc[4][4];
+  // Operands through buffer descriptors: the per-lane part of an address (row q of the k-step, 16-byte column chunk c) is
+  // a constant VGPR, the k-step's row offset a SCALAR — no vector ALU work per k-step (64-bit row * pitch products per
+  // lane cost as much issue time as a third of the MFMAs) — and rows past the end of the tensor read as zeros.
+  const float* gbase = p.dG + (int64_t)z * p.g_str + m0;
+  const float* ybase = (kind == 0 ? p.Hs + (int64_t)z * p.h_str : p.X + (int64_t)(z / p.x_div) * p.x_str) + n0;
+  const unsigned g_bytes = (unsigned)((int64_t)p.S * p.B * p.ldg * 4 - (int64_t)m0 * 4);
+  const unsigned y_bytes = (unsigned)((int64_t)p.S * p.B * p.ldh * 4 - (int64_t)n0 * 4);
+  const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc((void*)gbase, 0, (int)g_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)ybase, 0, (int)y_bytes, 0x00020000);
+  const int voff_g = (q * p.ldg + 4 * c) * 4, voff_y = (q * p.ldh + 4 * nc) * 4;
+  f32x4 acc[TM][4][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};                      // column sums of dG (this lane's rows 4s + q)
-  // k-step ks -> rows t*B + lo + 4*(ks % nb) + q, walked incrementally (state of the next k-step to request).  The loop
-  // body is branch-free: requests past the end repeat the last k-step, whose operand is zeroed where it is consumed.
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[tm][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum[TM];                                         // column sums of dG (this lane's rows 4s + q)
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) bsum[tm] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // k-step ks -> rows t*B + lo + 4*(ks % nb) + q, walked incrementally in scalar registers (state of the next k-step to
+  // request).  Requests past the last k-step go out of bounds: zeros, nothing to undo.  Rows of a 4-row step past the
+  // run hold the exact zeros of other nets' rows (sorted) — or, unsorted with B % 4 != 0, the next time step's rows:
+  // only then is the operand masked (MASK).
   int t_n = 0, b_n = 0, ks_n = 0;
-  f32x4 aq[PD], yq[PD];
+  const bool MASK = p.row_seg == nullptr && (p.B & 3) != 0;
+  f32x4 aq[PD][TM], yq[PD];
   auto request = [&](int slot) {
-    const int row = min(lo + 4 * b_n + q, p.B - 1);
-    const int64_t r = (int64_t)t_n * p.B + row;
-    aq[slot] = *reinterpret_cast<const f32x4*>(ga + r * p.ldg);
-    yq[slot] = *reinterpret_cast<const f32x4*>(yb + r * p.ldh);
-    const int adv = ks_n + 1 < KT ? 1 : 0;
-    ks_n += adv;
-    const int b1 = b_n + adv;
+    const int row = t_n * p.B + lo + 4 * b_n;             // scalar
+    const int so_g = ks_n < KT ? row * p.ldg * 4 : 0x7fffffff;
+    const int so_y = ks_n < KT ? row * p.ldh * 4 : 0x7fffffff;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+      aq[slot][tm] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, voff_g + 256 * tm, so_g, 0));
+    yq[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsY, voff_y, so_y, 0));
+    ++ks_n;
+    const int b1 = b_n + 1;
     const int wrap = b1 == nb ? 1 : 0;
     b_n = wrap ? 0 : b1;
     t_n += wrap;
   };
-  if (KT > 0) {
+  // (KT == 0 — a net without rows — runs no iteration: every prologue request is out of bounds)
 #pragma unroll
-    for (int s = 0; s < PD; ++s) request(s);
-    __builtin_amdgcn_sched_barrier(0);                   // (PD k-steps stay in flight: the loads are not sunk to their use)
-    int b_c = 0;                                          // k-step inside its time step, consumer side
-    for (int ks = 0; ks < KT; ks += PD) {
+  for (int s = 0; s < PD; ++s) request(s);
+  __builtin_amdgcn_sched_barrier(0);                     // (PD k-steps stay in flight: the loads are not sunk to their use)
+  int b_c = 0;                                            // k-step inside its time step, consumer side
+  for (int ks = 0; ks < KT; ks += PD) {
 #pragma unroll
-      for (int s = 0; s < PD; ++s) {
-        f32x4 av = aq[s];
-        const f32x4 yv = yq[s];
-        request(s);
-        __builtin_amdgcn_sched_barrier(0);
-        // rows past the run (tail of a 4-row step) and k-steps past the end contribute nothing
-        const bool dead = (lo + 4 * b_c + q >= hi) | (ks + s >= KT);
+    for (int s = 0; s < PD; ++s) {
+      f32x4 av[TM];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) av[i] = dead ? 0.f : av[i];
-        const int b1 = b_c + 1;
-        b_c = b1 == nb ? 0 : b1;
-        bsum += av;
+      for (int tm = 0; tm < TM; ++tm) av[tm] = aq[s][tm];
+      const f32x4 yv = yq[s];
+      request(s);
+      __builtin_amdgcn_sched_barrier(0);
+      if (MASK) {
+        const bool dead = lo + 4 * b_c + q >= hi;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) av[tm][i] = dead ? 0.f : av[tm][i];
+      }
+      const int b1 = b_c + 1;
+      b_c = b1 == nb ? 0 : b1;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        bsum[tm] += av[tm];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], yv[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+          for (int j = 0; j < 4; ++j)
+            acc[tm][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[tm][i], yv[j], acc[tm][i][j], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
-  // ---- store: lane (c, q) holds rows m0 + 16q + 4r + i, columns n0 + 4c .. +3
+  // ---- store: lane (c, q) holds rows m0 + 64*tm + 16q + 4r + i, columns n0 + 4c .. +3
   float* out = (kind == 0 ? p.dWhh : p.dWih) + (int64_t)z * p.w_str;
   if (n0 + 4 * c < p.N) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m = m0 + 16 * q + 4 * r + i;
-        if (m < p.H4)
-          *reinterpret_cast<f32x4*>(out + (int64_t)m * p.ldw + n0 + 4 * c) = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
-      }
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = m0 + 64 * tm + 16 * q + 4 * r + i;
+          if (m < p.H4)
+            *reinterpret_cast<f32x4*>(out + (int64_t)m * p.ldw + n0 + 4 * c) =
+                f32x4{acc[tm][i][0][r], acc[tm][i][1][r], acc[tm][i][2][r], acc[tm][i][3][r]};
+        }
   }
   if (kind == 0 && ng == 0) {                              // bias gradients: sum the four row quarters (q) of the wave
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float v = bsum[i];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      bsum[i] = v;
-    }
-    if (q == 0) {
+    for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int m = m0 + 4 * c + i;
-        if (m < p.H4) {
-          p.dbih[(int64_t)z * p.w_str + m] = bsum[i];
-          p.dbhh[(int64_t)z * p.w_str + m] = bsum[i];
+        float v = bsum[tm][i];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        bsum[tm][i] = v;
+      }
+      if (q == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = m0 + 64 * tm + 4 * c + i;
+          if (m < p.H4) {
+            p.dbih[(int64_t)z * p.w_str + m] = bsum[tm][i];
+            p.dbhh[(int64_t)z * p.w_str + m] = bsum[tm][i];
+          }
         }
       }
     }
@@ -511,9 +545,16 @@ extern "C" int cadre_lstm_dw(const float* dG, int32_t ldg, int64_t g_str, const 
               (((uintptr_t)dG | (uintptr_t)Hs | (uintptr_t)X | (uintptr_t)dWhh | (uintptr_t)dWih) & 15) ||
               ((g_str | h_str | x_str | w_str) & 3),
           "cadre_lstm_dw: 16-byte aligned operands, N % 4 == 0, N <= ldh / ldw, ldg >= H4 rounded up to 64 (zero padded)");
-  const int MG = (H4 + 63) / 64, NG = (N + 63) / 64;
+  FAIL_IF((int64_t)S * B * ldg * 4 >= (1ll << 31) || (int64_t)(S + 1) * B * ldh * 4 >= (1ll << 31),
+          "cadre_lstm_dw: a net's dG / h rows must stay below the 2 GiB buffer window");
+  // wave tile 64 x 64; 128 x 64 (CADRE_DW_TM=2: a third less operand traffic per MFMA, one wave per SIMD) measured slower:
+  // 277 vs 218 us at minibatch 256 — operand traffic is not what bounds the launch
+  static const int tm_env = [] { const char* e = getenv("CADRE_DW_TM"); return e ? atoi(e) : 1; }();
+  const int TM = (tm_env == 2 && ldg >= ((H4 + 127) & ~127)) ? 2 : 1;
+  const int MG = (H4 + 64 * TM - 1) / (64 * TM), NG = (N + 63) / 64;
   dw_args a{dG, Hs, X, dWhh, dWih, dbih, dbhh, row_seg, g_str, h_str, x_str, w_str, ldg, ldh, ldw, B, S, H4, N, Z, x_div, MG, NG};
   const int wgs = (2 * MG * NG + 3) / 4;
-  hipLaunchKernelGGL(lstm_dw_kernel, dim3(Z * wgs), dim3(256), 0, ST(stream), a);
+  if (TM == 1) hipLaunchKernelGGL(lstm_dw_kernel<1>, dim3(Z * wgs), dim3(256), 0, ST(stream), a);
+  else hipLaunchKernelGGL(lstm_dw_kernel<2>, dim3(Z * wgs), dim3(256), 0, ST(stream), a);
   return (int)hipGetLastError();
 }
