@@ -45,6 +45,60 @@ extern "C" int cadre_mfma_peak(int32_t bf16, int32_t workgroups, int32_t iters, 
   return (int)hipGetLastError();
 }
 
+// bf16 MFMA shape comparison on RANDOM operands (MI355X_MICROARCH.md, DVFS give-back item 7: the chip can hold a higher
+// clock on v_mfma_f32_16x16x32_bf16 than on v_mfma_f32_32x32x16_bf16 at equal cycles per FLOP — zeros or constants hide
+// it).  Each wave holds 8 + 8 pseudo-random operand fragments and cycles through them; same FLOPs per iteration for both
+// shapes (32x32x16: 8 MFMAs on 8 accumulators; 16x16x32: 16 MFMAs on 16 accumulators); static register indices only.
+typedef float f32x4p __attribute__((ext_vector_type(4)));
+template <int SHAPE>
+__global__ __launch_bounds__(256) void mfma_shape_kernel(int iters, float* sink) {
+  bf16x8 a[8], b[8];
+  unsigned h = (threadIdx.x + 1) * 2654435761u ^ (blockIdx.x * 40503u);
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      h = h * 1664525u + 1013904223u;
+      a[i][e] = (__bf16)(((int)(h >> 16 & 0xffff) - 32768) * (1.f / 32768.f));
+      h = h * 1664525u + 1013904223u;
+      b[i][e] = (__bf16)(((int)(h >> 16 & 0xffff) - 32768) * (1.f / 32768.f));
+    }
+  float s = 0.f;
+  if constexpr (SHAPE == 32) {
+    f32x16 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], b[(j + 3) & 7], acc[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += acc[j][0];
+  } else {
+    f32x4p acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = f32x4p{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j & 7], b[(j + 3 + (j >> 3)) & 7], acc[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += acc[j][0];
+  }
+  if (s == 12345.678f) sink[0] = s;
+}
+
+// shape 32: 8 x v_mfma_f32_32x32x16_bf16 per iteration, shape 16: 16 x v_mfma_f32_16x16x32_bf16 (262144 FLOP per wave
+// and iteration either way), random operands.  The caller times the launch.
+extern "C" int cadre_mfma_shape(int32_t shape, int32_t workgroups, int32_t iters, float* sink, void* stream) {
+  if (!sink || workgroups < 1 || iters < 1 || (shape != 16 && shape != 32)) return cadre_fail("cadre_mfma_shape: bad argument");
+  if (shape == 32) hipLaunchKernelGGL((mfma_shape_kernel<32>), dim3(workgroups), dim3(256), 0, (hipStream_t)stream, iters, sink);
+  else hipLaunchKernelGGL((mfma_shape_kernel<16>), dim3(workgroups), dim3(256), 0, (hipStream_t)stream, iters, sink);
+  return (int)hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // HBM stream peaks: what a kernel that only moves bytes reaches on this device (the denominator for the HBM-bound
 // kernels' `frac_of_measured`).  16 B per lane, 8 independent loads in flight per lane, grid-stride over 2048 workgroups

@@ -14,7 +14,7 @@ def _hyper(optimizer):
     return g["lr"], tuple(g.get("betas", (0.9, 0.999))), g.get("eps", 1e-8)
 
 
-def chief_step(shared_grad_buffers, optimizer, max_grad_norm, lr=None):
+def chief_step(shared_grad_buffers, optimizer, max_grad_norm, lr=None, zero_grads=False):
     """One optimiser step (chief.py:13-23) on the arena behind `shared_grad_buffers`: the pending
     cross-rank SUM of the gradients (ONE exchange per optimiser step, however many worker agents of this
     process handed gradients in), then per-model clip + Adam, then clear the buffers.  Two forms of the
@@ -41,14 +41,16 @@ def chief_step(shared_grad_buffers, optimizer, max_grad_norm, lr=None):
     else:
         shared_grad_buffers.all_reduce()
         step.clip_adam(lr=lr, max_grad_norm=max_grad_norm, betas=betas, eps=eps)
-    shared_grad_buffers.reset()
+    # (in-process hand-off of this arena's own nets: the gradient arena is overwritten by the next update, no fill needed;
+    #  the spawned chief of main.py:57-60 goes through chief() below and keeps the reference's zero-fill)
+    shared_grad_buffers.reset(zero=zero_grads)
 
 
 def chief(update_threshold, traffic_light, counter, shared_model_list, shared_grad_buffers, optimizer,
           son_process_counter, max_grad_norm, total_thread):
     while True:
         if counter.get() >= update_threshold:
-            chief_step(shared_grad_buffers, optimizer, max_grad_norm)
+            chief_step(shared_grad_buffers, optimizer, max_grad_norm, zero_grads=True)
             # separate-process mode (main.py:57-60): the workers' weight pull and next add_gradient run on
             # their own streams in other processes — the clip+Adam graph and the gradient clear must have
             # finished on the device before the light flips

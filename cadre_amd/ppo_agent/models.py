@@ -254,6 +254,7 @@ class Shared_grad_buffers(object):
         with self.lock:
             if src is not self.arena:                     # a worker agent with its own nets (reference topology)
                 self.arena.grads.add_(src.grads)
+                self._accumulated = True
                 if self.arena.grads.is_cuda:              # the worker overwrites src.grads in its next update
                     torch.cuda.current_stream().synchronize()
             self.counter.increment()
@@ -356,7 +357,12 @@ class Shared_grad_buffers(object):
     def average_gradient(self):
         self.arena.grads.div_(max(1, self.counter.get()))
 
-    def reset(self):
+    def reset(self, zero=True):
+        """models.py:255-258.  `zero=False` (chief_step, when only nets of this arena handed in): the next
+        update_policy WRITES every gradient element of the arena (it does not accumulate), so the 80 MB fill would
+        be overwritten unread; a foreign arena accumulated with `add_` always gets the fill."""
         self.counter.reset()
         self._reduced_at.reset()
-        self.arena.grads.zero_()
+        if zero or getattr(self, "_accumulated", False):
+            self.arena.grads.zero_()
+            self._accumulated = False

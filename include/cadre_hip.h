@@ -101,6 +101,9 @@ int cadre_conv3x3_ring_ntile(int32_t F, int32_t H, int32_t W, int32_t N, int32_t
  * one): workgroups x 4 waves, each iters x 8 register-operand MFMAs on independent accumulators (fp32:
  * v_mfma_f32_32x32x2_f32 = 4096 FLOP, bf16: v_mfma_f32_32x32x16_bf16 = 32768 FLOP).  The caller times the launch. */
 int cadre_mfma_peak(int32_t bf16, int32_t workgroups, int32_t iters, float* sink, void* stream);
+/* bf16 MFMA shape comparison on pseudo-random register operands (peaks.hip): shape 32 = v_mfma_f32_32x32x16_bf16,
+ * shape 16 = v_mfma_f32_16x16x32_bf16; 262144 FLOP per wave and iteration either way; workgroups x 4 waves. */
+int cadre_mfma_shape(int32_t shape, int32_t workgroups, int32_t iters, float* sink, void* stream);
 /* HBM stream peaks of this device (peaks.hip): mode 0 reads `bytes` from src with 16-B loads, 8 in flight per lane
  * (nothing stored), mode 1 copies src -> dst.  The caller times the launch (read: bytes / t, copy: 2 * bytes / t). */
 int cadre_hbm_stream(int32_t mode, const void* src, void* dst, int64_t bytes, float* sink, void* stream);

@@ -41,6 +41,11 @@ def measure():
             tf = wgs * 4 * iters * 8 * flop / t / 1e12
             out["mfma_%s_%dwave_TFLOPs" % (name, wps)] = round(tf, 1)
             out["mfma_%s_%dwave_clock_GHz" % (name, wps)] = round(tf * 1e12 / (1024 * per_clk) / 1e9, 3)
+    # bf16 MFMA shapes on random operands: FLOP/s at the clock the chip holds for each
+    for shape in (32, 16):
+        wgs, iters = 512, 20000
+        t = timed(lambda: hip.check(L.cadre_mfma_shape(shape, wgs, iters, hip.ptr(sink), hip.stream()), "cadre_mfma_shape"), reps=3)
+        out["mfma_bf16_random_%s_TFLOPs" % ("32x32x16" if shape == 32 else "16x16x32")] = round(wgs * 4 * iters * 262144.0 / t / 1e12, 1)
     return out
 
 
