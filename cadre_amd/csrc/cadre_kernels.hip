@@ -39,6 +39,17 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
+// Device-side fill used instead of hipMemsetAsync: every launch function here may be captured into a hipGraph, and a
+// memset NODE was observed to replay a 0xD3 byte pattern instead of zeros on ROCm 7.2 (act() replays encoded the new
+// frame with garbage route maxima; the update graph's loss sums likewise).
+__global__ void zero_u32_kernel(uint32_t* p, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline void zero_words(void* p, int64_t n_words, hipStream_t st) {
+  const int blocks = (int)std::min<int64_t>((n_words + 255) / 256, 64);
+  hipLaunchKernelGGL(zero_u32_kernel, dim3(blocks), dim3(256), 0, st, (uint32_t*)p, n_words);
+}
+
 // ============================================================================ pre_process
 __global__ void route_max_kernel(const uint8_t* route, uint32_t* frame_max, int per_frame, const int64_t* frame_idx = nullptr) {
   const int f = blockIdx.y;
@@ -152,8 +163,7 @@ extern "C" int cadre_preprocess_bf16pad(const uint8_t* rgb, const uint8_t* route
   FAIL_IF(!rgb || !route || !lut255 || !out || !frame_max || F < 1 || H < 1 || W < 1 || pad_t < 0 || pad_l < 0 ||
               Hp < H + pad_t || Wp < W + pad_l,
           "cadre_preprocess_bf16pad: bad argument");
-  hipError_t e = hipMemsetAsync(frame_max, 0, sizeof(uint32_t) * F, ST(stream));
-  if (e != hipSuccess) return (int)e;
+  zero_words(frame_max, F, ST(stream));
   const int per = H * W;
   dim3 g1(min(64, (per + 255) / 256), F);
   hipLaunchKernelGGL(route_max_kernel, g1, dim3(256), 0, ST(stream), route, frame_max, per);
@@ -236,8 +246,7 @@ extern "C" int cadre_pack_obs(const uint8_t* rgb, const uint8_t* route, uint32_t
                               void* stream) {
   FAIL_IF(!rgb || !route || !out || !frame_max || F < 1 || H < 1 || W < 1 || (frame_idx && n_src < 1), "cadre_pack_obs: bad argument");
   const int nmax = frame_idx ? n_src : F;                 // route maxima per SOURCE frame (frame_max holds that many)
-  hipError_t e = hipMemsetAsync(frame_max, 0, sizeof(uint32_t) * nmax, ST(stream));
-  if (e != hipSuccess) return (int)e;
+  zero_words(frame_max, nmax, ST(stream));
   const int per = H * W;
   dim3 g1(min(64, (per + 255) / 256), nmax);
   hipLaunchKernelGGL(route_max_kernel, g1, dim3(256), 0, ST(stream), route, frame_max, per, (const int64_t*)nullptr);
@@ -255,8 +264,7 @@ extern "C" int cadre_preprocess(const uint8_t* rgb, const uint8_t* route, const 
                                 int32_t F, int32_t H, int32_t W, void* stream) {
   FAIL_IF(!rgb || !route || !lut255 || !out || !frame_max || F < 1 || H < 1 || W < 1,
           "cadre_preprocess: bad argument");
-  hipError_t e = hipMemsetAsync(frame_max, 0, sizeof(uint32_t) * F, ST(stream));
-  if (e != hipSuccess) return (int)e;
+  zero_words(frame_max, F, ST(stream));
   const int per = H * W;
   dim3 g1(min(64, (per + 255) / 256), F);
   hipLaunchKernelGGL(route_max_kernel, g1, dim3(256), 0, ST(stream), route, frame_max, per);
@@ -1477,8 +1485,7 @@ extern "C" int cadre_clip_adam(float* params, const float* grads, float* exp_avg
                                double beta1, double beta2, double eps, int32_t step, void* stream) {
   FAIL_IF(!params || !grads || !exp_avg || !exp_avg_sq || !seg_off || !norms2 || n_models < 1 || step < 1,
           "cadre_clip_adam: bad argument");
-  hipError_t e = hipMemsetAsync(norms2, 0, sizeof(double) * n_models, ST(stream));
-  if (e != hipSuccess) return (int)e;
+  zero_words(norms2, 2 * (int64_t)n_models, ST(stream));
   dim3 grid(64, n_models);
   hipLaunchKernelGGL(sqnorm_kernel, grid, dim3(256), 0, ST(stream), grads, seg_off, norms2, (int64_t)0, (int64_t)1 << 62);
   const double bc1 = 1.0 - pow(beta1, (double)step);

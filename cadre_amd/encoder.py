@@ -185,7 +185,16 @@ class DANetEncoderHIP:
         self.ita_b2 = torch.stack(b2).contiguous().to(dev)                # [6][256]
         self.temperature = 256 ** 0.5                                     # intertask_att.py:29
         self.lut255 = torch.from_numpy((np.arange(256) / 255.).astype(np.float32)).to(dev)   # agent.py:46
+        if self.fused_stem and not self.bf16:
+            # the fused front converts bytes arithmetically (x * fl(1/255) + one correction) instead of through the table:
+            # bit-exactness with float32(i / 255.) depends on the compiler keeping that sequence — checked once per
+            # encoder on the device, the table path takes over if a single byte differs
+            bad = torch.zeros(1, dtype=torch.int32, device=dev)
+            hip.check(hip.lib().cadre_div255_selfcheck(hip.ptr(self.lut255), hip.ptr(bad), hip.stream()), "cadre_div255_selfcheck")
+            if int(bad.item()) != 0:
+                self.fused_stem = False
         self._ws = {}
+        self.ws_generation = 0
         self.n_weights = sum(t.numel() for t in self._all_weight_tensors())
 
     def _all_weight_tensors(self):
@@ -199,10 +208,20 @@ class DANetEncoderHIP:
 
     # ------------------------------------------------------------------ workspace
     def _buf(self, key, shape, dtype=torch.float32, zero=False):
-        t = self._ws.get(key)
-        if t is None or t.shape != torch.Size(shape) or t.dtype != dtype:
-            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
-            self._ws[key] = t
+        """Workspace tensor `key` of the given shape: the two most recent shapes of a key stay alive (act() alternates
+        between 1-frame and 8-frame passes; hipGraphs captured over these tensors hold their addresses), a third one
+        replaces the older and bumps `ws_generation` — holders of captured graphs re-capture when it moved."""
+        slot = self._ws.setdefault(key, [])
+        for i, t in enumerate(slot):
+            if t.shape == torch.Size(shape) and t.dtype == dtype:
+                if i:
+                    slot.insert(0, slot.pop(i))
+                return t
+        t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+        slot.insert(0, t)
+        if len(slot) > 2:
+            slot.pop()
+            self.ws_generation += 1
         return t
 
     # ------------------------------------------------------------------ layers

@@ -35,6 +35,7 @@ class PPOLearnerHIP:
         self._graphs = {}
         self._wp = None            # recurrent weights in MFMA fragment order (forward, backward), re-packed per optimiser step
         self._wp_key = None
+        self.pack_outside_capture = False      # act() graphs: the copies are refreshed eagerly before each replay
         self.launches = {}
         self.use_graphs = os.environ.get("CADRE_HIP_GRAPHS", "1") != "0"
         self.use_sorted = os.environ.get("CADRE_SORTED_UPDATE", "1") != "0"
@@ -79,7 +80,10 @@ class PPOLearnerHIP:
         if self._wp is None:
             n = ((a.D + 15) // 16) * 4 * (a.DP // 16) * 256
             self._wp = torch.zeros(2, a.Z, n, device=a.device)
-        if key != self._wp_key or torch.cuda.is_current_stream_capturing():
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing and self.pack_outside_capture:
+            return self._wp[0, g0:], gs * self._wp.stride(1)     # (the caller refreshed the copies before the replay)
+        if key != self._wp_key or capturing:
             hip.check(hip.lib().cadre_pack_lstm_weights(hip.ptr(a.params[a.o_whh:]), a.size_L, a.DP, a.D, a.Z, hip.ptr(self._wp[0]),
                                                         hip.ptr(self._wp[1]), self._wp.stride(1), hip.stream()),
                       "cadre_pack_lstm_weights")

@@ -149,6 +149,53 @@ def test_act_matches_reference(golden):
         assert len(ctl) == 3
 
 
+def test_act_graph_equals_eager_launch_chain():
+    """act() captured into one hipGraph per (window mode, command) (reference agent.py:114-141; ~150 launches per env
+    step otherwise): identical features, actions, log-probs, values, route mutation and global-RNG consumption as the
+    eager launch chain over 14 sliding-window steps (every command, first pass / warm-up / capture / replays), also when
+    the eager path (get_latent_feature) runs in between and when the encoder workspace is re-shaped by a bigger batch."""
+    import time
+    H, W = 144, 256
+    eager, graphed = make_agent(H, W), make_agent(H, W)
+    eager.act_graph, graphed.act_graph = False, True
+    steps = synth.synth_rollout(14, H, W, seed=31)
+    for i in range(len(steps)):
+        steps[i]["command"] = i % 4 if i < 12 else 1
+    outs = []
+    for ag in (eager, graphed):
+        torch.manual_seed(77)
+        res, t_steps = [], []
+        for i, td in enumerate(steps):
+            obs = dict(rgb=td["rgb"], route_fig=td["route_fig"].copy(), measurements=td["measurements"], command=td["command"])
+            if ag is graphed and i == 9:      # the eager feature path in between: the latent cache stays consistent
+                f2 = ag.get_latent_feature(dict(obs, route_fig=obs["route_fig"].copy()))
+                assert tuple(f2.shape) == (8, 530)
+            if ag is graphed and i == 11:     # a bigger encoder batch re-shapes workspace tensors the graphs were captured over
+                big = torch.zeros(24, H, W, 3, dtype=torch.uint8, device="cuda"); bigr = torch.zeros(24, W, H, dtype=torch.uint8, device="cuda")
+                ag.vae_model.max_frames = 24
+                ag.vae_model.latent(big, bigr)
+                ag.vae_model.latent(big[:16], bigr[:16])
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            feat, a, lp, v, hid = ag.act(obs)
+            ai = [int(a[0]), int(a[1])]
+            t_steps.append(time.perf_counter() - t0)
+            res.append((feat.cpu(), ai, lp[0].cpu(), lp[1].cpu(), v[0].cpu(), v[1].cpu(), obs["route_fig"].copy()))
+            assert a[0].dim() == 0 and a[0].dtype == torch.int64 and tuple(lp[0].shape) == (1, 1) and tuple(v[0].shape) == (1, 1)
+            assert float(hid[0].abs().sum()) == 0.0
+        outs.append((res, torch.rand(1).item(), t_steps))
+    (r0, rng0, t0s), (r1, rng1, t1s) = outs
+    assert rng0 == rng1                                               # same global-generator consumption
+    for i, (x, y) in enumerate(zip(r0, r1)):
+        assert torch.equal(x[0], y[0]), i
+        assert x[1] == y[1], i
+        for k in (2, 3, 4, 5):
+            assert torch.equal(x[k], y[k]), (i, k)
+        assert np.array_equal(x[6], y[6]), i
+    assert len(graphed._ag["graphs"]) >= 1 and graphed._ag["gen"] > 0      # re-captured after the workspace moved
+    print("act() per env step (144x256, incl. H2D / D2H): eager %.2f ms, hipGraph replay %.2f ms" % (
+        1e3 * np.median(t0s[4:9]), 1e3 * np.median(t1s[6:9] + t1s[12:])))
+
+
 def test_snapshot_roundtrip(tmp_path):
     agent = make_agent(84, 84)
     p = str(tmp_path / "ppo_model_0.pt")

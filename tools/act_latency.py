@@ -20,9 +20,11 @@ agent = CadreAgent(rank=0, model_cfg=cfg, frame=8, STEER_CONTROL={i: (i - 16) / 
                    THROTTLE_CONTROL={0: [0, 0], 1: [0, 1], 2: [0.6, 0]}, ent_coeff=0.01, value_coeff=0.1,
                    clip_coeff=1.0, clip=0.1)
 agent.arena.load_numpy_state(synth.ppo_state(11))
-steps = synth.synth_rollout(40, H, W, seed=3)
-for cache in (True, False):
+steps = synth.synth_rollout(60, H, W, seed=3)
+for cache, graph in ((True, True), (True, False), (False, False)):
     agent.latent_cache = cache
+    agent.act_graph = graph
+    agent._ag = None
     agent._cache = None
     ts = []
     for td in steps:
@@ -31,5 +33,5 @@ for cache in (True, False):
         feat, a, lp, v, _ = agent.act(obs)
         ctl = agent.convert_action(a)          # .item() sync, like the reference loop
         ts.append(time.perf_counter() - t0)
-    ts = np.array(ts[5:]) * 1e3
-    print("act() %dx%d latent_cache=%s: median %.2f ms  p90 %.2f ms" % (H, W, cache, np.median(ts), np.percentile(ts, 90)))
+    ts = np.array(ts[20:]) * 1e3
+    print("act() %dx%d latent_cache=%s hipGraph=%s: median %.2f ms  p90 %.2f ms" % (H, W, cache, graph, np.median(ts), np.percentile(ts, 90)))
