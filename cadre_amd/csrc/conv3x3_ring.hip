@@ -564,11 +564,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
 
   // ---- epilogue of one item (coordinates passed in: it runs in the R(0) slot of the NEXT item)
   constexpr int NBLK = 2 * WN;
-  const int row0 = lane >> 3, c4 = (lane & 7) * 4;
+  // bf16 output (and bf16 / no residual): a lane stores EIGHT channels = 16 bytes per instruction (two passes of 16 rows per
+  // 32 x 32 block instead of four passes of 8 rows with 8-byte stores): the store tail is issue-bound, half the store and
+  // residual-load instructions at the same bytes (cdna_hip_programming.md T21)
+  constexpr bool WIDE = OUTB && RES != 1;
+  constexpr int NPASS = WIDE ? 2 : 4, RSTEP = WIDE ? 16 : 8;
+  const int row0 = WIDE ? (lane >> 2) : (lane >> 3), c4 = WIDE ? (lane & 3) * 8 : (lane & 7) * 4;
   typedef typename std::conditional<M16, f32x4, f32x16>::type acc_t;
   acc_t acc[PR][CT];                                        // [position sub-tile][channel sub-tile]
-  typedef typename std::conditional<RES == 2, u32x2, u32x4>::type rq_t;
-  rq_t rq[NBLK][4];                                        // residual quads of every block: requested during the last k-tiles
+  typedef typename std::conditional<RES == 2 && !WIDE, u32x2, u32x4>::type rq_t;
+  rq_t rq[NBLK][NPASS];                                    // residual pieces of every block: requested during the last k-tiles
   // Output addressing: element offset = ebase(item) + (32*rb + 8*i) * N + 32*cb, one add per store; a position past
   // M lies past num_records (dropped by the buffer unit), a channel past N is sent there by hand.
   auto ebase_of = [&](int mt_e, int nt_e) -> int {
@@ -578,10 +583,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
     if constexpr (RES != 0) {
       const int cb = b >> 1, rb = b & 1;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int eo = eb + (32 * rb + 8 * i) * a.N + 32 * cb;
+      for (int i = 0; i < NPASS; ++i) {
+        const int eo = eb + (32 * rb + RSTEP * i) * a.N + 32 * cb;
         const int bo = ((chm >> cb) & 1u) ? eo * RSZ : (int)OOB;
-        if constexpr (RES == 2) dst[i] = __builtin_bit_cast(rq_t, __builtin_amdgcn_raw_buffer_load_b64(rsR, bo, 0, 0));
+        if constexpr (RES == 2 && !WIDE) dst[i] = __builtin_bit_cast(rq_t, __builtin_amdgcn_raw_buffer_load_b64(rsR, bo, 0, 0));
         else dst[i] = __builtin_bit_cast(rq_t, __builtin_amdgcn_raw_buffer_load_b128(rsR, bo, 0, 0));
       }
     }
@@ -599,13 +604,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
     float* cs = reinterpret_cast<float*>(win0 + phl * win_bytes + wave * RG_SLAB);
     const int eb = ebase_of(mt_e, nt_e);
     const unsigned chm = chmask_of(nt_e);
-    f32x4 sc4[WN], sh4[WN];
+    constexpr int NV = WIDE ? 2 : 1;                        // f32x4 groups per lane and pass
+    f32x4 sc4[WN][NV], sh4[WN][NV];
 #pragma unroll
-    for (int cb = 0; cb < WN; ++cb) {
-      const int nl = nt_e * NTILE + (NTILE / 2) * wn + 32 * cb + c4;
-      sc4[cb] = *reinterpret_cast<const f32x4*>(sc_lds + nl);
-      sh4[cb] = *reinterpret_cast<const f32x4*>(sc_lds + a.ntiles * NTILE + nl);
-    }
+    for (int cb = 0; cb < WN; ++cb)
+#pragma unroll
+      for (int h = 0; h < NV; ++h) {
+        const int nl = nt_e * NTILE + (NTILE / 2) * wn + 32 * cb + c4 + 4 * h;
+        sc4[cb][h] = *reinterpret_cast<const f32x4*>(sc_lds + nl);
+        sh4[cb][h] = *reinterpret_cast<const f32x4*>(sc_lds + a.ntiles * NTILE + nl);
+      }
 #pragma unroll
     for (int b = 2; b < NBLK; ++b) req(eb, chm, b, rq[b]);
 #pragma unroll
@@ -622,34 +630,52 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
         }
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(cs + (8 * i + row0) * 36 + c4);
-        v = v * sc4[cb] + sh4[cb];
+      for (int i = 0; i < NPASS; ++i) {
+        f32x4 v[NV];
+#pragma unroll
+        for (int h = 0; h < NV; ++h) {
+          v[h] = *reinterpret_cast<const f32x4*>(cs + (RSTEP * i + row0) * 36 + c4 + 4 * h);
+          v[h] = v[h] * sc4[cb][h] + sh4[cb][h];
+        }
         if constexpr (RES != 0) {
-          f32x4 rv;
-          if constexpr (RES == 2) {
+          f32x4 rv[NV];
+          if constexpr (WIDE) {
+            const bf16x8 t = __builtin_bit_cast(bf16x8, rq[b][i]);
+            rv[0] = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+            rv[1] = f32x4{(float)t[4], (float)t[5], (float)t[6], (float)t[7]};
+          } else if constexpr (RES == 2) {
             const bf16x4 t = __builtin_bit_cast(bf16x4, rq[b][i]);
-            rv = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+            rv[0] = f32x4{(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
           } else {
-            rv = __builtin_bit_cast(f32x4, rq[b][i]);
+            rv[0] = __builtin_bit_cast(f32x4, rq[b][i]);
           }
           const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-          v += post ? zero : rv;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], act_floor);
-          v += post ? rv : zero;
+          for (int h = 0; h < NV; ++h) {
+            v[h] += post ? zero : rv[h];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[h][e] = fmaxf(v[h][e], act_floor);
+            v[h] += post ? rv[h] : zero;
+          }
         } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], act_floor);
+          for (int h = 0; h < NV; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[h][e] = fmaxf(v[h][e], act_floor);
         }
-        const int eo = eb + (32 * rb + 8 * i) * a.N + 32 * cb;
+        const int eo = eb + (32 * rb + RSTEP * i) * a.N + 32 * cb;
         const int bo = ((chm >> cb) & 1u) ? eo * ESZ : (int)OOB;
-        if constexpr (OUTB) {
+        if constexpr (WIDE) {
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { o[e] = (__bf16)v[0][e]; o[4 + e] = (__bf16)v[1][e]; }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsC, bo, 0, 0);
+        } else if constexpr (OUTB) {
           bf16x4 o;
-          o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
+          o[0] = (__bf16)v[0][0]; o[1] = (__bf16)v[0][1]; o[2] = (__bf16)v[0][2]; o[3] = (__bf16)v[0][3];
           __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rsC, bo, 0, 0);
         } else {
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsC, bo, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[0]), rsC, bo, 0, 0);
         }
       }
     }
@@ -748,7 +774,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
         // operations this wave issues in this R slot / issued in its previous one (folds: tap is unrolled)
         // (residual of output blocks 0 and 1: requested at k-tiles 7 and 8 of the item's last chunk — an HBM round trip
         //  ahead of the epilogue that adds them; the later blocks when the epilogue starts, two blocks ahead)
-        auto n_res = [&](int t) -> int { return (RES != 0 && t >= 7) ? 4 : 0; };
+        auto n_res = [&](int t) -> int { return (RES != 0 && t >= 7) ? NPASS : 0; };
         const int n_now = NBPW + sl_of(tap) + (last_c ? n_res(tap) : 0);
         const char* bs = bst + (tap % RG_NSTB) * STG_B;     // 9 k-tiles per chunk, 3 stages: the stage of k-tile `tap` is tap % 3 — static
         f32x4 afr[PR][KS], bfr[CT][KS];
@@ -910,7 +936,9 @@ static int ring_capable(int F, int H, int W, int Cin, int N, int bf16) {      //
   const long long M = (long long)F * H * W;
   // 32-bit buffer offsets: input, weights, and the output / residual at the operands' element size (an fp32 output of
   // bf16 operands is checked again at launch)
-  if (M * Cin * eb >= (1ll << 31) || M * N * eb >= (1ll << 31) || (long long)N * Cin * 9 * eb >= (1ll << 31)) return 0;
+  // (the output / residual at FOUR bytes per element: a bf16 conv may write an fp32 map — conv5a / conv5c feed PAM / CAM —
+  //  and the caller commits to this kernel on the strength of cadre_conv3x3_ring_supported)
+  if (M * Cin * eb >= (1ll << 31) || M * N * 4 >= (1ll << 31) || (long long)N * Cin * 9 * eb >= (1ll << 31)) return 0;
   ring_cfg c;
   ring_pick(M, W, N, bf16, &c);
   return c.lds <= 160 * 1024;
@@ -960,6 +988,7 @@ extern "C" int cadre_conv3x3_ring(const void* x, const void* w, const float* sca
   const int bf16 = flags & 1, out_bf16 = (flags >> 1) & 1, resid_bf16 = (flags >> 2) & 1;
   if (!x || !w || !out) return cadre_fail("cadre_conv3x3_ring: null operand");
   if (!ring_capable(F, H, W, Cin, N, bf16)) return cadre_fail("cadre_conv3x3_ring: unsupported geometry (W in 2..95, Cin a multiple of 128 bytes, N % 32 == 0, tensors < 2 GiB)");
+  if ((act & 15) > 1) return cadre_fail("cadre_conv3x3_ring: the window kernels implement act 0 (none) and 1 (ReLU) only");
   if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)out | (uintptr_t)resid) & 15) return cadre_fail("cadre_conv3x3_ring: operands must be 16-byte aligned");
   if ((long long)F * H * W * N * (out_bf16 ? 2 : 4) >= (1ll << 31) || (resid && (long long)F * H * W * N * (resid_bf16 ? 2 : 4) >= (1ll << 31)))
     return cadre_fail("cadre_conv3x3_ring: output / residual spans >= 2 GiB: chunk the batch");
