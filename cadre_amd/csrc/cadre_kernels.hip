@@ -1108,7 +1108,8 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const float* logits, int6
                                                        const float* old_logp, const float* adv, int B, int n_steer,
                                                        int n_throttle, float clip, float value_coeff,
                                                        float clip_coeff, float ent_coeff, float inv_b,
-                                                       float* losses, float* dlogits, float* dvalues, float* scratch) {
+                                                       float* losses, float* dlogits, float* dvalues, float* scratch,
+                                                       const int32_t* poison) {
   const int hd = blockIdx.y;                       // 0 steer, 1 throttle
   const int K = hd == 0 ? n_steer : n_throttle;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1195,9 +1196,11 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const float* logits, int6
         sa += __hip_atomic_load(part + 3 * w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sn += __hip_atomic_load(part + 3 * w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      losses[0] = value_coeff * 0.5f * sv * inv_b;
-      losses[1] = clip_coeff * sa * inv_b;
-      losses[2] = ent_coeff * sn * inv_b;
+      // a forward pass whose inter-workgroup wait timed out (cadre_lstm_seq_fwd) is reported where the caller looks
+      const float bad = (poison && __hip_atomic_load(poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ? __builtin_nanf("") : 0.f;
+      losses[0] = value_coeff * 0.5f * sv * inv_b + bad;
+      losses[1] = clip_coeff * sa * inv_b + bad;
+      losses[2] = ent_coeff * sn * inv_b + bad;
     }
   }
 }
@@ -1211,7 +1214,7 @@ extern "C" int cadre_ppo_loss(const float* logits, int64_t ldl, int64_t l_ns, co
                               const float* old_logp, const float* adv, int32_t B, int32_t n_out_steer,
                               int32_t n_out_throttle, float clip, float value_coeff, float clip_coeff,
                               float ent_coeff, float inv_b, float* losses, float* dlogits, float* dvalues,
-                              float* scratch, void* stream) {
+                              float* scratch, const int32_t* poison, void* stream) {
   FAIL_IF(!logits || !values || !actions || !commands || !old_values || !returns || !old_logp || !adv || !losses ||
               !dlogits || !dvalues || !scratch || B < 1 || n_out_steer < 1 || n_out_steer > MAX_NOUT || n_out_throttle < 1 ||
               n_out_throttle > MAX_NOUT || ldl < n_out_steer || ldl < n_out_throttle || ldl > 64,
@@ -1222,7 +1225,7 @@ extern "C" int cadre_ppo_loss(const float* logits, int64_t ldl, int64_t l_ns, co
   hipLaunchKernelGGL(ppo_loss_kernel, dim3((B + 15) / 16, 2), dim3(256), 0, ST(stream), logits, ldl, l_ns, values, ldv, v_ns,
                      actions, commands,
                      old_values, returns, old_logp, adv, B, n_out_steer, n_out_throttle, clip, value_coeff,
-                     clip_coeff, ent_coeff, inv_b, losses, dlogits, dvalues, scratch);
+                     clip_coeff, ent_coeff, inv_b, losses, dlogits, dvalues, scratch, poison);
   return (int)hipGetLastError();
 }
 

@@ -929,22 +929,22 @@ static void ring_pick(long long M, int W, int N, int bf16, ring_cfg* c) {
 
 static int g_ring_mode = [] { const char* e = getenv("CADRE_RING_CONV"); return e ? atoi(e) : 1; }();   // 0 off, 1 auto, 2 wherever supported
 
-static int ring_capable(int F, int H, int W, int Cin, int N, int bf16) {      // geometry the kernel can run at all
+static int ring_capable(int F, int H, int W, int Cin, int N, int bf16, int out_bytes, int resid_bytes) {   // geometry the kernel can run at all
   const int eb = bf16 ? 2 : 4;
   if (F < 1 || H < 1 || W < 2 || W > 95) return 0;
   if ((Cin * eb) % 128 != 0 || N % 32 != 0) return 0;
-  const long long M = (long long)F * H * W;
-  // 32-bit buffer offsets: input, weights, and the output / residual at the operands' element size (an fp32 output of
-  // bf16 operands is checked again at launch)
-  // (the output / residual at FOUR bytes per element: a bf16 conv may write an fp32 map — conv5a / conv5c feed PAM / CAM —
-  //  and the caller commits to this kernel on the strength of cadre_conv3x3_ring_supported)
-  if (M * Cin * eb >= (1ll << 31) || M * N * 4 >= (1ll << 31) || (long long)N * Cin * 9 * eb >= (1ll << 31)) return 0;
+  const long long M = (long long)F * H * W, lim = 1ll << 31;
+  // 32-bit buffer offsets: input, weights, output and residual each at their own element size (resid_bytes 0 = none)
+  if (M * Cin * eb >= lim || (long long)N * Cin * 9 * eb >= lim || M * N * out_bytes >= lim || M * N * resid_bytes >= lim) return 0;
   ring_cfg c;
   ring_pick(M, W, N, bf16, &c);
   return c.lds <= 160 * 1024;
 }
-extern "C" int cadre_conv3x3_ring_supported(int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t bf16) {
-  if (g_ring_mode == 0 || !ring_capable(F, H, W, Cin, N, bf16)) return 0;
+// flags: the launch's word (1 bf16 operands, 2 bf16 output, 4 bf16 residual) + 8 = a residual is present; a caller that
+// commits to this kernel on a 1 here gets no geometry failure from cadre_conv3x3_ring with the same flags
+extern "C" int cadre_conv3x3_ring_supported(int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t flags) {
+  const int bf16 = flags & 1;
+  if (g_ring_mode == 0 || !ring_capable(F, H, W, Cin, N, bf16, (flags & 2) ? 2 : 4, (flags & 8) ? ((flags & 4) ? 2 : 4) : 0)) return 0;
   if (g_ring_mode == 1 && !bf16 && N > 64) return 0;      // fp32: the tile kernels win from N = 128 on
   return 1;
 }
@@ -987,11 +987,10 @@ extern "C" int cadre_conv3x3_ring(const void* x, const void* w, const float* sca
                                   int32_t flags, void* stream) {
   const int bf16 = flags & 1, out_bf16 = (flags >> 1) & 1, resid_bf16 = (flags >> 2) & 1;
   if (!x || !w || !out) return cadre_fail("cadre_conv3x3_ring: null operand");
-  if (!ring_capable(F, H, W, Cin, N, bf16)) return cadre_fail("cadre_conv3x3_ring: unsupported geometry (W in 2..95, Cin a multiple of 128 bytes, N % 32 == 0, tensors < 2 GiB)");
+  if (!ring_capable(F, H, W, Cin, N, bf16, out_bf16 ? 2 : 4, resid ? (resid_bf16 ? 2 : 4) : 0))
+    return cadre_fail("cadre_conv3x3_ring: unsupported geometry (W in 2..95, Cin a multiple of 128 bytes, N % 32 == 0, every tensor < 2 GiB: chunk the batch)");
   if ((act & 15) > 1) return cadre_fail("cadre_conv3x3_ring: the window kernels implement act 0 (none) and 1 (ReLU) only");
   if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)out | (uintptr_t)resid) & 15) return cadre_fail("cadre_conv3x3_ring: operands must be 16-byte aligned");
-  if ((long long)F * H * W * N * (out_bf16 ? 2 : 4) >= (1ll << 31) || (resid && (long long)F * H * W * N * (resid_bf16 ? 2 : 4) >= (1ll << 31)))
-    return cadre_fail("cadre_conv3x3_ring: output / residual spans >= 2 GiB: chunk the batch");
   ring_args a;
   a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.resid = resid; a.out = out;
   a.M = F * H * W; a.H = H; a.W = W; a.Cin = Cin; a.N = N; a.NC = Cin * (bf16 ? 2 : 4) / 128;

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64 * WVM * WVN, ((WVM * WM + WVN * WN) * 2 * 32 * 3
   const int tilesN = (p.N + BN - 1) / BN;
   int bid = blockIdx.x;
 #ifndef GEMM_NO_XCD_REMAP
-  {
+  if (p.seg_mode != 3) {      // (compact rows: the live tiles are the grid's first ones — dealt round-robin they cover all XCDs)
     const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
@@ -92,6 +92,20 @@ __global__ __launch_bounds__(64 * WVM * WVN, ((WVM * WM + WVN * WN) * 2 * 32 * 3
       if (seg_cnt <= 0 || b_lo + BM <= seg_beg || b_lo >= seg_beg + seg_cnt) return;
     }
   }
+  // seg_mode 3: the M index runs over the batch entry's OWN rows only, period after period — compact row mc is row
+  // (mc / cnt) * seg_period + beg + mc % cnt of A and C — so a tile holds BM useful rows wherever the run starts
+  int c_cnt = 1, c_rows = 0;
+  if constexpr (AMODE == 0 && BMODE == 0) {
+    if (p.seg_mode == 3) {
+      c_cnt = max(seg_cnt, 1);
+      c_rows = seg_cnt > 0 ? (p.M / p.seg_period) * seg_cnt : 0;
+      if (m0 >= c_rows) return;
+    }
+  }
+  auto compact_row = [&](int mc) {          // mc < c_rows
+    const int t = mc / c_cnt;
+    return t * p.seg_period + seg_beg + (mc - t * c_cnt);
+  };
   const int nk_total = (p.K + BK - 1) / BK;
   int kt_begin = 0, kt_end = nk_total;
   int k_per = 1, k_first = 0, k_run = 1;       // seg_mode 2: k-tiles [k_first, k_first+k_run) of each period
@@ -128,6 +142,9 @@ __global__ __launch_bounds__(64 * WVM * WVN, ((WVM * WM + WVN * WN) * 2 * 32 * 3
     for (int i = 0; i < RA; ++i) {
       const int m = m0 + rr + RP * i;
       aoff[i] = m < p.M ? (unsigned)(((int64_t)m * p.lda + cc * 4) * 4) : OOB;
+      if constexpr (BMODE == 0) {
+        if (p.seg_mode == 3) aoff[i] = m < c_rows ? (unsigned)(((int64_t)compact_row(m) * p.lda + cc * 4) * 4) : OOB;
+      }
       amask[i] = 0;
     }
   } else if constexpr (AMODE >= 2) {
@@ -418,10 +435,12 @@ __global__ __launch_bounds__(64 * WVM * WVN, ((WVM * WM + WVN * WN) * 2 * 32 * 3
     const bool cvalid = col < p.N;
     const bool c16 = (p.flags & 2) != 0;      // C is bf16 (config C3: fp32 stem feeding the bf16 trunk)
     const int esz = c16 ? 2 : 4;
-    const int64_t rows_left = (int64_t)p.M - m0;
+    bool seg3 = false;
+    if constexpr (AMODE == 0 && BMODE == 0) seg3 = p.seg_mode == 3;
+    const int64_t rows_left = seg3 ? (int64_t)p.M : (int64_t)p.M - m0;      // (compact rows: offsets from the operand's first row)
     auto window = [](int64_t bytes) { return (int)(bytes < 0x7fffffff ? bytes : 0x7fffffff); };
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(reinterpret_cast<char*>(C) + (int64_t)m0 * p.ldc * esz), 0, window(rows_left * p.ldc * esz), 0x00020000);
+        (void*)(reinterpret_cast<char*>(C) + (seg3 ? 0 : (int64_t)m0 * p.ldc * esz)), 0, window(rows_left * p.ldc * esz), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(resid ? resid + (int64_t)m0 * p.ldr : p.C), 0, resid ? window(rows_left * p.ldr * 4) : 0, 0x00020000);
     const int lrow = lane / LPR;
@@ -463,7 +482,13 @@ __global__ __launch_bounds__(64 * WVM * WVN, ((WVM * WM + WVN * WN) * 2 * 32 * 3
             }
             if constexpr (RES) { if (post) v += rv[it]; }
           }
-          const unsigned off = coff + (unsigned)((r0 + it * RPI) * p.ldc * esz);
+          unsigned off = coff + (unsigned)((r0 + it * RPI) * p.ldc * esz);
+          if constexpr (AMODE == 0 && BMODE == 0) {
+            if (seg3) {
+              const int mc = m0 + r0 + it * RPI + lrow;
+              off = (cvalid && mc < c_rows) ? (unsigned)((compact_row(mc) * p.ldc + col) * esz) : OOB;
+            }
+          }
           if (c16) {
             typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -580,6 +605,7 @@ static int pick_tile(const cadre_gemm_t& p) {
   if (p.seg_mode == 1 && skinny && cadre_gemm_f32_skinny_ok(p)) return 11;
 #endif
   if (p.seg_mode == 1 && (p.N >= 96 || p.seg_period % 64 != 0)) return 9;
+  if (p.seg_mode == 3) return p.N >= 96 ? 9 : 3;
   const Cand* c = p.N <= 64 ? narrow : (p.a_mode >= 2 ? big_conv : big);
   int best = c[0].id;
   double best_e = -1.0;
@@ -645,7 +671,11 @@ extern "C" int cadre_gemm_f32(const cadre_gemm_t* pp, void* stream) {
   if (p.r_mod < 1) p.r_mod = 1 << 30;
   GEMM_CHECK(p.split_k == 1 || p.batch == 1 || p.c_str >= (int64_t)p.M * p.ldc, "batched split_k needs c_str >= M*ldc");
   if (p.seg_mode) {
-    GEMM_CHECK(p.row_seg && p.seg_period > 0 && p.seg_div > 0 && (p.seg_mode == 1 || p.seg_mode == 2), "bad row segment fields");
+    GEMM_CHECK(p.row_seg && p.seg_period > 0 && p.seg_div > 0 && p.seg_mode >= 1 && p.seg_mode <= 3, "bad row segment fields");
+    if (p.seg_mode == 3)
+      GEMM_CHECK(p.a_mode == 0 && p.b_mode == 0 && p.split_k == 1 && !p.resid && !(p.flags & 2) && p.M % p.seg_period == 0 &&
+                     ((p.N | p.ldc) & 3) == 0 && ((uintptr_t)p.C & 15) == 0 && (int64_t)p.M * p.ldc * 4 < (1ll << 31),
+                 "seg_mode 3 (compact rows) needs an NT product, no split / residual, M%seg_period==0, N%4==0, ldc%4==0, C below 2 GiB");
     if (p.seg_mode == 1) GEMM_CHECK(p.seg_period % 32 == 0 && p.M % p.seg_period == 0, "seg_mode 1 needs seg_period%32==0, M%seg_period==0");
     if (p.seg_mode == 2) GEMM_CHECK(p.seg_period % 32 == 0 && p.K % p.seg_period == 0 && p.split_k == 1 && p.a_mode == 1 && p.b_mode == 1,
                                     "seg_mode 2 needs k-major operands, seg_period%32==0, K%seg_period==0");

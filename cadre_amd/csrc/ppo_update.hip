@@ -42,6 +42,21 @@ namespace {
 
 __device__ __forceinline__ float sigmoid_(float x) { return 1.f / (1.f + expf(-x)); }
 
+// -DLSTM_TRACE (tools/lstm_trace.py builds its own library; the product build has no stamp): wave 0 of every workgroup
+// of the step kernels stamps the shader clock at section boundaries and the 100 MHz wall clock at entry and exit
+#ifdef LSTM_TRACE
+__device__ long long* g_lstm_trace_dev = nullptr;
+#define LS_DECL unsigned long long ls_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long ls_r0 = __builtin_amdgcn_s_memrealtime()
+#define LS_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ls_t[k]) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define LS_FLUSH() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); LS_STAMP(6); if (g_lstm_trace_dev && threadIdx.x == 0) { \
+    long long* tr_ = g_lstm_trace_dev + (size_t)blockIdx.x * 16; for (int k_ = 0; k_ < 7; ++k_) tr_[k_] = (long long)ls_t[k_]; \
+    tr_[8] = (long long)ls_r0; tr_[9] = (long long)__builtin_amdgcn_s_memrealtime(); tr_[10] = 1; } } while (0)
+#else
+#define LS_DECL do { } while (0)
+#define LS_STAMP(k) do { } while (0)
+#define LS_FLUSH() do { } while (0)
+#endif
+
 struct fwd_args {
   const float* Wp;      // recurrent weights in fragment order (cadre_pack_lstm_weights), net stride wp_str
   const float* bias;    // [H4] of net 0, net stride b_str (may be null)
@@ -61,126 +76,309 @@ struct fwd_args {
 // in that XCD's 4 MB L2 between time steps instead of coming from the Infinity Cache every step; `rev` walks the unit
 // slices in the opposite order on alternate steps (the most recently used weights are re-used first: an LRU cache
 // slightly smaller than the set it cycles through would otherwise miss every time).  Placement only affects speed.
+// Rows sorted by command: the chunks start AT the net's first row and cover exactly its run [r_lo, r_hi) — traced
+// (tools/lstm_trace.py) the MFMA loop runs at 93 % of the fp32 matrix-pipe rate, so every 16-row tile of other nets' rows
+// inside an aligned cover was pipe time on the step's critical path (a 16-row run unaligned in 32-row tiles: 64 rows).
 __device__ __forceinline__ bool step_item(int Z, int NS, int rev, const int32_t* row_seg, int B, int rows, int& z, int& slice,
-                                          int& row0, int& r_hi) {
+                                          int& row0, int& r_lo, int& r_hi) {
   const int id = blockIdx.x;
   z = id % Z;
   const int rest = id / Z;
   slice = rest % NS;
   if (rev) slice = NS - 1 - slice;
-  int r_lo = 0;
+  r_lo = 0;
   r_hi = B;
-  if (row_seg) {             // the 32-row tiles that intersect the net's run: the rows the segment-aware GEMMs read and write
+  if (row_seg) {
     const int beg = row_seg[2 * z], cnt = row_seg[2 * z + 1];
     if (cnt <= 0) return false;
-    r_lo = beg & ~31;
-    r_hi = min(B, (beg + cnt + 31) & ~31);
+    r_lo = beg;
+    r_hi = min(B, beg + cnt);
   }
   row0 = r_lo + (rest / NS) * rows;
   return row0 < r_hi;
 }
 
-// 16*RT rows x 16 units x 4 gates per workgroup; NB = K / 16 k-blocks (K = ldh, zero padded past D).
+template <int V>
+struct int_c { static constexpr int value = V; };
+
+// 16*RT rows x 16 units x 4 gates per workgroup (the last chunk of a run: only its live 16-row tiles); NB = K / 16
+// k-blocks (K = ldh, zero padded past D).
 // LDS: the h_{t-1} rows of the chunk (shared by the four gate waves), pitch 552 floats = 138 16-byte slots:
 // conflict-free for the fragment reads (lane (c, q) reads slot 138*row + 4j + q: 16 distinct slots mod 16 per lane group).
 template <int RT, int NB>
 __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(fwd_args p) {
   constexpr int PD = NB / 2;                              // k-blocks of weights in flight per wave (17 KiB)
   constexpr int AP = 552;                                 // LDS row pitch of the activation rows (floats)
-  constexpr int ROWS = 16 * RT, K = 16 * NB, NCH = ROWS * (K / 4), NLD = (NCH + 255) / 256;
-  __shared__ __attribute__((aligned(16))) float ah[ROWS * AP];
-  __shared__ float xg[4][ROWS][16];
+  constexpr int K = 16 * NB;
+  __shared__ __attribute__((aligned(16))) float ah[16 * RT * AP];
+  __shared__ float xg[4 * 16 * RT * 16];
   const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
   const int c = lane & 15, q = lane >> 4;
-  int z, slice, row0, r_hi;
-  if (!step_item(p.Z, p.NS, p.rev, p.row_seg, p.B, ROWS, z, slice, row0, r_hi)) return;
+  int z, slice, row0, r_lo, r_hi;
+  if (!step_item(p.Z, p.NS, p.rev, p.row_seg, p.B, 16 * RT, z, slice, row0, r_lo, r_hi)) return;
+  LS_DECL;
+  LS_STAMP(0);
   const int D = p.D, u = slice * 16 + c;
   const int uc = u < D ? u : D - 1;                       // units past D: zero weights, result discarded
-  // fragment order: [slice][gate][k-block][lane][4] — one contiguous KiB per wave and k-block
-  const float* wp = p.Wp + (int64_t)z * p.wp_str + ((int64_t)(slice * 4 + g) * NB * 64 + lane) * 4;
-  f32x4 bq[PD];
-#pragma unroll
-  for (int j = 0; j < PD; ++j) bq[j] = *reinterpret_cast<const f32x4*>(wp + 256 * j);
-  // activation rows -> LDS (every thread 16-byte chunks, coalesced along the rows; rows past the chunk repeat the last)
-  const float* hp = p.Hprev + (int64_t)z * p.h_str;
-  f32x4 st[NLD];
-#pragma unroll
-  for (int i = 0; i < NLD; ++i) {
-    const int idx = min(tid + 256 * i, NCH - 1), r = idx / (K / 4), ch = idx - r * (K / 4);
-    st[i] = *reinterpret_cast<const f32x4*>(hp + (int64_t)min(row0 + r, r_hi - 1) * p.ldh + 4 * ch);
-  }
-  // accumulators start from the x-projection (+ b_ih, folded there) and b_hh: D[row = 4q + r][col = c]
-  // (loaded unconditionally from clamped addresses: a load under a per-element condition is a branch + vmcnt(0) each)
-  float* gz = p.G + (int64_t)z * p.g_str;
-  const float bv = p.bias ? p.bias[(int64_t)z * p.b_str + g * D + uc] : 0.f;
-  // (two accumulators per row tile, even / odd k-steps: a single chain of this MFMA is latency- not issue-paced)
-  f32x4 acc[RT][2];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    acc[rt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      acc[rt][0][r] = gz[(int64_t)min(row0 + 16 * rt + 4 * q + r, r_hi - 1) * p.ldg + g * D + uc] + bv;
-  }
-#pragma unroll
-  for (int i = 0; i < NLD; ++i) {
-    const int idx = tid + 256 * i, r = idx / (K / 4), ch = idx - r * (K / 4);
-    if (idx < NCH) *reinterpret_cast<f32x4*>(ah + r * AP + 4 * ch) = st[i];
-  }
-  __syncthreads();
-  const float* arow = ah + c * AP + 4 * q;
-  // (the scheduler sinks loads towards their use to save registers; the order is pinned so that PD blocks of weights
-  //  stay in flight — one wave per SIMD has only its own loads to hide the L2 / Infinity Cache latency — and the
-  //  activation fragments are read from LDS one k-block ahead of the MFMAs that use them)
-  f32x4 an[RT];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) an[rt] = *reinterpret_cast<const f32x4*>(arow + 16 * rt * AP);
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    const int s = j % PD;
-    const f32x4 b = bq[s];
-    f32x4 a[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) a[rt] = an[rt];
-    if (j + 1 < NB) {
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) an[rt] = *reinterpret_cast<const f32x4*>(arow + 16 * rt * AP + 16 * (j + 1));
-    }
-    if (j + PD < NB) bq[s] = *reinterpret_cast<const f32x4*>(wp + 256 * (j + PD));
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-        acc[rt][i & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][i], b[i], acc[rt][i & 1], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  // the four gate tiles meet in LDS
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) xg[g][16 * rt + 4 * q + r][c] = acc[rt][0][r] + acc[rt][1][r];
-  __syncthreads();
   const int64_t hz = (int64_t)z * p.h_str;
+  float* gz = p.G + (int64_t)z * p.g_str;
+  auto body = [&](auto lt_) {
+    constexpr int LT = decltype(lt_)::value;              // live 16-row tiles of this chunk
+    constexpr int ROWS = 16 * LT, NCH = ROWS * (K / 4), NLD = (NCH + 255) / 256;
+    // Issue order = arrival order (vmcnt retires in order): the activation rows first — they go to LDS while the weights
+    // are still in flight — then the accumulator seeds and the cell state, then the weight ring.
+    // activation rows -> LDS (every thread 16-byte chunks, coalesced along the rows; rows past the chunk repeat the last)
+    const float* hp = p.Hprev + hz;
+    f32x4 st[NLD];
 #pragma unroll
-  for (int e = 0; e < RT; ++e) {
-    const int pr = tid + 256 * e, rl = pr >> 4, uu = pr & 15;
-    const int row = row0 + rl, un = slice * 16 + uu;
-    if (row >= r_hi || un >= D) continue;
-    const float ig = sigmoid_(xg[0][rl][uu]);
-    const float fg = sigmoid_(xg[1][rl][uu]);
-    const float gg = tanhf(xg[2][rl][uu]);
-    const float og = sigmoid_(xg[3][rl][uu]);
-    const int64_t o = hz + (int64_t)row * p.ldh + un;
-    const float cn = fg * p.Cprev[o] + ig * gg;
-    const float tc = tanhf(cn);
-    float* gr = gz + (int64_t)row * p.ldg + un;
-    gr[0] = ig; gr[D] = fg; gr[2 * D] = gg; gr[3 * D] = og;
-    p.Cout[o] = cn;
-    p.TCout[o] = tc;
-    p.Hout[o] = og * tc;
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = min(tid + 256 * i, NCH - 1), r = idx / (K / 4), ch = idx - r * (K / 4);
+      st[i] = *reinterpret_cast<const f32x4*>(hp + (int64_t)min(row0 + r, r_hi - 1) * p.ldh + 4 * ch);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // accumulators start from the x-projection (+ b_ih, folded there) and b_hh: D[row = 4q + r][col = c]
+    // (loaded unconditionally from clamped addresses: a load under a per-element condition is a branch + vmcnt(0) each)
+    const float bv = p.bias ? p.bias[(int64_t)z * p.b_str + g * D + uc] : 0.f;
+    // (two accumulators per row tile, even / odd k-steps: a single chain of this MFMA is latency- not issue-paced)
+    f32x4 acc[LT][2];
+#pragma unroll
+    for (int rt = 0; rt < LT; ++rt) {
+      acc[rt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        acc[rt][0][r] = gz[(int64_t)min(row0 + 16 * rt + 4 * q + r, r_hi - 1) * p.ldg + g * D + uc];
+    }
+    float cprev[LT];                                      // c_{t-1} of the elements this thread finishes (clamped: discarded past the run)
+#pragma unroll
+    for (int e = 0; e < LT; ++e) {
+      const int pr = tid + 256 * e, rl = pr >> 4, uu = pr & 15;
+      cprev[e] = p.Cprev[hz + (int64_t)min(row0 + rl, r_hi - 1) * p.ldh + min(slice * 16 + uu, D - 1)];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // fragment order: [slice][gate][k-block][lane][4] — one contiguous KiB per wave and k-block
+    const float* wp = p.Wp + (int64_t)z * p.wp_str + ((int64_t)(slice * 4 + g) * NB * 64 + lane) * 4;
+    f32x4 bq[PD];
+#pragma unroll
+    for (int j = 0; j < PD; ++j) bq[j] = *reinterpret_cast<const f32x4*>(wp + 256 * j);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + 256 * i, r = idx / (K / 4), ch = idx - r * (K / 4);
+      if (idx < NCH) *reinterpret_cast<f32x4*>(ah + r * AP + 4 * ch) = st[i];
+    }
+#pragma unroll
+    for (int rt = 0; rt < LT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[rt][0][r] += bv;
+    LS_STAMP(1);
+    __syncthreads();
+    LS_STAMP(2);
+    const float* arow = ah + c * AP + 4 * q;
+    // (the scheduler sinks loads towards their use to save registers; the order is pinned so that PD blocks of weights
+    //  stay in flight — one wave per SIMD has only its own loads to hide the L2 / Infinity Cache latency — and the
+    //  activation fragments are read from LDS one k-block ahead of the MFMAs that use them)
+    f32x4 an[LT];
+#pragma unroll
+    for (int rt = 0; rt < LT; ++rt) an[rt] = *reinterpret_cast<const f32x4*>(arow + 16 * rt * AP);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int s = j % PD;
+      const f32x4 b = bq[s];
+      f32x4 a[LT];
+#pragma unroll
+      for (int rt = 0; rt < LT; ++rt) a[rt] = an[rt];
+      if (j + 1 < NB) {
+#pragma unroll
+        for (int rt = 0; rt < LT; ++rt) an[rt] = *reinterpret_cast<const f32x4*>(arow + 16 * rt * AP + 16 * (j + 1));
+      }
+      if (j + PD < NB) bq[s] = *reinterpret_cast<const f32x4*>(wp + 256 * (j + PD));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int rt = 0; rt < LT; ++rt)
+          acc[rt][i & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][i], b[i], acc[rt][i & 1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    LS_STAMP(3);
+    // the four gate tiles meet in LDS: xg[gate][row][unit]
+#pragma unroll
+    for (int rt = 0; rt < LT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xg[(g * ROWS + 16 * rt + 4 * q + r) * 16 + c] = acc[rt][0][r] + acc[rt][1][r];
+    __syncthreads();
+    LS_STAMP(4);
+#pragma unroll
+    for (int e = 0; e < LT; ++e) {
+      const int pr = tid + 256 * e, rl = pr >> 4, uu = pr & 15;
+      const int row = row0 + rl, un = slice * 16 + uu;
+      if (row >= r_hi || un >= D) continue;
+      const float ig = sigmoid_(xg[(0 * ROWS + rl) * 16 + uu]);
+      const float fg = sigmoid_(xg[(1 * ROWS + rl) * 16 + uu]);
+      const float gg = tanhf(xg[(2 * ROWS + rl) * 16 + uu]);
+      const float og = sigmoid_(xg[(3 * ROWS + rl) * 16 + uu]);
+      const int64_t o = hz + (int64_t)row * p.ldh + un;
+      const float cn = __builtin_fmaf(fg, cprev[e], ig * gg);      // (spelled out: the persistent kernel must round the same way)
+      const float tc = tanhf(cn);
+      float* gr = gz + (int64_t)row * p.ldg + un;
+      gr[0] = ig; gr[D] = fg; gr[2 * D] = gg; gr[3 * D] = og;
+      p.Cout[o] = cn;
+      p.TCout[o] = tc;
+      p.Hout[o] = og * tc;
+    }
+  };
+  if constexpr (RT == 2) {
+    if (r_hi - row0 > 16) body(int_c<2>{}); else body(int_c<1>{});
+  } else {
+    body(int_c<RT>{});
   }
+  LS_STAMP(5);
+  LS_FLUSH();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The S forward steps of all nets in ONE launch (the update's minibatch: Z = 8 nets, S = 8 steps).  A launch per step
+// re-streams its 139 KB of recurrent weights per workgroup from the Infinity Cache (37 MB per step over the chip: the 8
+// nets' weights do not fit the 32 MB of L2) behind a chain of dependent round trips (kernel arguments -> row segment ->
+// operands -> c_{t-1}); measured 19-24 us per step against 3.6 us of MFMA time.  Here a workgroup = (net, 16 hidden
+// units) keeps ITS weights in registers for all S steps (34 KiB per wave) and only the activation rows h_{t-1} move:
+// the workgroups of a net exchange them through L2 with the publish / consume protocol of cdna_hip_programming.md
+// Guideline 16 (recipe R1): h_t is stored write-through (agent-scope atomic stores), every storing wave drains its
+// stores, the workgroup's barrier, ONE lane adds to the counter of (net, step); a consumer polls that counter (relaxed,
+// one lane), ONE agent-scope acquire, then plain loads.  Results never depend on placement or timing; all Z * ceil(D/16)
+// workgroups must be resident together (2 per CU fit: <= 256 VGPRs, 78 KB of LDS — 272 of 512 slots), every spin is
+// bounded by the shader clock and reports through `status` instead of hanging.
+struct seq_fwd_args {
+  const float* Wp;      // packed recurrent weights (forward copy), net stride wp_str
+  const float* bias;    // b_hh
+  float* G;             // [S][B][ldg] per net: in x-projection, out activated gates
+  float* Hs;            // [S+1][B][ldh] per net: slot 0 = h_{-1} (in), slots 1..S written
+  float* Cs;
+  float* TC;
+  const int32_t* row_seg;
+  int32_t* counters;    // [Z][S] arrivals, zeroed by the launch function
+  int32_t* status;      // [0] != 0: a wait timed out (results invalid)
+  int64_t wp_str, b_str, g_str, h_str;
+  int ldg, ldh, B, D, S, Z, NS;
+};
+
+template <int NB>
+__global__ __launch_bounds__(256, 2) void lstm_seq_fwd_kernel(seq_fwd_args p) {
+  constexpr int AP = 552, ROWS = 32, K = 16 * NB;
+  __shared__ __attribute__((aligned(16))) float ah[ROWS * AP + 256];     // (+ the tail of the last 1-KiB piece)
+  __shared__ float xg[4][ROWS][16];
+  __shared__ int s_ok;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int g = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const int z = blockIdx.x % p.Z, slice = blockIdx.x / p.Z;
+  int r_lo = 0, r_hi = p.B;
+  if (p.row_seg) {
+    const int beg = p.row_seg[2 * z], cnt = p.row_seg[2 * z + 1];
+    r_lo = beg & ~31;
+    r_hi = cnt > 0 ? min(p.B, (beg + cnt + 31) & ~31) : r_lo;      // a net without rows still takes part in the counters
+  }
+  const int D = p.D, u = slice * 16 + c, uc = u < D ? u : D - 1;
+  // this wave's weights: gate g of the slice, all K — resident for the whole launch
+  const float* wp = p.Wp + (int64_t)z * p.wp_str + ((int64_t)(slice * 4 + g) * NB * 64 + lane) * 4;
+  f32x4 bq[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) bq[j] = *reinterpret_cast<const f32x4*>(wp + 256 * j);
+  const float bv = p.bias ? p.bias[(int64_t)z * p.b_str + g * D + uc] : 0.f;
+  float* gz = p.G + (int64_t)z * p.g_str;
+  float* hz = p.Hs + (int64_t)z * p.h_str;
+  float* cz = p.Cs + (int64_t)z * p.h_str;
+  float* tz = p.TC + (int64_t)z * p.h_str;
+  const int64_t slot_g = (int64_t)p.B * p.ldg, slot_h = (int64_t)p.B * p.ldh;
+  const float* arow = ah + c * AP + 4 * q;
+  const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc((void*)hz, 0, (int)((int64_t)(p.S + 1) * p.B * p.ldh * 4), 0x00020000);
+  for (int t = 0; t < p.S; ++t) {
+    if (t > 0) {
+      // ---- consume: every slice of net z has published h_{t-1} (slot t).  One lane polls, one acquire, then plain loads.
+      if (tid == 0) {
+        int ok = 1;
+        const long long t0 = __builtin_amdgcn_s_memtime();
+        while (__hip_atomic_load(p.counters + z * p.S + (t - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < p.NS) {
+          __builtin_amdgcn_s_sleep(2);
+          if (__builtin_amdgcn_s_memtime() - t0 > 400000000ll) { ok = 0; break; }      // ~0.2 s: report, never hang
+        }
+        if (!ok) __hip_atomic_store(p.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_ok = ok;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+      if (!s_ok) return;                                    // uniform over the workgroup
+    }
+    for (int row0 = r_lo; row0 < r_hi; row0 += ROWS) {
+      __syncthreads();                                      // the previous chunk's fragment and gate-tile reads are done
+      // h_{t-1} rows of the chunk -> LDS by LDS-DMA (no staging registers: the weights own the register file): piece pi =
+      // 64 consecutive 16-byte slots of the padded image, lane l brings slot 64*pi + l = (row, chunk) = divmod(slot, 138)
+      for (int pi = g; pi < (ROWS * (AP / 4) + 63) / 64; pi += 4) {
+        const int sl = min(64 * pi + lane, ROWS * (AP / 4) - 1), r = sl / (AP / 4), ch = min(sl - r * (AP / 4), K / 4 - 1);
+        const int voff = ((t * p.B + min(row0 + r, r_hi - 1)) * p.ldh + 4 * ch) * 4;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsH, (__attribute__((address_space(3))) void*)(ah + pi * 256), 16, voff, 0, 0, 0);
+      }
+      f32x4 acc[2][2];
+      const float* gt = gz + (int64_t)t * slot_g;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        acc[rt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc[rt][0][r] = gt[(int64_t)min(row0 + 16 * rt + 4 * q + r, r_hi - 1) * p.ldg + g * D + uc] + bv;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces have landed
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const f32x4 b = bq[j];
+        f32x4 a[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) a[rt] = *reinterpret_cast<const f32x4*>(arow + 16 * rt * AP + 16 * j);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int rt = 0; rt < 2; ++rt)
+            acc[rt][i & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][i], b[i], acc[rt][i & 1], 0, 0, 0);
+      }
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xg[g][16 * rt + 4 * q + r][c] = acc[rt][0][r] + acc[rt][1][r];
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int pr = tid + 256 * e, rl = pr >> 4, uu = pr & 15;
+        const int row = row0 + rl, un = slice * 16 + uu;
+        if (row >= r_hi || un >= D) continue;
+        const float ig = sigmoid_(xg[0][rl][uu]);
+        const float fg = sigmoid_(xg[1][rl][uu]);
+        const float gg = tanhf(xg[2][rl][uu]);
+        const float og = sigmoid_(xg[3][rl][uu]);
+        const int64_t o = (int64_t)row * p.ldh + un;
+        const float cn = __builtin_fmaf(fg, cz[(int64_t)t * slot_h + o], ig * gg);      // c_{t-1}: this workgroup's own store of the last step
+        const float tc = tanhf(cn);
+        float* gr = gz + (int64_t)t * slot_g + (int64_t)row * p.ldg + un;
+        gr[0] = ig; gr[D] = fg; gr[2 * D] = gg; gr[3 * D] = og;
+        cz[(int64_t)(t + 1) * slot_h + o] = cn;
+        tz[(int64_t)(t + 1) * slot_h + o] = tc;
+        // h_t is what the other workgroups of the net read: write-through store (agent scope)
+        __hip_atomic_store(hz + (int64_t)(t + 1) * slot_h + o, og * tc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    // ---- publish: every storing wave drains its stores, the workgroup's barrier, one lane signals
+    if (t + 1 < p.S) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(p.counters + z * p.S + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+__global__ void zero_i32_kernel(int32_t* p, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0;
 }
 
 struct bwd_args {
@@ -199,96 +397,131 @@ struct bwd_args {
   int ldg, ldh, B, D, C, Z, NS, rev;
 };
 
-// wave w multiplies k-blocks [w*NB, (w+1)*NB) of the 4*NB blocks of the (zero padded) gate axis
+// wave w multiplies k-blocks [w*NB, (w+1)*NB) of the 4*NB blocks of the (zero padded) gate axis.
+// The fragment-order copies of dG index their 16-row tiles RELATIVE to the net's first row (r_lo): producer (step t) and
+// consumer (step t-1) see the same row segment.
 template <int RT, int NB, bool GEMM>
 __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(bwd_args p) {
-  constexpr int PD = RT == 1 ? 16 : (RT == 2 ? 11 : 7);    // k-blocks ((1 + RT) KiB each) in flight per wave
-  constexpr int ROWS = 16 * RT;
-  __shared__ float xs[4][ROWS][16];
+  __shared__ float xs[4 * 16 * RT * 16];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = lane & 15, q = lane >> 4;
-  int z, slice, row0, r_hi;
-  if (!step_item(p.Z, p.NS, p.rev, p.row_seg, p.B, ROWS, z, slice, row0, r_hi)) return;
+  int z, slice, row0, r_lo, r_hi;
+  if (!step_item(p.Z, p.NS, p.rev, p.row_seg, p.B, 16 * RT, z, slice, row0, r_lo, r_hi)) return;
+  LS_DECL;
+  LS_STAMP(0);
   const int D = p.D;
-  if constexpr (GEMM) {
-    // fragment order: weights [slice][K quarter][k-block][lane][4], dG_t [16-row tile][k-block of the whole gate axis][lane][4]
-    const float* wp = p.Wp + (int64_t)z * p.wp_str + ((int64_t)(slice * 4 + w) * NB * 64 + lane) * 4;
-    const float* ap[RT];
+  const int64_t gzo = (int64_t)z * p.g_str, hz = (int64_t)z * p.h_str, dz = (int64_t)z * p.d_str;
+  auto body = [&](auto lt_) {
+    constexpr int LT = decltype(lt_)::value;              // live 16-row tiles of this chunk
+    constexpr int PD = LT == 1 ? 16 : 11;                 // k-blocks ((1 + LT) KiB each) in flight per wave
+    constexpr int ROWS = 16 * LT;
+    // the cell-backward operands of the elements this thread finishes: requested before the product, used after it
+    // (clamped addresses, discarded past the run — no load under a per-element condition)
+    float e_ga[LT][4], e_tc[LT], e_dc[LT], e_cp[LT], e_dh[LT];
+    int e_cmd[LT];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-      ap[rt] = p.dGp_in + (int64_t)z * p.gp_str + (((int64_t)(row0 / 16 + rt) * 4 + w) * NB * 64 + lane) * 4;
-    // two accumulators per row tile (even / odd k-blocks): a single chain of this MFMA is latency- not issue-paced
-    f32x4 acc[RT][2];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) acc[rt][0] = acc[rt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 bq[PD], aq[PD][RT];
-#pragma unroll
-    for (int j = 0; j < PD; ++j) {
-      bq[j] = *reinterpret_cast<const f32x4*>(wp + 256 * j);
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) aq[j][rt] = *reinterpret_cast<const f32x4*>(ap[rt] + 256 * j);
+    for (int e = 0; e < LT; ++e) {
+      const int pr = tid + 256 * e, rl = pr >> 4, uu = pr & 15;
+      const int row = min(row0 + rl, r_hi - 1), un = min(slice * 16 + uu, D - 1);
+      const float* ga = p.G_act + gzo + (int64_t)row * p.ldg + un;
+      e_ga[e][0] = ga[0]; e_ga[e][1] = ga[D]; e_ga[e][2] = ga[2 * D]; e_ga[e][3] = ga[3 * D];
+      e_tc[e] = p.TC[hz + (int64_t)row * p.ldh + un];
+      e_cp[e] = p.Cprev[hz + (int64_t)row * p.ldh + un];
+      e_dc[e] = p.dC[dz + (int64_t)row * p.ldh + un];
+      e_dh[e] = p.dh_in ? p.dh_in[dz + (int64_t)row * p.ldh + un] : 0.f;
+      e_cmd[e] = p.commands ? p.commands[(z / p.C) * p.B + row] : z % p.C;
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (GEMM) {
+      // fragment order: weights [slice][K quarter][k-block][lane][4], dG_t [16-row tile][k-block of the whole gate axis][lane][4]
+      const float* wp = p.Wp + (int64_t)z * p.wp_str + ((int64_t)(slice * 4 + w) * NB * 64 + lane) * 4;
+      const float* ap[LT];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const int s = j % PD;
-      const f32x4 b = bq[s];
-      f32x4 a[RT];
+      for (int rt = 0; rt < LT; ++rt)
+        ap[rt] = p.dGp_in + (int64_t)z * p.gp_str + (((int64_t)((row0 - r_lo) / 16 + rt) * 4 + w) * NB * 64 + lane) * 4;
+      // two accumulators per row tile (even / odd k-blocks): a single chain of this MFMA is latency- not issue-paced
+      f32x4 acc[LT][2];
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) a[rt] = aq[s][rt];
-      if (j + PD < NB) {
-        bq[s] = *reinterpret_cast<const f32x4*>(wp + 256 * (j + PD));
+      for (int rt = 0; rt < LT; ++rt) acc[rt][0] = acc[rt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 bq[PD], aq[PD][LT];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) aq[s][rt] = *reinterpret_cast<const f32x4*>(ap[rt] + 256 * (j + PD));
+      for (int j = 0; j < PD; ++j) {
+        bq[j] = *reinterpret_cast<const f32x4*>(wp + 256 * j);
+#pragma unroll
+        for (int rt = 0; rt < LT; ++rt) aq[j][rt] = *reinterpret_cast<const f32x4*>(ap[rt] + 256 * j);
       }
       __builtin_amdgcn_sched_barrier(0);
+      LS_STAMP(1);
+      LS_STAMP(2);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < NB; ++j) {
+        const int s = j % PD;
+        const f32x4 b = bq[s];
+        f32x4 a[LT];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-          acc[rt][i & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][i], b[i], acc[rt][i & 1], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+        for (int rt = 0; rt < LT; ++rt) a[rt] = aq[s][rt];
+        if (j + PD < NB) {
+          bq[s] = *reinterpret_cast<const f32x4*>(wp + 256 * (j + PD));
+#pragma unroll
+          for (int rt = 0; rt < LT; ++rt) aq[s][rt] = *reinterpret_cast<const f32x4*>(ap[rt] + 256 * (j + PD));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int rt = 0; rt < LT; ++rt)
+            acc[rt][i & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][i], b[i], acc[rt][i & 1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      LS_STAMP(3);
+#pragma unroll
+      for (int rt = 0; rt < LT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xs[(w * ROWS + 16 * rt + 4 * q + r) * 16 + c] = acc[rt][0][r] + acc[rt][1][r];
+      __syncthreads();
+      LS_STAMP(4);
     }
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) xs[w][16 * rt + 4 * q + r][c] = acc[rt][0][r] + acc[rt][1][r];
-    __syncthreads();
-  }
-  const int64_t gzo = (int64_t)z * p.g_str, hz = (int64_t)z * p.h_str, dz = (int64_t)z * p.d_str;
-#pragma unroll
-  for (int e = 0; e < RT; ++e) {
-    const int pr = tid + 256 * e, rl = pr >> 4, uu = pr & 15;
-    const int row = row0 + rl, un = slice * 16 + uu;
-    if (row >= r_hi || un >= D) continue;
-    float* dg = p.dG_out + gzo + (int64_t)row * p.ldg + un;
-    const int64_t od = dz + (int64_t)row * p.ldh + un;
-    // fragment-order copy: element (row, n) at [(row / 16) * 4*NB + n / 16][((n % 16) / 4) * 16 + row % 16][n % 4]
-    float* dgp = p.dGp_out + (int64_t)z * p.gp_str + ((int64_t)(row >> 4) * 4 * NB * 64 + (row & 15)) * 4;
-    auto put = [&](int gate, float v) {
-      const int n = gate * D + un;
-      dg[gate * D] = v;
-      dgp[(n >> 4) * 256 + ((n >> 2) & 3) * 64 + (n & 3)] = v;
-    };
-    if (p.commands && p.commands[(z / p.C) * p.B + row] != z % p.C) {      // row of another command net: exact zeros
-      put(0, 0.f); put(1, 0.f); put(2, 0.f); put(3, 0.f);
-      p.dC[od] = 0.f;
-      continue;
+    for (int e = 0; e < LT; ++e) {
+      const int pr = tid + 256 * e, rl = pr >> 4, uu = pr & 15;
+      const int row = row0 + rl, un = slice * 16 + uu;
+      if (row >= r_hi || un >= D) continue;
+      float* dg = p.dG_out + gzo + (int64_t)row * p.ldg + un;
+      const int64_t od = dz + (int64_t)row * p.ldh + un;
+      // fragment-order copy: element (row, n) at [((row - r_lo) / 16) * 4*NB + n / 16][((n % 16) / 4) * 16 + (row - r_lo) % 16][n % 4]
+      const int rr = row - r_lo;
+      float* dgp = p.dGp_out + (int64_t)z * p.gp_str + ((int64_t)(rr >> 4) * 4 * NB * 64 + (rr & 15)) * 4;
+      auto put = [&](int gate, float v) {
+        const int n = gate * D + un;
+        dg[gate * D] = v;
+        dgp[(n >> 4) * 256 + ((n >> 2) & 3) * 64 + (n & 3)] = v;
+      };
+      if (e_cmd[e] != z % p.C) {                           // row of another command net (unsorted minibatch): exact zeros
+        put(0, 0.f); put(1, 0.f); put(2, 0.f); put(3, 0.f);
+        p.dC[od] = 0.f;
+        continue;
+      }
+      float dht = e_dh[e];
+      if constexpr (GEMM)
+        dht += (xs[(0 * ROWS + rl) * 16 + uu] + xs[(1 * ROWS + rl) * 16 + uu]) + (xs[(2 * ROWS + rl) * 16 + uu] + xs[(3 * ROWS + rl) * 16 + uu]);
+      const float ig = e_ga[e][0], fg = e_ga[e][1], gg = e_ga[e][2], og = e_ga[e][3];
+      const float tc = e_tc[e];
+      const float dct = e_dc[e] + dht * og * (1.f - tc * tc);
+      const float cp = e_cp[e];
+      put(0, dct * gg * ig * (1.f - ig));
+      put(1, dct * cp * fg * (1.f - fg));
+      put(2, dct * ig * (1.f - gg * gg));
+      put(3, dht * tc * og * (1.f - og));
+      p.dC[od] = dct * fg;
     }
-    float dht = p.dh_in ? p.dh_in[od] : 0.f;
-    if constexpr (GEMM) dht += (xs[0][rl][uu] + xs[1][rl][uu]) + (xs[2][rl][uu] + xs[3][rl][uu]);
-    const float* ga = p.G_act + gzo + (int64_t)row * p.ldg + un;
-    const float ig = ga[0], fg = ga[D], gg = ga[2 * D], og = ga[3 * D];
-    const int64_t o = hz + (int64_t)row * p.ldh + un;
-    const float tc = p.TC[o];
-    const float dct = p.dC[od] + dht * og * (1.f - tc * tc);
-    const float cp = p.Cprev[o];
-    put(0, dct * gg * ig * (1.f - ig));
-    put(1, dct * cp * fg * (1.f - fg));
-    put(2, dct * ig * (1.f - gg * gg));
-    put(3, dht * tc * og * (1.f - og));
-    p.dC[od] = dct * fg;
+  };
+  if constexpr (RT == 2) {
+    if (r_hi - row0 > 16) body(int_c<2>{}); else body(int_c<1>{});
+  } else {
+    body(int_c<RT>{});
   }
+  LS_STAMP(5);
+  LS_FLUSH();
 }
 
 struct dw_args {
@@ -311,7 +544,7 @@ struct dw_args {
 // FOUR row tiles (output rows m0 + 4c + i, i = 0..3, interleaved), Y[row][n0 + 4c ..+3] the B operand of four column
 // tiles: a wave owns a 64*TM x 64 output tile = 16*TM v_mfma_f32_16x16x4_f32 per 1 + TM KiB loads, no LDS, and its results
 // are 16 (m) x 4 (n) blocks per lane: 16-byte stores, 256 B per output row.  Only a net's own run of rows is
-// multiplied (4-row granularity; the rows of other nets hold exact zeros).  Work item = wave tile; the net is the
+// multiplied (4-row k-steps from its first row; the tail of the last step is masked).  Work item = wave tile; the net is the
 // fastest index of the 1-D grid (one XCD per net: its dG / h / x rows stay in that XCD's L2).
 template <int TM>
 __global__ __launch_bounds__(256, TM == 1 ? 2 : 1) void lstm_dw_kernel(dw_args p) {
@@ -329,8 +562,8 @@ __global__ __launch_bounds__(256, TM == 1 ? 2 : 1) void lstm_dw_kernel(dw_args p
   int lo = 0, hi = p.B;
   if (p.row_seg) {
     const int beg = p.row_seg[2 * z], cnt = p.row_seg[2 * z + 1];
-    lo = beg & ~3;
-    hi = cnt > 0 ? beg + cnt : lo;
+    lo = beg;                                             // exactly the net's run: the step kernels write no other row
+    hi = cnt > 0 ? min(p.B, beg + cnt) : lo;
   }
   const int nb = (hi - lo + 3) >> 2;                      // k-steps per time step
   const int KT = nb * p.S;
@@ -357,11 +590,11 @@ __global__ __launch_bounds__(256, TM == 1 ? 2 : 1) void lstm_dw_kernel(dw_args p
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) bsum[tm] = f32x4{0.f, 0.f, 0.f, 0.f};
   // k-step ks -> rows t*B + lo + 4*(ks % nb) + q, walked incrementally in scalar registers (state of the next k-step to
-  // request).  Requests past the last k-step go out of bounds: zeros, nothing to undo.  Rows of a 4-row step past the
-  // run hold the exact zeros of other nets' rows (sorted) — or, unsorted with B % 4 != 0, the next time step's rows:
-  // only then is the operand masked (MASK).
+  // request).  Requests past the last k-step go out of bounds: zeros, nothing to undo.  Rows of the run's last 4-row step
+  // past its end belong to another net (never written in this net's dG: stale) or to the next time step: the dG operand
+  // of those rows is masked to zero when it is used (MASK; h / x rows are finite whatever they hold).
   int t_n = 0, b_n = 0, ks_n = 0;
-  const bool MASK = p.row_seg == nullptr && (p.B & 3) != 0;
+  const bool MASK = ((hi - lo) & 3) != 0;
   f32x4 aq[PD][TM], yq[PD];
   auto request = [&](int slot) {
     const int row = t_n * p.B + lo + 4 * b_n;             // scalar
@@ -480,10 +713,19 @@ __global__ __launch_bounds__(256) void pack_lstm_weights_kernel(const float* W, 
 int rt_for(int B) {
   static const int forced = [] { const char* e = getenv("CADRE_LSTM_RT"); return e ? atoi(e) : 0; }();
   if (forced == 1 || forced == 2) return forced;
-  return B <= 16 ? 1 : 2;                                 // chunk = one 32-row tile of the row-sorted minibatch
+  // minibatch 64 (a net owns ~16 rows): one 16-row tile per workgroup — ~1.5 tiles per (net, slice), at most two
+  // workgroups on a CU; bigger minibatches: two tiles per workgroup (each weight KiB feeds both)
+  return B <= 64 ? 1 : 2;
 }
 
 }  // namespace
+
+#ifdef LSTM_TRACE
+extern "C" int cadre_lstm_set_trace(void* ptr) {
+  long long* v = (long long*)ptr;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_lstm_trace_dev), &v, sizeof(v));
+}
+#endif
 
 extern "C" int cadre_lstm_step_fwd(const float* Wp, int64_t wp_str, const float* bias, int64_t b_str, float* G, int32_t ldg,
                                    int64_t g_str, const float* Hprev, const float* Cprev, float* Hout, float* Cout,
@@ -556,5 +798,24 @@ extern "C" int cadre_lstm_dw(const float* dG, int32_t ldg, int64_t g_str, const 
   const int wgs = (2 * MG * NG + 3) / 4;
   if (TM == 1) hipLaunchKernelGGL(lstm_dw_kernel<1>, dim3(Z * wgs), dim3(256), 0, ST(stream), a);
   else hipLaunchKernelGGL(lstm_dw_kernel<2>, dim3(Z * wgs), dim3(256), 0, ST(stream), a);
+  return (int)hipGetLastError();
+}
+
+// All S forward steps of `Z` nets in one persistent launch (see lstm_seq_fwd_kernel): G [S][B][ldg], Hs / Cs / TC
+// [S+1][B][ldh] per net with slot 0 = the initial state.  `sync_ws`: Z * S + 1 int32 of device memory (arrival counters,
+// zeroed here, + a status word that a timed-out wait sets to 1 — check it with the results; it is never cleared here).
+// Needs all Z * ceil(D/16) workgroups resident (<= 512): launched on an otherwise idle stream order, as the update does.
+extern "C" int cadre_lstm_seq_fwd(const float* Wp, int64_t wp_str, const float* bias, int64_t b_str, float* G, int32_t ldg,
+                                  int64_t g_str, float* Hs, float* Cs, float* TC, int32_t ldh, int64_t h_str, int32_t B,
+                                  int32_t D, int32_t S, int32_t Z, const int32_t* row_seg, int32_t* sync_ws, void* stream) {
+  FAIL_IF(!Wp || !G || !Hs || !Cs || !TC || !sync_ws || B < 1 || D < 1 || S < 1 || Z < 1, "cadre_lstm_seq_fwd: bad argument");
+  FAIL_IF(ldh != 544 || D > ldh || ldg < 4 * D, "cadre_lstm_seq_fwd: built for K = ldh = 544 (hidden 530 zero padded), ldg >= 4*D");
+  FAIL_IF((((uintptr_t)Wp | (uintptr_t)Hs) & 15) || (wp_str & 3) || (h_str & 3), "cadre_lstm_seq_fwd: operands must be 16-byte aligned");
+  const int NS = (D + 15) / 16;
+  FAIL_IF(Z * NS > 512, "cadre_lstm_seq_fwd: more workgroups than can be resident together (2 per CU)");
+  FAIL_IF((int64_t)(S + 1) * B * ldh * 4 >= (1ll << 31), "cadre_lstm_seq_fwd: a net's h rows must stay below the 2 GiB buffer window");
+  hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(256), 0, ST(stream), sync_ws, Z * S);
+  seq_fwd_args a{Wp, bias, G, Hs, Cs, TC, row_seg, sync_ws, sync_ws + Z * S, wp_str, b_str, g_str, h_str, ldg, ldh, B, D, S, Z, NS};
+  hipLaunchKernelGGL((lstm_seq_fwd_kernel<34>), dim3(Z * NS), dim3(256), 0, ST(stream), a);
   return (int)hipGetLastError();
 }

@@ -238,8 +238,10 @@ class DANetEncoderHIP:
         use_c64 = (wbf and self.c64_kernel and c.k == 3 and c.stride == 1 and c.pad == 1 and c.cin == 64 and c.cout == 64
                    and odt == torch.bfloat16 and (act & 16) == 0 and (resid is None or resid.dtype == torch.bfloat16)
                    and M * 128 < 2 ** 31)
+        ring_flags = ((1 if wbf else 0) | (2 if odt == torch.bfloat16 else 0)
+                      | (0 if resid is None else (8 | (4 if resid.dtype == torch.bfloat16 else 0))))
         use_ring = (c.w_ring is not None and self.ring_conv and x.dtype == c.w_ring.dtype and (act & 15) <= 1
-                    and bool(hip.lib().cadre_conv3x3_ring_supported(F, H, W, c.cin, c.cout, 1 if wbf else 0)))
+                    and bool(hip.lib().cadre_conv3x3_ring_supported(F, H, W, c.cin, c.cout, ring_flags)))
         if use_c64 and (self.c64_kernel == 2 or not use_ring):
             # stage-1 convs of the bf16 encoder with the weights resident in LDS (bit-identical to cadre_gemm_bf16);
             # the window kernel below measures 3 % faster on them and takes precedence unless CADRE_C64_KERNEL=2

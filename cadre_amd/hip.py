@@ -66,6 +66,7 @@ SYMBOLS = {
     "cadre_lstm_pointwise_bwd": [vp, vp, i64, i64, vp, vp, i64, vp, vp, i64, i32, i64, i64, i32, i32, i32, vp, i32, vp, vp],
     "cadre_pack_lstm_weights": [vp, i64, i32, i32, i32, vp, vp, i64, vp],
     "cadre_lstm_step_fwd": [vp, i64, vp, i64, vp, i32, i64, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, vp, i32, vp],
+    "cadre_lstm_seq_fwd": [vp, i64, vp, i64, vp, i32, i64, vp, vp, vp, i32, i64, i32, i32, i32, i32, vp, vp, vp],
     "cadre_lstm_step_bwd": [vp, i64, vp, vp, i64, vp, vp, i32, i64, vp, vp, i64, vp, vp, i32, i64, i32, i32, i32, vp, i32, vp, i32, vp],
     "cadre_lstm_dw": [vp, i32, i64, vp, vp, i32, i64, i64, i32, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, vp, vp],
     "cadre_colsum": [vp, i64, i64, vp, i64, i32, i32, i32, i32, vp],
@@ -77,7 +78,7 @@ SYMBOLS = {
     "cadre_mfma_shape": [i32, i32, i32, vp, vp],
     "cadre_sort_rows_by_command": [vp, i32, i32, vp, vp, vp],
     "cadre_permute_minibatch": [vp, i32, i32, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
-    "cadre_ppo_loss": [vp, i64, i64, vp, i64, i64, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, f32, vp, vp, vp, vp, vp],
+    "cadre_ppo_loss": [vp, i64, i64, vp, i64, i64, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, f32, vp, vp, vp, vp, vp, vp],
     "cadre_sample": [vp, i64, vp, i64, i32, i32, vp, vp, vp],
     "cadre_categorical_eval": [vp, i64, vp, i32, i32, vp, vp, vp],
     "cadre_categorical_dist": [vp, i64, i32, i32, vp, vp, vp, vp],

@@ -68,7 +68,11 @@ typedef struct {
      `seg_period` rows (seg_period % 32 == 0; the M tile must divide it: 32- or 64-row tiles).
      seg_mode 1: M-tiles that own no row of their period return without writing; seg_mode 2: k-tiles (k = row index, K % seg_period == 0) outside the segment are
      not multiplied.  Rows of other nets inside a computed tile are still multiplied — callers
-     keep their gradients exactly zero (cadre_relu_bwd / cadre_lstm_pointwise_bwd masks).   */
+     keep their gradients exactly zero (cadre_relu_bwd / cadre_lstm_pointwise_bwd masks).
+     seg_mode 3 (NT products, no split-K / residual): the M index runs over the entry's OWN rows
+     only, period after period (compact row mc = row (mc / cnt) * seg_period + beg + mc % cnt
+     of A and C): no row of another net is read, multiplied or written, whatever the run's
+     alignment (the LSTM input projection of the update: [S*B] rows, period B).              */
   int32_t seg_mode;    /* 0 off                                                               */
   const int32_t* row_seg;
   int32_t seg_period, seg_div;
@@ -88,11 +92,13 @@ int cadre_gemm_bf16_pick_tile(const cadre_gemm_t* p);
  * x [F][H][W][Cin], w [N][NC][9][128 B] (NC = Cin*elem/128 channel chunks; chunk-major, tap = kh*3+kw, then the
  * chunk's channels), y = act(conv*scale[n] + shift[n] (+ resid)) (+ resid after act when act & 16), out [F*H*W][N].
  * flags bit 0: bf16 operands (else fp32); bit 1: out bf16; bit 2: resid bf16.  Each input pixel goes through LDS once
- * per channel chunk (conv3x3_ring.hip).  cadre_conv3x3_ring_supported: host logic, no launch. */
+ * per channel chunk (conv3x3_ring.hip).  cadre_conv3x3_ring_supported: host logic, no launch; it takes the same flags
+ * word plus 8 = a residual is present and bounds every tensor (< 2 GiB: 32-bit buffer offsets) at its own element size,
+ * so a 1 from it means cadre_conv3x3_ring with those flags does not fail on geometry. */
 int cadre_conv3x3_ring(const void* x, const void* w, const float* scale, const float* shift, const void* resid,
                        void* out, int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t act,
                        int32_t flags, void* stream);
-int cadre_conv3x3_ring_supported(int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t bf16);
+int cadre_conv3x3_ring_supported(int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t flags);
 /* tile configuration as ntile (64 / 128) + 1000 * WVM (waves along the positions: 4 = 256-position tile on 8 waves, one
  * workgroup per CU) + 100000 when the 8-wave ping-pong kernel runs (bf16): names the instantiation
  * conv3x3_ring_kernel<bf16, ntile, res, out_bf16, WVM> / conv3x3_ring_pp_kernel<bf16, ntile, res, out_bf16> */
@@ -254,6 +260,16 @@ int cadre_lstm_step_fwd(const float* Wp, int64_t wp_str, const float* bias, int6
                         int64_t g_str, const float* Hprev, const float* Cprev, float* Hout, float* Cout, float* TCout,
                         int32_t ldh, int64_t h_str, int32_t B, int32_t D, int32_t Z, const int32_t* row_seg,
                         int32_t rev, void* stream);
+/* All S forward steps of `Z` nets in ONE persistent launch (ppo_update.hip, lstm_seq_fwd_kernel): a workgroup = (net, 16
+ * hidden units) keeps its packed recurrent weights in registers for the whole launch, the workgroups of a net exchange
+ * the activation rows h_t through L2 (write-through stores, one arrival counter per (net, step), one agent-scope
+ * acquire per step: cdna_hip_programming.md Guideline 16).  G [S][B][ldg], Hs / Cs / TC [S+1][B][ldh] per net, slot 0 =
+ * initial state (in), slots 1..S written.  sync_ws: Z*S + 1 int32 of device memory — the counters (zeroed here) and a
+ * status word that a timed-out wait (bounded spins: a launch can never hang) sets to 1; pass it to cadre_ppo_loss, which
+ * then returns NaN losses.  Same results, bit for bit, as S calls of cadre_lstm_step_fwd. */
+int cadre_lstm_seq_fwd(const float* Wp, int64_t wp_str, const float* bias, int64_t b_str, float* G, int32_t ldg,
+                       int64_t g_str, float* Hs, float* Cs, float* TC, int32_t ldh, int64_t h_str, int32_t B, int32_t D,
+                       int32_t S, int32_t Z, const int32_t* row_seg, int32_t* sync_ws, void* stream);
 /* One backward time step: dh_{t-1} = dG_t W (+ dh_in) on the packed transposed weights (`bwd` of
  * cadre_pack_lstm_weights) and dG_t in fragment order (dGp_in: what the previous call left in its dGp_out), then the
  * cell backward of step t-1 in the same launch: dG_{t-1} from the activated gates G_act, tanh(c_{t-1}), c_{t-2}, written
@@ -304,13 +320,14 @@ int cadre_permute_minibatch(const int32_t* pos, int32_t B, int32_t S, const floa
  *   whole dlogits rows (ldl columns) are written, only column 0 of a dvalues row.
  * `inv_b` = 1/(rows per worker minibatch) (sum of per-worker means).
  * `scratch`: 4 + 6 * ceil(B / 16) floats of device memory (arrival counter + per-workgroup partial sums: the losses are
- * summed in a fixed order whatever the order the workgroups finish in). */
+ * summed in a fixed order whatever the order the workgroups finish in).  `poison` (may be NULL): device int32; when
+ * nonzero (the status word of cadre_lstm_seq_fwd) the three losses come out NaN. */
 int cadre_ppo_loss(const float* logits, int64_t ldl, int64_t l_ns, const float* values, int64_t ldv,
                    int64_t v_ns, const int64_t* actions, const int32_t* commands, const float* old_values, const float* returns,
                    const float* old_logp, const float* adv, int32_t B, int32_t n_out_steer,
                    int32_t n_out_throttle, float clip, float value_coeff, float clip_coeff,
                    float ent_coeff, float inv_b, float* losses, float* dlogits, float* dvalues,
-                   float* scratch, void* stream);
+                   float* scratch, const int32_t* poison, void* stream);
 /* Model.act sampling (models.py:184-189, distributions.py:96-99) == argmax(p/q), q supplied
  * by the host from the torch CPU generator.  logits [R][ldl] raw; outputs action i64 [R],
  * log_prob f32 [R] of the sampled action. */

@@ -204,7 +204,7 @@ def test_window_conv_policy_is_host_logic():
     F = 1024
     trunk = [(72, 64, 64), (36, 128, 128), (18, 256, 256), (9, 512, 512), (9, 512, 128), (9, 128, 128)]
     for hw, cin, n in trunk:
-        assert L.cadre_conv3x3_ring_supported(F, hw, hw, cin, n, 1) == 1
+        assert L.cadre_conv3x3_ring_supported(F, hw, hw, cin, n, 1 | 2 | 8 | 4) == 1, (hw, cin, n)
         code = L.cadre_conv3x3_ring_ntile(F, hw, hw, n, 1)            # ntile + 1000 * waves-along-positions + 100000 * ping-pong
         assert code == (64 if n < 128 else 128) + 4000 + 100000
     assert L.cadre_conv3x3_ring_supported(F, 72, 72, 64, 64, 0) == 1
@@ -214,6 +214,13 @@ def test_window_conv_policy_is_host_logic():
         assert L.cadre_conv3x3_ring_supported(F, hw, hw, cin, n, 0) == 0  # fp32 N >= 128: the tile kernels
     assert L.cadre_conv3x3_ring_supported(1, 144, 144, 64, 64, 1) == 0    # W > 95: two windows do not fit LDS
     assert L.cadre_conv3x3_ring_supported(F, 36, 36, 48, 64, 1) == 0      # channel chunk not 128 bytes
+    # every tensor at its own element size against the 32-bit offset bound: the joint 2048-frame chunk's layer-1 maps
+    # (10,616,832 x 64) fit as bf16 (1.27 GiB) and not as fp32 (2.53 GiB) — output and residual separately
+    assert L.cadre_conv3x3_ring_supported(2048, 72, 72, 64, 64, 1 | 2) == 1
+    assert L.cadre_conv3x3_ring_supported(2048, 72, 72, 64, 64, 1) == 0
+    assert L.cadre_conv3x3_ring_supported(2048, 72, 72, 64, 64, 1 | 2 | 8 | 4) == 1
+    assert L.cadre_conv3x3_ring_supported(2048, 72, 72, 64, 64, 1 | 2 | 8) == 0
+    assert L.cadre_conv3x3_ring_supported(2048, 9, 9, 512, 512, 1) == 1    # conv5a / conv5c: fp32 out of bf16 operands
 
 
 def test_drop_in_package_keeps_reference_meta_importable(tmp_path):

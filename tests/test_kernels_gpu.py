@@ -316,7 +316,7 @@ def _lstm_step_case(Z, B, seed, sorted_rows):
 @pytest.mark.parametrize("Z,B,sorted_rows", [(8, 64, True), (8, 256, True), (8, 24, False), (2, 1, False), (8, 96, True)])
 def test_lstm_step_fwd_fused(hip, Z, B, sorted_rows):
     """cadre_lstm_step_fwd: gates = x-projection + h W_hh^T + b_hh, nn.LSTMCell cell math (models.py:139-152), in one
-    launch, against float64 torch; rows outside a net's 32-row tiles untouched, padding columns never written."""
+    launch, against float64 torch; rows outside a net's run untouched, padding columns never written."""
     D, DP, H4, H4P, W, b, Gx, hp, cp, seg = _lstm_step_case(Z, B, 100 + B, sorted_rows)
     pre = Gx.double() + torch.bmm(hp[:, :, :D].double(), W[:, :, :D].double().transpose(1, 2)) + b.double()[:, None]
     i, f, gg, o = pre.chunk(4, -1)
@@ -353,7 +353,7 @@ def test_lstm_step_fwd_fused(hip, Z, B, sorted_rows):
     torch.cuda.synchronize()
     worst = 0.0
     for z in range(Z):
-        lo, hi = (0, B) if seg is None else (int(seg[z, 0]) & ~31, min(B, (int(seg[z, 0]) + int(seg[z, 1]) + 31) & ~31) if int(seg[z, 1]) else int(seg[z, 0]) & ~31)
+        lo, hi = (0, B) if seg is None else (int(seg[z, 0]), min(B, int(seg[z, 0]) + int(seg[z, 1])))      # exactly the net's run
         if hi > lo:
             worst = max(worst, rel(ho[z, lo:hi, :D], h[z, lo:hi]), rel(co[z, lo:hi, :D], c[z, lo:hi]),
                         rel(tco[z, lo:hi, :D], torch.tanh(c[z, lo:hi])), rel(Gd[z, lo:hi, :H4], act[z, lo:hi]))
@@ -379,9 +379,12 @@ def test_lstm_step_bwd_fused(hip, Z, B, sorted_rows):
     hip.check(L.cadre_pack_lstm_weights(Wd.data_ptr(), H4 * DP, DP, D, Z, packed[0].data_ptr(), packed[1].data_ptr(), NP,
                                         hip.stream()), "cadre_pack_lstm_weights")
 
-    def frag(t):                                          # [Z][B][H4] -> fragment order [Z][tile][k-block][q][r16][i], B padded to 16
-        Bp = (B + 15) // 16 * 16
-        full = torch.zeros(Z, Bp, H4P); full[:, :B, :H4] = t
+    def frag(t):                                          # [Z][B][H4] -> fragment order [Z][tile][k-block][q][r16][i], B padded to 16;
+        Bp = (B + 15) // 16 * 16                          # tiles count from the first row of the net's run (NaN where no row lives)
+        full = torch.full((Z, Bp, H4P), float("nan")); full[:, :, H4:] = 0
+        for z in range(Z):
+            lo, n = (0, B) if seg is None else (int(seg[z, 0]), int(seg[z, 1]))
+            full[z, :n, :H4] = t[z, lo:lo + n]
         return full.view(Z, Bp // 16, 16, 136, 4, 4).permute(0, 1, 3, 4, 2, 5).contiguous()
     # cell of step t-1 (activated gates, tanh c, c_prev) and incoming gradients
     pre = torch.randn(Z, B, H4, generator=g)
@@ -424,7 +427,7 @@ def test_lstm_step_bwd_fused(hip, Z, B, sorted_rows):
         torch.cuda.synchronize()
         worst = 0.0
         for z in range(Z):
-            lo, hi = (0, B) if seg is None else (int(seg[z, 0]) & ~31, min(B, (int(seg[z, 0]) + int(seg[z, 1]) + 31) & ~31) if int(seg[z, 1]) else int(seg[z, 0]) & ~31)
+            lo, hi = (0, B) if seg is None else (int(seg[z, 0]), min(B, int(seg[z, 0]) + int(seg[z, 1])))      # exactly the net's run
             if hi > lo:
                 scale = float(want[z].abs().max()) or 1.0
                 worst = max(worst, float((dGo[z, lo:hi, :H4].double().cpu() - want[z, lo:hi]).abs().max()) / scale,
@@ -435,11 +438,11 @@ def test_lstm_step_bwd_fused(hip, Z, B, sorted_rows):
             rows_out = torch.ones(B, dtype=torch.bool); rows_out[lo:hi] = False
             assert bool((dGo[z][rows_out.cuda()] == 7.0).all())
             assert bool((dGo[z, :, H4:] == 7.0).all())
-            # the fragment-order copy holds the same values as the row-major one (rows written), 7.0 elsewhere
+            # the fragment-order copy holds the same values as the row-major one, rows counted from the run's first; 7.0 elsewhere
             got_p = dGpo[z].permute(0, 3, 1, 2, 4).reshape(-1, H4P)[:B]
             if hi > lo:
-                assert torch.equal(got_p[lo:hi, :H4], dGo[z, lo:hi, :H4])
-            assert bool((got_p[rows_out.cuda()] == 7.0).all()) and bool((got_p[:, H4:] == 7.0).all())
+                assert torch.equal(got_p[:hi - lo, :H4], dGo[z, lo:hi, :H4])
+            assert bool((got_p[hi - lo:] == 7.0).all()) and bool((got_p[:, H4:] == 7.0).all())
         print("lstm_step_bwd Z=%d B=%d sorted=%s product=%s: rel-max-err %.2e" % (Z, B, sorted_rows, with_product, worst))
         assert worst < 2e-5
 
@@ -447,8 +450,8 @@ def test_lstm_step_bwd_fused(hip, Z, B, sorted_rows):
 @pytest.mark.parametrize("B,sorted_rows", [(64, True), (256, True), (24, False), (6, False), (96, True)])
 def test_lstm_dw_fused(hip, B, sorted_rows):
     """cadre_lstm_dw: dW_hh = sum_t dG_t^T h_{t-1}, dW_ih = sum_t dG_t^T x_t, db = column sums of dG for 8 nets in one
-    launch (autograd of models.py:139-152) against float64; only a net's run of rows is multiplied (the others hold the
-    exact zeros the backward writes); padding columns of the gradient rows come out zero; bit-identical on repeat."""
+    launch (autograd of models.py:139-152) against float64; only a net's run of rows is multiplied (the others are stale
+    memory — NaN here); padding columns of the gradient rows come out zero; bit-identical on repeat."""
     g = torch.Generator().manual_seed(900 + B)
     Z, S, C, D, DP, H4, H4P = 8, 8, 4, 530, 544, 2120, 2176
     seg = None
@@ -469,6 +472,7 @@ def test_lstm_dw_fused(hip, B, sorted_rows):
     sL = 2 * H4 * DP + 2 * H4
     grads = torch.full((Z * sL,), 7.0, device="cuda")
     dGd, Hsd, Xd = dev(dG), dev(Hs), dev(X)
+    dGd[(~own).cuda()[:, None].expand(Z, S, B)] = float("nan")          # rows of other nets: never written by the backward, never read
     segd = None if seg is None else dev(seg)
     L = hip.lib()
 
@@ -488,6 +492,53 @@ def test_lstm_dw_fused(hip, B, sorted_rows):
     assert torch.equal(b_ih, b_hh)
     assert float(hh[:, :, D:].abs().max()) == 0.0 and float(ih[:, :, D:].abs().max()) == 0.0
     assert torch.equal(run(), out.view(-1))
+
+
+@pytest.mark.parametrize("B,sorted_rows", [(64, True), (256, True), (24, False), (96, True)])
+def test_lstm_seq_fwd_persistent_equals_per_step(hip, B, sorted_rows):
+    """cadre_lstm_seq_fwd — all S steps of the 8 nets in one persistent launch, the h rows exchanged between workgroups
+    through L2 (agent-scope publish / consume) — gives the bits of S launches of cadre_lstm_step_fwd, on every one of 30
+    launches with every CU busy, and never reports a timed-out wait."""
+    Z, S = 8, 8
+    D, DP, H4, H4P, W, b, Gx, hp, cp, seg = _lstm_step_case(Z, B, 500 + B, sorted_rows)
+    g = torch.Generator().manual_seed(B)
+    Gall = torch.zeros(Z, S, B, H4P); Gall[..., :H4] = torch.randn(Z, S, B, H4, generator=g) * 0.5
+    w_str = H4 * DP + H4
+    buf = torch.zeros(Z * w_str)
+    for z in range(Z):
+        buf[z * w_str: z * w_str + H4 * DP] = W[z].reshape(-1)
+        buf[z * w_str + H4 * DP: (z + 1) * w_str] = b[z]
+    bufd = dev(buf)
+    L = hip.lib()
+    NP = 34 * 4 * 34 * 256
+    packed = torch.zeros(2, Z, NP, device="cuda")
+    hip.check(L.cadre_pack_lstm_weights(bufd.data_ptr(), w_str, DP, D, Z, packed[0].data_ptr(), packed[1].data_ptr(), NP, hip.stream()), "pack")
+    segd = None if seg is None else dev(seg)
+    sp = None if segd is None else segd.data_ptr()
+
+    def state():
+        Hs = torch.full((Z, S + 1, B, DP), 0.0, device="cuda"); Cs = torch.zeros_like(Hs); TC = torch.zeros_like(Hs)
+        Hs[:, 0] = hp.cuda(); Cs[:, 0] = cp.cuda()
+        return dev(Gall.clone()), Hs, Cs, TC
+    G1, H1, C1, T1 = state()
+    for t in range(S):
+        hip.check(L.cadre_lstm_step_fwd(packed[0].data_ptr(), NP, bufd.data_ptr() + 4 * H4 * DP, w_str, G1[:, t].data_ptr(), H4P,
+                                        S * B * H4P, H1[:, t].data_ptr(), C1[:, t].data_ptr(), H1[:, t + 1].data_ptr(),
+                                        C1[:, t + 1].data_ptr(), T1[:, t + 1].data_ptr(), DP, (S + 1) * B * DP, B, D, Z, sp, t & 1,
+                                        hip.stream()), "step")
+    torch.cuda.synchronize()
+    sync = torch.zeros(Z * S + 1, dtype=torch.int32, device="cuda")
+    for rep in range(30):
+        G2, H2, C2, T2 = state()
+        hip.check(L.cadre_lstm_seq_fwd(packed[0].data_ptr(), NP, bufd.data_ptr() + 4 * H4 * DP, w_str, G2.data_ptr(), H4P, S * B * H4P,
+                                       H2.data_ptr(), C2.data_ptr(), T2.data_ptr(), DP, (S + 1) * B * DP, B, D, S, Z, sp,
+                                       sync.data_ptr(), hip.stream()), "seq")
+        torch.cuda.synchronize()
+        assert int(sync[-1]) == 0, "a wait timed out"
+        for z in range(Z):          # (the persistent kernel works on the 32-row tiles around a run, the step kernel on the run itself)
+            lo, hi = (0, B) if seg is None else (int(seg[z, 0]), min(B, int(seg[z, 0]) + int(seg[z, 1])))
+            assert all(torch.equal(x[z, :, lo:hi], y[z, :, lo:hi]) for x, y in ((H2, H1), (C2, C1), (T2, T1), (G2, G1))), (rep, z)
+    assert bool(torch.isfinite(H1).all()) and float(H1[:, S].abs().max()) > 0
 
 
 def test_lstm_pointwise_and_colsum2_row_segments(hip):
@@ -609,7 +660,7 @@ def test_ppo_loss_fwd_bwd(hip, B, scale):
                                        d_[3].data_ptr(), d_[4].data_ptr(), d_[5].data_ptr(),
                                        d_[6].data_ptr(), d_[7].data_ptr(), B, nS, nT, clip, vc, cc, ec,
                                        1.0 / B, losses.data_ptr(), dl.data_ptr(), dv.data_ptr(), scratch.data_ptr(),
-                                       hip.stream()), "loss")
+                                       None, hip.stream()), "loss")
     want = torch.tensor([float(tot_v * vc), float(tot_a * cc), float(tot_e * ec)])
     assert rel(losses, want) < 1e-5
     # the loss sums are combined in a fixed order (last-arriving workgroup): bit-identical over repeated launches
@@ -619,8 +670,15 @@ def test_ppo_loss_fwd_bwd(hip, B, scale):
                                            d_[3].data_ptr(), d_[4].data_ptr(), d_[5].data_ptr(),
                                            d_[6].data_ptr(), d_[7].data_ptr(), B, nS, nT, clip, vc, cc, ec,
                                            1.0 / B, losses.data_ptr(), dl.data_ptr(), dv.data_ptr(), scratch.data_ptr(),
-                                           hip.stream()), "loss")
+                                           None, hip.stream()), "loss")
         assert torch.equal(losses, first)
+    poison = torch.ones(1, dtype=torch.int32, device="cuda")                 # a reported forward-pass timeout: NaN losses
+    hip.check(hip.lib().cadre_ppo_loss(d_[0].data_ptr(), ldl, B * ldl, d_[1].data_ptr(), 1, B, d_[2].data_ptr(),
+                                       d_[3].data_ptr(), d_[4].data_ptr(), d_[5].data_ptr(),
+                                       d_[6].data_ptr(), d_[7].data_ptr(), B, nS, nT, clip, vc, cc, ec,
+                                       1.0 / B, losses.data_ptr(), dl.data_ptr(), dv.data_ptr(), scratch.data_ptr(),
+                                       poison.data_ptr(), hip.stream()), "loss")
+    assert bool(torch.isnan(losses).all())
     assert rel(dv, vv.grad) < 1e-5
     assert rel(dl, lg.grad) < 2e-5
 
@@ -829,6 +887,36 @@ def test_gemm_row_segments(hip, P, tile, BM, segs):
     for z in range(Z):
         if int(seg[z, 1]) == 0:
             assert float(dW[z].abs().max()) == 0.0                                        # empty net: exact zeros
+
+
+@pytest.mark.parametrize("P,tile,N,segs", [(64, 0, 2120, [[0, 13], [13, 22], [35, 11], [46, 18]]),
+                                          (64, 3, 96, [[0, 0], [0, 64], [64, 0], [64, 0]]),
+                                          (100, 9, 128, [[3, 1], [4, 37], [41, 59], [100, 0]]),       # period not a multiple of 32
+                                          (256, 8, 2120, [[0, 70], [70, 58], [128, 49], [177, 79]])])
+def test_gemm_compact_row_segments(hip, P, tile, N, segs):
+    """seg_mode 3: the M index runs over the batch entry's own rows only, period after period (the update's LSTM
+    input projection, models.py:148-151: rows [S][B] sorted by command): own rows = the full product (+ bias), every
+    other row of C untouched, empty runs write nothing."""
+    g = torch.Generator().manual_seed(23)
+    Z, S, K = 4, 8, 544
+    seg = torch.tensor(segs, dtype=torch.int32)
+    A = torch.randn(S * P, K, generator=g); W = torch.randn(Z, N, K, generator=g) * 0.05; b = torch.randn(Z, N, generator=g)
+    ldc = (N + 63) // 64 * 64
+    own = torch.zeros(Z, P, dtype=torch.bool)
+    for z in range(Z):
+        own[z, int(seg[z, 0]):int(seg[z, 0]) + int(seg[z, 1])] = True
+    out = torch.full((Z, S * P, ldc), 7.0, device="cuda")
+    Ad, Wd, bd, sd_ = dev(A), dev(W), dev(b), dev(seg)
+    hip.gemm(Ad, Wd, out, S * P, N, K, K, K, ldc, shift=bd, batch=Z, a_z=(1, 1, 0), b_z=(1, 0, N * K), c_z=(1, 0, S * P * ldc),
+             s_z=(1, 0, N), seg=(3, sd_, P, 1), tile=tile)
+    want = torch.einsum("mk,znk->zmn", A.double(), W.double()) + b.double()[:, None]
+    o = out.cpu()
+    for z in range(Z):
+        rows = own[z].repeat(S)
+        if bool(rows.any()):
+            assert rel(o[z][rows][:, :N], want[z][rows]) < 2e-5, z
+        assert float((o[z][~rows] - 7.0).abs().max() if bool((~rows).any()) else 0.0) == 0.0, z       # foreign rows: untouched
+        assert float((o[z][:, N:] - 7.0).abs().max() if ldc > N else 0.0) == 0.0                       # padding columns too
 
 
 @needs_ab

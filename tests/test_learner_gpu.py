@@ -393,8 +393,9 @@ def test_row_sorted_update_equals_unsorted(Bw, nW):
     losses, same gradients up to fp32 summation order — over several updates so that skipped tiles
     really hold stale data from earlier minibatches."""
     from ppo_agent.storage import RolloutStorage
-    a_s, a_u = make_agent(84, 84), make_agent(84, 84)
+    a_s, a_u, a_p = make_agent(84, 84), make_agent(84, 84), make_agent(84, 84)
     a_u.learner.use_sorted = False
+    a_p.learner.persistent_lstm = True        # forward LSTM as one persistent launch (cadre_lstm_seq_fwd): bit-identical
     assert a_s.learner.sorted_rows(Bw * nW) and not a_u.learner.sorted_rows(Bw * nW)
     T = 2 * Bw
     stor = []
@@ -422,6 +423,9 @@ def test_row_sorted_update_equals_unsorted(Bw, nW):
         gs, gu = a_s.arena.grads, a_u.arena.grads
         assert float((gs - gu).abs().max() / gu.abs().max()) < 2e-5, it
         assert torch.isfinite(gs).all()
+        l_p = a_p.update_policy_from_storages(batches)
+        assert torch.equal(torch.as_tensor(l_p).cpu(), torch.as_tensor(l_s).cpu()) and torch.equal(a_p.arena.grads, gs), it
+        assert int(a_p.learner.workspace(Bw * nW)["sync"][-1]) == 0      # no bounded spin ran out
 
 
 def test_full_size_learner_section_vs_oracle():

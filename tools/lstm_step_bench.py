@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timing of the fused LSTM step kernels (ppo_update.hip) alone, in the update's layout: 8 nets, rows sorted by command
-(B = 64: ~16 rows per net, B = 256: ~64), 20 launches back to back per kernel (HIP events on the launch stream)."""
+(B = 64: 9-22 rows per net, B = 256: 49-79; uneven runs), 20 launches back to back per kernel (HIP events on the launch stream)."""
 import os
 import sys
 
@@ -34,9 +34,16 @@ def main():
     packed = torch.zeros(2, Z, NP, device="cuda")
     st = hip.stream()
     for B in (64, 256):
-        per = B // 4
-        seg = torch.tensor([[c * per, per] for c in range(4)] * 2, dtype=torch.int32, device="cuda")
-        cmds = torch.arange(B, device="cuda", dtype=torch.int32).div(per, rounding_mode="floor").repeat(2, 1).contiguous()
+        # uneven runs, as a sampled minibatch has them (not aligned to 16- or 32-row tiles)
+        runs = {64: ([13, 22, 11, 18], [19, 9, 21, 15]), 256: ([70, 58, 49, 79], [61, 66, 72, 57])}[B]
+        seg_l, cmd_l = [], []
+        for head in runs:
+            b0, cm = 0, []
+            for c, n in enumerate(head):
+                seg_l.append([b0, n]); cm += [c] * n; b0 += n
+            cmd_l.append(cm)
+        seg = torch.tensor(seg_l, dtype=torch.int32, device="cuda")
+        cmds = torch.tensor(cmd_l, dtype=torch.int32, device="cuda")
         G = torch.randn(Z, S, B, H4P, device="cuda", generator=g) * 0.3
         dG = torch.randn(Z, S, B, H4P, device="cuda", generator=g) * 0.3
         Hs = torch.randn(Z, S + 1, B, DP, device="cuda", generator=g) * 0.3
@@ -54,6 +61,13 @@ def main():
                                             Hs[:, k + 1].data_ptr(), Cs[:, k + 1].data_ptr(), TC[:, k + 1].data_ptr(), DP,
                                             (S + 1) * B * DP, B, D, Z, seg.data_ptr(), k & 1, st), "f")
 
+        sync = torch.zeros(Z * S + 1, dtype=torch.int32, device="cuda")
+
+        def seq():
+            hip.check(L.cadre_lstm_seq_fwd(packed[0].data_ptr(), NP, params.data_ptr() + 4 * (2 * H4 * DP + H4), sL, G.data_ptr(), H4P,
+                                           S * B * H4P, Hs.data_ptr(), Cs.data_ptr(), TC.data_ptr(), DP, (S + 1) * B * DP, B, D, S, Z,
+                                           seg.data_ptr(), sync.data_ptr(), st), "q")
+
         def bwd():
             k = 1 + t[0] % (S - 1); t[0] += 1
             hip.check(L.cadre_lstm_step_bwd(packed[1].data_ptr(), NP, dGp[k & 1].data_ptr(), dGp[(k - 1) & 1].data_ptr(), dGp.stride(1),
@@ -69,8 +83,8 @@ def main():
         def tr():
             hip.check(L.cadre_pack_lstm_weights(params.data_ptr() + 4 * H4 * DP, sL, DP, D, Z, packed[0].data_ptr(), packed[1].data_ptr(), NP, st), "t")
         tr()
-        print("B=%d: lstm_step_fwd %.1f us, lstm_step_bwd %.1f us, lstm_dw %.1f us, pack_weights %.1f us" % (
-            B, timeit(fwd), timeit(bwd), timeit(dw, 10), timeit(tr, 10)), flush=True)
+        print("B=%d: lstm_step_fwd %.1f us, lstm_seq_fwd (8 steps) %.1f us, lstm_step_bwd %.1f us, lstm_dw %.1f us, pack_weights %.1f us, "
+              "seq status %d" % (B, timeit(fwd), timeit(seq, 10), timeit(bwd), timeit(dw, 10), timeit(tr, 10), int(sync[-1])), flush=True)
 
 
 if __name__ == "__main__":
