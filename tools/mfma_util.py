@@ -13,7 +13,7 @@ root = sys.argv[1]
 cnt = defaultdict(lambda: defaultdict(float))
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        cnt[(r["Dispatch_Id"], r["Kernel_Name"].split("(")[0])][r["Counter_Name"]] += float(r["Counter_Value"])
+        cnt[(r["Dispatch_Id"], r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0])][r["Counter_Name"]] += float(r["Counter_Value"])
 dur = {}
 for f in glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):

@@ -17,7 +17,7 @@ for name, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != name:
                 continue
-            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
             acc[k] += float(r["Counter_Value"]) * 1024.0 * mult
             cnt[k] += 1
         for k in acc:
