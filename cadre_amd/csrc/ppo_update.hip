@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include "../../include/cadre_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -592,7 +593,7 @@ __global__ __launch_bounds__(256, TM == 1 ? 2 : 1) void lstm_dw_kernel(dw_args p
   // k-step ks -> rows t*B + lo + 4*(ks % nb) + q, walked incrementally in scalar registers (state of the next k-step to
   // request).  Requests past the last k-step go out of bounds: zeros, nothing to undo.  Rows of the run's last 4-row step
   // past its end belong to another net (never written in this net's dG: stale) or to the next time step: the dG operand
-  // of those rows is masked to zero when it is used (MASK; h / x rows are finite whatever they hold).
+  // and h / x operands of those rows are masked to zero when they are used (MASK).
   int t_n = 0, b_n = 0, ks_n = 0;
   const bool MASK = ((hi - lo) & 3) != 0;
   f32x4 aq[PD][TM], yq[PD];
@@ -621,7 +622,7 @@ __global__ __launch_bounds__(256, TM == 1 ? 2 : 1) void lstm_dw_kernel(dw_args p
       f32x4 av[TM];
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) av[tm] = aq[s][tm];
-      const f32x4 yv = yq[s];
+      f32x4 yv = yq[s];
       request(s);
       __builtin_amdgcn_sched_barrier(0);
       if (MASK) {
@@ -630,6 +631,8 @@ __global__ __launch_bounds__(256, TM == 1 ? 2 : 1) void lstm_dw_kernel(dw_args p
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
           for (int i = 0; i < 4; ++i) av[tm][i] = dead ? 0.f : av[tm][i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) yv[i] = dead ? 0.f : yv[i];
       }
       const int b1 = b_c + 1;
       b_c = b1 == nb ? 0 : b1;
@@ -706,6 +709,402 @@ __global__ __launch_bounds__(256) void pack_lstm_weights_kernel(const float* W, 
       for (int i = 0; i < 4; ++i)
         if (n + i < 4 * D && u < D) v[i] = w[(int64_t)(n + i) * ldw + u];
       *reinterpret_cast<f32x4*>(bwd + (int64_t)z * p_str + ((blk + j) * 64 + lane) * 4) = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// MLP towers of the update (models.py:171-177 critic, distributions.py:34-40 actor): Linear(530 -> 128) ReLU
+// Linear(128 -> 128) ReLU Linear(128 -> n_out), 16 towers (tower z2 = 2*net + {actor, critic}), each on its net's run of
+// rows.  Per tower the products are a few MFLOP: as 17 tile-GEMM / column-sum / mask launches of 5-9 us they cost 98 us
+// of a 650 us minibatch step.  Three launches instead: the three layers forward; the dX chain backward (dO3 -> dA2 ->
+// dA1 -> dh_S, both towers of a net summed in registers); the three weight gradients + bias gradients.
+// Weights are read in place (row-major, k contiguous): forward B fragments are 16 rows x 64 bytes per wave instruction,
+// backward ones 4 rows x 64 bytes of single floats — the slow scattered pattern the LSTM kernels avoid by packing, but a
+// tower's weights are 377 KB read by a handful of workgroups once per step: not worth a packed copy.
+constexpr int MLP_HID = 128, MLP_NP = 64, MLP_K1 = 544;
+
+struct mlp_fwd_args {
+  const float* P;        // tower z2 at P + z2 * t_str; weights [out][in] row-major at the offsets below
+  const float* Hin;      // h_S rows [B][ldh] of net z2 / 2 at Hin + (z2 / 2) * h_str
+  float* A1;             // [Z2][B][128] relu(layer 1)
+  float* A2;             // [Z2][B][128] relu(layer 2)
+  float* O3;             // [Z2][B][64]  layer 3 (+ bias)
+  const int32_t* row_seg;
+  int64_t t_str, h_str;
+  int o_w1, o_b1, o_w2, o_b2, o_w3, o_b3;
+  int ldh, B, Z2;
+};
+
+__device__ __forceinline__ bool mlp_item(int n_z, const int32_t* row_seg, int B, int& z, int& net_of_seg, int& row0, int& r_hi,
+                                         int seg_shift) {
+  z = blockIdx.x % n_z;
+  const int chunk = blockIdx.x / n_z;
+  net_of_seg = z >> seg_shift;
+  int r_lo = 0;
+  r_hi = B;
+  if (row_seg) {
+    const int beg = row_seg[2 * net_of_seg], cnt = row_seg[2 * net_of_seg + 1];
+    if (cnt <= 0) return false;
+    r_lo = beg;
+    r_hi = min(B, beg + cnt);
+  }
+  row0 = r_lo + 16 * chunk;
+  return row0 < r_hi;
+}
+
+// workgroup = (tower, 16 rows of its run), 8 waves: wave w owns hidden units 16w .. 16w+15 of layers 1 and 2, output
+// columns 16w .. of layer 3 (w < 4).  Activations meet in LDS between the layers.
+__global__ __launch_bounds__(512) void mlp_fwd_kernel(mlp_fwd_args p) {
+  constexpr int AP = 552, HP = 132, PD = 8;
+  __shared__ __attribute__((aligned(16))) float hs[16 * AP];
+  __shared__ __attribute__((aligned(16))) float a1s[16 * HP];
+  __shared__ __attribute__((aligned(16))) float a2s[16 * HP];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  int z2, net, row0, r_hi;
+  if (!mlp_item(p.Z2, p.row_seg, p.B, z2, net, row0, r_hi, 1)) return;
+  const float* P = p.P + (int64_t)z2 * p.t_str;
+  // h rows -> LDS (16 rows x 136 chunks of 16 bytes; rows past the run repeat the last)
+  const float* hp = p.Hin + (int64_t)net * p.h_str;
+  constexpr int NCH = 16 * (MLP_K1 / 4), NLD = (NCH + 511) / 512;
+  f32x4 st[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int idx = min(tid + 512 * i, NCH - 1), r = idx / (MLP_K1 / 4), ch = idx - r * (MLP_K1 / 4);
+    st[i] = *reinterpret_cast<const f32x4*>(hp + (int64_t)min(row0 + r, r_hi - 1) * p.ldh + 4 * ch);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const int n = 16 * w + c;
+  const float* w1 = P + p.o_w1 + (int64_t)n * MLP_K1 + 4 * q;
+  f32x4 bq[PD];
+#pragma unroll
+  for (int j = 0; j < PD; ++j) bq[j] = *reinterpret_cast<const f32x4*>(w1 + 16 * j);
+  // layer 2 / 3 fragments of this wave: requested now, used after layer 1
+  f32x4 b2q[MLP_HID / 16], b3q[MLP_HID / 16];
+  const float* w2 = P + p.o_w2 + (int64_t)n * MLP_HID + 4 * q;
+  const float* w3 = P + p.o_w3 + (int64_t)(n & (MLP_NP - 1)) * MLP_HID + 4 * q;
+#pragma unroll
+  for (int j = 0; j < MLP_HID / 16; ++j) {
+    b2q[j] = *reinterpret_cast<const f32x4*>(w2 + 16 * j);
+    b3q[j] = *reinterpret_cast<const f32x4*>(w3 + 16 * j);
+  }
+  const float bias1 = P[p.o_b1 + n], bias2 = P[p.o_b2 + n], bias3 = P[p.o_b3 + (n & (MLP_NP - 1))];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int idx = tid + 512 * i, r = idx / (MLP_K1 / 4), ch = idx - r * (MLP_K1 / 4);
+    if (idx < NCH) *reinterpret_cast<f32x4*>(hs + r * AP + 4 * ch) = st[i];
+  }
+  __syncthreads();
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const float* arow = hs + c * AP + 4 * q;
+#pragma unroll
+  for (int j = 0; j < MLP_K1 / 16; ++j) {
+    const int s = j % PD;
+    const f32x4 b = bq[s];
+    const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 16 * j);
+    if (j + PD < MLP_K1 / 16) bq[s] = *reinterpret_cast<const f32x4*>(w1 + 16 * (j + PD));
+    __builtin_amdgcn_sched_barrier(0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc1, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const int64_t ob = (int64_t)z2 * p.B;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * q + r;
+    const float v = fmaxf((acc0[r] + acc1[r]) + bias1, 0.f);
+    a1s[row * HP + n] = v;
+    if (row0 + row < r_hi) p.A1[(ob + row0 + row) * MLP_HID + n] = v;
+  }
+  __syncthreads();
+  acc0 = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < MLP_HID / 16; ++j) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(a1s + c * HP + 16 * j + 4 * q);
+    const f32x4 b = b2q[j];
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * q + r;
+    const float v = fmaxf((acc0[r] + acc1[r]) + bias2, 0.f);
+    a2s[row * HP + n] = v;
+    if (row0 + row < r_hi) p.A2[(ob + row0 + row) * MLP_HID + n] = v;
+  }
+  __syncthreads();
+  if (w < MLP_NP / 16) {
+    acc0 = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < MLP_HID / 16; ++j) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(a2s + c * HP + 16 * j + 4 * q);
+      const f32x4 b = b3q[j];
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * q + r;
+      if (row0 + row < r_hi) p.O3[(ob + row0 + row) * MLP_NP + n] = (acc0[r] + acc1[r]) + bias3;
+    }
+  }
+}
+
+struct mlp_bwd_args {
+  const float* P;
+  const float* dO3;      // [Z2][B][64]
+  const float* A1;       // [Z2][B][128] (ReLU masks)
+  const float* A2;
+  float* dA1;            // [Z2][B][128] out: dL/d(pre-activation of layer 1)
+  float* dA2;
+  float* dH;             // [Z][B][ldh] out: dL/dh_S, both towers of the net summed
+  const int32_t* row_seg;
+  int64_t t_str, d_str;
+  int o_w1, o_w2, o_w3;
+  int ldh, B, Z, NG;     // NG column groups of dh: workgroup (net, 16 rows, g) owns the 16-column tiles t % NG == g
+};
+
+// B operand of a dX product: b[k][j] = W[k0 + k][j0 + j] with W row-major [k][ld] — lane (c = j, q): rows 4q .. 4q+3 of
+// k-block jb, one float each (64 contiguous bytes per row and wave instruction)
+__device__ __forceinline__ f32x4 ld_kmajor(const float* W, int ld, int jb, int q, int col) {
+  const float* s = W + (int64_t)(16 * jb + 4 * q) * ld + col;
+  return f32x4{s[0], s[ld], s[2 * ld], s[3 * ld]};
+}
+
+__global__ __launch_bounds__(512) void mlp_bwd_kernel(mlp_bwd_args p) {
+  constexpr int HP = 132, OP = 68, NT = MLP_K1 / 16;      // 34 column tiles of dh
+  __shared__ __attribute__((aligned(16))) float d3s[16 * OP];
+  __shared__ __attribute__((aligned(16))) float d2s[16 * HP];
+  __shared__ __attribute__((aligned(16))) float d1s[16 * HP];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c = lane & 15, q = lane >> 4;
+  const int zg = blockIdx.x % (p.Z * p.NG);
+  const int z = zg % p.Z, g = zg / p.Z;
+  const int chunk = blockIdx.x / (p.Z * p.NG);
+  int r_lo = 0, r_hi = p.B;
+  if (p.row_seg) {
+    const int beg = p.row_seg[2 * z], cnt = p.row_seg[2 * z + 1];
+    if (cnt <= 0) return;
+    r_lo = beg;
+    r_hi = min(p.B, beg + cnt);
+  }
+  const int row0 = r_lo + 16 * chunk;
+  if (row0 >= r_hi) return;
+  // dh tiles of this wave: t = g + NG * (w + 8 m), m = 0 .. : at most MT
+  constexpr int MT = 2;
+  f32x4 acc_h[MT][2];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc_h[m][0] = acc_h[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int n = 16 * w + c;
+  for (int tw = 0; tw < 2; ++tw) {
+    const int z2 = 2 * z + tw;
+    const float* P = p.P + (int64_t)z2 * p.t_str;
+    const int64_t ob = (int64_t)z2 * p.B;
+    if (tw) __syncthreads();                               // the previous tower's tiles have been read
+    if (tid < 256) {
+      const int r = tid >> 4, ch = tid & 15;
+      *reinterpret_cast<f32x4*>(d3s + r * OP + 4 * ch) =
+          *reinterpret_cast<const f32x4*>(p.dO3 + (ob + min(row0 + r, r_hi - 1)) * MLP_NP + 4 * ch);
+    }
+    // ReLU masks of this lane's elements (rows 4q + r, column n)
+    float m2[4], m1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t o = (ob + min(row0 + 4 * q + r, r_hi - 1)) * MLP_HID + n;
+      m2[r] = p.A2[o];
+      m1[r] = p.A1[o];
+    }
+    f32x4 b3[MLP_NP / 16], b2[MLP_HID / 16];
+#pragma unroll
+    for (int j = 0; j < MLP_NP / 16; ++j) b3[j] = ld_kmajor(P + p.o_w3, MLP_HID, j, q, n);
+#pragma unroll
+    for (int j = 0; j < MLP_HID / 16; ++j) b2[j] = ld_kmajor(P + p.o_w2, MLP_HID, j, q, n);
+    __syncthreads();
+    // dA2 = (dO3 W3) masked by A2 > 0: tile w
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < MLP_NP / 16; ++j) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(d3s + c * OP + 16 * j + 4 * q);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b3[j][0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b3[j][1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b3[j][2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b3[j][3], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * q + r;
+      const float v = m2[r] > 0.f ? acc0[r] + acc1[r] : 0.f;
+      d2s[row * HP + n] = v;
+      if (g == 0 && row0 + row < r_hi) p.dA2[(ob + row0 + row) * MLP_HID + n] = v;
+    }
+    __syncthreads();
+    // dA1 = (dA2 W2) masked by A1 > 0
+    acc0 = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < MLP_HID / 16; ++j) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(d2s + c * HP + 16 * j + 4 * q);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b2[j][0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b2[j][1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b2[j][2], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b2[j][3], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * q + r;
+      const float v = m1[r] > 0.f ? acc0[r] + acc1[r] : 0.f;
+      d1s[row * HP + n] = v;
+      if (g == 0 && row0 + row < r_hi) p.dA1[(ob + row0 + row) * MLP_HID + n] = v;
+    }
+    __syncthreads();
+    // dh += dA1 W1: this wave's column tiles
+    f32x4 a1f[MLP_HID / 16];
+#pragma unroll
+    for (int j = 0; j < MLP_HID / 16; ++j) a1f[j] = *reinterpret_cast<const f32x4*>(d1s + c * HP + 16 * j + 4 * q);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int t = g + p.NG * (w + 8 * m);
+      if (t >= NT) continue;                               // wave-uniform
+      f32x4 b1[MLP_HID / 16];
+#pragma unroll
+      for (int j = 0; j < MLP_HID / 16; ++j) b1[j] = ld_kmajor(P + p.o_w1, MLP_K1, j, q, 16 * t + c);
+#pragma unroll
+      for (int j = 0; j < MLP_HID / 16; ++j) {
+        acc_h[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1f[j][0], b1[j][0], acc_h[m][0], 0, 0, 0);
+        acc_h[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1f[j][1], b1[j][1], acc_h[m][1], 0, 0, 0);
+        acc_h[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1f[j][2], b1[j][2], acc_h[m][0], 0, 0, 0);
+        acc_h[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1f[j][3], b1[j][3], acc_h[m][1], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int t = g + p.NG * (w + 8 * m);
+    if (t >= NT) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + 4 * q + r;
+      if (row < r_hi) p.dH[(int64_t)z * p.d_str + (int64_t)row * p.ldh + 16 * t + c] = acc_h[m][0][r] + acc_h[m][1][r];
+    }
+  }
+}
+
+struct mlp_dw_args {
+  const float* dO3;      // [Z2][B][64]
+  const float* dA2;      // [Z2][B][128]
+  const float* dA1;
+  const float* A2;
+  const float* A1;
+  const float* Hin;      // [B][ldh] of net z2 / 2
+  float* G;              // gradient arena of the towers: tower z2 at G + z2 * t_str, same offsets as the parameters
+  const int32_t* row_seg;
+  int64_t t_str, h_str;
+  int o_w1, o_b1, o_w2, o_b2, o_w3, o_b3;
+  int ldh, B, Z2;
+};
+
+// dW_l = dY_l^T X_l and db_l = colsum dY_l of the three layers of a tower over its run of rows: both operands k-major
+// (the reduction index is the row), fragments are coalesced 16-byte loads through buffer descriptors, a wave owns a
+// 64 x 64 output tile (lstm_dw_kernel's scheme): 18 + 4 + 2 wave tiles per tower, 6 workgroups.
+__global__ __launch_bounds__(256, 2) void mlp_dw_kernel(mlp_dw_args p) {
+  constexpr int PD = 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c = lane & 15, q = lane >> 4;
+  const int z2 = blockIdx.x % p.Z2;
+  const int tile = (blockIdx.x / p.Z2) * 4 + wave;        // 0 .. 23
+  if (tile >= 24) return;
+  int lo = 0, hi = p.B;
+  if (p.row_seg) {
+    const int beg = p.row_seg[2 * (z2 >> 1)], cnt = p.row_seg[2 * (z2 >> 1) + 1];
+    lo = beg;
+    hi = cnt > 0 ? min(p.B, beg + cnt) : lo;
+  }
+  // layer of the tile: 1 (tiles 0..17: 2 m-groups x 9 n-groups), 2 (18..21: 2 x 2), 3 (22..23: 1 x 2)
+  const float *A, *Y;
+  int lda, ldy, M, N, mg, ng, o_w, o_b;
+  const int64_t ob = (int64_t)z2 * p.B;
+  if (tile < 18) {
+    A = p.dA1 + ob * MLP_HID; lda = MLP_HID; M = MLP_HID; Y = p.Hin + (int64_t)(z2 >> 1) * p.h_str; ldy = p.ldh; N = MLP_K1;
+    mg = tile / 9; ng = tile - 9 * mg; o_w = p.o_w1; o_b = p.o_b1;
+  } else if (tile < 22) {
+    A = p.dA2 + ob * MLP_HID; lda = MLP_HID; M = MLP_HID; Y = p.A1 + ob * MLP_HID; ldy = MLP_HID; N = MLP_HID;
+    mg = (tile - 18) >> 1; ng = (tile - 18) & 1; o_w = p.o_w2; o_b = p.o_b2;
+  } else {
+    A = p.dO3 + ob * MLP_NP; lda = MLP_NP; M = MLP_NP; Y = p.A2 + ob * MLP_HID; ldy = MLP_HID; N = MLP_HID;
+    mg = 0; ng = tile - 22; o_w = p.o_w3; o_b = p.o_b3;
+  }
+  const int m0 = 64 * mg, n0 = 64 * ng;
+  const int nc = (n0 + 4 * c < N) ? c : 0;                 // column chunk past the row: a valid one, discarded
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(A + m0), 0, (int)(((int64_t)p.B * lda - m0) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc((void*)(Y + n0), 0, (int)(((int64_t)p.B * ldy - n0) * 4), 0x00020000);
+  const int voff_a = (q * lda + 4 * c) * 4, voff_y = (q * ldy + 4 * nc) * 4;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  const int KT = (hi - lo + 3) >> 2;                       // 4-row k-steps from the run's first row; the tail is masked
+  f32x4 aq[PD], yq[PD];
+  auto request = [&](int slot, int ks) {
+    const int so_a = ks < KT ? (lo + 4 * ks) * lda * 4 : 0x7fffffff;
+    const int so_y = ks < KT ? (lo + 4 * ks) * ldy * 4 : 0x7fffffff;
+    aq[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, voff_a, so_a, 0));
+    yq[slot] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsY, voff_y, so_y, 0));
+  };
+#pragma unroll
+  for (int s = 0; s < PD; ++s) request(s, s);
+  __builtin_amdgcn_sched_barrier(0);
+  for (int ks = 0; ks < KT; ks += PD) {
+#pragma unroll
+    for (int s = 0; s < PD; ++s) {
+      f32x4 av = aq[s];
+      f32x4 yv = yq[s];
+      request(s, ks + s + PD);
+      __builtin_amdgcn_sched_barrier(0);
+      const bool dead = lo + 4 * (ks + s) + q >= hi;       // (k-steps past KT: zeros from the bounds check; the tail row by row,
+#pragma unroll                                             //  both operands: a row past the run may hold anything)
+      for (int i = 0; i < 4; ++i) { av[i] = dead ? 0.f : av[i]; yv[i] = dead ? 0.f : yv[i]; }
+      bsum += av;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], yv[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  float* G = p.G + (int64_t)z2 * p.t_str;
+  if (n0 + 4 * c < N) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + 16 * q + 4 * r + i;
+        if (m < M) *reinterpret_cast<f32x4*>(G + o_w + (int64_t)m * N + n0 + 4 * c) = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+      }
+  }
+  if (ng == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = bsum[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      bsum[i] = v;
+    }
+    if (q == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + 4 * c + i;
+        if (m < M) G[o_b + m] = bsum[i];
+      }
     }
   }
 }
@@ -798,6 +1197,54 @@ extern "C" int cadre_lstm_dw(const float* dG, int32_t ldg, int64_t g_str, const 
   const int wgs = (2 * MG * NG + 3) / 4;
   if (TM == 1) hipLaunchKernelGGL(lstm_dw_kernel<1>, dim3(Z * wgs), dim3(256), 0, ST(stream), a);
   else hipLaunchKernelGGL(lstm_dw_kernel<2>, dim3(Z * wgs), dim3(256), 0, ST(stream), a);
+  return (int)hipGetLastError();
+}
+
+// The MLP towers of the update in three launches (mlp_fwd_kernel / mlp_bwd_kernel / mlp_dw_kernel above): hidden width
+// 128, output rows padded to 64, input width ldh = 544.  Towers z2 = 2*net + {0, 1} at P + z2 * t_str with the weight /
+// bias offsets o_* (floats) inside a tower; row_seg [Z2/2][2] (may be null): only each net's run of rows.
+static int mlp_check(const char* who, int64_t t_str, const int32_t* o, int32_t ldh, int32_t B, int32_t Z2) {
+  static thread_local char msg[160];
+  if (ldh != MLP_K1 || B < 1 || Z2 < 2 || (Z2 & 1) || (t_str & 3) || ((o[0] | o[2] | o[4]) & 3) || o[0] < 0 || o[1] < 0 || o[2] < 0 || o[3] < 0 ||
+      o[4] < 0 || o[5] < 0) {
+    snprintf(msg, sizeof msg, "%s: built for towers 544 -> 128 -> 128 -> 64 (ldh = 544), 16-byte aligned weight offsets, an even tower count", who);
+    return cadre_fail(msg);
+  }
+  return 0;
+}
+
+extern "C" int cadre_mlp_fwd(const float* P, int64_t t_str, const int32_t* offs, const float* Hin, int32_t ldh, int64_t h_str,
+                             float* A1, float* A2, float* O3, int32_t B, int32_t Z2, const int32_t* row_seg, void* stream) {
+  FAIL_IF(!P || !offs || !Hin || !A1 || !A2 || !O3, "cadre_mlp_fwd: null operand");
+  if (int rc = mlp_check("cadre_mlp_fwd", t_str, offs, ldh, B, Z2)) return rc;
+  FAIL_IF((((uintptr_t)P | (uintptr_t)Hin) & 15) || (h_str & 3), "cadre_mlp_fwd: operands must be 16-byte aligned");
+  mlp_fwd_args a{P, Hin, A1, A2, O3, row_seg, t_str, h_str, offs[0], offs[1], offs[2], offs[3], offs[4], offs[5], ldh, B, Z2};
+  hipLaunchKernelGGL(mlp_fwd_kernel, dim3(Z2 * ((B + 15) / 16)), dim3(512), 0, ST(stream), a);
+  return (int)hipGetLastError();
+}
+
+extern "C" int cadre_mlp_bwd(const float* P, int64_t t_str, const int32_t* offs, const float* dO3, const float* A1, const float* A2,
+                             float* dA1, float* dA2, float* dH, int32_t ldh, int64_t d_str, int32_t B, int32_t Z2,
+                             const int32_t* row_seg, void* stream) {
+  FAIL_IF(!P || !offs || !dO3 || !A1 || !A2 || !dA1 || !dA2 || !dH, "cadre_mlp_bwd: null operand");
+  if (int rc = mlp_check("cadre_mlp_bwd", t_str, offs, ldh, B, Z2)) return rc;
+  FAIL_IF(((uintptr_t)dO3 & 15), "cadre_mlp_bwd: dO3 must be 16-byte aligned");
+  constexpr int NG = 4;                                   // column groups of dh: 8 waves x 2 tiles x 4 groups >= 34 tiles
+  mlp_bwd_args a{P, dO3, A1, A2, dA1, dA2, dH, row_seg, t_str, d_str, offs[0], offs[2], offs[4], ldh, B, Z2 / 2, NG};
+  hipLaunchKernelGGL(mlp_bwd_kernel, dim3((Z2 / 2) * NG * ((B + 15) / 16)), dim3(512), 0, ST(stream), a);
+  return (int)hipGetLastError();
+}
+
+extern "C" int cadre_mlp_dw(const float* dO3, const float* dA2, const float* dA1, const float* A2, const float* A1, const float* Hin,
+                            int32_t ldh, int64_t h_str, float* G, int64_t t_str, const int32_t* offs, int32_t B, int32_t Z2,
+                            const int32_t* row_seg, void* stream) {
+  FAIL_IF(!dO3 || !dA2 || !dA1 || !A2 || !A1 || !Hin || !G || !offs, "cadre_mlp_dw: null operand");
+  if (int rc = mlp_check("cadre_mlp_dw", t_str, offs, ldh, B, Z2)) return rc;
+  FAIL_IF((((uintptr_t)dO3 | (uintptr_t)dA2 | (uintptr_t)dA1 | (uintptr_t)A2 | (uintptr_t)A1 | (uintptr_t)Hin | (uintptr_t)G) & 15) || (h_str & 3),
+          "cadre_mlp_dw: operands must be 16-byte aligned");
+  FAIL_IF((int64_t)B * ldh * 4 >= (1ll << 31), "cadre_mlp_dw: a net's rows must stay below the 2 GiB buffer window");
+  mlp_dw_args a{dO3, dA2, dA1, A2, A1, Hin, G, row_seg, t_str, h_str, offs[0], offs[1], offs[2], offs[3], offs[4], offs[5], ldh, B, Z2};
+  hipLaunchKernelGGL(mlp_dw_kernel, dim3(Z2 * 6), dim3(256), 0, ST(stream), a);
   return (int)hipGetLastError();
 }
 

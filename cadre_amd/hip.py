@@ -68,6 +68,9 @@ SYMBOLS = {
     "cadre_lstm_step_fwd": [vp, i64, vp, i64, vp, i32, i64, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, vp, i32, vp],
     "cadre_lstm_seq_fwd": [vp, i64, vp, i64, vp, i32, i64, vp, vp, vp, i32, i64, i32, i32, i32, i32, vp, vp, vp],
     "cadre_lstm_step_bwd": [vp, i64, vp, vp, i64, vp, vp, i32, i64, vp, vp, i64, vp, vp, i32, i64, i32, i32, i32, vp, i32, vp, i32, vp],
+    "cadre_mlp_fwd": [vp, i64, vp, vp, i32, i64, vp, vp, vp, i32, i32, vp, vp],
+    "cadre_mlp_bwd": [vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, vp, vp],
+    "cadre_mlp_dw": [vp, vp, vp, vp, vp, vp, i32, i64, vp, i64, vp, i32, i32, vp, vp],
     "cadre_lstm_dw": [vp, i32, i64, vp, vp, i32, i64, i64, i32, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, vp, vp],
     "cadre_colsum": [vp, i64, i64, vp, i64, i32, i32, i32, i32, vp],
     "cadre_relu_bwd": [vp, vp, i64, vp, i32, i32, i32, vp],
@@ -94,7 +97,7 @@ AB_SYMBOLS = {
 }
 
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class CadreHipError(RuntimeError):

@@ -42,6 +42,10 @@ class PPOLearnerHIP:
         # forward LSTM of the update as one persistent launch (cadre_lstm_seq_fwd) instead of one launch per time step:
         # opt-in, measured slower in place (C2 208 vs 192 us, C3 376 vs 295 us for the 8 steps)
         self.persistent_lstm = os.environ.get("CADRE_LSTM_PERSISTENT", "0") != "0"
+        # MLP towers of the update as three fused launches (cadre_mlp_fwd / _bwd / _dw) instead of 17 GEMM / column-sum /
+        # mask launches; CADRE_FUSED_MLP=0 keeps the GEMM chain (A/B)
+        self.fused_mlp = os.environ.get("CADRE_FUSED_MLP", "1") != "0"
+        self._mlp_offs = None
         hip.lib()
 
     # ------------------------------------------------------------------ workspace
@@ -94,7 +98,7 @@ class PPOLearnerHIP:
         return self._wp[0, g0:], gs * self._wp.stride(1)
 
     # ------------------------------------------------------------------ forward
-    def _forward(self, w, B, nets, x_div, S=None, mlp=True, seg=None):
+    def _forward(self, w, B, nets, x_div, S=None, mlp=True, seg=None, fused_mlp=False):
         """LSTM (S steps) + (optionally) both MLP towers for `Z` nets.  nets = (g0, g_stride, Z): arena net
         indices g0 + i*g_stride.  Net i reads inputs X[i // x_div], h0/c0[i // x_div]."""
         a = self.a
@@ -127,9 +131,17 @@ class PPOLearnerHIP:
                                             hip.ptr(Cs[:, t + 1]), hip.ptr(TC[:, t + 1]), DP, (S + 1) * B * DP, B, a.D, Z,
                                             sgp, t & 1, st), "cadre_lstm_step_fwd")
         if mlp:
-            self._mlp(w, B, nets, Hs[:, S], (S + 1) * B * DP, seg=seg)
+            self._mlp(w, B, nets, Hs[:, S], (S + 1) * B * DP, seg=seg, fused=fused_mlp)
 
-    def _mlp(self, w, B, nets, inp, inp_zstride, seg=None):
+    def mlp_offs(self):
+        """(W1, b1, W2, b2, W3, b3) float offsets inside a tower, as the int32[6] the cadre_mlp_* entry points take."""
+        if self._mlp_offs is None:
+            import ctypes
+            a = self.a
+            self._mlp_offs = (ctypes.c_int32 * 6)(a.t_w1, a.t_b1, a.t_w2, a.t_b2, a.t_w3, a.t_b3)
+        return self._mlp_offs
+
+    def _mlp(self, w, B, nets, inp, inp_zstride, seg=None, fused=False):
         """actor (tower 0) + critic (tower 1) of each net on `inp` ([Z][B][DP] rows, net stride
         inp_zstride): z = 2*i + tower  (models.py:171-177, distributions.py:34-40)."""
         a = self.a
@@ -139,6 +151,11 @@ class PPOLearnerHIP:
         pP = P[a.P0 + g0 * a.size_P:]
         sT = a.size_T if gs == 1 else None
         A1, A2, O3 = w["A1"], w["A2"], w["O3"]
+        if sT and fused and self.fused_mlp:
+            hip.check(hip.lib().cadre_mlp_fwd(hip.ptr(pP), a.size_T, self.mlp_offs(), hip.ptr(inp), DP, inp_zstride, hip.ptr(A1),
+                                              hip.ptr(A2), hip.ptr(O3), B, 2 * Z, None if seg is None else hip.ptr(seg), hip.stream()),
+                      "cadre_mlp_fwd")
+            return
         for tower in ((None,) if sT else (0, 1)):
             if sT:      # contiguous nets: 2Z towers with uniform stride
                 pw, zb, nb, div, zs, cs = pP, 0, 2 * Z, 2, a.size_T, 1
@@ -222,7 +239,7 @@ class PPOLearnerHIP:
         front, back = part in ("all", "front"), part in ("all", "back")
         O3, dO3 = w["O3"], w["dO3"]
         if front:
-            self._forward(w, B, (0, 1, Z), C, seg=seg)
+            self._forward(w, B, (0, 1, Z), C, seg=seg, fused_mlp=True)
             hip.check(L.cadre_ppo_loss(hip.ptr(O3), NP, 2 * B * NP, hip.ptr(O3[1]), NP, 2 * B * NP,
                                        hip.ptr(w["actions"]), hip.ptr(w["commands"]), hip.ptr(w["old_values"]),
                                        hip.ptr(w["returns"]), hip.ptr(w["old_logp"]), hip.ptr(w["adv"]), B,
@@ -247,7 +264,13 @@ class PPOLearnerHIP:
                          a_z=(1, 0, B * n_y), b_z=zT, c_z=(1, 0, B * n_x), seg=sgM2)
 
         dH, dC = w["dH"], w["dC"]
-        if front:
+        if front and self.fused_mlp:
+            sgq = None if seg is None else hip.ptr(seg)
+            hip.check(L.cadre_mlp_bwd(hip.ptr(pP), sT, self.mlp_offs(), hip.ptr(dO3), hip.ptr(A1), hip.ptr(A2), hip.ptr(dA1), hip.ptr(dA2),
+                                      hip.ptr(dH), DP, B * DP, B, nb, sgq, st), "cadre_mlp_bwd")
+            hip.check(L.cadre_mlp_dw(hip.ptr(dO3), hip.ptr(dA2), hip.ptr(dA1), hip.ptr(A2), hip.ptr(A1), hip.ptr(Hs[:, S]), DP,
+                                     (S + 1) * B * DP, hip.ptr(gP), sT, self.mlp_offs(), B, nb, sgq, st), "cadre_mlp_dw")
+        elif front:
             layer_bwd(dO3, NP, A2, hid, hid, (1, 0, B * hid), a.t_w3, a.t_b3, dA2)
             hip.check(L.cadre_relu_bwd(hip.ptr(A2), hip.ptr(dA2), nb * B * hid, cmd, B, hid, C, st), "cadre_relu_bwd")
             layer_bwd(dA2, hid, A1, hid, hid, (1, 0, B * hid), a.t_w2, a.t_b2, dA1)

@@ -15,7 +15,7 @@
 extern "C" {
 #endif
 
-#define CADRE_ABI_VERSION 5
+#define CADRE_ABI_VERSION 6
 int cadre_abi_version(void);
 /* human-readable last argument error of the calling thread ("" if none) */
 const char* cadre_last_error(void);
@@ -253,13 +253,31 @@ int cadre_pack_lstm_weights(const float* W, int64_t w_str, int32_t ldw, int32_t 
 /* One LSTM time step of `Z` nets, product AND cell math in one launch (ppo_update.hip; models.py:139-152 nn.LSTMCell):
  * gates = G (x-projection + b_ih, [B][ldg] per net) + h_{t-1} W^T + bias; G <- (i, f, g, o) activated; c_t, h_t,
  * tanh(c_t) written.  Wp: the packed weights (`fwd` of cadre_pack_lstm_weights); K = ldh = 544 (hidden D zero padded);
- * net z at + z * *_str.  row_seg as in cadre_lstm_pointwise_fwd (the 32-row tiles that intersect net z's run of rows).
+ * net z at + z * *_str.  row_seg [Z][2] (may be NULL): (first row, count) of net z's run of rows — exactly those rows
+ * are read and written (16-row tiles from the run's first row).
  * `rev` (0/1): order in which the unit slices are walked — alternate it from step to step so that each XCD's L2
  * re-uses the most recently read weights first (speed only). */
 int cadre_lstm_step_fwd(const float* Wp, int64_t wp_str, const float* bias, int64_t b_str, float* G, int32_t ldg,
                         int64_t g_str, const float* Hprev, const float* Cprev, float* Hout, float* Cout, float* TCout,
                         int32_t ldh, int64_t h_str, int32_t B, int32_t D, int32_t Z, const int32_t* row_seg,
                         int32_t rev, void* stream);
+/* The MLP towers of update_policy (models.py:171-177 critic, distributions.py:34-40 actor; Linear(530 -> 128) ReLU
+ * Linear(128 -> 128) ReLU Linear(128 -> n_out), n_out rows padded to 64, input rows [B][ldh = 544]) for Z2 = 2 * nets
+ * towers in three launches (ppo_update.hip).  Tower z2 = 2*net + {actor, critic} at P + z2 * t_str; offs[6] = float
+ * offsets of (W1, b1, W2, b2, W3, b3) inside a tower, weights [out][in] row-major; A1 / A2 / dA1 / dA2 [Z2][B][128],
+ * O3 / dO3 [Z2][B][64]; net z's input rows at Hin + z * h_str.  row_seg [Z2/2][2] (may be NULL = every row): (first
+ * row, count) of the run of rows net z owns in the row-sorted minibatch — no other row is read or written.
+ * cadre_mlp_fwd: A1, A2 (post-ReLU) and O3.  cadre_mlp_bwd: dA2 = (dO3 W3) [A2 > 0], dA1 = (dA2 W2) [A1 > 0] and
+ * dH[net] = sum over the net's two towers of dA1 W1 ([B][ldh] at dH + net * d_str).  cadre_mlp_dw: the gradients of the
+ * six parameter blocks of every tower at G + z2 * t_str + offs[...] (written, not accumulated). */
+int cadre_mlp_fwd(const float* P, int64_t t_str, const int32_t* offs, const float* Hin, int32_t ldh, int64_t h_str,
+                  float* A1, float* A2, float* O3, int32_t B, int32_t Z2, const int32_t* row_seg, void* stream);
+int cadre_mlp_bwd(const float* P, int64_t t_str, const int32_t* offs, const float* dO3, const float* A1, const float* A2,
+                  float* dA1, float* dA2, float* dH, int32_t ldh, int64_t d_str, int32_t B, int32_t Z2,
+                  const int32_t* row_seg, void* stream);
+int cadre_mlp_dw(const float* dO3, const float* dA2, const float* dA1, const float* A2, const float* A1, const float* Hin,
+                 int32_t ldh, int64_t h_str, float* G, int64_t t_str, const int32_t* offs, int32_t B, int32_t Z2,
+                 const int32_t* row_seg, void* stream);
 /* All S forward steps of `Z` nets in ONE persistent launch (ppo_update.hip, lstm_seq_fwd_kernel): a workgroup = (net, 16
  * hidden units) keeps its packed recurrent weights in registers for the whole launch, the workgroups of a net exchange
  * the activation rows h_t through L2 (write-through stores, one arrival counter per (net, step), one agent-scope

@@ -473,6 +473,7 @@ def test_lstm_dw_fused(hip, B, sorted_rows):
     grads = torch.full((Z * sL,), 7.0, device="cuda")
     dGd, Hsd, Xd = dev(dG), dev(Hs), dev(X)
     dGd[(~own).cuda()[:, None].expand(Z, S, B)] = float("nan")          # rows of other nets: never written by the backward, never read
+    Hsd[:, :S][(~own).cuda()[:, None].expand(Z, S, B)] = float("nan")   # (their h rows hold whatever an earlier minibatch left)
     segd = None if seg is None else dev(seg)
     L = hip.lib()
 
@@ -492,6 +493,86 @@ def test_lstm_dw_fused(hip, B, sorted_rows):
     assert torch.equal(b_ih, b_hh)
     assert float(hh[:, :, D:].abs().max()) == 0.0 and float(ih[:, :, D:].abs().max()) == 0.0
     assert torch.equal(run(), out.view(-1))
+
+
+@pytest.mark.parametrize("B,segs", [(64, [[0, 13], [13, 22], [35, 11], [46, 18]]), (256, [[0, 70], [70, 58], [128, 49], [177, 79]]),
+                                    (24, None), (5, None), (96, [[0, 0], [0, 96], [96, 0], [96, 0]])])
+def test_mlp_towers_fused(hip, B, segs):
+    """cadre_mlp_fwd / cadre_mlp_bwd / cadre_mlp_dw: the three layers of the 16 actor / critic towers (models.py:171-177,
+    distributions.py:34-40) forward, the dX chain backward (dh summed over a net's two towers) and the six parameter
+    gradients per tower, each on exactly its net's run of rows — against float64 torch autograd; rows outside a run are
+    neither read (NaN there) nor written, an empty run writes zero gradients."""
+    import ctypes
+    g = torch.Generator().manual_seed(1234 + B)
+    Z, Z2, D, DP, hid, NP = 8, 16, 530, 544, 128, 64
+    n_out = [33, 1] * 4 + [3, 1] * 4                       # actor / critic rows of W3 that exist
+    t_w1, t_b1 = 0, hid * DP
+    t_w2, t_b2 = t_b1 + hid, t_b1 + hid + hid * hid
+    t_w3, t_b3 = t_b2 + hid, t_b2 + hid + NP * hid
+    sT = t_b3 + NP
+    offs = (ctypes.c_int32 * 6)(t_w1, t_b1, t_w2, t_b2, t_w3, t_b3)
+    W1 = torch.zeros(Z2, hid, DP); W1[:, :, :D] = torch.randn(Z2, hid, D, generator=g) * 0.05
+    W2 = torch.randn(Z2, hid, hid, generator=g) * 0.1
+    W3 = torch.zeros(Z2, NP, hid)
+    b1, b2, b3 = torch.randn(Z2, hid, generator=g) * 0.1, torch.randn(Z2, hid, generator=g) * 0.1, torch.zeros(Z2, NP)
+    for z2 in range(Z2):
+        W3[z2, :n_out[z2]] = torch.randn(n_out[z2], hid, generator=g) * 0.1
+        b3[z2, :n_out[z2]] = torch.randn(n_out[z2], generator=g) * 0.1
+    P = torch.cat([torch.cat([W1[z].reshape(-1), b1[z], W2[z].reshape(-1), b2[z], W3[z].reshape(-1), b3[z]]) for z in range(Z2)])
+    assert P.numel() == Z2 * sT
+    seg = None if segs is None else torch.tensor(segs + segs, dtype=torch.int32)
+    own = torch.ones(Z, B, dtype=torch.bool)
+    if seg is not None:
+        own[:] = False
+        for z in range(Z):
+            own[z, int(seg[z, 0]):int(seg[z, 0]) + int(seg[z, 1])] = True
+    own2 = own.repeat_interleave(2, 0)                      # [Z2][B]
+    H = torch.zeros(Z, B, DP); H[..., :D] = torch.randn(Z, B, D, generator=g)
+    dO3 = torch.zeros(Z2, B, NP)
+    for z2 in range(Z2):
+        dO3[z2, :, :n_out[z2]] = torch.randn(B, n_out[z2], generator=g) * 0.3
+    # float64 reference through autograd, per tower on its own rows
+    Wd = [t.double().requires_grad_() for t in (W1, b1, W2, b2, W3, b3)]
+    Hd = H.double().requires_grad_()
+    Hin2 = Hd.repeat_interleave(2, 0)
+    a1 = torch.relu(torch.einsum("zbk,znk->zbn", Hin2, Wd[0]) + Wd[1][:, None])
+    a2 = torch.relu(torch.einsum("zbk,znk->zbn", a1, Wd[2]) + Wd[3][:, None])
+    o3 = torch.einsum("zbk,znk->zbn", a2, Wd[4]) + Wd[5][:, None]
+    (o3 * (dO3.double() * own2[:, :, None])).sum().backward()
+    # device run: NaN in every row a tower does not own
+    nan_rows = lambda t, o: torch.where(o[..., None].expand_as(t), t, torch.full_like(t, float("nan")))
+    Pd, Hdv = dev(P), dev(nan_rows(H, own) if seg is not None else H)
+    A1 = torch.full((Z2, B, hid), 7.0, device="cuda"); A2 = torch.full_like(A1, 7.0); O3 = torch.full((Z2, B, NP), 7.0, device="cuda")
+    L = hip.lib()
+    sp = None if seg is None else dev(seg)
+    spp = None if sp is None else sp.data_ptr()
+    hip.check(L.cadre_mlp_fwd(Pd.data_ptr(), sT, offs, Hdv.data_ptr(), DP, B * DP, A1.data_ptr(), A2.data_ptr(), O3.data_ptr(), B, Z2,
+                              spp, hip.stream()), "cadre_mlp_fwd")
+    torch.cuda.synchronize()
+    m2 = own2.cuda()
+    e_f = max(rel(A1[m2], a1.detach()[own2]), rel(A2[m2], a2.detach()[own2]), rel(O3[m2], o3.detach()[own2])) if bool(own2.any()) else 0.0
+    assert bool((A1[~m2] == 7.0).all()) and bool((A2[~m2] == 7.0).all()) and bool((O3[~m2] == 7.0).all())
+    dO3d = dev(nan_rows(dO3, own2) if seg is not None else dO3)
+    dA1 = torch.full((Z2, B, hid), 7.0, device="cuda"); dA2 = torch.full_like(dA1, 7.0); dH = torch.full((Z, B, DP), 7.0, device="cuda")
+    hip.check(L.cadre_mlp_bwd(Pd.data_ptr(), sT, offs, dO3d.data_ptr(), A1.data_ptr(), A2.data_ptr(), dA1.data_ptr(), dA2.data_ptr(),
+                              dH.data_ptr(), DP, B * DP, B, Z2, spp, hip.stream()), "cadre_mlp_bwd")
+    G = torch.full((Z2 * sT,), 7.0, device="cuda")
+    hip.check(L.cadre_mlp_dw(dO3d.data_ptr(), dA2.data_ptr(), dA1.data_ptr(), A2.data_ptr(), A1.data_ptr(), Hdv.data_ptr(), DP, B * DP,
+                             G.data_ptr(), sT, offs, B, Z2, spp, hip.stream()), "cadre_mlp_dw")
+    torch.cuda.synchronize()
+    mo = own.cuda()
+    e_h = rel(dH[mo], Hd.grad[own]) if bool(own.any()) else 0.0
+    assert bool((dH[~mo] == 7.0).all()) and bool((dA1[~m2] == 7.0).all()) and bool((dA2[~m2] == 7.0).all())
+    Gv = G.view(Z2, sT).cpu()
+    got = [Gv[:, t_w1:t_b1].view(Z2, hid, DP), Gv[:, t_b1:t_w2], Gv[:, t_w2:t_b2].view(Z2, hid, hid), Gv[:, t_b2:t_w3],
+           Gv[:, t_w3:t_b3].view(Z2, NP, hid), Gv[:, t_b3:]]
+    e_w = max(rel(gt, wt.grad) for gt, wt in zip(got, Wd))
+    print("mlp towers B=%d sorted=%s: rel-max-err forward %.2e, dh %.2e, parameter gradients %.2e" % (B, seg is not None, e_f, e_h, e_w))
+    assert max(e_f, e_h, e_w) < 2e-5
+    for z2 in range(Z2):
+        if not bool(own2[z2].any()):
+            assert float(Gv[z2].abs().max()) == 0.0        # a net without rows: exact zero gradients
+    assert float(got[0][:, :, D:].abs().max()) == 0.0       # padding columns of W1
 
 
 @pytest.mark.parametrize("B,sorted_rows", [(64, True), (256, True), (24, False), (96, True)])
