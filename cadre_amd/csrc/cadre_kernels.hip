@@ -9,6 +9,9 @@
 #include <string.h>
 #include <algorithm>
 #include "../../include/cadre_hip.h"
+#ifdef CADRE_AB_KERNELS
+#include "../../include/cadre_hip_ab.h"
+#endif
 
 thread_local char g_cadre_err[256] = {0};
 int cadre_fail(const char* msg) {
@@ -353,14 +356,19 @@ extern "C" int cadre_maxpool3x3s2(const float* x, float* y, int32_t F, int32_t H
 // reduction over LDS.  Rows / columns >= Np are zero padding (their energies are -inf before the softmax).
 #define PAM_MAXNP 96
 typedef float pam_f32x16 __attribute__((ext_vector_type(16)));
+// R = Np rounded up to 32 (1, 2 or 3 row blocks): the staged rows, the LDS footprint (25 / 58 / 97 KB) and the tile
+// counts follow the map — the reference's native 5 x 8 map (Np = 40) runs 4 + 8 tiles instead of 9 + 12 and two
+// workgroups per CU.  The padding contributes exact zeros at the END of every fma chain, so the results do not depend
+// on R (same bits as the fixed 96-row form).
 __global__ __launch_bounds__(256) void pam_kernel(const float* qkv, const float* x, float gamma, float* y, int Np,
                                                   int out_bf16) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  constexpr int R = PAM_MAXNP, QP = 17, AP = R + 1;
-  float* q = sm;                    // [96][17]
-  float* k = q + R * QP;            // [96][17]
-  float* v = k + R * QP;            // [96][128]
-  float* att = v + R * 128;         // [96][97]
+  constexpr int QP = 17;
+  const int RB = (Np + 31) >> 5, R = 32 * RB, AP = R + 1;
+  float* q = sm;                    // [R][17]
+  float* k = q + R * QP;            // [R][17]
+  float* v = k + R * QP;            // [R][128]
+  float* att = v + R * 128;         // [R][R + 1]
   const int f = blockIdx.x, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const float* src = qkv + (int64_t)f * Np * 160;
@@ -372,9 +380,9 @@ __global__ __launch_bounds__(256) void pam_kernel(const float* qkv, const float*
     else v[n * 128 + c - 32] = val;
   }
   __syncthreads();
-  // ---- energy[n][m] = q[n] . k[m]: 9 tiles of 32x32 over 4 waves, 8 MFMAs (K = 16) each
-  for (int t = wave; t < 9; t += 4) {
-    const int n0 = (t / 3) * 32, m0 = (t % 3) * 32;
+  // ---- energy[n][m] = q[n] . k[m]: RB x RB tiles of 32x32 over 4 waves, 8 MFMAs (K = 16) each
+  for (int t = wave; t < RB * RB; t += 4) {
+    const int n0 = (t / RB) * 32, m0 = (t % RB) * 32;
     pam_f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -404,7 +412,7 @@ __global__ __launch_bounds__(256) void pam_kernel(const float* qkv, const float*
     for (int m = lane; m < R; m += 64) att[n * AP + m] = att[n * AP + m] / s;
   }
   __syncthreads();
-  // ---- out[n][c] = sum_m att[n][m] v[m][c]: wave w owns channel block w (32 channels), all three row blocks
+  // ---- out[n][c] = sum_m att[n][m] v[m][c]: wave w owns channel block w (32 channels), all row blocks
   pam_f32x16 o[3];
 #pragma unroll
   for (int b = 0; b < 3; ++b)
@@ -414,7 +422,8 @@ __global__ __launch_bounds__(256) void pam_kernel(const float* qkv, const float*
   for (int kk = 0; kk < R / 2; ++kk) {
     const float bv = v[(2 * kk + lh) * 128 + c];
 #pragma unroll
-    for (int b = 0; b < 3; ++b) o[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(att[(32 * b + l31) * AP + 2 * kk + lh], bv, o[b], 0, 0, 0);
+    for (int b = 0; b < 3; ++b)
+      if (b < RB) o[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(att[(32 * b + l31) * AP + 2 * kk + lh], bv, o[b], 0, 0, 0);
   }
   const float* xf = x + (int64_t)f * Np * 128;
 #pragma unroll
@@ -443,7 +452,8 @@ extern "C" int cadre_pam_bf16out(const float* x, const float* qkv, float gamma, 
 static int pam_launch(const float* x, const float* qkv, float gamma, void* y, int32_t F, int32_t Np, int out_bf16,
                       void* stream) {
   FAIL_IF(!x || !qkv || !y || F < 1 || Np < 1 || Np > PAM_MAXNP, "cadre_pam: bad argument (Np<=96)");
-  const size_t shm = sizeof(float) * ((size_t)PAM_MAXNP * 34 + (size_t)PAM_MAXNP * 128 + (size_t)PAM_MAXNP * (PAM_MAXNP + 1));
+  const size_t R = (size_t)((Np + 31) / 32) * 32;
+  const size_t shm = sizeof(float) * (R * 34 + R * 128 + R * (R + 1));
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)pam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -824,6 +834,7 @@ extern "C" int cadre_gather_minibatch_multi(const void* src_table, int32_t n_src
   return (int)hipGetLastError();
 }
 
+#ifdef CADRE_AB_KERNELS      // A/B build only (include/cadre_hip_ab.h): the update's cell math now lives in ppo_update.hip
 // ============================================================================ LSTM cell pointwise
 // Rows sorted by command (row_seg != NULL: net z owns rows [row_seg[2z], +row_seg[2z+1]) of its B): only the rows of
 // the 32-row tiles that intersect the run are touched — the same rows the segment-aware GEMMs read and write; the
@@ -913,6 +924,8 @@ extern "C" int cadre_lstm_pointwise_bwd(const float* gates, float* dgates, int64
   return (int)hipGetLastError();
 }
 
+#endif
+
 // ============================================================================ column sums / relu backward
 __global__ void colsum_kernel(const float* X, int64_t ldx, int64_t x_str, float* out, int64_t o_str, int M, int N,
                               int accumulate, float* out2, const int32_t* row_seg, int period) {
@@ -967,6 +980,7 @@ extern "C" int cadre_colsum(const float* X, int64_t ldx, int64_t x_str, float* o
                      o_str, M, N, accumulate, (float*)nullptr, (const int32_t*)nullptr, 0);
   return (int)hipGetLastError();
 }
+#ifdef CADRE_AB_KERNELS
 extern "C" int cadre_colsum2(const float* X, int64_t ldx, int64_t x_str, float* out, float* out2, int64_t o_str, int32_t M,
                              int32_t N, int32_t batch, const int32_t* row_seg, int32_t period, void* stream) {
   FAIL_IF(!X || !out || !out2 || M < 1 || N < 1 || batch < 1, "cadre_colsum2: bad argument");
@@ -975,6 +989,7 @@ extern "C" int cadre_colsum2(const float* X, int64_t ldx, int64_t x_str, float* 
                      o_str, M, N, 0, out2, row_seg, period);
   return (int)hipGetLastError();
 }
+#endif
 
 // LSTM state slots: Hs[z][0] <- h0[z / x_div], Cs[z][0] <- c0[z / x_div] for z < Z (rows of ld floats, n_per = B*ld
 // floats per net and slot), and dC (Z * n_per floats, may be null) <- 0: the initial hidden state of agent.py:166-175

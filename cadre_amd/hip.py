@@ -62,8 +62,6 @@ SYMBOLS = {
                                vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp],
     "cadre_gather_minibatch_multi": [vp, i32, i64, i32, i64, vp, i32, i32, i32, i32, vp, i64, i64, vp, vp, i64, i64,
                                      vp, vp, vp, vp, vp, vp, vp],
-    "cadre_lstm_pointwise_fwd": [vp, i64, i64, vp, i64, i32, vp, vp, vp, i64, i64, i32, i32, i32, vp, vp],
-    "cadre_lstm_pointwise_bwd": [vp, vp, i64, i64, vp, vp, i64, vp, vp, i64, i32, i64, i64, i32, i32, i32, vp, i32, vp, vp],
     "cadre_pack_lstm_weights": [vp, i64, i32, i32, i32, vp, vp, i64, vp],
     "cadre_lstm_step_fwd": [vp, i64, vp, i64, vp, i32, i64, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, vp, i32, vp],
     "cadre_lstm_seq_fwd": [vp, i64, vp, i64, vp, i32, i64, vp, vp, vp, i32, i64, i32, i32, i32, i32, vp, vp, vp],
@@ -74,7 +72,6 @@ SYMBOLS = {
     "cadre_lstm_dw": [vp, i32, i64, vp, vp, i32, i64, i64, i32, vp, vp, vp, vp, i32, i64, i32, i32, i32, i32, i32, vp, vp],
     "cadre_colsum": [vp, i64, i64, vp, i64, i32, i32, i32, i32, vp],
     "cadre_relu_bwd": [vp, vp, i64, vp, i32, i32, i32, vp],
-    "cadre_colsum2": [vp, i64, i64, vp, vp, i64, i32, i32, i32, vp, i32, vp],
     "cadre_lstm_init": [vp, vp, vp, vp, vp, i64, i64, i32, i32, vp],
     "cadre_mfma_peak": [i32, i32, i32, vp, vp],
     "cadre_hbm_stream": [i32, vp, vp, i64, vp, vp],
@@ -93,6 +90,9 @@ SYMBOLS = {
 # entry points of the A/B build only (include/cadre_hip_ab.h; CADRE_BUILD_AB=1 python -m cadre_amd.build, then
 # CADRE_HIP_LIB=.../libcadre_hip_ab.so): bound when the loaded library has them
 AB_SYMBOLS = {
+    "cadre_lstm_pointwise_fwd": [vp, i64, i64, vp, i64, i32, vp, vp, vp, i64, i64, i32, i32, i32, vp, vp],
+    "cadre_lstm_pointwise_bwd": [vp, vp, i64, i64, vp, vp, i64, vp, vp, i64, i32, i64, i64, i32, i32, i32, vp, i32, vp, vp],
+    "cadre_colsum2": [vp, i64, i64, vp, vp, i64, i32, i32, i32, vp, i32, vp],
     "cadre_conv3x3_c64_bf16": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
 }
 

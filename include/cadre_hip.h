@@ -219,30 +219,6 @@ int cadre_gather_minibatch_multi(const void* src_table, int32_t n_src, int64_t l
                                  int64_t ldho, int64_t* actions_o, int32_t* commands_o, float* old_values_o,
                                  float* returns_o, float* old_logp_o, float* adv_o, void* stream);
 
-/* ---------------------------------------------------------------- LSTM cell pointwise
- * nn.LSTMCell gate math (models.py:130-152).  gates [B][ldg] pre-activations (i,f,g,o blocks
- * of Hd), batched over `batch` nets with strides; c_prev of net z is read at
- * c_prev + (z / c_prev_div) * c_prev_str (step 0 shares the head's c0 across its 4 command
- * nets).  Forward overwrites gates with the activated values (kept for backward), writes
- * c_out, h_out, tanh_c. */
-int cadre_lstm_pointwise_fwd(float* gates, int64_t ldg, int64_t g_str, const float* c_prev,
-                             int64_t c_prev_str, int32_t c_prev_div, float* c_out, float* h_out,
-                             float* tanh_c, int64_t ldh, int64_t h_str, int32_t B, int32_t Hd,
-                             int32_t batch, const int32_t* row_seg, void* stream);
-/* row_seg (may be NULL; [batch][2] = (first row, count) of the run of rows net z owns when the minibatch is sorted by
- * command, cadre_sort_rows_by_command): only rows of the 32-row tiles that intersect the run are touched — the rows the
- * segment-aware GEMMs (cadre_gemm_t.seg_mode) read and write. */
-/* backward of one step: dh (in: upstream+recurrent grad of h_t), dc (in/out: grad of c_t ->
- * grad of c_{t-1}), both [batch][B][ldh] with net stride d_str; activated gates, tanh_c,
- * c_prev -> dgates [B][ldg] */
-int cadre_lstm_pointwise_bwd(const float* gates, float* dgates, int64_t ldg, int64_t g_str,
-                             const float* dh, float* dc, int64_t d_str, const float* tanh_c,
-                             const float* c_prev,
-                             int64_t c_prev_str, int32_t c_prev_div, int64_t ldh, int64_t h_str,
-                             int32_t B, int32_t Hd, int32_t batch, const int32_t* commands, int32_t C,
-                             const int32_t* row_seg, void* stream);
-/* (commands != NULL: net z = head*C + c only keeps rows whose command is c; the other rows get
- * dgates = 0 and dc = 0 whatever dh holds — see cadre_gemm_t.seg_mode.) */
 /* Recurrent weights W [4*D][ldw = 544] of `Z` nets (net z at + z * w_str) -> MFMA FRAGMENT ORDER for the fused LSTM
  * steps, both directions (ppo_update.hip): `fwd` for cadre_lstm_step_fwd, `bwd` (the transpose: the backward reduces
  * over the gate axis) for cadre_lstm_step_bwd; ceil(D / 16) * 4 * 34 * 256 floats per net each, net stride p_str.
@@ -362,11 +338,6 @@ int cadre_categorical_eval(const float* logits, int64_t ldl, const int64_t* acti
 int cadre_categorical_dist(const float* raw, int64_t ldl, int32_t R, int32_t n_out, float* logits_out,
                            float* probs_out, int64_t* mode_out, void* stream);
 
-/* db_ih = db_hh = colsum(dG) in one pass (both biases enter the LSTM gates as a sum): out and out2 [batch][o_str] */
-int cadre_colsum2(const float* X, int64_t ldx, int64_t x_str, float* out, float* out2, int64_t o_str, int32_t M,
-                  int32_t N, int32_t batch, const int32_t* row_seg, int32_t period, void* stream);
-/* (row_seg != NULL: rows sorted by command, `period` rows per time step — rows outside the 32-row tiles of net z's run
- * are exact zeros by construction and are skipped; the sum is bit-identical to the full one.) */
 /* Initial LSTM state of every net z < Z: Hs[z*z_str ..] <- h0[(z / x_div)*n_per ..], same for Cs <- c0 (n_per floats
  * each, agent.py:166-175 hidden_state_batch shared by a head's command nets) and dC (Z*n_per floats, may be NULL) <- 0 */
 int cadre_lstm_init(const float* h0, const float* c0, float* Hs, float* Cs, float* dC, int64_t n_per,

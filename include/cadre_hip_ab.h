@@ -5,6 +5,8 @@
  *   conv_stream_f32.hip / conv_stream_bf16.hip  cadre_gemm_t.tile 12: 64x64 conv, several M-tiles per workgroup
  *   gemm_f32_skinny.hip                         cadre_gemm_t.tile 11 (fp32): register-direct skinny GEMM
  *   conv3x3_c64_bf16.hip                        cadre_conv3x3_c64_bf16 below
+ *   cadre_kernels.hip (under CADRE_AB_KERNELS)  the unfused LSTM cell passes and the two-output column sum of the
+ *                                               round-2 update (superseded by ppo_update.hip)
  */
 #ifndef CADRE_HIP_AB_H
 #define CADRE_HIP_AB_H
@@ -19,6 +21,35 @@ extern "C" {
 int cadre_conv3x3_c64_bf16(const void* x, const void* w, const float* scale, const float* shift,
                            const void* resid, void* out, int32_t F, int32_t H, int32_t W, int32_t relu,
                            void* stream);
+/* ---------------------------------------------------------------- LSTM cell pointwise
+ * nn.LSTMCell gate math (models.py:130-152).  gates [B][ldg] pre-activations (i,f,g,o blocks
+ * of Hd), batched over `batch` nets with strides; c_prev of net z is read at
+ * c_prev + (z / c_prev_div) * c_prev_str (step 0 shares the head's c0 across its 4 command
+ * nets).  Forward overwrites gates with the activated values (kept for backward), writes
+ * c_out, h_out, tanh_c. */
+int cadre_lstm_pointwise_fwd(float* gates, int64_t ldg, int64_t g_str, const float* c_prev,
+                             int64_t c_prev_str, int32_t c_prev_div, float* c_out, float* h_out,
+                             float* tanh_c, int64_t ldh, int64_t h_str, int32_t B, int32_t Hd,
+                             int32_t batch, const int32_t* row_seg, void* stream);
+/* row_seg (may be NULL; [batch][2] = (first row, count) of the run of rows net z owns when the minibatch is sorted by
+ * command, cadre_sort_rows_by_command): only rows of the 32-row tiles that intersect the run are touched — the rows the
+ * segment-aware GEMMs (cadre_gemm_t.seg_mode) read and write. */
+/* backward of one step: dh (in: upstream+recurrent grad of h_t), dc (in/out: grad of c_t ->
+ * grad of c_{t-1}), both [batch][B][ldh] with net stride d_str; activated gates, tanh_c,
+ * c_prev -> dgates [B][ldg] */
+int cadre_lstm_pointwise_bwd(const float* gates, float* dgates, int64_t ldg, int64_t g_str,
+                             const float* dh, float* dc, int64_t d_str, const float* tanh_c,
+                             const float* c_prev,
+                             int64_t c_prev_str, int32_t c_prev_div, int64_t ldh, int64_t h_str,
+                             int32_t B, int32_t Hd, int32_t batch, const int32_t* commands, int32_t C,
+                             const int32_t* row_seg, void* stream);
+/* (commands != NULL: net z = head*C + c only keeps rows whose command is c; the other rows get
+ * dgates = 0 and dc = 0 whatever dh holds — see cadre_gemm_t.seg_mode.) */
+/* db_ih = db_hh = colsum(dG) in one pass (both biases enter the LSTM gates as a sum): out and out2 [batch][o_str] */
+int cadre_colsum2(const float* X, int64_t ldx, int64_t x_str, float* out, float* out2, int64_t o_str, int32_t M,
+                  int32_t N, int32_t batch, const int32_t* row_seg, int32_t period, void* stream);
+/* (row_seg != NULL: rows sorted by command, `period` rows per time step — rows outside the 32-row tiles of net z's run
+ * are exact zeros by construction and are skipped; the sum is bit-identical to the full one.) */
 #ifdef __cplusplus
 }
 #endif

@@ -259,6 +259,7 @@ def test_gather_obs(hip):
 
 
 # ----------------------------------------------------------------------------- LSTM pointwise
+@needs_ab
 def test_lstm_pointwise_fwd_bwd(hip):
     g = torch.Generator().manual_seed(9)
     Z, B, Hd, ldg, ldh = 8, 6, 530, 2120, 544
@@ -622,6 +623,7 @@ def test_lstm_seq_fwd_persistent_equals_per_step(hip, B, sorted_rows):
     assert bool(torch.isfinite(H1).all()) and float(H1[:, S].abs().max()) > 0
 
 
+@needs_ab
 def test_lstm_pointwise_and_colsum2_row_segments(hip):
     """Rows sorted by command: the pointwise LSTM passes and the bias-gradient column sum touch only the 32-row tiles
     that intersect each net's run of rows — same values there as the unrestricted kernels, bit for bit; rows outside
