@@ -80,8 +80,10 @@ class PPOArena:
         return g if kind == "lstm" else self.Z + g
 
     # ------------------------------------------------------------------ views
-    def lstm_views(self, buf, g):
-        b = g * self.size_L
+    def lstm_views(self, buf, g, base=None):
+        """parameter-shaped views of net g's LSTM block in `buf` (arena layout; `base`: the block starts there instead —
+        a buffer that holds just this block)"""
+        b = g * self.size_L if base is None else base
         D, DP, H4 = self.D, self.DP, self.H4
         return {
             "rnn.weight_ih": buf[b + self.o_wih: b + self.o_wih + H4 * DP].view(H4, DP)[:, :D],
@@ -90,12 +92,12 @@ class PPOArena:
             "rnn.bias_hh": buf[b + self.o_bhh: b + self.o_bhh + H4],
         }
 
-    def ppo_views(self, buf, g):
+    def ppo_views(self, buf, g, base=None):
         out = {}
         hid, DP, D, NP = self.hid, self.DP, self.D, self.NP
         head = g // self.C
         for tower, name in ((0, "control.linear"), (1, "critic")):
-            b = self.P0 + g * self.size_P + tower * self.size_T
+            b = (self.P0 + g * self.size_P if base is None else base) + tower * self.size_T
             n3 = self.n_out[head] if tower == 0 else 1
             out[name + ".0.weight"] = buf[b + self.t_w1: b + self.t_w1 + hid * DP].view(hid, DP)[:, :D]
             out[name + ".0.bias"] = buf[b + self.t_b1: b + self.t_b1 + hid]

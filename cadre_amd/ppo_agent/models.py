@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from ..arena import PPOArena
 from ..encoder import DANetEncoderHIP
-from .. import hip
+from .. import autograd, hip
 from .distributions import Categorical_1d
 from .utils import Counter, init
 
@@ -83,10 +83,16 @@ class LSTM(nn.Module):
         self.rnn.bias_hh.data.fill_(0)
 
     def forward(self, x, hidden_state):
-        """models.py:139-152 (inference; training gradients come from CadreAgent.update_policy):
-        one cell step if x.size(0) == h.size(0), else [T*N, D] time-major unrolled over T."""
+        """models.py:139-152: one cell step if x.size(0) == h.size(0), else [T*N, D] time-major unrolled over T.
+        Differentiable (cadre_amd/autograd.py: backward through time on the fused step kernels) when gradients are
+        enabled and the parameters or inputs require them; `update_policy` does not come through here."""
         arena, learner, g = _module_net(self)
-        h, c = learner.lstm_module_forward(g, x, hidden_state[0], hidden_state[1])
+        r = self.rnn
+        if autograd.wants_grad(x, hidden_state[0], hidden_state[1], r.weight_ih, r.weight_hh, r.bias_ih, r.bias_hh):
+            h, c = autograd.LstmSequence.apply(learner, g, x, hidden_state[0], hidden_state[1], r.weight_ih, r.weight_hh,
+                                               r.bias_ih, r.bias_hh)
+        else:
+            h, c = learner.lstm_module_forward(g, x, hidden_state[0], hidden_state[1])
         return h, (h, c)
 
 
@@ -111,8 +117,20 @@ class Model(nn.Module):
     def get_log_probs(self, action):
         return self.control.log_probs(action)
 
+    def _towers(self, obs_feature):
+        """(raw logits [N, n_out], value [N, 1]) with an autograd graph (cadre_amd/autograd.py), or None when no
+        gradient is wanted."""
+        params = autograd.tower_params(self)
+        if not autograd.wants_grad(obs_feature, *params):
+            return None
+        _a, learner, g = _module_net(self)
+        return autograd.TowerPair.apply(learner, g, self.control.num_outputs, obs_feature, *params)
+
     def get_value(self, obs_feature):
-        """models.py:195-197 (inference)."""
+        """models.py:195-197."""
+        tw = self._towers(obs_feature)
+        if tw is not None:
+            return tw[1]
         _a, learner, g = _module_net(self)
         return learner.mlp_module_forward(g, obs_feature)[1].clone()
 
@@ -131,7 +149,15 @@ class Model(nn.Module):
         return value.clone(), action, obs_feature.clone().detach()
 
     def evaluate_actions(self, obs_feature, action):
-        """models.py:199-208 forward (no autograd graph) -> (value [N,1], log_prob [N,1], entropy [N,1])."""
+        """models.py:199-208 -> (value [N,1], log_prob [N,1], entropy [N,1]); differentiable when gradients are wanted
+        (towers on the HIP kernels, the categorical tail on [N, n_out] in torch)."""
+        tw = self._towers(obs_feature)
+        if tw is not None:
+            raw, value = tw
+            logits = raw - raw.logsumexp(dim=-1, keepdim=True)           # distributions.py:66-83 Categorical(logits=...)
+            logp = logits.gather(1, action.reshape(-1, 1).to(torch.int64))
+            ent = -(logits.exp() * logits).sum(-1, keepdim=True)
+            return value, logp, ent
         arena, learner, g = _module_net(self)
         logits, value = learner.mlp_module_forward(g, obs_feature)
         R = obs_feature.shape[0]

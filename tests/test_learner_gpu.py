@@ -321,18 +321,24 @@ def test_module_level_api_matches_oracle():
     lstm = agent.model_dict["throttle_lstm_2"]
     h, (h2, c2) = lstm(x.cuda(), (h0.cuda(), c0.cuda()))
     wh, (_, wc) = ppo_ref.lstm_forward(x, (h0, c0), P["throttle_lstm_2"])
-    assert rel(h.cpu().numpy(), wh.numpy()) < 1e-5 and rel(c2.cpu().numpy(), wc.numpy()) < 1e-5
+    assert rel(h.detach().cpu().numpy(), wh.numpy()) < 1e-5 and rel(c2.detach().cpu().numpy(), wc.numpy()) < 1e-5
     h1, _ = lstm(x[:N].cuda(), (h0.cuda(), c0.cuda()))                     # single-step branch
     w1, _ = ppo_ref.lstm_forward(x[:N], (h0, c0), P["throttle_lstm_2"])
-    assert rel(h1.cpu().numpy(), w1.numpy()) < 1e-5
+    assert rel(h1.detach().cpu().numpy(), w1.numpy()) < 1e-5
     model = agent.model_dict["steer_ppo_1"]
     feat = wh
     acts = torch.from_numpy(r.randint(0, 33, (N, 1)))
     v, lp, ent = model.evaluate_actions(feat.cuda(), acts.cuda())
     wv, wlp, went = ppo_ref.evaluate_actions(feat, acts, P["steer_ppo_1"])
-    assert rel(v.cpu().numpy(), wv.numpy()) < 1e-5 and rel(lp.cpu().numpy(), wlp.numpy()) < 1e-5
-    assert rel(ent.cpu().numpy(), went.numpy()) < 1e-5
-    assert rel(model.get_value(feat.cuda()).cpu().numpy(), wv.numpy()) < 1e-5
+    assert rel(v.detach().cpu().numpy(), wv.numpy()) < 1e-5 and rel(lp.detach().cpu().numpy(), wlp.numpy()) < 1e-5
+    assert rel(ent.detach().cpu().numpy(), went.numpy()) < 1e-5
+    assert rel(model.get_value(feat.cuda()).detach().cpu().numpy(), wv.numpy()) < 1e-5
+    with torch.no_grad():                                                  # the no-graph path: same values
+        v0, lp0, ent0 = model.evaluate_actions(feat.cuda(), acts.cuda())
+        assert not v0.requires_grad and rel(v0.cpu().numpy(), wv.numpy()) < 1e-5 and rel(lp0.cpu().numpy(), wlp.numpy()) < 1e-5
+        assert rel(ent0.cpu().numpy(), went.numpy()) < 1e-5
+        hn, _ = lstm(x.cuda(), (h0.cuda(), c0.cuda()))
+        assert not hn.requires_grad and rel(hn.cpu().numpy(), wh.numpy()) < 1e-5
     torch.manual_seed(7)
     value, action, _f = model.act(feat.cuda())
     torch.manual_seed(7)
@@ -341,6 +347,57 @@ def test_module_level_api_matches_oracle():
     assert torch.equal(action.cpu(), want_a)
     assert rel(model.get_log_probs(action).cpu().numpy(),
                ppo_ref.categorical_logits(feat, P["steer_ppo_1"]).gather(1, want_a.view(-1, 1)).numpy()) < 1e-5
+
+
+def test_module_autograd_matches_torch():
+    """A caller that builds its OWN loss on the stand-alone modules (reference ppo_agent/models.py:139-152 LSTM.forward,
+    199-208 Model.evaluate_actions, 195-197 get_value — all differentiable there): gradients of every parameter and of
+    the inputs equal torch autograd of the oracle restatement, and land in the parameters' `.grad` (arena views)."""
+    from oracle import ppo_ref
+    agent = make_agent(84, 84)
+    st0 = synth.ppo_state(11)
+    P = ppo_ref.to_torch_params(st0, requires_grad=True)
+    r = np.random.RandomState(5)
+    f32 = lambda *shape, s=1.0: torch.from_numpy((r.standard_normal(shape) * s).astype(np.float32))
+    for N, T in ((5, 8), (33, 3), (4, 1)):
+        agent.arena.grads.zero_()
+        for d in P.values():
+            for p in d.values():
+                p.grad = None
+        x, h0, c0 = f32(T * N, 530, s=0.5), f32(N, 530, s=0.1), f32(N, 530, s=0.1)
+        wh_, wc_ = f32(N, 530), f32(N, 530)
+        # ---- LSTM: loss = <h_T, wh> + <c_T, wc>
+        xd, hd, cd = (t.cuda().requires_grad_() for t in (x, h0, c0))
+        lstm = agent.model_dict["throttle_lstm_2"]
+        h, (_h, c) = lstm(xd, (hd, cd))
+        ((h * wh_.cuda()).sum() + (c * wc_.cuda()).sum()).backward()
+        xr, hr, cr = (t.clone().requires_grad_() for t in (x, h0, c0))
+        rh, (_rh, rc) = ppo_ref.lstm_forward(xr, (hr, cr), P["throttle_lstm_2"])
+        ((rh * wh_).sum() + (rc * wc_).sum()).backward()
+        errs = {"x": rel(xd.grad.cpu().numpy(), xr.grad.numpy()), "h0": rel(hd.grad.cpu().numpy(), hr.grad.numpy()),
+                "c0": rel(cd.grad.cpu().numpy(), cr.grad.numpy())}
+        for k, p in lstm.named_parameters():
+            errs[k] = rel(p.grad.cpu().numpy(), P["throttle_lstm_2"][k].grad.numpy())
+        # ---- towers: loss = <value, wv> + <log_prob, wl> + 0.3 sum(entropy) + sum(get_value^2)
+        model = agent.model_dict["steer_ppo_1"]
+        feat, acts = f32(N, 530, s=0.5), torch.from_numpy(r.randint(0, 33, (N, 1)))
+        wv, wl = f32(N, 1), f32(N, 1)
+        fd = feat.cuda().requires_grad_()
+        v, lp, ent = model.evaluate_actions(fd, acts.cuda())
+        ((v * wv.cuda()).sum() + (lp * wl.cuda()).sum() + 0.3 * ent.sum() + (model.get_value(fd) ** 2).sum()).backward()
+        fr = feat.clone().requires_grad_()
+        rv, rlp, rent = ppo_ref.evaluate_actions(fr, acts, P["steer_ppo_1"])
+        ((rv * wv).sum() + (rlp * wl).sum() + 0.3 * rent.sum() + (ppo_ref.mlp3(fr, P["steer_ppo_1"], "critic") ** 2).sum()).backward()
+        errs["feat"] = rel(fd.grad.cpu().numpy(), fr.grad.numpy())
+        for k, p in model.named_parameters():
+            errs["ppo." + k] = rel(p.grad.cpu().numpy(), P["steer_ppo_1"][k].grad.numpy())
+            assert p.grad.data_ptr() >= agent.arena.grads.data_ptr() and \
+                p.grad.data_ptr() < agent.arena.grads.data_ptr() + 4 * agent.arena.grads.numel()      # still the arena's view
+        print("module autograd N=%d T=%d: worst %s" % (N, T, max(errs.items(), key=lambda kv: kv[1])))
+        assert max(errs.values()) < 2e-5, errs
+        # no other net's gradients were touched
+        other = agent.arena.views(agent.arena.grads, "steer_lstm_0")
+        assert all(float(t.abs().max()) == 0.0 for t in other.values())
 
 
 def test_reference_topology_shared_nets_and_worker_agent():
