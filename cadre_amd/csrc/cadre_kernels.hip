@@ -360,10 +360,14 @@ typedef float pam_f32x16 __attribute__((ext_vector_type(16)));
 // counts follow the map — the reference's native 5 x 8 map (Np = 40) runs 4 + 8 tiles instead of 9 + 12 and two
 // workgroups per CU.  The padding contributes exact zeros at the END of every fma chain, so the results do not depend
 // on R (same bits as the fixed 96-row form).
-__global__ __launch_bounds__(256) void pam_kernel(const float* qkv, const float* x, float gamma, float* y, int Np,
-                                                  int out_bf16) {
+// 8 waves per workgroup (two per SIMD): one workgroup per CU fits (97 KB of LDS at Np = 81), and with a single wave
+// per SIMD every LDS round trip of the softmax and of the scalar fragment reads was exposed (PMC: 8 k VALU + 0.7 k LDS
+// instructions per wave in 129 k wave cycles) — 217 -> 124 us per 1024 frames at Np = 81, 23 -> 14 us for one 5 x 8 frame.
+#define PAM_THREADS 512
+__global__ __launch_bounds__(PAM_THREADS) void pam_kernel(const float* qkv, const float* x, float gamma, float* y, int Np,
+                                                          int out_bf16) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  constexpr int QP = 17;
+  constexpr int QP = 17, NW = PAM_THREADS / 64;
   const int RB = (Np + 31) >> 5, R = 32 * RB, AP = R + 1;
   float* q = sm;                    // [R][17]
   float* k = q + R * QP;            // [R][17]
@@ -371,17 +375,32 @@ __global__ __launch_bounds__(256) void pam_kernel(const float* qkv, const float*
   float* att = v + R * 128;         // [R][R + 1]
   const int f = blockIdx.x, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
-  const float* src = qkv + (int64_t)f * Np * 160;
-  for (int i = tid; i < R * 160; i += 256) {
-    const int n = i / 160, c = i % 160;
-    const float val = n < Np ? src[i] : 0.f;
-    if (c < 16) q[n * QP + c] = val;
-    else if (c < 32) k[n * QP + c - 16] = val;
-    else v[n * 128 + c - 32] = val;
+  // staging: the frame's rows as 16-byte pieces (40 per row), ALL requested before the first LDS write
+  const float4* src4 = reinterpret_cast<const float4*>(qkv + (int64_t)f * Np * 160);
+  constexpr int NST = (PAM_MAXNP * 40 + PAM_THREADS - 1) / PAM_THREADS;
+  float4 stg[NST];
+#pragma unroll
+  for (int j = 0; j < NST; ++j) {
+    const int i = tid + PAM_THREADS * j;
+    const float4 t = src4[min(i, Np * 40 - 1)];
+    stg[j] = i < Np * 40 ? t : float4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int j = 0; j < NST; ++j) {
+    const int i = tid + PAM_THREADS * j;
+    if (i < R * 40) {
+      const int n = i / 40, c4 = i - 40 * n;
+      if (c4 < 8) {
+        float* d = (c4 < 4 ? q : k) + n * QP + 4 * (c4 & 3);
+        d[0] = stg[j].x; d[1] = stg[j].y; d[2] = stg[j].z; d[3] = stg[j].w;
+      } else {
+        *reinterpret_cast<float4*>(v + n * 128 + 4 * (c4 - 8)) = stg[j];
+      }
+    }
   }
   __syncthreads();
-  // ---- energy[n][m] = q[n] . k[m]: RB x RB tiles of 32x32 over 4 waves, 8 MFMAs (K = 16) each
-  for (int t = wave; t < RB * RB; t += 4) {
+  // ---- energy[n][m] = q[n] . k[m]: RB x RB tiles of 32x32 over the waves, 8 MFMAs (K = 16) each
+  for (int t = wave; t < RB * RB; t += NW) {
     const int n0 = (t / RB) * 32, m0 = (t % RB) * 32;
     pam_f32x16 acc;
 #pragma unroll
@@ -394,7 +413,7 @@ __global__ __launch_bounds__(256) void pam_kernel(const float* qkv, const float*
     for (int r = 0; r < 16; ++r) att[(n0 + (r & 3) + 8 * (r >> 2) + 4 * lh) * AP + m] = m < Np ? acc[r] : -INFINITY;
   }
   __syncthreads();
-  for (int n = wave; n < R; n += 4) {                // row softmax (da_att.py:44); padded rows become zeros
+  for (int n = wave; n < R; n += NW) {               // row softmax (da_att.py:44); padded rows become zeros
     if (n >= Np) {
       for (int m = lane; m < R; m += 64) att[n * AP + m] = 0.f;
       continue;
@@ -412,27 +431,32 @@ __global__ __launch_bounds__(256) void pam_kernel(const float* qkv, const float*
     for (int m = lane; m < R; m += 64) att[n * AP + m] = att[n * AP + m] / s;
   }
   __syncthreads();
-  // ---- out[n][c] = sum_m att[n][m] v[m][c]: wave w owns channel block w (32 channels), all row blocks
-  pam_f32x16 o[3];
+  // ---- out[n][c] = sum_m att[n][m] v[m][c]: wave w owns channel block w & 3 (32 channels) and the row blocks
+  // b = (w >> 2) + 2 j (the k order of every output's chain is 0 .. R-1 as before: same bits)
+  const int half = wave >> 2;
+  pam_f32x16 o[2];
 #pragma unroll
-  for (int b = 0; b < 3; ++b)
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[b][r] = 0.f;
-  const int c = 32 * wave + l31;
-  for (int kk = 0; kk < R / 2; ++kk) {
-    const float bv = v[(2 * kk + lh) * 128 + c];
-#pragma unroll
-    for (int b = 0; b < 3; ++b)
-      if (b < RB) o[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(att[(32 * b + l31) * AP + 2 * kk + lh], bv, o[b], 0, 0, 0);
+    for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
+  const int c = 32 * (wave & 3) + l31;
+  const bool two = half + 2 < RB;
+  if (half < RB) {
+#pragma unroll 8
+    for (int kk = 0; kk < R / 2; ++kk) {
+      const float bv = v[(2 * kk + lh) * 128 + c];
+      o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(att[(32 * half + l31) * AP + 2 * kk + lh], bv, o[0], 0, 0, 0);
+      if (two) o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(att[(32 * (half + 2) + l31) * AP + 2 * kk + lh], bv, o[1], 0, 0, 0);
+    }
   }
   const float* xf = x + (int64_t)f * Np * 128;
 #pragma unroll
-  for (int b = 0; b < 3; ++b)
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int n = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int n = 32 * (half + 2 * j) + (r & 3) + 8 * (r >> 2) + 4 * lh;
       if (n < Np) {
-        const float res = gamma * o[b][r] + xf[n * 128 + c];
+        const float res = gamma * o[j][r] + xf[n * 128 + c];
         if (out_bf16) reinterpret_cast<__bf16*>(y)[(int64_t)f * Np * 128 + n * 128 + c] = (__bf16)res;
         else y[(int64_t)f * Np * 128 + n * 128 + c] = res;
       }
@@ -459,51 +483,66 @@ static int pam_launch(const float* x, const float* qkv, float gamma, void* y, in
     (void)hipFuncSetAttribute((const void*)pam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(pam_kernel, dim3(F), dim3(256), shm, ST(stream), qkv, x, gamma, (float*)y, Np, out_bf16);
+  hipLaunchKernelGGL(pam_kernel, dim3(F), dim3(PAM_THREADS), shm, ST(stream), qkv, x, gamma, (float*)y, Np, out_bf16);
   return (int)hipGetLastError();
 }
 
 // ============================================================================ CAM (channel attention)
 #define CAM_XP 132                // row pitch of the staged frame [Np][128] (+4: rows 14 apart land on different banks)
 #define CAM_EP 132                // row pitch of the energy / attention matrix [128][128]
-__global__ __launch_bounds__(256) void cam_kernel(const float* x, float gamma, float* y, int Np, int out_bf16) {
+// Both products on the matrix cores (v_mfma_f32_32x32x2_f32: the fp32 fma chain of a scalar loop in ascending k), 8 waves
+// per workgroup: energy = x^T x (da_att.py:74; 128 x 128, K = Np) as 4 x 4 tiles, out^T[n][c] = sum_d x[n][d] att[c][d]
+// (:79; Np x 128, K = 128) as 3 x 4 tiles with the channel on the lanes (row-contiguous stores).  The VALU form this
+// replaces ran 13 k vector instructions per wave with one wave per SIMD (PMC): 231 -> 119 us per 1024 frames at Np = 81,
+// 47 -> 24 us for one 5 x 8 frame.
+#define CAM_THREADS 512
+__global__ __launch_bounds__(CAM_THREADS) void cam_kernel(const float* x, float gamma, float* y, int Np, int out_bf16) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* xs = sm;                 // [Np][CAM_XP]
-  float* E = xs + Np * CAM_XP;    // [128][CAM_EP]
+  constexpr int NW = CAM_THREADS / 64;
+  const int RB = (Np + 31) >> 5, R = 32 * RB;
+  float* xs = sm;                 // [R][CAM_XP], rows >= Np zero
+  float* E = xs + R * CAM_XP;     // [128][CAM_EP]
   const int f = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
   const float* xf = x + (int64_t)f * Np * 128;
-  for (int i = tid; i < Np * 32; i += 256)
-    *reinterpret_cast<float4*>(xs + (i >> 5) * CAM_XP + (i & 31) * 4) = reinterpret_cast<const float4*>(xf)[i];
-  __syncthreads();
-  {  // energy[c][d] = sum_n x[n][c] x[n][d]   (da_att.py:74): 8x8 register block per thread
-    const int c0 = (tid >> 4) * 8, d0 = (tid & 15) * 8;
-    float acc[8][8];
+  {  // staging: all 16-byte pieces requested before the first LDS write (one HBM round trip per workgroup)
+    constexpr int NST = (PAM_MAXNP * 32 + CAM_THREADS - 1) / CAM_THREADS;
+    float4 stg[NST];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
-    for (int n = 0; n < Np; ++n) {
-      float a[8], b[8];
-      const float4 a0 = *reinterpret_cast<const float4*>(xs + n * CAM_XP + c0);
-      const float4 a1 = *reinterpret_cast<const float4*>(xs + n * CAM_XP + c0 + 4);
-      const float4 b0 = *reinterpret_cast<const float4*>(xs + n * CAM_XP + d0);
-      const float4 b1 = *reinterpret_cast<const float4*>(xs + n * CAM_XP + d0 + 4);
-      a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
-      b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] += a[i] * b[j];
+    for (int j = 0; j < NST; ++j) {
+      const int i = tid + CAM_THREADS * j;
+      const float4 t = reinterpret_cast<const float4*>(xf)[min(i, Np * 32 - 1)];
+      stg[j] = i < Np * 32 ? t : float4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      *reinterpret_cast<float4*>(E + (c0 + i) * CAM_EP + d0) = float4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
-      *reinterpret_cast<float4*>(E + (c0 + i) * CAM_EP + d0 + 4) = float4{acc[i][4], acc[i][5], acc[i][6], acc[i][7]};
+    for (int j = 0; j < NST; ++j) {
+      const int i = tid + CAM_THREADS * j;
+      if (i < R * 32) *reinterpret_cast<float4*>(xs + (i >> 5) * CAM_XP + (i & 31) * 4) = stg[j];
     }
   }
   __syncthreads();
-  const int lane = tid & 63, wave = tid >> 6;
-  for (int c = wave; c < 128; c += 4) {               // energy_new = rowmax - energy; softmax (:75-76)
+  {  // energy[c][d] = sum_n x[n][c] x[n][d]: wave w owns tile row w >> 1 and the two tile columns 2 (w & 1), + 1
+    const int c0 = 32 * (wave >> 1), d0 = 64 * (wave & 1);
+    pam_f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int nk = (Np + 1) >> 1;                    // (row Np is zero when Np is odd)
+#pragma unroll 8
+    for (int kk = 0; kk < nk; ++kk) {
+      const float* row = xs + (2 * kk + lh) * CAM_XP;
+      const float a = row[c0 + l31];
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, row[d0 + l31], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, row[d0 + 32 + l31], acc[1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) E[(c0 + (r & 3) + 8 * (r >> 2) + 4 * lh) * CAM_EP + d0 + 32 * j + l31] = acc[j][r];
+  }
+  __syncthreads();
+  for (int c = wave; c < 128; c += NW) {              // energy_new = rowmax - energy; softmax (:75-76)
     const float e0 = E[c * CAM_EP + lane], e1 = E[c * CAM_EP + lane + 64];
     const float rmax = wave_max(fmaxf(e0, e1));
     const float n0 = rmax - e0, n1 = rmax - e1;
@@ -514,48 +553,36 @@ __global__ __launch_bounds__(256) void cam_kernel(const float* x, float gamma, f
     E[c * CAM_EP + lane + 64] = p1 / s;
   }
   __syncthreads();
-  // out[c][n] = sum_d att[c][d] x[d][n]  (:79), the d sum in order 0..127 per output.  Register block of 8 channels
-  // (c = cg + 16 i: rows of different threads on different banks) x 7 positions (n = ng + 14 j <= 97) per thread, d in steps
-  // of 4: 15 ds_read_b128 per 224 FMAs (one thread per output read two words per FMA: the LDS bound this phase).
-  if (tid < 224) {
-    const int cg = tid / 14, ng = tid % 14;
-    float o[8][7];
+  // out[n][c] = sum_d x[n][d] att[c][d] (d ascending): wave w owns channel block w & 3 and position blocks (w >> 2) + 2 j
+  const int half = wave >> 2, c = 32 * (wave & 3) + l31;
+  const bool two = half + 2 < RB;
+  pam_f32x16 o[2];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int j = 0; j < 7; ++j) o[i][j] = 0.f;
-    int nrow[7];
-#pragma unroll
-    for (int j = 0; j < 7; ++j) nrow[j] = min(ng + 14 * j, Np - 1) * CAM_XP;      // (rows past Np: clamped, not stored)
-    for (int d = 0; d < 128; d += 4) {
-      float4 av[8], xv[7];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) av[i] = *reinterpret_cast<const float4*>(E + (cg + 16 * i) * CAM_EP + d);
-#pragma unroll
-      for (int j = 0; j < 7; ++j) xv[j] = *reinterpret_cast<const float4*>(xs + nrow[j] + d);
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 7; ++j) {
-          o[i][j] += av[i].x * xv[j].x;
-          o[i][j] += av[i].y * xv[j].y;
-          o[i][j] += av[i].z * xv[j].z;
-          o[i][j] += av[i].w * xv[j].w;
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 7; ++j) {
-      const int n = ng + 14 * j;
-      if (n >= Np) continue;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c = cg + 16 * i;
-        const float r = gamma * o[i][j] + xs[n * CAM_XP + c];
-        if (out_bf16) reinterpret_cast<__bf16*>(y)[(int64_t)f * Np * 128 + n * 128 + c] = (__bf16)r;
-        else y[(int64_t)f * Np * 128 + n * 128 + c] = r;
-      }
+    for (int r = 0; r < 16; ++r) o[j][r] = 0.f;
+  if (half < RB) {
+    const float* er = E + c * CAM_EP + lh;
+    const float* x0 = xs + (32 * half + l31) * CAM_XP + lh;
+    const float* x1 = xs + (32 * (two ? half + 2 : half) + l31) * CAM_XP + lh;
+#pragma unroll 8
+    for (int kk = 0; kk < 64; ++kk) {
+      const float bv = er[2 * kk];
+      o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[2 * kk], bv, o[0], 0, 0, 0);
+      if (two) o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1[2 * kk], bv, o[1], 0, 0, 0);
     }
   }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = 32 * (half + 2 * j) + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (n < Np) {
+        const float res = gamma * o[j][r] + xs[n * CAM_XP + c];
+        if (out_bf16) reinterpret_cast<__bf16*>(y)[(int64_t)f * Np * 128 + n * 128 + c] = (__bf16)res;
+        else y[(int64_t)f * Np * 128 + n * 128 + c] = res;
+      }
+    }
 }
 
 static int cam_launch(const float* x, float gamma, void* y, int32_t F, int32_t Np, int out_bf16, void* stream);
@@ -567,13 +594,13 @@ extern "C" int cadre_cam_bf16out(const float* x, float gamma, void* y, int32_t F
 }
 static int cam_launch(const float* x, float gamma, void* y, int32_t F, int32_t Np, int out_bf16, void* stream) {
   FAIL_IF(!x || !y || F < 1 || Np < 1 || Np > PAM_MAXNP, "cadre_cam: bad argument (Np<=96)");
-  const size_t shm = sizeof(float) * ((size_t)Np * CAM_XP + 128 * CAM_EP);
+  const size_t shm = sizeof(float) * ((size_t)((Np + 31) / 32) * 32 * CAM_XP + 128 * CAM_EP);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)cam_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(cam_kernel, dim3(F), dim3(256), shm, ST(stream), x, gamma, (float*)y, Np, out_bf16);
+  hipLaunchKernelGGL(cam_kernel, dim3(F), dim3(CAM_THREADS), shm, ST(stream), x, gamma, (float*)y, Np, out_bf16);
   return (int)hipGetLastError();
 }
 
