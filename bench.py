@@ -162,20 +162,28 @@ def learner_round(agent, workers, cfg, shared, timers=None, joint=None):
     HIP-event time of each of the 8 minibatch steps (gather + update_policy + gradient exchange + clip + Adam)."""
     from ppo_agent.chief import chief_step
     t0 = time.perf_counter()
+    host = [] if os.environ.get("CADRE_BENCH_HOST_TRACE") else None      # host-side enqueue times of the round's phases (no syncs added)
     if joint is not None:
         encode_joint(agent, workers, joint, cfg, cfg["chunk_windows"])
     else:
         for wk in workers:
             encode_worker(agent, wk, cfg, cfg["chunk_windows"])
+    if host is not None:
+        host.append(("encode enqueued", time.perf_counter() - t0))
     if timers is not None:
         torch.cuda.synchronize(); t1 = time.perf_counter()
     advs = []
+    # (commands stay on the device: .item() in get_last would wait for the encoder pass and expose ~1 ms of host work)
     if len(workers) > 1:      # bootstrap values of all workers in one LSTM + critic pass
-        vals = agent.get_values([(wk.stor[0].get_last(), wk.stor[1].get_last()) for wk in workers])
+        vals = agent.get_values([(wk.stor[0].get_last(as_tensor=True), wk.stor[1].get_last(as_tensor=True)) for wk in workers])
     else:
-        vals = [agent.get_value(False, wk.stor[0].get_last(), wk.stor[1].get_last()) for wk in workers]
+        vals = [agent.get_value(False, wk.stor[0].get_last(as_tensor=True), wk.stor[1].get_last(as_tensor=True)) for wk in workers]
+    if host is not None:
+        host.append(("bootstrap values enqueued", time.perf_counter() - t0))
     for wk, (nv_s, nv_t) in zip(workers, vals):
         advs.append((wk.stor[0].compute_returns(nv_s), wk.stor[1].compute_returns(nv_t)))
+    if host is not None:
+        host.append(("GAE enqueued", time.perf_counter() - t0))
     nW = len(workers)
     dev_losses = []
     hook = None
@@ -195,7 +203,12 @@ def learner_round(agent, workers, cfg, shared, timers=None, joint=None):
             chief_step(shared, None, 250.0)
     if timers is not None:
         evs.append(torch.cuda.Event(enable_timing=True)); evs[-1].record()
+    if host is not None:
+        host.append(("updates enqueued", time.perf_counter() - t0))
     losses = torch.stack(dev_losses).tolist()                     # the round's single host sync
+    if host is not None:
+        host.append(("losses on the host", time.perf_counter() - t0))
+        log("[bench] host timeline (ms since round start): " + ", ".join("%s %.2f" % (k, 1e3 * v) for k, v in host))
     if timers is not None:
         torch.cuda.synchronize(); t2 = time.perf_counter()
         timers.append((t1 - t0, t2 - t1, [evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1)]))

@@ -241,6 +241,8 @@ class CadreAgent(object):
             return torch.zeros(1), torch.zeros(1)
         s_obs, s_cmd = steer_batch
         t_obs, t_cmd = throttle_batch
+        if torch.is_tensor(s_cmd) or torch.is_tensor(t_cmd):        # get_last(as_tensor=True): no host sync, net picked on the device
+            return self.get_values([(steer_batch, throttle_batch)])[0]
         O3, _, _ = self.learner.infer(torch.stack([s_obs, t_obs]), (int(s_cmd), int(t_cmd)))
         return O3[1, :, :1].clone(), O3[3, :, :1].clone()
 
@@ -252,10 +254,22 @@ class CadreAgent(object):
         feats = torch.stack([torch.stack([sb[0] for sb, _tb in batches]), torch.stack([tb[0] for _sb, tb in batches])])
         O3 = self.learner.infer_rows(feats).clone()
         C = self.arena.C
+        dev_cmd = any(torch.is_tensor(sb[1]) or torch.is_tensor(tb[1]) for sb, tb in batches)
+        if dev_cmd:
+            # commands as device tensors (RolloutStorage.get_last(as_tensor=True)): every row's critic tower is picked by an
+            # index computed on the device — no .item(), so the host runs ahead of the encoder pass still in flight
+            dev = O3.device
+            as_t = lambda c: c.reshape(()).to(dev, torch.int64) if torch.is_tensor(c) else torch.tensor(int(c), device=dev)
+            cs = torch.stack([as_t(sb[1]) for sb, _tb in batches])
+            ct = torch.stack([as_t(tb[1]) for _sb, tb in batches])
+            rows = torch.arange(len(batches), device=dev)
+            vs, vt = O3[2 * cs + 1, rows, 0], O3[2 * (C + ct) + 1, rows, 0]
         out = []
         for i, (sb, tb) in enumerate(batches):
             if dones is not None and dones[i]:
                 out.append((torch.zeros(1), torch.zeros(1)))
+            elif dev_cmd:
+                out.append((vs[i:i + 1].view(1, 1), vt[i:i + 1].view(1, 1)))
             else:
                 out.append((O3[2 * int(sb[1]) + 1, i:i + 1, :1], O3[2 * (C + int(tb[1])) + 1, i:i + 1, :1]))
         return out

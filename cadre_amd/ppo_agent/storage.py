@@ -100,7 +100,13 @@ class RolloutStorage(object):
                                       self.num_steps, g32, gt32, 1 if normalise else 0, hip.stream()), "cadre_gae")
         return self.advantages
 
-    def get_last(self):
+    def get_last(self, as_tensor=False):
+        """storage.py:88-91: (obs[-1], command[-1].item()).  `.item()` on a device tensor is a host sync — in the learner
+        section it waits for the whole encoder pass and leaves the GPU idle while the host then enqueues the bootstrap
+        values, GAE and the first minibatch (traced: 1.2-2 ms per round).  as_tensor=True returns the command as the
+        0-dim device tensor instead; `CadreAgent.get_value(s)` then pick the command net on the device."""
+        if as_tensor:
+            return self.obs[-1], self.command[-1]
         return self.obs[-1], int(self.command[-1].item())
 
     def sample_indices(self):

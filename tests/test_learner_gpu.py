@@ -560,7 +560,15 @@ def test_get_values_equals_per_worker_get_value():
         batches.append(((fs, i % 4), (ft, (i + 2) % 4)))
     want = [agent.get_value(False, sb, tb) for sb, tb in batches]
     got = agent.get_values(batches)
-    for (ws, wt), (gs, gt) in zip(want, got):
+    # commands as 0-dim device tensors (RolloutStorage.get_last(as_tensor=True)): the net is picked on the device, same bits
+    dev_batches = [((fs, torch.tensor(cs, dtype=torch.int32, device="cuda")), (ft, torch.tensor(ct, dtype=torch.int32, device="cuda")))
+                   for (fs, cs), (ft, ct) in batches]
+    got_dev = agent.get_values(dev_batches)
+    one_dev = agent.get_value(False, dev_batches[2][0], dev_batches[2][1])
+    for i, ((ws, wt), (gs, gt)) in enumerate(zip(want, got)):
         assert gs.shape == ws.shape == (1, 1) and gt.shape == wt.shape
         assert abs(float(ws) - float(gs)) <= 1e-6 * max(1.0, abs(float(ws)))
         assert abs(float(wt) - float(gt)) <= 1e-6 * max(1.0, abs(float(wt)))
+        assert got_dev[i][0].shape == (1, 1) and torch.equal(got_dev[i][0], gs) and torch.equal(got_dev[i][1], gt)
+    assert abs(float(one_dev[0]) - float(want[2][0])) <= 1e-6 * max(1.0, abs(float(want[2][0])))
+    assert abs(float(one_dev[1]) - float(want[2][1])) <= 1e-6 * max(1.0, abs(float(want[2][1])))
