@@ -157,7 +157,7 @@ def encode_joint(agent, workers, joint, cfg, chunk_windows):
         wk.stor[1]._obs.copy_(wk.stor[0]._obs)
 
 
-def learner_round(agent, workers, cfg, shared, timers=None, joint=None):
+def learner_round(agent, workers, cfg, shared, timers=None, joint=None, losses_to_host=True):
     """One learner round.  timers (list, untimed split pass only): receives (t_encode, t_update, step_ms) with step_ms the
     HIP-event time of each of the 8 minibatch steps (gather + update_policy + gradient exchange + clip + Adam)."""
     from ppo_agent.chief import chief_step
@@ -205,6 +205,8 @@ def learner_round(agent, workers, cfg, shared, timers=None, joint=None):
         evs.append(torch.cuda.Event(enable_timing=True)); evs[-1].record()
     if host is not None:
         host.append(("updates enqueued", time.perf_counter() - t0))
+    if not losses_to_host:                                        # the caller reads them later: the host never waits inside a round
+        return torch.stack(dev_losses)
     losses = torch.stack(dev_losses).tolist()                     # the round's single host sync
     if host is not None:
         host.append(("losses on the host", time.perf_counter() - t0))
@@ -404,10 +406,13 @@ def run_config(name, args, rank, local_rank, world, use_dist, steps, warmup, epi
     t0 = time.perf_counter()
     for i in range(steps):
         marks[i].record()
-        losses = learner_round(agent, workers, cfg, shared, joint=joint)
+        # losses stay on the device until the region's closing sync (a per-round .tolist() leaves the GPU idle for the
+        # ~0.2 ms the host needs to get the next round's first launches out)
+        dev_l = learner_round(agent, workers, cfg, shared, joint=joint, losses_to_host=bool(os.environ.get("CADRE_BENCH_SYNC_LOSSES")))
     marks[steps].record()
     sync()
     elapsed = time.perf_counter() - t0
+    losses = dev_l if isinstance(dev_l, list) else dev_l.tolist()
     hip.PROFILE = None
     n_ex = shared.n_allreduce - n_ex0
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
