@@ -23,9 +23,8 @@
 //     no split-K slabs, no reduction pass, no pointwise pass.  dG_{t-1} is written twice: row-major (the weight-gradient
 //     kernel reads whole rows) and in fragment order for the next step's A operand (contiguous KiB loads again).
 //
-// Rows sorted by command (row_seg): a net touches the 32-row tiles that intersect its run of rows — the rows the
-// segment-aware GEMMs (cadre_gemm_t.seg_mode) read and write; rows of other nets inside those tiles are computed forward
-// (finite, never used: the loss reads each row's own command net) and get exact zeros backward.
+// Rows sorted by command (row_seg): every kernel here works on exactly a net's run of rows [first, first + count) —
+// 16-row tiles from the run's first row; no row of another net is read or written (see step_item).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>

@@ -5,10 +5,11 @@ HIP launches over the parameter arena (cadre_amd/arena.py).
 The reference runs 8 (head x command) LSTM+MLP nets one after another, each through 8
 LSTMCell calls, and lets autograd replay ~1000 tiny kernels.  Here the 8 nets are ONE strided
 batch: the input projections of all 8 time steps and 4 command nets of a head are one GEMM,
-each recurrent step is one GEMM + one pointwise launch for all 8 nets, the backward pass is
-written out explicitly (same formulas autograd would apply) and writes straight into the flat
-gradient arena.  No autograd graph, no per-parameter tensors, nothing on the host between
-launches — the whole update is ~60 launches on one stream.
+each recurrent step is ONE launch for all 8 nets (product + cell math, csrc/ppo_update.hip), the
+MLP towers three launches, the backward pass is written out explicitly (same formulas autograd
+would apply) and writes straight into the flat gradient arena.  No autograd graph, no
+per-parameter tensors, nothing on the host between launches — the whole update is 24 launches
+on one stream, replayed as a hipGraph.
 """
 import os
 
@@ -21,10 +22,10 @@ class PPOLearnerHIP:
     SORT_MIN_B = 64
 
     def sorted_rows(self, B):
-        """Row-sorted update (rows of a minibatch grouped by command, GEMM tiles a command net does not
-        own are skipped; 32-row M tiles).  At minibatch 64 a command net owns ~16 of the 64 rows, so the
-        unsorted form spends 4x the fp32-MFMA time the update needs — and its skinny GEMMs are bound by
-        exactly that (one MFMA chain per SIMD), not by the weight stream."""
+        """Row-sorted update (rows of a minibatch grouped by command; every kernel of the step then works on exactly
+        the run of rows a command net owns).  At minibatch 64 a command net owns ~16 of the 64 rows, so the
+        unsorted form spends 4x the fp32-MFMA time the update needs — and the recurrent steps are bound by
+        exactly that (the matrix pipe on their critical path), not by the weight stream."""
         return self.use_sorted and B >= self.SORT_MIN_B and B % 32 == 0
 
     def __init__(self, arena, clip=0.1, value_coeff=0.1, clip_coeff=1.0, ent_coeff=0.01, seq_length=8):

@@ -269,7 +269,10 @@ int cadre_lstm_seq_fwd(const float* Wp, int64_t wp_str, const float* bias, int64
  * cell backward of step t-1 in the same launch: dG_{t-1} from the activated gates G_act, tanh(c_{t-1}), c_{t-2}, written
  * row-major (dG_out, [B][ldg]) AND in fragment order (dGp_out: ceil(B / 16) tiles of 16 x 2176 floats per net, net stride
  * gp_str; zero-initialised by the caller, pad never written); dC in/out.  dGp_in == NULL: no product (first step:
- * dh = dh_in, the gradient of the MLP towers).  commands / row_seg as in cadre_lstm_pointwise_bwd. */
+ * dh = dh_in, the gradient of the MLP towers).  commands [2][B] (may be NULL): net z = head*C + c keeps only rows whose
+ * command is c, the others get dG = 0 and dc = 0 (unsorted minibatch); row_seg [Z][2] (may be NULL): (first row, count) of
+ * net z's run in the row-sorted minibatch — exactly those rows are read and written, and the 16-row tiles of dGp count
+ * from the run's first row. */
 int cadre_lstm_step_bwd(const float* Wp, int64_t wp_str, const float* dGp_in, float* dGp_out, int64_t gp_str,
                         float* dG_out, const float* G_act, int32_t ldg, int64_t g_str, const float* dh_in, float* dC,
                         int64_t d_str, const float* TC, const float* Cprev, int32_t ldh, int64_t h_str, int32_t B, int32_t D,
