@@ -546,9 +546,17 @@ struct dw_args {
 // are 16 (m) x 4 (n) blocks per lane: 16-byte stores, 256 B per output row.  Only a net's own run of rows is
 // multiplied (4-row k-steps from its first row; the tail of the last step is masked).  Work item = wave tile; the net is the
 // fastest index of the 1-D grid (one XCD per net: its dG / h / x rows stay in that XCD's L2).
+// three waves per SIMD with four k-steps in flight each (157 VGPRs) rather than two with eight (201): the launch's
+// ramp, tile epilogues and tail overlap with more MFMA work — 81 -> 76 us (minibatch 64), 229 -> 221 us (256)
+#ifndef DW_OCC
+#define DW_OCC 3
+#endif
+#ifndef DW_PD
+#define DW_PD 4
+#endif
 template <int TM>
-__global__ __launch_bounds__(256, TM == 1 ? 2 : 1) void lstm_dw_kernel(dw_args p) {
-  constexpr int PD = TM == 1 ? 8 : 6;                     // k-steps ((1 + TM) KiB per wave) in flight
+__global__ __launch_bounds__(256, TM == 1 ? DW_OCC : 1) void lstm_dw_kernel(dw_args p) {
+  constexpr int PD = TM == 1 ? DW_PD : 6;                     // k-steps ((1 + TM) KiB per wave) in flight
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: the buffer descriptors built from it
                                                                  // stay in scalar registers (no waterfall loop per load)
