@@ -1370,10 +1370,18 @@ __global__ void sqnorm_kernel(const float* g, const int64_t* seg_off, double* no
   if ((lo & 3) == 0) {          // arena segments start on 16-byte boundaries: 16 B per lane
     const int64_t n4 = (hi - lo) >> 2;
     const float4* g4 = reinterpret_cast<const float4*>(g + lo);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-      const float4 v = g4[i];
-      s += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+    // four 16-byte loads in flight per lane (one per iteration left the pass latency-bound at 3 TB/s), four partial sums
+    // combined in a fixed order
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    auto sq = [](const float4& v) { return ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w); };
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+      const float4 v0 = g4[i], v1 = g4[i + stride], v2 = g4[i + 2 * stride], v3 = g4[i + 3 * stride];
+      s0 += sq(v0); s1 += sq(v1); s2 += sq(v2); s3 += sq(v3);
     }
+    for (; i < n4; i += stride) s0 += sq(g4[i]);
+    s = (s0 + s1) + (s2 + s3);
     if (blockIdx.x == 0 && threadIdx.x < ((hi - lo) & 3)) {
       const double v = g[lo + (n4 << 2) + threadIdx.x];
       s += v * v;
