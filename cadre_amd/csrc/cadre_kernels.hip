@@ -1105,7 +1105,15 @@ __global__ void permute_minibatch_kernel(const int32_t* pos, int B, int S, const
                                          const int64_t* actions, const int32_t* commands, const float* old_values,
                                          const float* returns, const float* old_logp, const float* adv,
                                          int64_t* actions_o, int32_t* commands_o, float* old_values_o,
-                                         float* returns_o, float* old_logp_o, float* adv_o) {
+                                         float* returns_o, float* old_logp_o, float* adv_o, int64_t x_hstr, int64_t h_hstr) {
+  {   // head blockIdx.z: every per-head array is [heads][...] with the strides below
+    const int64_t hd = blockIdx.z;
+    pos += hd * B;
+    X += hd * x_hstr; Xo += hd * x_hstr;
+    h0 += hd * h_hstr; c0 += hd * h_hstr; h0o += hd * h_hstr; c0o += hd * h_hstr;
+    actions += hd * B; commands += hd * B; old_values += hd * B; returns += hd * B; old_logp += hd * B; adv += hd * B;
+    actions_o += hd * B; commands_o += hd * B; old_values_o += hd * B; returns_o += hd * B; old_logp_o += hd * B; adv_o += hd * B;
+  }
   const int b = blockIdx.x, s = blockIdx.y, d = pos[b];
   if (s < S) {
     const float4* src = reinterpret_cast<const float4*>(X + ((int64_t)s * B + b) * ldx);
@@ -1127,14 +1135,14 @@ extern "C" int cadre_permute_minibatch(const int32_t* pos, int32_t B, int32_t S,
                                        const int64_t* actions, const int32_t* commands, const float* old_values,
                                        const float* returns, const float* old_logp, const float* adv,
                                        int64_t* actions_o, int32_t* commands_o, float* old_values_o, float* returns_o,
-                                       float* old_logp_o, float* adv_o, void* stream) {
+                                       float* old_logp_o, float* adv_o, int32_t heads, int64_t x_hstr, int64_t h_hstr, void* stream) {
   FAIL_IF(!pos || !X || !Xo || !h0 || !c0 || !h0o || !c0o || !actions || !commands || !old_values || !returns ||
               !old_logp || !adv || !actions_o || !commands_o || !old_values_o || !returns_o || !old_logp_o || !adv_o ||
-              B < 1 || S < 1 || (ldx & 3),
+              B < 1 || S < 1 || (ldx & 3) || heads < 1 || (x_hstr & 3),
           "cadre_permute_minibatch: bad argument");
-  hipLaunchKernelGGL(permute_minibatch_kernel, dim3(B, S + 1), dim3(128), 0, ST(stream), pos, B, S, X, Xo, ldx, h0, c0,
+  hipLaunchKernelGGL(permute_minibatch_kernel, dim3(B, S + 1, heads), dim3(128), 0, ST(stream), pos, B, S, X, Xo, ldx, h0, c0,
                      h0o, c0o, ldh, actions, commands, old_values, returns, old_logp, adv, actions_o, commands_o,
-                     old_values_o, returns_o, old_logp_o, adv_o);
+                     old_values_o, returns_o, old_logp_o, adv_o, x_hstr, h_hstr);
   return (int)hipGetLastError();
 }
 
@@ -1222,7 +1230,7 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const float* logits, int6
   __syncthreads();
   if (threadIdx.x == 0) {
     const int nblk = gridDim.x, me = hd * nblk + blockIdx.x, total = 2 * nblk;
-    float* part = scratch + 4;                      // [total][3]; scratch[0] is the arrival counter (zeroed per call)
+    float* part = scratch + 4;                      // [total][3]; scratch[0] is the arrival counter (zero on entry, reset below)
     const float tv = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
     const float ta = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     const float te = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
@@ -1243,6 +1251,8 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const float* logits, int6
       losses[0] = value_coeff * 0.5f * sv * inv_b + bad;
       losses[1] = clip_coeff * sa * inv_b + bad;
       losses[2] = ent_coeff * sn * inv_b + bad;
+      // the counter goes back to zero for the next launch on this scratch (stream-ordered): no clearing launch per step
+      __hip_atomic_store(reinterpret_cast<unsigned*>(scratch), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -1261,9 +1271,8 @@ extern "C" int cadre_ppo_loss(const float* logits, int64_t ldl, int64_t l_ns, co
               !dlogits || !dvalues || !scratch || B < 1 || n_out_steer < 1 || n_out_steer > MAX_NOUT || n_out_throttle < 1 ||
               n_out_throttle > MAX_NOUT || ldl < n_out_steer || ldl < n_out_throttle || ldl > 64,
           "cadre_ppo_loss: bad argument");
-  // zeroed by a kernel, not hipMemsetAsync: a memset node captured into a hipGraph was observed to
-  // replay a 0xD3 byte pattern instead of 0 on ROCm 7.2 (second replay of the update graph)
-  hipLaunchKernelGGL(zero_f32_kernel, dim3(1), dim3(64), 0, ST(stream), scratch, 1);
+  // scratch[0] (arrival counter) must be zero on entry: zero-initialised by the caller once, reset by the kernel's last
+  // arriver after every launch
   hipLaunchKernelGGL(ppo_loss_kernel, dim3((B + 15) / 16, 2), dim3(256), 0, ST(stream), logits, ldl, l_ns, values, ldv, v_ns,
                      actions, commands,
                      old_values, returns, old_logp, adv, B, n_out_steer, n_out_throttle, clip, value_coeff,

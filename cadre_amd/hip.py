@@ -77,7 +77,7 @@ SYMBOLS = {
     "cadre_hbm_stream": [i32, vp, vp, i64, vp, vp],
     "cadre_mfma_shape": [i32, i32, i32, vp, vp],
     "cadre_sort_rows_by_command": [vp, i32, i32, vp, vp, vp],
-    "cadre_permute_minibatch": [vp, i32, i32, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "cadre_permute_minibatch": [vp, i32, i32, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, i64, vp],
     "cadre_ppo_loss": [vp, i64, i64, vp, i64, i64, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, f32, vp, vp, vp, vp, vp, vp],
     "cadre_sample": [vp, i64, vp, i64, i32, i32, vp, vp, vp],
     "cadre_categorical_eval": [vp, i64, vp, i32, i32, vp, vp, vp],
@@ -97,7 +97,7 @@ AB_SYMBOLS = {
 }
 
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class CadreHipError(RuntimeError):

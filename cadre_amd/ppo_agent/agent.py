@@ -391,15 +391,14 @@ class CadreAgent(object):
         if srt:
             hip.check(L.cadre_sort_rows_by_command(hip.ptr(w["commands_u"]), B, a.C, hip.ptr(w["pos"]), hip.ptr(w["seg"]),
                                                    st), "cadre_sort_rows_by_command")
-            for hd in (0, 1):
-                hip.check(L.cadre_permute_minibatch(
-                    hip.ptr(w["pos"][hd]), B, self.learner.S, hip.ptr(w["Xu"][hd]), hip.ptr(w["X"][hd]), a.DP,
-                    hip.ptr(w["h0u"][hd]), hip.ptr(w["c0u"][hd]), hip.ptr(w["h0"][hd]), hip.ptr(w["c0"][hd]), a.DP,
-                    hip.ptr(w["actions_u"][hd]), hip.ptr(w["commands_u"][hd]), hip.ptr(w["old_values_u"][hd]),
-                    hip.ptr(w["returns_u"][hd]), hip.ptr(w["old_logp_u"][hd]), hip.ptr(w["adv_u"][hd]),
-                    hip.ptr(w["actions"][hd]), hip.ptr(w["commands"][hd]), hip.ptr(w["old_values"][hd]),
-                    hip.ptr(w["returns"][hd]), hip.ptr(w["old_logp"][hd]), hip.ptr(w["adv"][hd]), st),
-                    "cadre_permute_minibatch")
+            hip.check(L.cadre_permute_minibatch(                   # both heads in one launch
+                hip.ptr(w["pos"]), B, self.learner.S, hip.ptr(w["Xu"]), hip.ptr(w["X"]), a.DP,
+                hip.ptr(w["h0u"]), hip.ptr(w["c0u"]), hip.ptr(w["h0"]), hip.ptr(w["c0"]), a.DP,
+                hip.ptr(w["actions_u"]), hip.ptr(w["commands_u"]), hip.ptr(w["old_values_u"]),
+                hip.ptr(w["returns_u"]), hip.ptr(w["old_logp_u"]), hip.ptr(w["adv_u"]),
+                hip.ptr(w["actions"]), hip.ptr(w["commands"]), hip.ptr(w["old_values"]),
+                hip.ptr(w["returns"]), hip.ptr(w["old_logp"]), hip.ptr(w["adv"]), 2, w["X"].stride(0), w["h0"].stride(0), st),
+                "cadre_permute_minibatch")
         losses = self.learner.update(B, float(nW) / B, sorted_rows=srt, mlp_grads_ready=mlp_grads_ready)
         self.arena.attach_grads(self.model_dict)
         if sync:

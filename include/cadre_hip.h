@@ -15,7 +15,7 @@
 extern "C" {
 #endif
 
-#define CADRE_ABI_VERSION 6
+#define CADRE_ABI_VERSION 7
 int cadre_abi_version(void);
 /* human-readable last argument error of the calling thread ("" if none) */
 const char* cadre_last_error(void);
@@ -297,14 +297,15 @@ int cadre_relu_bwd(const float* act, float* dy, int64_t n, const int32_t* comman
  * seg[hd*C + c] = (begin, count) of command c.  commands/pos are [2][B] i32, seg is [2*C][2] i32. */
 int cadre_sort_rows_by_command(const int32_t* commands, int32_t B, int32_t C, int32_t* pos, int32_t* seg,
                                void* stream);
-/* Apply pos to one head's packed minibatch (cadre_gather_minibatch outputs): dst row pos[b] = src row b
- * for X [S][B][ldx], h0/c0 [B][ldh] and the six per-row scalars. */
+/* Apply pos to the packed minibatch (cadre_gather_minibatch outputs) of `heads` heads in one launch: dst row pos[b] = src
+ * row b for X [S][B][ldx], h0/c0 [B][ldh] and the six per-row scalars; head h reads and writes X + h * x_hstr,
+ * h0 / c0 + h * h_hstr, pos and the scalars + h * B. */
 int cadre_permute_minibatch(const int32_t* pos, int32_t B, int32_t S, const float* X, float* Xo, int64_t ldx,
                             const float* h0, const float* c0, float* h0o, float* c0o, int64_t ldh,
                             const int64_t* actions, const int32_t* commands, const float* old_values,
                             const float* returns, const float* old_logp, const float* adv, int64_t* actions_o,
                             int32_t* commands_o, float* old_values_o, float* returns_o, float* old_logp_o,
-                            float* adv_o, void* stream);
+                            float* adv_o, int32_t heads, int64_t x_hstr, int64_t h_hstr, void* stream);
 
 /* ---------------------------------------------------------------- policy head + PPO loss
  * Replaces Model.evaluate_actions (models.py:199-208), Categorical_1d (distributions.py:
@@ -317,7 +318,8 @@ int cadre_permute_minibatch(const int32_t* pos, int32_t B, int32_t S, const floa
  *   whole dlogits rows (ldl columns) are written, only column 0 of a dvalues row.
  * `inv_b` = 1/(rows per worker minibatch) (sum of per-worker means).
  * `scratch`: 4 + 6 * ceil(B / 16) floats of device memory (arrival counter + per-workgroup partial sums: the losses are
- * summed in a fixed order whatever the order the workgroups finish in).  `poison` (may be NULL): device int32; when
+ * summed in a fixed order whatever the order the workgroups finish in; scratch[0] must be ZERO before the first launch on a
+ * scratch buffer — every launch leaves it zero again, so consecutive launches need no clearing).  `poison` (may be NULL): device int32; when
  * nonzero (the status word of cadre_lstm_seq_fwd) the three losses come out NaN. */
 int cadre_ppo_loss(const float* logits, int64_t ldl, int64_t l_ns, const float* values, int64_t ldv,
                    int64_t v_ns, const int64_t* actions, const int32_t* commands, const float* old_values, const float* returns,

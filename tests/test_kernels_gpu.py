@@ -737,7 +737,8 @@ def test_ppo_loss_fwd_bwd(hip, B, scale):
     total.backward()
     losses = torch.zeros(3, device="cuda"); dl = torch.full((8, B, ldl), 9.0, device="cuda")
     dv = torch.full((8, B), 9.0, device="cuda")
-    scratch = torch.full((4 + 6 * ((B + 15) // 16),), 3.0, device="cuda")     # counter zeroed by the call itself
+    scratch = torch.full((4 + 6 * ((B + 15) // 16),), 3.0, device="cuda")
+    scratch[0] = 0.0                                     # the arrival counter: zero on first use, reset by every launch
     d_ = [dev(t) for t in (logits, values, actions, cmds, old_v, rets, old_lp, adv)]
     hip.check(hip.lib().cadre_ppo_loss(d_[0].data_ptr(), ldl, B * ldl, d_[1].data_ptr(), 1, B, d_[2].data_ptr(),
                                        d_[3].data_ptr(), d_[4].data_ptr(), d_[5].data_ptr(),
@@ -912,18 +913,21 @@ def test_sort_rows_and_permute(hip):
         cnt = torch.bincount(cmds[hd].long(), minlength=C)
         off = torch.cumsum(cnt, 0) - cnt
         assert torch.equal(seg[hd * C:(hd + 1) * C].cpu().long(), torch.stack([off, cnt], 1))
-    X = torch.randn(S, B, ld, generator=g); h0 = torch.randn(B, ld, generator=g); c0 = torch.randn(B, ld, generator=g)
-    sc = [torch.randint(0, 9, (B,), generator=g), cmds[0].clone(), torch.randn(B, generator=g), torch.randn(B, generator=g),
-          torch.randn(B, generator=g), torch.randn(B, generator=g)]
+    # both heads in one launch: every per-head array is [2][...]
+    X = torch.randn(2, S, B, ld, generator=g); h0 = torch.randn(2, B, ld, generator=g); c0 = torch.randn(2, B, ld, generator=g)
+    sc = [torch.randint(0, 9, (2, B), generator=g), cmds.clone(), torch.randn(2, B, generator=g), torch.randn(2, B, generator=g),
+          torch.randn(2, B, generator=g), torch.randn(2, B, generator=g)]
     ins = [dev(t) for t in [X, h0, c0] + sc]
     outs = [torch.zeros_like(t) for t in ins]
-    hip.check(L.cadre_permute_minibatch(pos[0].data_ptr(), B, S, ins[0].data_ptr(), outs[0].data_ptr(), ld,
+    hip.check(L.cadre_permute_minibatch(pos.data_ptr(), B, S, ins[0].data_ptr(), outs[0].data_ptr(), ld,
                                         ins[1].data_ptr(), ins[2].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), ld,
-                                        *[t.data_ptr() for t in ins[3:]], *[t.data_ptr() for t in outs[3:]], hip.stream()),
-              "permute")
-    order = torch.sort(cmds[0], stable=True).indices
-    assert torch.equal(outs[0].cpu(), X[:, order]) and torch.equal(outs[1].cpu(), h0[order])
-    assert torch.equal(outs[4].cpu(), cmds[0][order]) and torch.equal(outs[8].cpu(), sc[5][order])
+                                        *[t.data_ptr() for t in ins[3:]], *[t.data_ptr() for t in outs[3:]], 2, S * B * ld, B * ld,
+                                        hip.stream()), "permute")
+    for hd in range(2):
+        order = torch.sort(cmds[hd], stable=True).indices
+        assert torch.equal(outs[0][hd].cpu(), X[hd][:, order]) and torch.equal(outs[1][hd].cpu(), h0[hd][order])
+        assert torch.equal(outs[2][hd].cpu(), c0[hd][order]) and torch.equal(outs[3][hd].cpu(), sc[0][hd][order])
+        assert torch.equal(outs[4][hd].cpu(), cmds[hd][order]) and torch.equal(outs[8][hd].cpu(), sc[5][hd][order])
 
 
 @pytest.mark.parametrize("P,tile,BM,segs", [(128, 3, 64, [[0, 40], [40, 0], [40, 70], [110, 18]]),
