@@ -763,7 +763,8 @@ __device__ __forceinline__ bool mlp_item(int n_z, const int32_t* row_seg, int B,
 // workgroup = (tower, 16 rows of its run), 8 waves: wave w owns hidden units 16w .. 16w+15 of layers 1 and 2, output
 // columns 16w .. of layer 3 (w < 4).  Activations meet in LDS between the layers.
 __global__ __launch_bounds__(512) void mlp_fwd_kernel(mlp_fwd_args p) {
-  constexpr int AP = 552, HP = 132, PD = 8;
+  constexpr int AP = 552, HP = 132, PD = 8;               // (all 34 layer-1 fragments up front measured slower: 19.2 vs 15.6 us —
+                                                           //  the scattered 64-byte pieces are paced by the texture addresser)
   __shared__ __attribute__((aligned(16))) float hs[16 * AP];
   __shared__ __attribute__((aligned(16))) float a1s[16 * HP];
   __shared__ __attribute__((aligned(16))) float a2s[16 * HP];
@@ -929,11 +930,18 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(mlp_bwd_args p) {
       m2[r] = p.A2[o];
       m1[r] = p.A1[o];
     }
-    f32x4 b3[MLP_NP / 16], b2[MLP_HID / 16];
+    f32x4 b3[MLP_NP / 16], b2[MLP_HID / 16], b1[MT][MLP_HID / 16];
 #pragma unroll
     for (int j = 0; j < MLP_NP / 16; ++j) b3[j] = ld_kmajor(P + p.o_w3, MLP_HID, j, q, n);
 #pragma unroll
     for (int j = 0; j < MLP_HID / 16; ++j) b2[j] = ld_kmajor(P + p.o_w2, MLP_HID, j, q, n);
+    // (the W1 fragments of this wave's dh tiles too: their round trip runs under the dA2 / dA1 phases)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int t = min(g + p.NG * (w + 8 * m), NT - 1);
+#pragma unroll
+      for (int j = 0; j < MLP_HID / 16; ++j) b1[m][j] = ld_kmajor(P + p.o_w1, MLP_K1, j, q, 16 * t + c);
+    }
     __syncthreads();
     // dA2 = (dO3 W3) masked by A2 > 0: tile w
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -979,15 +987,12 @@ __global__ __launch_bounds__(512) void mlp_bwd_kernel(mlp_bwd_args p) {
     for (int m = 0; m < MT; ++m) {
       const int t = g + p.NG * (w + 8 * m);
       if (t >= NT) continue;                               // wave-uniform
-      f32x4 b1[MLP_HID / 16];
-#pragma unroll
-      for (int j = 0; j < MLP_HID / 16; ++j) b1[j] = ld_kmajor(P + p.o_w1, MLP_K1, j, q, 16 * t + c);
 #pragma unroll
       for (int j = 0; j < MLP_HID / 16; ++j) {
-        acc_h[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1f[j][0], b1[j][0], acc_h[m][0], 0, 0, 0);
-        acc_h[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1f[j][1], b1[j][1], acc_h[m][1], 0, 0, 0);
-        acc_h[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1f[j][2], b1[j][2], acc_h[m][0], 0, 0, 0);
-        acc_h[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1f[j][3], b1[j][3], acc_h[m][1], 0, 0, 0);
+        acc_h[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1f[j][0], b1[m][j][0], acc_h[m][0], 0, 0, 0);
+        acc_h[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1f[j][1], b1[m][j][1], acc_h[m][1], 0, 0, 0);
+        acc_h[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1f[j][2], b1[m][j][2], acc_h[m][0], 0, 0, 0);
+        acc_h[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1f[j][3], b1[m][j][3], acc_h[m][1], 0, 0, 0);
       }
     }
   }
