@@ -35,6 +35,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f3
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 PEAK_HBM_GBPS = 8000.0              # MI355X_MICROARCH.md: HBM3E peak (6.3 TB/s achievable)
 PPO_EPOCH, MINI_BATCH_NUM, SEQ = 4, 2, 8
+# reference config/train_config.py values the learner section reads
+TRAIN_CFG = dict(use_adv_norm=True, ppo_epoch=PPO_EPOCH, max_grad_norm=250.0, lr=3e-4)
 
 
 def log(*a):
@@ -161,6 +163,7 @@ def learner_round(agent, workers, cfg, shared, timers=None, joint=None, losses_t
     """One learner round.  timers (list, untimed split pass only): receives (t_encode, t_update, step_ms) with step_ms the
     HIP-event time of each of the 8 minibatch steps (gather + update_policy + gradient exchange + clip + Adam)."""
     from ppo_agent.chief import chief_step
+    from ppo_agent.train import learner_section
     t0 = time.perf_counter()
     host = [] if os.environ.get("CADRE_BENCH_HOST_TRACE") else None      # host-side enqueue times of the round's phases (no syncs added)
     if joint is not None:
@@ -172,6 +175,25 @@ def learner_round(agent, workers, cfg, shared, timers=None, joint=None, losses_t
         host.append(("encode enqueued", time.perf_counter() - t0))
     if timers is not None:
         torch.cuda.synchronize(); t1 = time.perf_counter()
+    if len(workers) == 1 and not cfg.get("grad_buckets"):
+        # ONE worker per GPU (C1 / C2): the learner section is the function train() itself runs
+        # (cadre_amd/ppo_agent/train.py:learner_section = reference train.py:76-110) — bootstrap values, GAE,
+        # 4 epochs x 2 minibatches of update_policy + hand-off + in-process chief_step; nothing bench-specific
+        evs = [] if timers is not None else None
+        dev_l = learner_section(agent, workers[0].stor[0], workers[0].stor[1], False, TRAIN_CFG, shared,
+                                in_process_chief=True, losses_on_device=True, step_events=evs)
+        if host is not None:
+            host.append(("updates enqueued", time.perf_counter() - t0))
+        if not losses_to_host:
+            return dev_l
+        losses = dev_l.tolist()
+        if host is not None:
+            host.append(("losses on the host", time.perf_counter() - t0))
+            log("[bench] host timeline (ms since round start): " + ", ".join("%s %.2f" % (k, 1e3 * v) for k, v in host))
+        if timers is not None:
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            timers.append((t1 - t0, t2 - t1, [evs[i].elapsed_time(evs[i + 1]) for i in range(len(evs) - 1)]))
+        return losses
     advs = []
     # (commands stay on the device: .item() in get_last would wait for the encoder pass and expose ~1 ms of host work)
     if len(workers) > 1:      # bootstrap values of all workers in one LSTM + critic pass
@@ -200,7 +222,7 @@ def learner_round(agent, workers, cfg, shared, timers=None, joint=None, losses_t
                 evs.append(torch.cuda.Event(enable_timing=True)); evs[-1].record()
             dev_losses.append(agent.update_policy_from_storages(batches, sync=False, mlp_grads_ready=hook))
             shared.add_gradient(agent.model_dict)                 # hand-off; chief_step runs the cross-rank exchange (SUM)
-            chief_step(shared, None, 250.0)
+            chief_step(shared, None, 250.0, zero_grads=False)     # next writer: the fused update (overwrites)
     if timers is not None:
         evs.append(torch.cuda.Event(enable_timing=True)); evs[-1].record()
     if host is not None:
@@ -498,15 +520,15 @@ def run_config(name, args, rank, local_rank, world, use_dist, steps, warmup, epi
         sync()
         e0.record()
         for _ in range(reps):
-            if mode == "sharded":
-                lo, hi = shared.shard()
-                dist.reduce_scatter_tensor(g[lo:hi], g, op=dist.ReduceOp.SUM)
-                dist.all_gather_into_tensor(agent.arena.params, agent.arena.params[lo:hi])
+            if mode == "sharded":                          # (the collectives chief_step issues in this mode)
+                shared.counter.increment()
+                shared.reduce_scatter()
+                shared.all_gather_params()
             else:
                 dist.all_reduce(g, op=dist.ReduceOp.SUM)
         e1.record()
         sync()
-        g.zero_()
+        shared.reset(zero=True)
         out["rccl_ranks"] = world
         out["grad_exchange"] = mode + (" + MLP bucket beside the LSTM backward" if cfg.get("grad_buckets") and mode == "allreduce" else "")
         out["allreduce_ms_per_step"] = round(e0.elapsed_time(e1) / reps, 4)
@@ -517,27 +539,67 @@ def run_config(name, args, rank, local_rank, world, use_dist, steps, warmup, epi
     return out, cfg, enc_state, ppo_state
 
 
-def spawn_ranks(n):
+def spawn_ranks(n, timeout_s=None):
     """One process per GPU, started from a parent that never initialises HIP (a process that has touched the GPU must
     not exec or fork GPU work on this pool): children get RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* like
-    torch.distributed.run would set them; rank 0's stdout (the JSON line) is relayed, every stderr goes through."""
+    torch.distributed.run would set them; rank 0's stdout (the JSON line) is relayed, every stderr goes through.
+    Every child is polled: when one exits non-zero (OOM, build or ABI mismatch) the others — which would sit in a
+    collective forever — are terminated (fresh children of this parent only) and that status is returned; the same
+    after `timeout_s` (CADRE_BENCH_SPAWN_TIMEOUT, default 1800 s).  The rendezvous port is chosen by bind-then-close;
+    a rendezvous that fails because another process took the port in between is retried once on a new port."""
     import socket
     import subprocess
-    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0]
-    rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0.decode())
-    sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        log("[bench] ranks failed: %s" % bad)
-    return 0 if not bad else (bad[0][1] if 0 < bad[0][1] < 256 else 1)
+    import tempfile
+    timeout_s = float(os.environ.get("CADRE_BENCH_SPAWN_TIMEOUT", "1800")) if timeout_s is None else timeout_s
+    for attempt in range(2):
+        sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+        out0 = tempfile.TemporaryFile()
+        procs = []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        t_end = time.monotonic() + timeout_s
+        rcs = [None] * n
+        failed = None
+        while any(rc is None for rc in rcs):
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    rcs[r] = p.poll()
+                    if rcs[r] not in (None, 0) and failed is None:
+                        failed = (r, rcs[r])
+            if failed is not None or time.monotonic() > t_end:
+                if failed is None:
+                    failed = (-1, 124)
+                    log("[bench] ranks did not finish within %.0f s: terminating them" % timeout_s)
+                for r, p in enumerate(procs):               # the peers of a dead rank wait in a collective for ever
+                    if rcs[r] is None:
+                        p.terminate()
+                for r, p in enumerate(procs):
+                    if rcs[r] is None:
+                        try:
+                            rcs[r] = p.wait(timeout=20)
+                        except subprocess.TimeoutExpired:
+                            p.kill(); rcs[r] = p.wait()
+                break
+            time.sleep(0.05)
+        out0.seek(0)
+        text = out0.read().decode()
+        out0.close()
+        if failed is not None and attempt == 0 and failed[1] == RC_RENDEZVOUS:
+            log("[bench] rendezvous on port %d failed, retrying on a new port" % port)
+            continue
+        sys.stdout.write(text)
+        sys.stdout.flush()
+        if failed is not None:
+            log("[bench] rank %d failed with status %s (all statuses: %s)" % (failed[0], failed[1], rcs))
+            return failed[1] if 0 < failed[1] < 256 else 1
+        return 0
+    return 1
+
+
+RC_RENDEZVOUS = 75      # a child's exit status when init_process_group could not bind / connect (EX_TEMPFAIL)
 
 
 def main():
@@ -545,13 +607,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
+                    help="headline config (default: C2 on one GPU; C3 per GPU on several = BASELINE C4, the shape the "
+                         "1 -> 8 scaling target is defined on; the other one rides along as a nested section)")
     ap.add_argument("--chunk-windows", type=int, default=0,
                     help="windows (x8 frames) per encoder launch chain (default: 128, or 256 across the workers of a GPU)")
     ap.add_argument("--no-joint-encode", action="store_true", help="encode each worker's windows separately (chunks of 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-peaks", action="store_true", help="skip the measured-peaks microbenchmarks (HBM copy, MFMA chains; ~2 s)")
-    ap.add_argument("--no-c3", action="store_true", help="skip the extra C3 section (4 workers/GPU, bf16 encoder) of the line")
+    ap.add_argument("--no-c3", "--no-nested", dest="no_c3", action="store_true",
+                    help="skip the nested section of the line (C3 next to a C2 headline, C2 next to a C3 headline)")
     ap.add_argument("--encoder-dtype", default=None, choices=["f32", "bf16"],
                     help="override the config's encoder arithmetic (C2: f32, C3: bf16 storage / fp32 accumulate)")
     ap.add_argument("--replay", default=None, metavar="DIR",
@@ -583,6 +648,11 @@ def main():
         line = json.dumps({"rank": rank, "local_rank": local_rank, "world": world, "master": "%s:%s" % (
             os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")), "gpus": args.gpus})
         log("[bench] selftest " + line)
+        fail = os.environ.get("CADRE_BENCH_SELFTEST_FAIL_RANK")       # launcher check: one rank dies, its peers "wait in a collective"
+        if fail is not None:
+            if rank == int(fail):
+                sys.exit(3)
+            time.sleep(600)
         if rank == 0:
             print(line, flush=True)
         return
@@ -594,26 +664,49 @@ def main():
     sys.stdout.flush()
     stdout_fd = os.dup(1)
     os.dup2(2, 1)
-    torch.cuda.set_device(local_rank)
+    # Backend and rank -> device mapping come from the environment so that the WHOLE N > 1 path below (init, startup
+    # broadcast, barriers, MAX-reduce, exchange timing, the single line through the self-spawn) can run at world 2 on a
+    # ONE-GPU box (tests/test_bench_world2_gpu.py): CADRE_BENCH_BACKEND=gloo (collectives on device tensors through the
+    # host), CADRE_BENCH_ONE_DEVICE=1 (every rank on cuda:0).  Defaults: nccl (= RCCL), one GPU per LOCAL_RANK.
+    backend = os.environ.get("CADRE_BENCH_BACKEND", "nccl")
+    one_device = os.environ.get("CADRE_BENCH_ONE_DEVICE") == "1"
+    dev_index = 0 if one_device else local_rank
+    torch.cuda.set_device(dev_index)
     use_dist = world > 1 or os.environ.get("CADRE_BENCH_FORCE_DIST") == "1"     # force: exercise RCCL init at N=1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
+        except Exception as e:                               # (address in use / connection refused: the parent retries)
+            log("[bench] rank %d: init_process_group(%s) failed: %r" % (rank, backend, e))
+            sys.exit(RC_RENDEZVOUS)
 
-    res, cfg, enc_state, ppo_state = run_config(args.config, args, rank, local_rank, world, use_dist, args.steps, args.warmup,
+    # headline: C2 on one GPU (BASELINE.json's single-GPU fp32 config); on several GPUs C3 per GPU — BASELINE C4,
+    # num_processes = 4 per GPU, bf16 encoder / fp32 losses, the shape north_star's 1 -> 8 target is defined on
+    head = args.config or ("C3" if world > 1 else "C2")
+    other = {"C2": "C3", "C3": "C2"}.get(head) if args.config is None else None
+    res, cfg, enc_state, ppo_state = run_config(head, args, rank, dev_index, world, use_dist, args.steps, args.warmup,
                                                 args.replay)
     out = {"metric": "ppo_update_samples_per_sec", "value": res.pop("value"), "unit": "samples/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": res.pop("ms_per_step"), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None}
     res.pop("steps"); res.pop("warmup")
     out.update(res)
-    # BASELINE configs C3 / C4 (num_processes = 4 per GPU, minibatch 256, bf16 encoder / fp32 losses) in the same line:
-    # the 1 -> 8 GPU scaling target is defined on this shape (C4 = C3 on every GPU + the gradient all-reduce)
-    if args.config == "C2" and not args.no_c3 and not args.replay and not args.dedup and args.encoder_dtype is None:
-        c3, _c, _e, _p = run_config("C3", args, rank, local_rank, world, use_dist, max(2, args.c3_steps), 2)
-        c3["metric"], c3["unit"], c3["n_gpus"] = "ppo_update_samples_per_sec", "samples/s", world
-        out["c3"] = c3
+    if use_dist:
+        out["backend"] = backend if backend != "nccl" else "nccl (RCCL)"
+        if one_device:
+            out["one_device"] = True
+    # the other BASELINE shape in the same line: next to a C2 headline the C3 section (>= 10 timed rounds), next to a C3
+    # headline (N > 1) the C2 section
+    if other and not args.no_c3 and not args.replay and not args.dedup and args.encoder_dtype is None:
+        n_other = max(2, args.c3_steps) if other == "C3" else args.steps
+        sec, _c, _e, _p = run_config(other, args, rank, dev_index, world, use_dist, n_other, 2)
+        sec["metric"], sec["unit"], sec["n_gpus"] = "ppo_update_samples_per_sec", "samples/s", world
+        out[other.lower()] = sec
     if rank == 0:
         if not args.no_peaks and world == 1:
             # the datasheet peaks re-measured on this box (stream copy, register-operand MFMA chains): the
@@ -622,7 +715,7 @@ def main():
                 from tools.peaks_bench import measure
                 mp = measure()
                 out["measured_peaks"] = mp
-                for sect in (out, out.get("c3")):
+                for sect in (out, out.get("c3"), out.get("c2")):
                     rf = sect.get("roofline") if sect else None
                     if rf and rf.get("bound") == "mfma":
                         pk = mp["mfma_bf16_2wave_TFLOPs"] if rf["peak"] > 1000 else mp["mfma_f32_2wave_TFLOPs"]

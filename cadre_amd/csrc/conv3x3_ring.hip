@@ -969,6 +969,7 @@ static const int g_ring_m16 = [] { const char* e = getenv("CADRE_RING_M16"); ret
 
 template <bool BF, int NT, int RS, bool OB>
 static void ring_launch_pp(const ring_args& a, int grid, size_t lds, hipStream_t st) {
+#ifdef CADRE_AB_KERNELS      // (A/B build only: measured 5-10 % slower, see above)
   if constexpr (BF) {
     if (g_ring_m16) {
       (void)hipFuncSetAttribute((const void*)conv3x3_ring_pp_kernel<BF, NT, RS, OB, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -976,6 +977,7 @@ static void ring_launch_pp(const ring_args& a, int grid, size_t lds, hipStream_t
       return;
     }
   }
+#endif
   if constexpr (BF || NT == 64) {                          // (fp32: the 64-channel tile only — see ring_pick)
     (void)hipFuncSetAttribute((const void*)conv3x3_ring_pp_kernel<BF, NT, RS, OB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((conv3x3_ring_pp_kernel<BF, NT, RS, OB>), dim3(grid), dim3(512), lds, st, a);

@@ -30,6 +30,9 @@
 #include <stdlib.h>
 #include <stdio.h>
 #include "../../include/cadre_hip.h"
+#ifdef CADRE_AB_KERNELS
+#include "../../include/cadre_hip_ab.h"
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -237,6 +240,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(fwd_args p) {
   LS_FLUSH();
 }
 
+#ifdef CADRE_AB_KERNELS      // A/B build only (include/cadre_hip_ab.h): measured slower than the per-step launches
 // ---------------------------------------------------------------------------------------------------------------------
 // The S forward steps of all nets in ONE launch (the update's minibatch: Z = 8 nets, S = 8 steps).  A launch per step
 // re-streams its 139 KB of recurrent weights per workgroup from the Infinity Cache (37 MB per step over the chip: the 8
@@ -376,6 +380,8 @@ __global__ __launch_bounds__(256, 2) void lstm_seq_fwd_kernel(seq_fwd_args p) {
     }
   }
 }
+#endif
+
 
 __global__ void zero_i32_kernel(int32_t* p, int n) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0;
@@ -1260,6 +1266,7 @@ extern "C" int cadre_mlp_dw(const float* dO3, const float* dA2, const float* dA1
   return (int)hipGetLastError();
 }
 
+#ifdef CADRE_AB_KERNELS
 // All S forward steps of `Z` nets in one persistent launch (see lstm_seq_fwd_kernel): G [S][B][ldg], Hs / Cs / TC
 // [S+1][B][ldh] per net with slot 0 = the initial state.  `sync_ws`: Z * S + 1 int32 of device memory (arrival counters,
 // zeroed here, + a status word that a timed-out wait sets to 1 — check it with the results; it is never cleared here).
@@ -1278,3 +1285,5 @@ extern "C" int cadre_lstm_seq_fwd(const float* Wp, int64_t wp_str, const float* 
   hipLaunchKernelGGL((lstm_seq_fwd_kernel<34>), dim3(Z * NS), dim3(256), 0, ST(stream), a);
   return (int)hipGetLastError();
 }
+#endif
+

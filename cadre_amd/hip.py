@@ -64,7 +64,6 @@ SYMBOLS = {
                                      vp, vp, vp, vp, vp, vp, vp],
     "cadre_pack_lstm_weights": [vp, i64, i32, i32, i32, vp, vp, i64, vp],
     "cadre_lstm_step_fwd": [vp, i64, vp, i64, vp, i32, i64, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, vp, i32, vp],
-    "cadre_lstm_seq_fwd": [vp, i64, vp, i64, vp, i32, i64, vp, vp, vp, i32, i64, i32, i32, i32, i32, vp, vp, vp],
     "cadre_lstm_step_bwd": [vp, i64, vp, vp, i64, vp, vp, i32, i64, vp, vp, i64, vp, vp, i32, i64, i32, i32, i32, vp, i32, vp, i32, vp],
     "cadre_mlp_fwd": [vp, i64, vp, vp, i32, i64, vp, vp, vp, i32, i32, vp, vp],
     "cadre_mlp_bwd": [vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, i64, i32, i32, vp, vp],
@@ -94,6 +93,7 @@ AB_SYMBOLS = {
     "cadre_lstm_pointwise_bwd": [vp, vp, i64, i64, vp, vp, i64, vp, vp, i64, i32, i64, i64, i32, i32, i32, vp, i32, vp, vp],
     "cadre_colsum2": [vp, i64, i64, vp, vp, i64, i32, i32, i32, vp, i32, vp],
     "cadre_conv3x3_c64_bf16": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "cadre_lstm_seq_fwd": [vp, i64, vp, i64, vp, i32, i64, vp, vp, vp, i32, i64, i32, i32, i32, i32, vp, vp, vp],
 }
 
 

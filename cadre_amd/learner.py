@@ -42,7 +42,8 @@ class PPOLearnerHIP:
         self.use_sorted = os.environ.get("CADRE_SORTED_UPDATE", "1") != "0"
         # forward LSTM of the update as one persistent launch (cadre_lstm_seq_fwd) instead of one launch per time step:
         # opt-in, measured slower in place (C2 208 vs 192 us, C3 376 vs 295 us for the 8 steps)
-        self.persistent_lstm = os.environ.get("CADRE_LSTM_PERSISTENT", "0") != "0"
+        # (A/B build only: the default library does not export it)
+        self.persistent_lstm = os.environ.get("CADRE_LSTM_PERSISTENT", "0") != "0" and hip.has_ab_kernels()
         # MLP towers of the update as three fused launches (cadre_mlp_fwd / _bwd / _dw) instead of 17 GEMM / column-sum /
         # mask launches; CADRE_FUSED_MLP=0 keeps the GEMM chain (A/B)
         self.fused_mlp = os.environ.get("CADRE_FUSED_MLP", "1") != "0"

@@ -14,14 +14,18 @@ def _hyper(optimizer):
     return g["lr"], tuple(g.get("betas", (0.9, 0.999))), g.get("eps", 1e-8)
 
 
-def chief_step(shared_grad_buffers, optimizer, max_grad_norm, lr=None, zero_grads=False):
+def chief_step(shared_grad_buffers, optimizer, max_grad_norm, lr=None, zero_grads=True):
     """One optimiser step (chief.py:13-23) on the arena behind `shared_grad_buffers`: the pending
     cross-rank SUM of the gradients (ONE exchange per optimiser step, however many worker agents of this
     process handed gradients in), then per-model clip + Adam, then clear the buffers.  Two forms of the
     exchange (Shared_grad_buffers.exchange_mode): all-reduce + replicated optimiser, or reduce-scatter +
     optimiser on this rank's shard + all-gather of the parameters — identical parameters either way.
     Hyper-parameters come from `optimizer` (the reference's optim.Adam, main.py:52) or, without one,
-    from `lr` (train_cfg.lr) with Adam's defaults."""
+    from `lr` (train_cfg.lr) with Adam's defaults.
+    `zero_grads=True` is the reference's `shared_grad_buffers.reset()` (models.py:255-258): the gradient arena is
+    cleared.  A caller whose NEXT writer of the arena is the fused `update_policy` — which writes every element, it
+    does not accumulate — may pass False and save the 80 MB fill (`learner_section` does; the stand-alone modules'
+    autograd path and foreign arenas ACCUMULATE into `p.grad` / the arena and need the fill)."""
     arena = shared_grad_buffers.arena
     if optimizer is not None:
         lr, betas, eps = _hyper(optimizer)
@@ -31,18 +35,15 @@ def chief_step(shared_grad_buffers, optimizer, max_grad_norm, lr=None, zero_grad
     if step is None:
         arena._learner = step = PPOLearnerHIP(arena)
     if shared_grad_buffers.exchange_mode() == "sharded":
-        rng = shared_grad_buffers.reduce_scatter()
-        if rng is None:                                    # nothing handed in: plain local step
-            step.clip_adam(lr=lr, max_grad_norm=max_grad_norm, betas=betas, eps=eps)
-        else:
-            step.clip_adam_sharded(rng[0], rng[1], shared_grad_buffers.all_reduce_norms, lr=lr,
-                                   max_grad_norm=max_grad_norm, betas=betas, eps=eps)
-            shared_grad_buffers.all_gather_params()
+        # (nothing handed in since the last exchange: no collective, but still the SHARDED optimiser — the arena's Adam
+        #  moments exist for this rank's shard only; every rank's gradients are then its own, as in the replicated form)
+        rng = shared_grad_buffers.reduce_scatter() or shared_grad_buffers.shard()
+        step.clip_adam_sharded(rng[0], rng[1], shared_grad_buffers.all_reduce_norms, lr=lr,
+                               max_grad_norm=max_grad_norm, betas=betas, eps=eps)
+        shared_grad_buffers.all_gather_params()
     else:
         shared_grad_buffers.all_reduce()
         step.clip_adam(lr=lr, max_grad_norm=max_grad_norm, betas=betas, eps=eps)
-    # (in-process hand-off of this arena's own nets: the gradient arena is overwritten by the next update, no fill needed;
-    #  the spawned chief of main.py:57-60 goes through chief() below and keeps the reference's zero-fill)
     shared_grad_buffers.reset(zero=zero_grads)
 
 

@@ -320,6 +320,15 @@ class Shared_grad_buffers(object):
         n = self.arena.total // w
         return r * n, (r + 1) * n
 
+    @staticmethod
+    def native_scatter_gather():
+        """Whether the process group's backend has reduce-scatter / all-gather on device tensors: RCCL ('nccl') does,
+        gloo does not.  Decided ONCE from the backend's name, identically on every rank — never from an exception: a rank
+        that fell back to all_reduce after a genuine RCCL error while its peers wait in reduce_scatter would hang the
+        job instead of failing it.  Collective errors propagate."""
+        import torch.distributed as dist
+        return str(dist.get_backend()).lower() == "nccl"
+
     def all_reduce(self):
         """One all-reduce(SUM) of the flat gradient arena over all ranks (chief.py:18 sums, never averages);
         a no-op outside torch.distributed, at world_size 1, or when nothing was handed in since the last
@@ -357,9 +366,9 @@ class Shared_grad_buffers(object):
         self._mark()
         lo, hi = self.shard()
         g = self.arena.grads
-        try:
+        if self.native_scatter_gather():
             dist.reduce_scatter_tensor(g[lo:hi], g, op=dist.ReduceOp.SUM)
-        except RuntimeError:        # a backend without reduce-scatter on device tensors (gloo): same sums by all-reduce
+        else:                       # gloo: the same sums by all-reduce (every rank takes this branch)
             dist.all_reduce(g, op=dist.ReduceOp.SUM)
         self._n_exchange.increment()
         return lo, hi
@@ -374,9 +383,9 @@ class Shared_grad_buffers(object):
         import torch.distributed as dist
         lo, hi = self.shard()
         p = self.arena.params
-        try:
+        if self.native_scatter_gather():
             dist.all_gather_into_tensor(p, p[lo:hi])
-        except RuntimeError:        # backend without all-gather on device tensors: x + 0 + ... + 0 is x
+        else:                       # gloo: x + 0 + ... + 0 is x
             p[:lo].zero_(); p[hi:].zero_()
             dist.all_reduce(p, op=dist.ReduceOp.SUM)
 
@@ -387,6 +396,10 @@ class Shared_grad_buffers(object):
         """models.py:255-258.  `zero=False` (chief_step, when only nets of this arena handed in): the next
         update_policy WRITES every gradient element of the arena (it does not accumulate), so the 80 MB fill would
         be overwritten unread; a foreign arena accumulated with `add_` always gets the fill."""
+        done = getattr(self, "_bucket_done", None)
+        if done is not None:        # a bucket started by reduce_bucket_async that no all_reduce() collected (nothing was
+            self._bucket_done = None        # handed in afterwards): its collective must not outlive the buffers' reset
+            done[1].wait()
         self.counter.reset()
         self._reduced_at.reset()
         if zero or getattr(self, "_accumulated", False):

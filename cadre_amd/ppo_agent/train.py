@@ -32,14 +32,19 @@ def _default_logger():
 
 def learner_section(agent, steer_rollout, throttle_rollout, done, train_cfg, shared_grad_buffers,
                     optimizer=None, traffic_light=None, counter=None, shared_model_list=None, in_process_chief=True,
-                    fused_gather=True):
+                    fused_gather=True, losses_on_device=False, step_events=None):
     """train.py:76-110.  Returns (value_loss_list, policy_loss_list, ent_loss_list).
     With `in_process_chief` (one process per GPU) the optimiser step runs right after the gradient
     all-reduce instead of waiting on a separate chief process.  `fused_gather` uses the storage ->
     workspace gather kernel and keeps the per-minibatch losses on the device until the end of the
-    section (same numbers as the generator/tuple path, one host sync instead of eight)."""
+    section (same numbers as the generator/tuple path, one host sync instead of eight).
+    The stored command of the bootstrap observation stays on the device (`get_last(as_tensor=True)`): the reference's
+    `.item()` (storage.py:88-91) would wait for every kernel enqueued so far — the whole encoder pass — before the host
+    may enqueue the rest of the section (0.5-1.1 ms of idle GPU per round).  `losses_on_device` (needs fused_gather):
+    return the [steps, 3] loss tensor instead of the three lists, so the caller chooses when to wait; `step_events`:
+    a list that receives one timing event before every minibatch step and one after the last."""
     use_adv_norm = train_cfg["use_adv_norm"]
-    nv_s, nv_t = agent.get_value(done, steer_rollout.get_last(), throttle_rollout.get_last())
+    nv_s, nv_t = agent.get_value(done, steer_rollout.get_last(as_tensor=True), throttle_rollout.get_last(as_tensor=True))
     steer_adv = steer_rollout.compute_returns(nv_s.detach(), normalise=use_adv_norm)
     throttle_adv = throttle_rollout.compute_returns(nv_t.detach(), normalise=use_adv_norm)
     dev_losses = []
@@ -52,6 +57,8 @@ def learner_section(agent, steer_rollout, throttle_rollout, done, train_cfg, sha
             steps = [("tup", a, b) for a, b in zip(steer_rollout.feed_forward_generator(steer_adv),
                                                      throttle_rollout.feed_forward_generator(throttle_adv))]
         for kind, a, b in steps:
+            if step_events is not None:
+                step_events.append(torch.cuda.Event(enable_timing=True)); step_events[-1].record()
             if kind == "idx":
                 dev_losses.append(agent.update_policy_from_storages(
                     [(steer_rollout, a, steer_adv, throttle_rollout, b, throttle_adv)], sync=False))
@@ -60,7 +67,9 @@ def learner_section(agent, steer_rollout, throttle_rollout, done, train_cfg, sha
                 vl.append(v); pl.append(p); el.append(e)
             if in_process_chief:
                 shared_grad_buffers.add_gradient(agent.model_dict)
-                chief_step(shared_grad_buffers, optimizer, train_cfg["max_grad_norm"], lr=_get(train_cfg, "lr"))
+                # (the next writer of the gradient arena is the next fused update, which overwrites every element)
+                chief_step(shared_grad_buffers, optimizer, train_cfg["max_grad_norm"], lr=_get(train_cfg, "lr"),
+                           zero_grads=False)
             else:
                 signal_init = traffic_light.get()
                 shared_grad_buffers.add_gradient(agent.model_dict)
@@ -69,6 +78,12 @@ def learner_section(agent, steer_rollout, throttle_rollout, done, train_cfg, sha
                     pass
             if shared_model_list is not None:
                 agent.update_model(shared_model_list)
+    if step_events is not None:
+        step_events.append(torch.cuda.Event(enable_timing=True)); step_events[-1].record()
+    if losses_on_device:
+        if not dev_losses:
+            raise ValueError("losses_on_device needs fused_gather=True")
+        return torch.stack(dev_losses)
     if dev_losses:
         for v, p, e in torch.stack(dev_losses).tolist():
             vl.append(v); pl.append(p); el.append(e)

@@ -254,16 +254,6 @@ int cadre_mlp_bwd(const float* P, int64_t t_str, const int32_t* offs, const floa
 int cadre_mlp_dw(const float* dO3, const float* dA2, const float* dA1, const float* A2, const float* A1, const float* Hin,
                  int32_t ldh, int64_t h_str, float* G, int64_t t_str, const int32_t* offs, int32_t B, int32_t Z2,
                  const int32_t* row_seg, void* stream);
-/* All S forward steps of `Z` nets in ONE persistent launch (ppo_update.hip, lstm_seq_fwd_kernel): a workgroup = (net, 16
- * hidden units) keeps its packed recurrent weights in registers for the whole launch, the workgroups of a net exchange
- * the activation rows h_t through L2 (write-through stores, one arrival counter per (net, step), one agent-scope
- * acquire per step: cdna_hip_programming.md Guideline 16).  G [S][B][ldg], Hs / Cs / TC [S+1][B][ldh] per net, slot 0 =
- * initial state (in), slots 1..S written.  sync_ws: Z*S + 1 int32 of device memory — the counters (zeroed here) and a
- * status word that a timed-out wait (bounded spins: a launch can never hang) sets to 1; pass it to cadre_ppo_loss, which
- * then returns NaN losses.  Same results, bit for bit, as S calls of cadre_lstm_step_fwd. */
-int cadre_lstm_seq_fwd(const float* Wp, int64_t wp_str, const float* bias, int64_t b_str, float* G, int32_t ldg,
-                       int64_t g_str, float* Hs, float* Cs, float* TC, int32_t ldh, int64_t h_str, int32_t B, int32_t D,
-                       int32_t S, int32_t Z, const int32_t* row_seg, int32_t* sync_ws, void* stream);
 /* One backward time step: dh_{t-1} = dG_t W (+ dh_in) on the packed transposed weights (`bwd` of
  * cadre_pack_lstm_weights) and dG_t in fragment order (dGp_in: what the previous call left in its dGp_out), then the
  * cell backward of step t-1 in the same launch: dG_{t-1} from the activated gates G_act, tanh(c_{t-1}), c_{t-2}, written
@@ -320,7 +310,7 @@ int cadre_permute_minibatch(const int32_t* pos, int32_t B, int32_t S, const floa
  * `scratch`: 4 + 6 * ceil(B / 16) floats of device memory (arrival counter + per-workgroup partial sums: the losses are
  * summed in a fixed order whatever the order the workgroups finish in; scratch[0] must be ZERO before the first launch on a
  * scratch buffer — every launch leaves it zero again, so consecutive launches need no clearing).  `poison` (may be NULL): device int32; when
- * nonzero (the status word of cadre_lstm_seq_fwd) the three losses come out NaN. */
+ * nonzero (the status word of the A/B build's cadre_lstm_seq_fwd) the three losses come out NaN. */
 int cadre_ppo_loss(const float* logits, int64_t ldl, int64_t l_ns, const float* values, int64_t ldv,
                    int64_t v_ns, const int64_t* actions, const int32_t* commands, const float* old_values, const float* returns,
                    const float* old_logp, const float* adv, int32_t B, int32_t n_out_steer,

@@ -5,6 +5,8 @@
  *   conv_stream_f32.hip / conv_stream_bf16.hip  cadre_gemm_t.tile 12: 64x64 conv, several M-tiles per workgroup
  *   gemm_f32_skinny.hip                         cadre_gemm_t.tile 11 (fp32): register-direct skinny GEMM
  *   conv3x3_c64_bf16.hip                        cadre_conv3x3_c64_bf16 below
+ *   ppo_update.hip (under CADRE_AB_KERNELS)     cadre_lstm_seq_fwd below: the persistent forward LSTM (208 vs 110 us)
+ *   conv3x3_ring.hip (under CADRE_AB_KERNELS)   the 16x16x32-MFMA instantiations of the window conv (CADRE_RING_M16=1)
  *   cadre_kernels.hip (under CADRE_AB_KERNELS)  the unfused LSTM cell passes and the two-output column sum of the
  *                                               round-2 update (superseded by ppo_update.hip)
  */
@@ -50,6 +52,16 @@ int cadre_colsum2(const float* X, int64_t ldx, int64_t x_str, float* out, float*
                   int32_t N, int32_t batch, const int32_t* row_seg, int32_t period, void* stream);
 /* (row_seg != NULL: rows sorted by command, `period` rows per time step — rows outside the 32-row tiles of net z's run
  * are exact zeros by construction and are skipped; the sum is bit-identical to the full one.) */
+/* All S forward steps of `Z` nets in ONE persistent launch (ppo_update.hip, lstm_seq_fwd_kernel): a workgroup = (net, 16
+ * hidden units) keeps its packed recurrent weights in registers for the whole launch, the workgroups of a net exchange
+ * the activation rows h_t through L2 (write-through stores, one arrival counter per (net, step), one agent-scope
+ * acquire per step: cdna_hip_programming.md Guideline 16).  G [S][B][ldg], Hs / Cs / TC [S+1][B][ldh] per net, slot 0 =
+ * initial state (in), slots 1..S written.  sync_ws: Z*S + 1 int32 of device memory — the counters (zeroed here) and a
+ * status word that a timed-out wait (bounded spins: a launch can never hang) sets to 1; pass it to cadre_ppo_loss, which
+ * then returns NaN losses.  Same results, bit for bit, as S calls of cadre_lstm_step_fwd. */
+int cadre_lstm_seq_fwd(const float* Wp, int64_t wp_str, const float* bias, int64_t b_str, float* G, int32_t ldg,
+                       int64_t g_str, float* Hs, float* Cs, float* TC, int32_t ldh, int64_t h_str, int32_t B, int32_t D,
+                       int32_t S, int32_t Z, const int32_t* row_seg, int32_t* sync_ws, void* stream);
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,56 @@
+"""The WHOLE N > 1 path of bench.py on the one GPU of a test box: `python bench.py --gpus 2` (the parent never touches
+the GPU, starts two fresh children) with CADRE_BENCH_BACKEND=gloo and CADRE_BENCH_ONE_DEVICE=1 — init_process_group,
+startup broadcast of the parameters, barriers, MAX-reduce of the elapsed time, one gradient exchange per optimiser
+step (8 per round), the exchange-timing block and the single JSON line relayed through the self-spawn.  RCCL itself
+needs one GPU per rank (the driver's SCALE run); everything around the collective calls is exercised here.
+Reference topology this replaces: main.py:57-70 (N train processes + chief)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _run(extra, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(CADRE_BENCH_BACKEND="gloo", CADRE_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"] + extra,
+                       env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("mode", ["allreduce", "sharded", "buckets"])
+def test_bench_main_at_world_two_on_one_gpu(mode):
+    extra = ["--config", "C1", "--no-c3"]
+    if mode == "sharded":
+        extra += ["--grad-exchange", "sharded"]
+    if mode == "buckets":
+        extra += ["--grad-buckets"]
+    d = _run(extra)
+    assert d["n_gpus"] == 2 and d["metric"] == "ppo_update_samples_per_sec" and d["scaling"] == "weak"
+    assert d["rccl_ranks"] == 2 and d["backend"] == "gloo" and d["one_device"] is True
+    assert d["exchanges_in_timed_region"] == 16            # 2 rounds x 4 epochs x 2 minibatches: ONE exchange per optimiser step
+    assert d["config"]["parallelism"] == "dp2" and d["config"]["workers_per_gpu"] == 1
+    assert d["value"] > 0 and abs(d["value"] - 2 * 32 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
+    assert d["allreduce_ms_per_step"] > 0 and d["allreduce_bytes"] == 4 * 19998848
+    assert d["grad_exchange"].startswith("sharded" if mode == "sharded" else "allreduce")
+    assert "cpu_baseline" not in d and "measured_peaks" not in d           # rank 0 at N = 1 only
+    assert all(abs(x) < 1e3 for x in d["last_losses"])
+
+
+def test_default_headline_on_several_gpus_is_c3_per_gpu():
+    """No --config and N > 1: the headline is BASELINE C4's per-GPU shape (4 workers x 128 steps, bf16 encoder / fp32
+    losses — the shape north_star's 1 -> 8 target is defined on); C2 rides along as the nested section."""
+    d = _run(["--no-cpu-baseline", "--no-peaks"], timeout=1500)
+    assert d["n_gpus"] == 2 and d["config"]["workers_per_gpu"] == 4 and d["config"]["minibatch_per_gpu"] == 256
+    assert d["config"]["workload"].startswith("C3:") and "bf16" in d["dtype"]
+    assert abs(d["value"] - 2 * 4 * 128 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
+    assert d["exchanges_in_timed_region"] == 16
+    assert d["c2"]["config"]["workers_per_gpu"] == 1 and d["c2"]["dtype"] == "f32" and d["c2"]["n_gpus"] == 2

@@ -178,6 +178,23 @@ def test_bench_starts_one_fresh_process_per_rank():
     assert seen == [0, 1, 2, 3]
 
 
+def test_bench_parent_ends_the_peers_of_a_dead_rank():
+    """A rank that dies (OOM, ABI mismatch) leaves its peers waiting in a collective: the parent polls every child,
+    terminates the others and returns the dead rank's status instead of hanging until an outer timeout."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["CADRE_BENCH_SELFTEST_FAIL_RANK"] = "1"
+    t0 = time.monotonic()
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--spawn-selftest"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 3, (p.returncode, p.stderr[-2000:])
+    assert time.monotonic() - t0 < 120
+    assert "rank 1 failed with status 3" in p.stderr
+
+
 def test_gradient_allreduce_sum_gloo_world2():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -576,6 +576,7 @@ def test_mlp_towers_fused(hip, B, segs):
     assert float(got[0][:, :, D:].abs().max()) == 0.0       # padding columns of W1
 
 
+@needs_ab
 @pytest.mark.parametrize("B,sorted_rows", [(64, True), (256, True), (24, False), (96, True)])
 def test_lstm_seq_fwd_persistent_equals_per_step(hip, B, sorted_rows):
     """cadre_lstm_seq_fwd — all S steps of the 8 nets in one persistent launch, the h rows exchanged between workgroups

@@ -452,7 +452,8 @@ def test_row_sorted_update_equals_unsorted(Bw, nW):
     from ppo_agent.storage import RolloutStorage
     a_s, a_u, a_p = make_agent(84, 84), make_agent(84, 84), make_agent(84, 84)
     a_u.learner.use_sorted = False
-    a_p.learner.persistent_lstm = True        # forward LSTM as one persistent launch (cadre_lstm_seq_fwd): bit-identical
+    from cadre_amd import hip as _hip
+    a_p.learner.persistent_lstm = _hip.has_ab_kernels()     # A/B build: forward LSTM as one persistent launch (cadre_lstm_seq_fwd), bit-identical
     assert a_s.learner.sorted_rows(Bw * nW) and not a_u.learner.sorted_rows(Bw * nW)
     T = 2 * Bw
     stor = []
