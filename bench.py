@@ -320,7 +320,11 @@ def kname(k):
     """Exact kernel symbol as rocprofv3 prints it, from a hip.PROFILE key."""
     if k[0] == "ring":
         tf = ("true" if k[1] else "false", k[2], k[3], "true" if k[4] else "false")
-        return "conv3x3_ring_pp_kernel<%s, %d, %d, %s>" % tf if k[6] else ("conv3x3_ring_kernel<%s, %d, %d, %s, %%d>" % tf) % k[5]
+        if len(k) > 7 and k[7] == 9:             # the weight-stationary 64 -> 64 stage
+            return "conv3x3_c64s_kernel<%d, %s>" % (k[3], tf[3])
+        if len(k) > 7 and k[7]:                  # G k-tiles per ping-pong slot (bf16)
+            return "conv3x3_ring_pp2_kernel<%d, %d, %s, %d>" % (k[2], k[3], tf[3], k[7])
+        return "conv3x3_ring_pp_kernel<%s, %d, %d, %s, false>" % tf if k[6] else ("conv3x3_ring_kernel<%s, %d, %d, %s, %%d>" % tf) % k[5]
     if k[0] == "bf16":
         _, tile, am = k
         if tile == 12:

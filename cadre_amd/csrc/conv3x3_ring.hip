@@ -69,10 +69,24 @@ struct ring_args {
 #else
 #define RG_SLOT(k) do { } while (0)
 #endif
+#if defined(RING_TRACE) && RING_TRACE == 4      // in-kernel clock: shader clock and 100 MHz wall clock at a workgroup's entry and exit
+#define RG_CLK(k) do { if (a.trace && threadIdx.x == 0) { a.trace[(size_t)blockIdx.x * 4 + 2 * (k)] = __builtin_amdgcn_s_memtime(); \
+    a.trace[(size_t)blockIdx.x * 4 + 2 * (k) + 1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define RG_CLK(k) do { } while (0)
+#endif
 #if defined(RING_TRACE) && RING_TRACE == 2      // inside k-tiles 4 and 5 of the first chunk
 #define RG_STEP(k) RG_STAMP_(k)
 #else
 #define RG_STEP(k) do { } while (0)
+#endif
+
+// -DRING_ABL=<bits>: timing ablations of the ping-pong kernel (tools/ring_ablate.py; results are WRONG by construction, never
+// in the product build): 1 no MFMAs, 2 no fragment reads, 4 no window DMA after the prologue, 8 no weight DMA after the
+// prologue, 16 no global stores, 32 no epilogue at all, 64 no residual loads.  Skipped values stay live through empty asm
+// (a skipped producer must not let the compiler delete its consumers: cdna_hip_programming.md 5.4 rule 17).
+#ifndef RING_ABL
+#define RING_ABL 0
 #endif
 
 template <int N>
@@ -88,6 +102,9 @@ __device__ __forceinline__ void wait_vm_n(int n) {        // wave-uniform n in [
     default: wait_vm<0>(); break;
   }
 }
+
+template <int V>
+struct int_k { static constexpr int value = V; };
 
 // NTILE: output channels per workgroup tile (64 or 128); 8 waves as 4 (positions) x 2 (channels): a wave owns
 // 64 positions x NTILE/2 channels = 2 x WN MFMA tiles of 32x32.
@@ -510,8 +527,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
   auto voff_a = [&](int mt_n, int c_n, int j, bool live) -> unsigned {
     return (live && j < PA) ? (unsigned)((mt_n * RG_BM - a.W - 1 + 8 * j) * cin_b + c_n * 128 + a_lane) : OOB;
   };
+  bool abl_pro = true;                                     // (ablation builds: the prologue's loads always go out)
   auto send_a = [&](unsigned voff, int wsel, int j, bool live) {
     char* dst = (live && j < PA) ? win0 + wsel * win_bytes + j * 1024 : dump;
+    if ((RING_ABL & 4) && !abl_pro) { voff = OOB; dst = dump; }      // the DMA still issues, nothing is fetched, the window keeps its data
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)dst, 16, (int)voff, 0, 0, 0);
   };
   auto issue_a = [&](int mt_n, int c_n, int wsel, int j, bool live) { send_a(voff_a(mt_n, c_n, j, live), wsel, j, live); };
@@ -519,8 +538,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
     return live ? (unsigned)(nt_b * (NTILE * a.NC * 9 * 128) + (c * 9 + tap) * 128 + b_lane[k]) : OOB;
   };
   auto send_b = [&](unsigned voff, int stg, int k) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(bst + stg * STG_B + (wave * NBPW + k) * 1024),
-                                             16, (int)voff, 0, 0, 0);
+    char* dst = bst + stg * STG_B + (wave * NBPW + k) * 1024;
+    if ((RING_ABL & 8) && !abl_pro) { voff = OOB; dst = dump; }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)dst, 16, (int)voff, 0, 0, 0);
   };
   auto issue_b = [&](int nt_b, int c, int tap, int stg, bool live) {
 #pragma unroll
@@ -580,7 +600,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
     return (mt_e * RG_BM + 64 * wm + row0) * a.N + nt_e * NTILE + (NTILE / 2) * wn + c4;
   };
   auto req = [&](int eb, unsigned chm, int b, rq_t* dst) {  // residual quads of block b
-    if constexpr (RES != 0) {
+    if constexpr (RES != 0 && (RING_ABL & 64) != 0) {
+#pragma unroll
+      for (int i = 0; i < NPASS; ++i) dst[i] = rq_t{};
+    } else if constexpr (RES != 0) {
       const int cb = b >> 1, rb = b & 1;
 #pragma unroll
       for (int i = 0; i < NPASS; ++i) {
@@ -601,6 +624,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
   const float act_floor = (a.act & 15) == 1 ? 0.f : -__builtin_inff();      // y = max(x, floor): ReLU or identity
   const bool post = (a.act & 16) != 0;
   auto epilogue = [&](int mt_e, int nt_e, int phl) {
+    if constexpr ((RING_ABL & 32) != 0) {                   // no epilogue: the accumulators stay live
+#pragma unroll
+      for (int rb = 0; rb < PR; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < CT; ++cb)
+#pragma unroll
+          for (int r = 0; r < (M16 ? 4 : 16); ++r) { const float t = acc[rb][cb][r]; asm volatile("" :: "v"(t)); }
+    } else {
     float* cs = reinterpret_cast<float*>(win0 + phl * win_bytes + wave * RG_SLAB);
     const int eb = ebase_of(mt_e, nt_e);
     const unsigned chm = chmask_of(nt_e);
@@ -665,7 +696,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
         }
         const int eo = eb + (32 * rb + RSTEP * i) * a.N + 32 * cb;
         const int bo = ((chm >> cb) & 1u) ? eo * ESZ : (int)OOB;
-        if constexpr (WIDE) {
+        if constexpr ((RING_ABL & 16) != 0) {                 // no global stores: the values stay live
+#pragma unroll
+          for (int h = 0; h < NV; ++h) asm volatile("" :: "v"(v[h]), "v"(bo));
+        } else if constexpr (WIDE) {
           bf16x8 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) { o[e] = (__bf16)v[0][e]; o[4 + e] = (__bf16)v[1][e]; }
@@ -680,6 +714,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // slab reads done before this wave's loads may land in that window
+    }
   };
 
   // byte offsets (from the LDS base) of this lane's pixel fragments of k-tile `tap`.  Rows start on 128-byte boundaries,
@@ -705,13 +740,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
   // ---- prologue: window of the first phase, weights of k-tiles 0 .. LEAD-1; everything landed and published
   const int total_ph = nitems * a.NC;
   for (int j = wave; j < PA; j += NWAVES) issue_a(mt, 0, 0, j, true);
+  if constexpr ((RING_ABL & 4) != 0) { for (int j = wave; j < PA; j += NWAVES) issue_a(mt, 0, 1, j, true); }
 #pragma unroll
   for (int s = 0; s < LEAD; ++s) issue_b(nt, 0, s, s, true);                          // (LEAD <= 3 < 9 k-tiles of a chunk)
+  if constexpr ((RING_ABL & 8) != 0) issue_b(nt, 0, LEAD, LEAD, true);
   wait_vm<0>();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   if (grp == 1) __builtin_amdgcn_s_barrier();              // group 1 runs one slot behind
+  abl_pro = false;
+  RG_CLK(0);
   int mt_p = 0, nt_p = 0, phl_p = 0;
   bool have_prev = false;
 
@@ -774,7 +813,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
         // operations this wave issues in this R slot / issued in its previous one (folds: tap is unrolled)
         // (residual of output blocks 0 and 1: requested at k-tiles 7 and 8 of the item's last chunk — an HBM round trip
         //  ahead of the epilogue that adds them; the later blocks when the epilogue starts, two blocks ahead)
-        auto n_res = [&](int t) -> int { return (RES != 0 && t >= 7) ? NPASS : 0; };
+        auto n_res = [&](int t) -> int { return (RES != 0 && !(RING_ABL & 64) && t >= 7) ? NPASS : 0; };
         const int n_now = NBPW + sl_of(tap) + (last_c ? n_res(tap) : 0);
         const char* bs = bst + (tap % RG_NSTB) * STG_B;     // 9 k-tiles per chunk, 3 stages: the stage of k-tile `tap` is tap % 3 — static
         f32x4 afr[PR][KS], bfr[CT][KS];
@@ -813,6 +852,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
           for (int cb = 1; cb < CT; ++cb)
 #pragma unroll
             for (int s = 0; s < KS; ++s) bfr[cb][s] = *reinterpret_cast<const f32x4*>(bs + boff[cb][s]);
+        }
+        if constexpr ((RING_ABL & 2) != 0) {                 // no fragment reads: lane-dependent junk operands instead
+#pragma unroll
+          for (int s = 0; s < KS; ++s) {
+#pragma unroll
+            for (int rb = 0; rb < PR; ++rb) afr[rb][s] = f32x4{(float)(lane * 3 + s), 1.5f + rb, -0.75f * lane, 0.3f};
+#pragma unroll
+            for (int cb = 0; cb < CT; ++cb) bfr[cb][s] = f32x4{0.01f * lane, -2.5f + cb, 0.125f * s, 1.f};
+          }
         }
         __builtin_amdgcn_sched_barrier(0);                   // (the reads go out first: their latency runs under the issue below)
         {
@@ -856,7 +904,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
         for (int cb = 0; cb < CT; ++cb)
 #pragma unroll
           for (int s = 0; s < KS; ++s) {
-            if constexpr (M16) {
+            if constexpr ((RING_ABL & 1) != 0) {             // no MFMAs: the operands stay live
+#pragma unroll
+              for (int rb = 0; rb < PR; ++rb) asm volatile("" :: "v"(bfr[cb][s]), "v"(afr[rb][s]));
+            } else if constexpr (M16) {
 #pragma unroll
               for (int rb = 0; rb < PR; ++rb)
                 acc[rb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bfr[cb][s]), __builtin_bit_cast(bf16x8, afr[rb][s]),
@@ -897,17 +948,873 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
     mt = mt1; nt = nt1;
   }
   // ---- tail: the last item's epilogue, group 0 one slot before group 1
+  RG_CLK(1);
   epilogue(mt_p, nt_p, phl_p);
   __builtin_amdgcn_s_barrier();
 }
 
 
+
+#ifdef CADRE_AB_KERNELS
+// ---------------------------------------------------------------------------------------------------------------
+// PING-PONG, G K-TILES PER SLOT (bf16; round 4) — A/B BUILD ONLY (CADRE_BUILD_AB=1, then CADRE_RING_G=2): built, parity-green,
+// and measured SLOWER than the kernel above on every layer (same box, 2048 frames at 288 x 288: 64-channel tile 1.01 / 1.46
+// vs 0.96 / 1.04 ms, 128-channel tile 0.82 / 0.90 vs 0.65 / 0.75 ms; DESIGN.md 3.3 has the ablation and the slot trace).  The kernel above pays its fixed slot cost — two barriers, the turn in
+// which the staging group's reads come back, the priority flips — once per k-tile: traced, 8 MFMAs = 256 pipe cycles in a
+// 380-cycle slot + ~100 of barrier on the 64-channel tile, 16 MFMAs = 512 in 615 + 80-250 on the 128-channel tile.  Here a
+// slot carries G consecutive k-tiles (G = 3 with the 64-channel tile: one row of taps; G = 2 with the 128-channel tile),
+// the fixed cost once per 24 / 32 MFMAs.  What changes with it:
+//   * the two groups split the CHANNELS of the tile, not its positions: wave w = (position block w & 3, group w >> 2),
+//     group g owns channels [g * NTILE/2, (g+1) * NTILE/2).  A group then reads only ITS half of every weight stage, and
+//     a half-stage is written by the group that reads it: no weight byte crosses the groups, so two sets of G half-stages
+//     (read one, fill the other) replace the three stages — a group issues the weights of super-step u+1 at the start
+//     of R(u), right after its own last read of that set (end of M(u-1)), and confirms them at the END of M(u) by its
+//     counted vmcnt: almost two slots of lead for every piece, for both groups alike;
+//   * R(u) reads the fragments of the super-step's FIRST k-tile only; inside M(u) the fragments of k-tile j + 1 are read
+//     behind the MFMAs of k-tile j, one k-step at a time into the registers that k-step's MFMAs have just released (MFMA
+//     order: k-step outer) — the register budget of ONE k-tile of fragments, as in the kernel above;
+//   * window slices go out on a static per-group schedule (SL below) that follows from who reads which buffer when
+//     (group 1 runs one slot behind: a buffer whose last k-tile is read inside an M slot is free for group 1's next R
+//     slot but not yet for group 0's), confirmed by in-order completion: a slice issued in R(x) is complete when the
+//     weights issued in R(x+1) are confirmed (end of M(x+1)) — 3.9 slots of G k-tiles instead of 4 slots of one k-tile
+//     for an HBM round trip;
+//   * the epilogue needs no LDS: the accumulator holds (lane -> position, register quad -> 4 channels, lane half -> which
+//     4 of 8); one v_permlane32_swap per register pair leaves every lane with EIGHT consecutive channels = one 16-byte
+//     store (and one 16-byte residual load) per 32 x 16 half-tile; folded BN comes from the LDS table in that layout.
+//     No slab in a window, so the next phase's slices may start in the item's first slot, and no LDS round trip sits
+//     between the last MFMA and the stores.  Both groups run their epilogue in their own R slot of the next item's first
+//     super-step — under the other group's MFMAs.
+// Needs (9 * NC) % G == 0 (G = 2: an even number of 128-byte channel chunks); other shapes stay on the kernel above.
+template <int G_> struct pp2_geo {
+  static constexpr int L = (G_ == 2) ? 18 : 9;             // k-tiles per period = lcm(9, G)
+  static constexpr int P = L / G_;                         // super-steps per period (odd: 9 or 3)
+  static constexpr int CPP = L / 9;                        // channel chunks per period
+};
+
+template <int NTILE, int RES, bool OUTB, int G>
+__global__ __launch_bounds__(512, 2) void conv3x3_ring_pp2_kernel(ring_args a) {
+  static_assert(G == 2 || G == 3, "G k-tiles per slot");
+  static_assert(RES == 0 || RES == 2, "bf16 operands take a bf16 residual");
+  using geo = pp2_geo<G>;
+  constexpr int P = geo::P, CPP = geo::CPP;
+  constexpr int WN = NTILE / 64;                           // 32-channel blocks per wave
+  constexpr int RG_BM = 256, NWAVES = 8;
+  constexpr int PPK = NTILE / 16;                          // 1-KiB pieces of a half-stage (NTILE/2 rows x 128 B): 4 or 8
+  constexpr int NQ = PPK / 4;                              // pieces of one half-stage per wave (4 waves per group)
+  constexpr int NWP = G * NQ;                              // weight pieces per wave and super-step: piece i = (k-tile i / NQ, rows 8 (pb + 4 (i % NQ)) ..)
+  constexpr int HS_B = (NTILE / 2) * 128, SET_B = G * HS_B;
+  constexpr bool AHEAD = true;                             // R(ss + 1)'s addresses / offsets computed under the wave's own MFMAs of M(ss)
+  constexpr unsigned OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int pb = wave & 3, grp = wave >> 2;                // position block, channel half (waves w and w + 4 share a SIMD)
+  const int win_bytes = a.WPX * 128;
+  char* win0 = smem;
+  char* wts = smem + 2 * win_bytes;                        // [group][set][k-tile of the super-step][NTILE/2 rows][128 B]
+  char* dump = wts + 4 * SET_B;
+  const int i_begin = blockIdx.x * a.ipw, i_end = min(a.items, i_begin + a.ipw);
+  const int nitems = i_end - i_begin;
+  if (nitems <= 0) return;
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.M * a.Cin * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.N * a.NC * 9 * 128, 0x00020000);
+  constexpr int ESZ = OUTB ? 2 : 4;
+  const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.M * a.N * ESZ, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? a.resid : a.x), 0, RES ? a.M * a.N * 2 : 0, 0x00020000);
+  const int cin_b = a.Cin * 2;
+  const int PA = a.WPX >> 3;
+  const int NPER = a.NC / CPP;
+  for (int i = tid; i < 256; i += 512) reinterpret_cast<unsigned*>(dump)[i] = 0u;      // the ZERO ROW (halo taps) and the dummy DMA target
+  float* sc_lds = reinterpret_cast<float*>(dump + 1024);
+  for (int i = tid; i < a.ntiles * NTILE; i += 512) {
+    sc_lds[i] = (a.scale && i < a.N) ? a.scale[i] : 1.f;
+    sc_lds[a.ntiles * NTILE + i] = (a.shift && i < a.N) ? a.shift[i] : 0.f;
+  }
+  auto swz = [](int idx) constexpr -> int { return (idx >> 1) & 7; };
+  // window piece j = 8 n + wave (n = 0 .. 7): pixel 8 j + (lane >> 3), LDS chunk (lane & 7) <- source chunk ^ swz(pixel);
+  // swz(pixel) = (lane >> 4) ^ 4 (j & 1) and j has the parity of the wave: a per-lane constant
+  const int a_lane = (lane >> 3) * cin_b + ((((lane & 7) ^ (lane >> 4) ^ (4 * (wave & 1)))) << 4);
+  int b_lane[NQ];
+#pragma unroll
+  for (int k = 0; k < NQ; ++k) {
+    const int r = 8 * (pb + 4 * k) + (lane >> 3);          // row inside the group's half-stage
+    b_lane[k] = (grp * (NTILE / 2) + r) * a.NC * 9 * 128 + (((lane & 7) ^ swz(r)) << 4);
+  }
+  bool abl_pro = true;                                     // (ablation builds: the prologue's loads always go out)
+  auto send_a = [&](unsigned voff, int wsel, int j, bool live) {
+    char* dst = (live && j < PA) ? win0 + wsel * win_bytes + j * 1024 : dump;
+    if ((RING_ABL & 4) && !abl_pro) { voff = OOB; dst = dump; }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)dst, 16, (int)voff, 0, 0, 0);
+  };
+  auto voff_a = [&](int mt_n, int c_n, int j, bool live) -> unsigned {
+    return (live && j < PA) ? (unsigned)((mt_n * RG_BM - a.W - 1 + 8 * j) * cin_b + c_n * 128 + a_lane) : OOB;
+  };
+  auto voff_b = [&](int nt_b, int c, int tap, bool live, int k) -> unsigned {
+    return live ? (unsigned)(nt_b * (NTILE * a.NC * 9 * 128) + (c * 9 + tap) * 128 + b_lane[k]) : OOB;
+  };
+  auto send_b = [&](unsigned voff, int set, int i) {
+    char* dst = wts + (grp * 2 + set) * SET_B + (i / NQ) * HS_B + (pb + 4 * (i % NQ)) * 1024;
+    if ((RING_ABL & 8) && !abl_pro) { voff = OOB; dst = dump; }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)dst, 16, (int)voff, 0, 0, 0);
+  };
+  // ---- fragment addressing
+  const int base_idx = 64 * pb + l31;
+  int kc[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) kc[s] = (2 * s + lh) << 4;
+  int boff[4];                                             // weight fragment of column block 0 (block cb: + 32 * 128 * cb)
+#pragma unroll
+  for (int s = 0; s < 4; ++s) boff[s] = l31 * 128 + (((2 * s + lh) ^ swz(l31)) << 4);
+  const float inv_w = 1.0f / (float)a.W, inv_h = 1.0f / (float)a.H;
+  int ph[2], pw[2];
+  int mt = i_begin / a.ntiles, nt = i_begin - mt * a.ntiles;
+  {
+    const int HW = a.H * a.W;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int m = mt * RG_BM + 64 * pb + 32 * rb + l31;
+      const int rem = m % HW;
+      ph[rb] = rem / a.W;
+      pw[rb] = rem - ph[rb] * a.W;
+    }
+  }
+  auto advance_mtile = [&]() {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int x = pw[rb] + RG_BM;
+      const int q1 = (int)(((float)x + 0.5f) * inv_w);
+      pw[rb] = x - q1 * a.W;
+      const int y = ph[rb] + q1;
+      const int q2 = (int)(((float)y + 0.5f) * inv_h);
+      ph[rb] = y - q2 * a.H;
+    }
+  };
+  typedef const __attribute__((address_space(3))) char* lds_cptr;
+  typedef const __attribute__((address_space(3))) f32x4* lds_f4;
+  const lds_cptr lds0 = (lds_cptr)smem;
+  const unsigned zrow_off = (unsigned)(dump - smem);
+  const unsigned wts_off = (unsigned)(wts - smem);
+  lds_cptr a_addr[2][4];                                    // pixel fragment addresses of the next R slot's k-tile
+  // (bi = 64 pb + l31 and the two halo masks come in as per-super-step copies behind an empty asm: every address is then
+  //  computed where it is used — left to itself the compiler hoists the tap-dependent parts of all nine taps out of the
+  //  period loop and spills them)
+  auto frag_addr = [&](int tap, int win_off, int bi, unsigned mk0, unsigned mk1, int Wx, lds_cptr (*out)[4]) {
+    const int toff = (tap / 3) * Wx + (tap % 3);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int idx = bi + 32 * rb + toff;                 // window row of this lane's pixel; its bytes start at idx * 128
+      const unsigned row = (((rb ? mk1 : mk0) >> tap) & 1u) ? (unsigned)(win_off + (idx << 7)) : zrow_off;
+      const unsigned rsw = row ^ (unsigned)(swz(idx) << 4);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) out[rb][s] = lds0 + (rsw ^ (unsigned)kc[s]);
+    }
+  };
+
+  // ---- epilogue (no LDS slab): tile b = (cb, rb); after the lane-half exchange lane (l31, lh) holds, for position
+  // 32 rb + l31, channels 32 cb + 16 h + 8 lh .. + 7 (h = 0, 1): one 16-byte store / residual load per (tile, h)
+  constexpr int NT2 = 2 * WN;
+  f32x16 acc[2][WN];
+  u32x4 rq[NT2][2];
+  auto ebase_of = [&](int mt_e, int nt_e) -> int {
+    return (mt_e * RG_BM + 64 * pb + l31) * a.N + nt_e * NTILE + grp * (NTILE / 2) + 8 * lh;
+  };
+  auto chmask_of = [&](int nt_e) -> unsigned {             // bit cb: the 32-channel block exists (N % 32 == 0)
+    unsigned m = 0;
+#pragma unroll
+    for (int cb = 0; cb < WN; ++cb)
+      if (nt_e * NTILE + grp * (NTILE / 2) + 32 * cb < a.N) m |= 1u << cb;
+    return m;
+  };
+  auto req = [&](int eb, unsigned chm, int b) {
+    if constexpr (RES != 0 && (RING_ABL & 64) == 0) {
+      const int cb = b >> 1, rb = b & 1;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int eo = eb + 32 * rb * a.N + 32 * cb + 16 * h;
+        rq[b][h] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, ((chm >> cb) & 1u) ? eo * 2 : (int)OOB, 0, 0));
+      }
+    }
+  };
+  const float act_floor = (a.act & 15) == 1 ? 0.f : -__builtin_inff();      // y = max(x, floor): ReLU or identity
+  const bool post = (a.act & 16) != 0;
+  auto epilogue = [&](int mt_e, int nt_e) {
+    if constexpr ((RING_ABL & 32) != 0) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < WN; ++cb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { const float t = acc[rb][cb][r]; asm volatile("" :: "v"(t)); }
+    } else {
+    const int eb = ebase_of(mt_e, nt_e);
+    const unsigned chm = chmask_of(nt_e);
+#pragma unroll
+    for (int b = 0; b < NT2; ++b) {
+      const int cb = b >> 1, rb = b & 1;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        // register quads g = 2h (channels 16h + 4 lh ..) and g = 2h + 1 (16h + 8 + 4 lh ..): exchanging the upper lane
+        // half of the first with the lower lane half of the second leaves channels 16h + 8 lh .. + 7 in this lane
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          // v_permlane32_swap x, y: x <- [x.lo, y.lo], y <- [x.hi, y.hi].  As inline asm: ROCm 7.2's
+          // __builtin_amdgcn_permlane32_swap hands back its first result for BOTH elements of the pair (measured: channels
+          // 0-3 twice), and __builtin_bit_cast of a vector-element lvalue reads element 0.  The accumulator was written by
+          // MFMAs at least a barrier ago; the s_nop covers the VALU -> permlane operand wait states hipcc does not see here.
+          float fx = acc[rb][cb][8 * h + e], fy = acc[rb][cb][8 * h + 4 + e];
+          asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(fx), "+v"(fy));
+          v[e] = fx;
+          v[4 + e] = fy;
+        }
+        const int nl = nt_e * NTILE + grp * (NTILE / 2) + 32 * cb + 16 * h + 8 * lh;
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc_lds + nl), s1 = *reinterpret_cast<const f32x4*>(sc_lds + nl + 4);
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(sc_lds + a.ntiles * NTILE + nl);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(sc_lds + a.ntiles * NTILE + nl + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = v[e] * s0[e] + t0[e]; v[4 + e] = v[4 + e] * s1[e] + t1[e]; }
+        if constexpr (RES != 0) {
+          const bf16x8 t = __builtin_bit_cast(bf16x8, rq[b][h]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float rv = (float)t[e];
+            v[e] += post ? 0.f : rv;
+            v[e] = fmaxf(v[e], act_floor);
+            v[e] += post ? rv : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], act_floor);
+        }
+        const int eo = eb + 32 * rb * a.N + 32 * cb + 16 * h;
+        const int bo = ((chm >> cb) & 1u) ? eo * ESZ : (int)OOB;
+        if constexpr ((RING_ABL & 16) != 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) asm volatile("" :: "v"(v[e]), "v"(bo));
+        } else if constexpr (OUTB) {
+          bf16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsC, bo, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[0], v[1], v[2], v[3]}), rsC, bo, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[4], v[5], v[6], v[7]}), rsC, bo == (int)OOB ? bo : bo + 16, 0, 0);
+        }
+      }
+    }
+    }
+  };
+
+  // ---- static slice schedule: SL(g, ss) slices of a phase's window go out in R(ss) of a wave of group g (slot of G0's
+  // R(ss): 2 ss, M(ss): 2 ss + 1; group 1 one later).  A slice issued in R(x) is complete at the end of M(x + 1).
+  // G = 3, one chunk per period: the next phase's buffer was read last in the previous period's M(2) — by group 1 in this
+  //   period's slot 0 — and is read first in the next period's R(0) (slot 6): group 0 may issue in R(1) only, group 1 in
+  //   R(0) and R(1) (its R(1) slices forced complete at the end of its R(2), below).  Group 1's waves therefore carry two
+  //   thirds of the pieces: j = pb + 4 n (n = 0 .. 9), group 0's j = 40 + pb + 4 n (n = 0 .. 4); 60 pieces >= WPX / 8.
+  // G = 2, two chunks per period: chunk 1's buffer was read last in the previous period's M(8) (group 1: slot 0) and is
+  //   read first in M(4) (k-tile 9: slot 9): group 0 issues in R(1), R(2), group 1 in R(0) .. R(2); chunk 0's buffer is
+  //   read last in R(4) (k-tile 8) and first in the next period's R(0): R(5) .. R(7) for group 0, R(5), R(6) for group 1
+  //   (its slices complete one slot later).  Pieces j = 8 n + wave, n = 0 .. 7.
+  auto SL = [](int g, int ss) constexpr -> int {
+    if (G == 3) return g == 0 ? (ss == 1 ? 5 : 0) : (ss < 2 ? 5 : 0);
+    if (g == 0) return (ss == 1 || ss == 2) ? 4 : ((ss == 5 || ss == 6) ? 3 : (ss == 7 ? 2 : 0));
+    return (ss == 0 || ss == 1) ? 3 : (ss == 2 ? 2 : ((ss == 5 || ss == 6) ? 4 : 0));
+  };
+  auto SL0 = [&](int g, int ss) constexpr -> int {          // slices of the same phase this wave issued in earlier slots
+    int n = 0;
+    for (int t = (G == 3 || ss < 5) ? 0 : 5; t < ss; ++t) n += SL(g, t);
+    return n;
+  };
+  auto piece_of = [&](int n) -> int { return G == 3 ? (grp == 0 ? 40 + pb + 4 * n : pb + 4 * n) : 8 * n + wave; };
+  constexpr int MAXSL = 5;
+  constexpr int NRQ = (RES != 0 && (RING_ABL & 64) == 0) ? NT2 * 2 : 0;      // early residual loads per lane
+
+  unsigned dma_b[NWP], dma_a[MAXSL] = {OOB, OOB, OOB, OOB, OOB};
+
+  // ---- prologue: first window (all pieces), the group's weights of super-step 0 (set 0)
+  for (int j = wave; j < PA; j += NWAVES) send_a(voff_a(mt, 0, j, true), 0, j, true);
+  if constexpr ((RING_ABL & 4) != 0) { for (int j = wave; j < PA; j += NWAVES) send_a(voff_a(mt, 0, j, true), 1, j, true); }
+#pragma unroll
+  for (int i = 0; i < NWP; ++i) send_b(voff_b(nt, 0, i / NQ, true, i % NQ), 0, i);      // (G <= 3 < 9: chunk 0)
+  if constexpr ((RING_ABL & 8) != 0) {
+#pragma unroll
+    for (int i = 0; i < NWP; ++i) send_b(voff_b(nt, 0, i / NQ, true, i % NQ), 1, i);
+  }
+  wait_vm<0>();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (grp == 1) __builtin_amdgcn_s_barrier();              // group 1 runs one slot behind
+  abl_pro = false;
+  RG_CLK(0);
+  int mt_p = 0, nt_p = 0;
+  bool have_prev = false;
+  int par = 0;                                             // weight set of the current period's super-step 0 (P is odd)
+
+  for (int li = 0; li < nitems; ++li) {
+    int mt1 = mt, nt1 = nt + 1;
+    if (nt1 == a.ntiles) { nt1 = 0; ++mt1; }
+    const bool more = li + 1 < nitems;
+    unsigned mask[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int m = mt * RG_BM + 64 * pb + 32 * rb + l31;
+      unsigned mk = 0;
+      if (m < a.M) {
+        unsigned colm = 0;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+          if ((unsigned)(pw[rb] - 1 + kw) < (unsigned)a.W) colm |= 1u << kw;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+          if ((unsigned)(ph[rb] - 1 + kh) < (unsigned)a.H) mk |= colm << (3 * kh);
+      }
+      mask[rb] = mk;
+    }
+    for (int per = 0; per < NPER; ++per) {
+      const int c0 = per * CPP;                            // first chunk of the period
+      const int phg0 = li * a.NC + c0;                     // its phase: window buffer phg0 & 1 (chunk c0 + 1: the other one)
+      const bool last_per = per + 1 == NPER;
+      const bool has_next = !last_per || more;             // another period follows in this workgroup
+      // what R(ss) needs (static ss): source offsets of the weights of super-step ss + 1 and of its slices ...
+      auto slot_prep = [&](auto ss_c, int a_ln, const int* b_ln) {
+        constexpr int ss = decltype(ss_c)::value;
+        auto voff_b2 = [&](int nt_b, int c, int tap, bool live, int k) -> unsigned {
+          return live ? (unsigned)(nt_b * (NTILE * a.NC * 9 * 128) + (c * 9 + tap) * 128 + b_ln[k]) : OOB;
+        };
+        auto voff_a2 = [&](int mt_n, int c_n, int j, bool live) -> unsigned {
+          return (live && j < PA) ? (unsigned)((mt_n * RG_BM - a.W - 1 + 8 * j) * cin_b + c_n * 128 + a_ln) : OOB;
+        };
+#pragma unroll
+        for (int i = 0; i < NWP; ++i) {
+          if constexpr (ss + 1 < P) {
+            constexpr int ktg = (ss + 1) * G;              // first k-tile of super-step ss + 1 inside the period
+            dma_b[i] = voff_b2(nt, c0 + (ktg + i / NQ) / 9, (ktg + i / NQ) % 9, true, i % NQ);
+          } else {                                         // first super-step of the next period: taps 0 .. G-1 of its first chunk
+            dma_b[i] = !last_per ? voff_b2(nt, c0 + CPP, i / NQ, true, i % NQ) : voff_b2(nt1, 0, i / NQ, more, i % NQ);
+          }
+        }
+        constexpr bool tgt_next = (G == 3) || (ss >= 5);   // slices for the next period's first chunk (else: this period's chunk 1)
+        const int n0 = grp == 0 ? SL0(0, ss) : SL0(1, ss);
+#pragma unroll
+        for (int i = 0; i < MAXSL; ++i) {
+          if (i < SL(0, ss) || i < SL(1, ss)) {
+            const int j = piece_of(n0 + i);
+            if (tgt_next) dma_a[i] = !last_per ? voff_a2(mt, c0 + CPP, j, true) : voff_a2(mt1, 0, j, more);
+            else dma_a[i] = voff_a2(mt, c0 + 1, j, true);
+          }
+        }
+      };
+      // ... and the LDS addresses of the pixel fragments of its first k-tile
+      auto addr_prep = [&](auto ss_c, int bi, unsigned mk0, unsigned mk1, int Wx) {
+        constexpr int ss = decltype(ss_c)::value;
+        frag_addr((ss * G) % 9, ((phg0 + (ss * G) / 9) & 1) * win_bytes, bi, mk0, mk1, Wx, a_addr);
+      };
+      auto super_step = [&](auto ss_c) {
+        constexpr int ss = decltype(ss_c)::value;
+        const int set = (ss & 1) ^ par;
+        // per-super-step copies of the lane constants the address arithmetic starts from (see frag_addr)
+        int bi = base_idx, a_ln = a_lane, b_ln[NQ], Wx = a.W;
+        unsigned mk0 = mask[0], mk1 = mask[1];
+        asm volatile("" : "+v"(bi), "+v"(a_ln), "+v"(mk0), "+v"(mk1), "+s"(Wx));
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { b_ln[q] = b_lane[q]; asm volatile("" : "+v"(b_ln[q])); }
+        // ================= R slot (at raised priority: its instructions go between the other group's MFMAs)
+        if (a.prio) __builtin_amdgcn_s_setprio(2);
+        if (ss == 0 && per == 0) RG_STAMP(0);
+        if (ss == 1 && per == 0) RG_STAMP(2);
+        if (ss == 0 && per == 0) {
+          // the previous item's epilogue — each group in its own R slot, under the other group's MFMAs — BEFORE this slot's
+          // loads: nothing is in flight behind the residual it waits for
+          if (have_prev) epilogue(mt_p, nt_p);
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < WN; ++cb)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.f;
+          RG_STAMP(1);
+        }
+        if (!AHEAD || ss == 0) { slot_prep(ss_c, a_ln, b_ln); addr_prep(ss_c, bi, mk0, mk1, Wx); }      // (R(0): new period, possibly a new item)
+        f32x4 afr[2][4], bfr[WN][4];
+        const unsigned wbase = wts_off + (grp * 2 + set) * SET_B;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+          for (int cb = 0; cb < WN; ++cb) bfr[cb][s] = *reinterpret_cast<lds_f4>(lds0 + wbase + boff[s] + 32 * 128 * cb);
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb) afr[rb][s] = *reinterpret_cast<lds_f4>(a_addr[rb][s]);
+        }
+        auto junk = [&](int j) {                             // (ablation: no fragment reads — lane-dependent junk operands instead)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) afr[rb][s] = f32x4{(float)(lane * 3 + s), 1.5f + rb, -0.75f * lane, 0.3f + j};
+#pragma unroll
+            for (int cb = 0; cb < WN; ++cb) bfr[cb][s] = f32x4{0.01f * lane, -2.5f + cb, 0.125f * s, 1.f + j};
+          }
+        };
+        if constexpr ((RING_ABL & 2) != 0) junk(0);
+        __builtin_amdgcn_sched_barrier(0);                   // (the reads go out first: their latency runs under the issue below)
+        // this slot's loads: the weights of super-step ss + 1 FIRST (the end of M(ss) confirms them; what is issued after
+        // them may stay in flight), then window slices, then the early residual request
+        const int n_sl = grp == 0 ? SL(0, ss) : SL(1, ss);
+#pragma unroll
+        for (int i = 0; i < NWP; ++i) send_b(dma_b[i], set ^ 1, i);
+        {
+          constexpr bool tgt_next = (G == 3) || (ss >= 5);
+          const int wsel = tgt_next ? ((phg0 + CPP) & 1) : ((phg0 + 1) & 1);
+          const bool live = tgt_next ? has_next : true;
+          const int n0 = grp == 0 ? SL0(0, ss) : SL0(1, ss);
+#pragma unroll
+          for (int i = 0; i < MAXSL; ++i)
+            if ((i < SL(0, ss) || i < SL(1, ss)) && i < n_sl) send_a(dma_a[i], wsel, piece_of(n0 + i), live);
+        }
+        int n_after = n_sl;                                  // operations of this wave younger than the weight pieces
+        if constexpr (NRQ != 0 && ss == P - 2) {
+          if (last_per) {                                    // residual of the item's tiles: four slots ahead of the epilogue
+            const int eb = ebase_of(mt, nt);
+            const unsigned chm = chmask_of(nt);
+#pragma unroll
+            for (int b = 0; b < NT2; ++b) req(eb, chm, b);
+            n_after += NRQ;
+          }
+        }
+        // G = 3, group 1: its slices of R(1) must be complete — and published by this slot's barrier — before group 0 reads
+        // that window in R(0) of the next period, two slots from here: wait for everything older than this slot's weights
+        if constexpr (G == 3 && ss == 2) { if (grp == 1) wait_vm<NWP>(); }
+        if (ss == 1 && per == 0) RG_STAMP(3);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (ss == 1 && per == 0) RG_STAMP(4);
+        if (a.prio) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        // ================= M slot: G k-tiles, k-step outer; behind the MFMAs of k-step s of k-tile j go the reads of k-step s
+        // of k-tile j + 1 — into the registers those MFMAs have just released
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+          lds_cptr n_addr[2][4];
+          if (j + 1 < G) frag_addr((ss * G + j + 1) % 9, ((phg0 + (ss * G + j + 1) / 9) & 1) * win_bytes, bi, mk0, mk1, Wx, n_addr);
+          f32x4 nafr[2][4], nbfr[WN][4];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int cb = 0; cb < WN; ++cb)
+#pragma unroll
+              for (int rb = 0; rb < 2; ++rb) {
+                if constexpr ((RING_ABL & 1) != 0) asm volatile("" :: "v"(bfr[cb][s]), "v"(afr[rb][s]));
+                else acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bfr[cb][s]), __builtin_bit_cast(bf16x8, afr[rb][s]),
+                                                                           acc[rb][cb], 0, 0, 0);
+              }
+            if (j + 1 < G) {
+              if constexpr ((RING_ABL & 2) == 0) {
+#pragma unroll
+                for (int cb = 0; cb < WN; ++cb) nbfr[cb][s] = *reinterpret_cast<lds_f4>(lds0 + wbase + (j + 1) * HS_B + boff[s] + 32 * 128 * cb);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) nafr[rb][s] = *reinterpret_cast<lds_f4>(n_addr[rb][s]);
+              }
+            }
+          }
+          if (j + 1 < G) {
+            // issue order per k-step: its 2 WN MFMAs, then its WN + 2 reads
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 2 * WN, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, WN + 2, 0);
+            }
+            if constexpr ((RING_ABL & 2) == 0) {
+#pragma unroll
+              for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int cb = 0; cb < WN; ++cb) bfr[cb][s] = nbfr[cb][s];
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) afr[rb][s] = nafr[rb][s];
+              }
+            } else junk(j + 1);
+          }
+        }
+        if constexpr (AHEAD && ss + 1 < P) {                 // R(ss + 1)'s offsets and addresses: VALU work under OUR MFMAs
+          slot_prep(int_k<ss + 1>{}, a_ln, b_ln);
+          addr_prep(int_k<ss + 1>{}, bi, mk0, mk1, Wx);
+#pragma unroll
+          for (int i = 0; i < NWP; ++i) asm volatile("" : "+v"(dma_b[i]));
+#pragma unroll
+          for (int i = 0; i < MAXSL; ++i) asm volatile("" : "+v"(dma_a[i]));
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(a_addr[rb][s]));      // (materialised HERE: not sunk to the reads)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ss == 1 && per == 0) RG_STAMP(5);
+        wait_vm_n(n_after);                                  // this slot's weight pieces have landed (in-order completion)
+        if (ss == 1 && per == 0) RG_STAMP(6);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (ss == 1 && per == 0) RG_STAMP(7);
+      };
+      if constexpr (P == 3) { super_step(int_k<0>{}); super_step(int_k<1>{}); super_step(int_k<2>{}); }
+      else {
+        super_step(int_k<0>{}); super_step(int_k<1>{}); super_step(int_k<2>{}); super_step(int_k<3>{}); super_step(int_k<4>{});
+        super_step(int_k<5>{}); super_step(int_k<6>{}); super_step(int_k<7>{}); super_step(int_k<8>{});
+      }
+      par ^= 1;
+    }
+    mt_p = mt; nt_p = nt; have_prev = true;
+    if (mt1 != mt) advance_mtile();
+    mt = mt1; nt = nt1;
+  }
+  // ---- tail: the last item's epilogue; group 0 then meets the barrier that closes group 1's last M slot
+  RG_CLK(1);
+  epilogue(mt_p, nt_p);
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+}
+
+
+#endif      // CADRE_AB_KERNELS
+
+// ---------------------------------------------------------------------------------------------------------------
+// WEIGHT-STATIONARY 64 -> 64 CHANNEL STAGE (bf16; round 4): conv3x3_c64s_kernel.  resnet.py:26-55, layer1: Cin = N = 64, K = 576.
+// Measured on the ping-pong kernels (tools/ring_ablate.py, tools/ring_trace.py): on this stage the matrix pipe is busy 36 %
+// of the time at 1.96 GHz; an item's 73 KB of weights are re-streamed into LDS per 256 positions (more DMA bytes than the
+// pixels), 12 ds_read_b128 feed 8 MFMAs (LDS 75 % busy), and eighteen barriers per item order a weight ring that never
+// changes.  Here the weights never move:
+//   * 4 waves per workgroup, ONE per SIMD, up to 512 registers each: wave (ph, ch) owns 128 positions x 32 channels of a
+//     256-position item and keeps ITS 32 x 576 weights as MFMA A fragments in registers (144 VGPRs) for the whole launch —
+//     no weight DMA, no weight stage in LDS, no weight fragment reads: one ds_read_b128 (pixels) per MFMA;
+//   * LDS holds only pixels: THREE windows (item i being read, i + 1 landed or landing, i + 2 being requested): an HBM
+//     round trip has one to two items of lead;
+//   * ONE barrier per item, between its taps 7 and 8: behind it every wave's slices of the next window have landed and
+//     every wave has issued (and waited for) its last read of the current one, so the tap-0 fragments of the next item
+//     are prefetched under tap 8's MFMAs and the freed buffer takes window i + 2.  No other synchronisation: inside an item
+//     the four waves run free;
+//   * the fragments of tap t + 1 are read behind the MFMAs of tap t, one k-step at a time into the registers that
+//     k-step's four MFMAs have just released;
+//   * TWO accumulator sets: the epilogue of item i - 1 (no LDS: lane-half exchange -> eight consecutive channels per lane,
+//     folded BN from registers, residual, ReLU, one 16-byte store per 32 x 16 piece) is cut into eight pieces, one per tap
+//     of item i, and runs under item i's MFMAs — with one wave per SIMD nothing else could hide it;
+//   * loads are ordered by in-order completion and ONE counted vmcnt per item: between the last slice of window i + 1 and
+//     the wait in front of barrier i + 1 a wave issues exactly 13 slices, 8 residual loads and 8 stores.
+// Same k order (tap, k-step) and the same epilogue arithmetic as the ping-pong kernels: bit-identical outputs.
+template <int RES, bool OUTB>
+__global__ __launch_bounds__(256, 1) void conv3x3_c64s_kernel(ring_args a) {
+  static_assert(RES == 0 || RES == 2, "bf16 operands take a bf16 residual");
+  constexpr int RG_BM = 256, NWAVES = 4, NSLW = 13;        // 13 window slices of 8 pixels per wave and item: 416 pixels >= WPX
+  constexpr unsigned OOB = 0x80000000u;
+  constexpr int ESZ = OUTB ? 2 : 4;
+  constexpr int NST = OUTB ? 8 : 16, NRQ = RES ? 8 : 0;    // stores / residual loads per lane and item
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int phf = wave >> 1, chh = wave & 1;               // position half (128 positions), channel half (32 channels)
+  const int win_bytes = a.WPX * 128;
+  char* win0 = smem;
+  char* dump = smem + 3 * win_bytes;
+  const int i_begin = blockIdx.x * a.ipw, i_end = min(a.items, i_begin + a.ipw);
+  const int nitems = i_end - i_begin;
+  if (nitems <= 0) return;
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.M * 128, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 64 * 9 * 128, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.M * 64 * ESZ, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? a.resid : a.x), 0, RES ? a.M * 128 : 0, 0x00020000);
+  const int PA = a.WPX >> 3;
+  for (int i = tid; i < 256; i += 256) reinterpret_cast<unsigned*>(dump)[i] = 0u;      // the ZERO ROW (halo taps) and the dummy DMA target
+  // ---- this wave's weights: A fragments of its 32 output channels, all nine taps (w: [64][1][9][128 B]).  The folded-BN
+  // SCALE of an output channel multiplies its weight row once, here (fp32 product, rounded to bf16 again: a caller that
+  // wants single rounding folds the scale into the weights itself and passes scale = NULL, as cadre_amd/encoder.py does);
+  // the SHIFT is the accumulator's initial value (the C operand of an item's first MFMAs): the epilogue has no BN arithmetic.
+  f32x4 wfr[9][4];
+  {
+    const float wsc = a.scale ? a.scale[32 * chh + l31] : 1.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsW, (32 * chh + l31) * 1152 + t * 128 + (2 * s + lh) * 16, 0, 0);
+        bf16x8 wv = __builtin_bit_cast(bf16x8, raw);
+        if (a.scale) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) wv[e] = (__bf16)((float)wv[e] * wsc);
+        }
+        wfr[t][s] = __builtin_bit_cast(f32x4, wv);
+      }
+  }
+  f32x16 cinit;                                            // register r of a 32 x 32 tile: channel 32 chh + 8 (r >> 2) + 4 lh + (r & 3)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cinit[r] = a.shift ? a.shift[32 * chh + 8 * (r >> 2) + 4 * lh + (r & 3)] : 0.f;
+  auto swz = [](int idx) constexpr -> int { return (idx >> 1) & 7; };
+  // window slice n of this wave: piece j = 4 n + wave: pixel 8 j + (lane >> 3); LDS chunk (lane & 7) <- source chunk
+  // (lane & 7) ^ swz(pixel), swz(pixel) = (lane >> 4) ^ 4 (j & 1) and j has the parity of the wave
+  const int a_lane = (lane >> 3) * 128 + ((((lane & 7) ^ (lane >> 4) ^ (4 * (wave & 1)))) << 4);
+  bool abl_pro = true;
+  auto send_a = [&](int mt_n, int buf, int n, bool live) {
+    const int j = 4 * n + wave;
+    const bool ok = live && j < PA;
+    unsigned voff = ok ? (unsigned)((mt_n * RG_BM - a.W - 1 + 8 * j) * 128 + a_lane) : OOB;
+    char* dst = ok ? win0 + buf * win_bytes + j * 1024 : dump;
+    if ((RING_ABL & 4) && !abl_pro) { voff = OOB; dst = dump; }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)dst, 16, (int)voff, 0, 0, 0);
+  };
+  typedef const __attribute__((address_space(3))) char* lds_cptr;
+  typedef const __attribute__((address_space(3))) f32x4* lds_f4;
+  const lds_cptr lds0 = (lds_cptr)smem;
+  const unsigned zrow_off = (unsigned)(dump - smem);
+  const int base_idx = 128 * phf + l31;                    // window row of this lane's position (rb = 0) at tap (0, 0)
+  const unsigned lhb = (unsigned)lh << 4;                  // k-step s reads 16-byte chunk 2 s + lh: (lh << 4) ^ (s << 5), the latter an immediate
+  const float inv_w = 1.0f / (float)a.W, inv_h = 1.0f / (float)a.H;
+  // (h, w) of this lane's four fragment rows (positions 128 phf + 32 rb + l31 of an item), advanced by 256 per item
+  int ph[4], pw[4];
+  {
+    const int HW = a.H * a.W;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      const int m = i_begin * RG_BM + 128 * phf + 32 * rb + l31;
+      const int rem = m % HW;
+      ph[rb] = rem / a.W;
+      pw[rb] = rem - ph[rb] * a.W;
+    }
+  }
+  auto advance_item = [&]() {
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      const int x = pw[rb] + RG_BM;
+      const int q1 = (int)(((float)x + 0.5f) * inv_w);
+      pw[rb] = x - q1 * a.W;
+      const int y = ph[rb] + q1;
+      const int q2 = (int)(((float)y + 0.5f) * inv_h);
+      ph[rb] = y - q2 * a.H;
+    }
+  };
+  auto masks_of = [&](int mt_i, unsigned* mk) {             // 9-bit tap validity of this lane's four positions of item mt_i (branch-free)
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      const int m = mt_i * RG_BM + 128 * phf + 32 * rb + l31;
+      unsigned colm = 0, v = 0;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) colm |= ((unsigned)(pw[rb] - 1 + kw) < (unsigned)a.W) ? (1u << kw) : 0u;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) v |= ((unsigned)(ph[rb] - 1 + kh) < (unsigned)a.H) ? (colm << (3 * kh)) : 0u;
+      mk[rb] = m < a.M ? v : 0u;
+    }
+  };
+  // pixel fragment addresses of one tap: row idx = base_idx + 32 rb + toff of window buffer `buf` (or the zero row)
+  auto frag_addr = [&](int tap, int buf, int bi, const unsigned* mk, int Wx, lds_cptr (*out)[4]) {
+    const int toff = (tap / 3) * Wx + (tap % 3);
+    const int win_off = buf * win_bytes;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      const int idx = bi + 32 * rb + toff;
+      const unsigned row = ((mk[rb] >> tap) & 1u) ? (unsigned)(win_off + (idx << 7)) : zrow_off;
+      const unsigned rsw = row ^ (unsigned)(swz(idx) << 4) ^ lhb;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) out[rb][s] = lds0 + (rsw ^ (unsigned)(s << 5));
+    }
+  };
+  // ---- epilogue pieces: piece p = (rb = p >> 1, h = p & 1) of a finished accumulator set: position 128 phf + 32 rb + l31,
+  // channels 32 chh + 16 h + 8 lh .. + 7 after the lane-half exchange
+  f32x16 acc[2][4];
+  u32x4 rq[8];
+  const float act_floor = (a.act & 15) == 1 ? 0.f : -__builtin_inff();
+  const bool post = (a.act & 16) != 0;
+  auto ebyte = [&](int mt_e, int p, bool live, int esz) -> int {      // byte offset of piece p's 8 channels, or out of range
+    const int pos = mt_e * RG_BM + 128 * phf + 32 * (p >> 1) + l31;
+    return live ? (pos * 64 + 32 * chh + 16 * (p & 1) + 8 * lh) * esz : (int)OOB;      // (pos >= M lies past num_records)
+  };
+  auto rq_load = [&](int mt_e, int p, bool live) {
+    if constexpr (RES != 0 && (RING_ABL & 64) == 0)
+      rq[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, ebyte(mt_e, p, live, 2), 0, 0));
+  };
+  // The piece's arithmetic as single VALU instructions: left to the SLP vectoriser these become v_pk_* pairs fed by register
+  // shuffles (measured: 200 v_mov per item) — beside MFMAs a packed op costs more than its two halves
+  // (MI355X_MICROARCH.md, per-instruction constants).
+  auto vadd = [](float x, float y) -> float { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+  auto vmax = [](float x, float y) -> float { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+  auto epi_piece = [&](auto q_c, int mt_e, int p, bool live) {
+    constexpr int Q = decltype(q_c)::value;
+    if constexpr ((RING_ABL & 32) != 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float t = acc[Q][p >> 1][8 * (p & 1) + e]; asm volatile("" :: "v"(t)); }
+    } else {
+      const int rb = p >> 1, h = p & 1;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = acc[Q][rb][8 * h + e]; v[4 + e] = acc[Q][rb][8 * h + 4 + e]; }
+      // v_permlane32_swap x, y: x <- [x.lo, y.lo], y <- [x.hi, y.hi] (inline asm: see conv3x3_ring_pp2_kernel); the four
+      // exchanges of a piece in ONE statement: one leading s_nop covers the VALU -> permlane wait states of all of them
+      asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\tv_permlane32_swap_b32 %2, %6\n\t"
+          "v_permlane32_swap_b32 %3, %7\n\ts_nop 1"
+          : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+      if constexpr (RES != 0) {
+        const u32x4 t = rq[p];                               // (residual BEFORE the activation: act | 16 stays on the ping-pong kernels)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const unsigned rbits = (e & 1) ? (t[e >> 1] & 0xffff0000u) : (t[e >> 1] << 16);      // bf16 -> f32
+          v[e] = vmax(vadd(v[e], __builtin_bit_cast(float, rbits)), act_floor);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = vmax(v[e], act_floor);
+      }
+      const int bo = ebyte(mt_e, p, live, ESZ);
+      if constexpr ((RING_ABL & 16) != 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) asm volatile("" :: "v"(v[e]), "v"(bo));
+      } else if constexpr (OUTB) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsC, bo, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[0], v[1], v[2], v[3]}), rsC, bo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[4], v[5], v[6], v[7]}), rsC, bo == (int)OOB ? bo : bo + 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- prologue: windows of the first two items (buffers 0, 1), everything landed and published; then the two slices of
+  // window 2 that the steady state issues in the tap-8 slot of the previous item
+  const int mt0 = i_begin;
+#pragma unroll 1
+  for (int n = 0; n < NSLW; ++n) { send_a(mt0, 0, n, true); send_a(mt0 + 1, 1, n, nitems > 1); }
+  wait_vm<0>();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  abl_pro = false;
+  RG_CLK(0);
+  // slices of window i + 2 per tap slot (slot 8 belongs to the PREVIOUS item's tap 8): 2 2 2 2 1 1 1 1 | 1
+  auto sl_n = [](int slot) constexpr -> int { return slot == 8 ? 1 : (slot < 4 ? 2 : 1); };
+  auto sl_0 = [](int slot) constexpr -> int { return slot == 8 ? 0 : (slot < 4 ? 1 + 2 * slot : 5 + slot); };      // first slice index of the slot
+  send_a(mt0 + 2, 2, 0, nitems > 2);                       // (slot 8 of "item -1")
+  unsigned mk[4];
+  masks_of(mt0, mk);
+  lds_cptr p_addr[4][4];
+  f32x4 pfr[4][4];
+  {
+    int bi = base_idx, Wx = a.W;
+    frag_addr(0, 0, bi, mk, Wx, p_addr);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) pfr[rb][s] = *reinterpret_cast<lds_f4>(p_addr[rb][s]);
+  }
+  bool have_prev = false;
+
+  // one item on accumulator set Q; the epilogue pieces of the previous item (set Q ^ 1) ride on its taps 0 .. 7
+  auto item_body = [&](auto q_c, int li) {
+    constexpr int Q = decltype(q_c)::value;
+    const int mt = mt0 + li;
+    const int buf = li % 3, buf_n = (li + 1) % 3, buf_nn = (li + 2) % 3;
+    const bool more = li + 1 < nitems, more2 = li + 2 < nitems;
+    unsigned mkn[4];                                         // masks of the NEXT item (its tap-0 fragments are read in this item's tap 8)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      // per-tap copies of the lane constants behind an empty asm: the address arithmetic stays where it is used
+      int bi = base_idx, Wx = a.W;
+      asm volatile("" : "+v"(bi), "+s"(Wx));
+      if (tap == 8) {
+        // ---- the item's barrier.  This wave's slices of window li + 1 have landed: since the last of them (tap 7 of the
+        // previous item) it issued 13 slices, NRQ residual loads, NST stores — in-order completion; its reads of window li
+        // are done (tap 8's fragments are in registers).
+        wait_vm<NSLW + NRQ + NST>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      if (tap == 4) {                                        // the next item's positions and halo masks: vector work under this tap's MFMAs
+        advance_item();
+        masks_of(mt + 1, mkn);
+      }
+      // addresses of the next tap's fragments (tap 8: tap 0 of the next item, window li + 1)
+      lds_cptr n_addr[4][4];
+      if (tap < 8) frag_addr(tap + 1, buf, bi, mk, Wx, n_addr);
+      else frag_addr(0, buf_n, bi, mkn, Wx, n_addr);
+      // this tap slot's slices of window li + 2 (tap 8: the first slice of window li + 3, into the buffer the barrier freed)
+#pragma unroll
+      for (int i = 0; i < sl_n(tap); ++i) {
+        if (tap < 8) send_a(mt + 2, buf_nn, sl_0(tap) + i, more2);
+        else send_a(mt + 3, buf, 0, li + 3 < nitems);
+      }
+      // residual of THIS item's piece `tap`, for the epilogue piece that runs in the next item's tap `tap`: a whole item
+      // (~2.5 us) ahead — an HBM round trip under load is 2-4 us, the loads complete in order behind the window slices, and
+      // with one wave per SIMD a wait on them idles the matrix pipe (measured: 230 us of a 1.1 ms launch with two taps
+      // of lead).  Issued after the previous item's piece `tap` has consumed the same registers (below).
+      (void)0;
+      f32x4 nfr[4][4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+          if constexpr ((RING_ABL & 1) != 0) asm volatile("" :: "v"(wfr[tap][s]), "v"(pfr[rb][s]));
+          else if (tap == 0 && s == 0)
+            acc[Q][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wfr[tap][s]), __builtin_bit_cast(bf16x8, pfr[rb][s]),
+                                                                 cinit, 0, 0, 0);
+          else
+            acc[Q][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wfr[tap][s]), __builtin_bit_cast(bf16x8, pfr[rb][s]),
+                                                                 acc[Q][rb], 0, 0, 0);
+        }
+        if (tap < 8 || more) {
+          if constexpr ((RING_ABL & 2) == 0) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) nfr[rb][s] = *reinterpret_cast<lds_f4>(n_addr[rb][s]);
+          } else {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) nfr[rb][s] = f32x4{(float)(lane * 3 + s), 1.5f + rb, -0.75f * lane, 0.3f + tap};
+          }
+        }
+      }
+      // the previous item's epilogue piece `tap` (item 0: the same loads and stores, out of range — the vmcnt count is static)
+      if (tap < 8) {
+        epi_piece(int_k<Q ^ 1>{}, mt - 1, tap, have_prev);
+        if constexpr (RES != 0) rq_load(mt, tap, true);
+      }
+      // issue order per k-step: one MFMA, then a share of the tap's vector work (address arithmetic, the epilogue piece), four
+      // times; then the four reads into the registers the k-step released
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) pfr[rb][s] = nfr[rb][s];
+      if (tap == 8) {
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) mk[rb] = mkn[rb];
+      }
+    }
+    have_prev = true;
+  };
+  for (int li = 0; li < nitems; li += 2) {
+    item_body(int_k<0>{}, li);
+    if (li + 1 < nitems) item_body(int_k<1>{}, li + 1);
+  }
+  RG_CLK(1);
+  // ---- tail: the last item's epilogue (its residual pieces were requested during the item)
+  {
+    const int mt_l = mt0 + nitems - 1;
+    if ((nitems & 1) != 0) {
+#pragma unroll
+      for (int p = 0; p < 8; ++p) epi_piece(int_k<0>{}, mt_l, p, true);
+    } else {
+#pragma unroll
+      for (int p = 0; p < 8; ++p) epi_piece(int_k<1>{}, mt_l, p, true);
+    }
+  }
+}
+
 // Tile configuration (host logic): 256 positions x 64 / 128 channels on 8 waves, one persistent workgroup per CU.
 // Channel tile 128 unless N < 128 (CADRE_RING_NTILE forces one for A/B runs).  (A 128-position / 4-wave shape with two
 // workgroups per CU existed until the ping-pong kernel beat it on every shape it was picked for: layer3 bf16 1134 vs
 // 990 TFLOP/s; the kernel template still takes WVM = 2.)
-struct ring_cfg { int wvm, ntile, bm, wpx, wgs, pp; size_t lds; long long items; };
-static void ring_pick(long long M, int W, int N, int bf16, ring_cfg* c) {
+struct ring_cfg { int wvm, ntile, bm, wpx, wgs, pp, g; size_t lds; long long items; };
+static void ring_pick(long long M, int W, int N, int bf16, int NC_, ring_cfg* c) {
+  const int NC = NC_ < 0 ? -NC_ : NC_;                     // NC_ < 0: the caller rules out conv3x3_c64s_kernel (act | 16)
+  const bool no_c64s = NC_ < 0;
   static const int force_nt = [] { const char* e = getenv("CADRE_RING_NTILE"); return e ? atoi(e) : 0; }();
   static const int force_pp = [] { const char* e = getenv("CADRE_RING_PP"); return e ? atoi(e) : 1; }();
   int ntile = N >= 128 ? 128 : 64;
@@ -923,6 +1830,28 @@ static void ring_pick(long long M, int W, int N, int bf16, ring_cfg* c) {
   // slots carry no vector-ALU work; fp32 with 128-channel tiles is not instantiated — those layers run on the tile
   // kernels, and a forced window conv takes the lockstep kernel).  CADRE_RING_PP=0: lockstep everywhere, for A/B runs.
   c->pp = (force_pp > 0 && (bf16 || ntile == 64)) ? 1 : 0;
+  // G k-tiles per slot (conv3x3_ring_pp2_kernel, bf16; A/B build + CADRE_RING_G=2 only — measured slower): G = 3 with the
+  // 64-channel tile, G = 2 with the 128-channel tile when the item has an even number of k-tiles (NC even) and the two
+  // sets of G weight half-stages per group fit beside the windows.
+  static const int force_g = [] { const char* e = getenv("CADRE_RING_G"); return e ? atoi(e) : 1; }();
+  c->g = 1;
+#ifdef CADRE_AB_KERNELS
+  const bool pp2_built = true;
+#else
+  const bool pp2_built = false;
+#endif
+  if (pp2_built && c->pp && bf16 && force_g == 2 && NC > 0) {
+    const int g = ntile == 64 ? 3 : 2;
+    const size_t lds2 = (size_t)2 * wpx * 128 + (size_t)4 * g * (ntile / 2) * 128 + 1024 + bn_table;
+    if ((9 * NC) % g == 0 && lds2 <= 160 * 1024) { c->g = g; c->lds = lds2; }
+  }
+  // the 64 -> 64 channel stage in bf16 (one 128-byte chunk, one channel tile): conv3x3_c64s_kernel — weights resident in
+  // registers, three pixel windows in LDS (CADRE_RING_C64S=0: off, for A/B runs); reported as g = 9
+  static const int c64s_on = [] { const char* e = getenv("CADRE_RING_C64S"); return e ? atoi(e) : 1; }();
+  if (bf16 && N == 64 && NC == 1 && c64s_on && force_pp > 0 && !no_c64s) {
+    const int wpx3 = (bm + 2 * W + 2 + 7) & ~7;
+    if (wpx3 <= 416) { c->g = 9; c->pp = 1; c->wpx = wpx3; c->lds = (size_t)3 * wpx3 * 128 + 1024; }
+  }
   c->items = ((M + bm - 1) / bm) * ((N + ntile - 1) / ntile);
   c->wgs = (int)(c->items < 256 ? c->items : 256);                  // persistent workgroups: one per CU
 }
@@ -937,7 +1866,7 @@ static int ring_capable(int F, int H, int W, int Cin, int N, int bf16, int out_b
   // 32-bit buffer offsets: input, weights, output and residual each at their own element size (resid_bytes 0 = none)
   if (M * Cin * eb >= lim || (long long)N * Cin * 9 * eb >= lim || M * N * out_bytes >= lim || M * N * resid_bytes >= lim) return 0;
   ring_cfg c;
-  ring_pick(M, W, N, bf16, &c);
+  ring_pick(M, W, N, bf16, Cin * eb / 128, &c);
   return c.lds <= 160 * 1024;
 }
 // flags: the launch's word (1 bf16 operands, 2 bf16 output, 4 bf16 residual) + 8 = a residual is present; a caller that
@@ -949,12 +1878,13 @@ extern "C" int cadre_conv3x3_ring_supported(int32_t F, int32_t H, int32_t W, int
   return 1;
 }
 
-// tile configuration cadre_conv3x3_ring would use, as ntile (64 / 128) + 1000 * WVM (host logic; names the kernel
-// instantiation conv3x3_ring_kernel<bf16, ntile, res, out_bf16, WVM> for profiles)
-extern "C" int cadre_conv3x3_ring_ntile(int32_t F, int32_t H, int32_t W, int32_t N, int32_t bf16) {
+// tile configuration cadre_conv3x3_ring would use, as ntile (64 / 128) + 1000 * WVM + 100000 * ping-pong + 1000000 * G
+// (host logic; names the kernel instantiation for profiles: conv3x3_ring_kernel<bf16, ntile, res, out_bf16, WVM>,
+// conv3x3_ring_pp_kernel<bf16, ntile, res, out_bf16, false> or, G > 0, conv3x3_ring_pp2_kernel<ntile, res, out_bf16, G>)
+extern "C" int cadre_conv3x3_ring_ntile(int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t bf16) {
   ring_cfg c;
-  ring_pick((long long)F * H * W, W, N, bf16, &c);
-  return c.ntile + 1000 * c.wvm + 100000 * c.pp;
+  ring_pick((long long)F * H * W, W, N, bf16, Cin * (bf16 ? 2 : 4) / 128, &c);
+  return c.ntile + 1000 * c.wvm + 100000 * c.pp + 1000000 * (c.g > 1 ? c.g : 0);
 }
 
 #ifdef RING_TRACE
@@ -998,7 +1928,7 @@ extern "C" int cadre_conv3x3_ring(const void* x, const void* w, const float* sca
   a.M = F * H * W; a.H = H; a.W = W; a.Cin = Cin; a.N = N; a.NC = Cin * (bf16 ? 2 : 4) / 128;
   a.act = act; a.out_bf16 = out_bf16; a.resid_bf16 = resid_bf16;
   ring_cfg cfg;
-  ring_pick(a.M, W, N, bf16, &cfg);
+  ring_pick(a.M, W, N, bf16, (act & 16) ? -a.NC : a.NC, &cfg);      // (residual after the activation: not on the weight-stationary kernel)
   const int ntile = cfg.ntile;
   a.mtiles = (a.M + cfg.bm - 1) / cfg.bm;
   a.ntiles = (N + ntile - 1) / ntile;
@@ -1029,7 +1959,34 @@ extern "C" int cadre_conv3x3_ring(const void* x, const void* w, const float* sca
       else RG_LAUNCH(BF, 64, RS_, OB_, 4);                                                                    \
     }                                                                                                            \
   } while (0)
-  if (bf16) {
+#ifdef CADRE_AB_KERNELS
+#define RG_PP2(NT_, RS_, OB_, G_)                                                                                  \
+  do {                                                                                                           \
+    (void)hipFuncSetAttribute((const void*)conv3x3_ring_pp2_kernel<NT_, RS_, OB_, G_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL((conv3x3_ring_pp2_kernel<NT_, RS_, OB_, G_>), dim3(grid), dim3(512), lds, st, a);        \
+  } while (0)
+#endif
+#define RG_C64S(RS_, OB_)                                                                                        \
+  do {                                                                                                           \
+    (void)hipFuncSetAttribute((const void*)conv3x3_c64s_kernel<RS_, OB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL((conv3x3_c64s_kernel<RS_, OB_>), dim3(grid), dim3(256), lds, st, a);                     \
+  } while (0)
+  if (bf16 && cfg.g == 9) {
+    if (resid && !resid_bf16) return cadre_fail("cadre_conv3x3_ring: bf16 operands take a bf16 residual");
+    if (resid) { if (out_bf16) RG_C64S(2, true); else RG_C64S(2, false); }
+    else { if (out_bf16) RG_C64S(0, true); else RG_C64S(0, false); }
+#ifdef CADRE_AB_KERNELS
+  } else if (bf16 && cfg.g > 1) {
+    if (resid && !resid_bf16) return cadre_fail("cadre_conv3x3_ring: bf16 operands take a bf16 residual");
+    if (ntile == 64) {
+      if (resid) { if (out_bf16) RG_PP2(64, 2, true, 3); else RG_PP2(64, 2, false, 3); }
+      else { if (out_bf16) RG_PP2(64, 0, true, 3); else RG_PP2(64, 0, false, 3); }
+    } else {
+      if (resid) { if (out_bf16) RG_PP2(128, 2, true, 2); else RG_PP2(128, 2, false, 2); }
+      else { if (out_bf16) RG_PP2(128, 0, true, 2); else RG_PP2(128, 0, false, 2); }
+    }
+#endif
+  } else if (bf16) {
     if (resid && !resid_bf16) return cadre_fail("cadre_conv3x3_ring: bf16 operands take a bf16 residual");
     if (resid) { if (out_bf16) RG_NT(true, 2, true); else RG_NT(true, 2, false); }
     else { if (out_bf16) RG_NT(true, 0, true); else RG_NT(true, 0, false); }
@@ -1037,6 +1994,10 @@ extern "C" int cadre_conv3x3_ring(const void* x, const void* w, const float* sca
     if (out_bf16 || (resid && resid_bf16)) return cadre_fail("cadre_conv3x3_ring: fp32 operands take fp32 residual / output");
     if (resid) RG_NT(false, 1, false); else RG_NT(false, 0, false);
   }
+#undef RG_C64S
+#ifdef CADRE_AB_KERNELS
+#undef RG_PP2
+#endif
 #undef RG_NT
 #undef RG_PP
 #undef RG_LAUNCH

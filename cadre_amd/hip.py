@@ -40,7 +40,7 @@ SYMBOLS = {
     "cadre_gemm_bf16_pick_tile": [C.POINTER(GemmDesc)],
     "cadre_conv3x3_ring": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "cadre_conv3x3_ring_supported": [i32, i32, i32, i32, i32, i32],
-    "cadre_conv3x3_ring_ntile": [i32, i32, i32, i32, i32],
+    "cadre_conv3x3_ring_ntile": [i32, i32, i32, i32, i32, i32],
     "cadre_maxpool3x3s2_bf16": [vp, vp, i32, i32, i32, i32, vp],
     "cadre_pam_bf16out": [vp, vp, f32, vp, i32, i32, vp],
     "cadre_cam_bf16out": [vp, f32, vp, i32, i32, vp],
@@ -97,7 +97,7 @@ AB_SYMBOLS = {
 }
 
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class CadreHipError(RuntimeError):
@@ -227,8 +227,9 @@ def conv3x3_c64_bf16(x, w, scale, shift, resid, out, F, H, W, relu):
 
 def conv3x3_ring(x, w_ring, scale, shift, resid, out, F, H, W, Cin, N, act):
     """cadre_conv3x3_ring (3x3 / s1 / p1, each pixel through LDS once per channel chunk); profiling key
-    ("ring", bf16, ntile, res, out_bf16, WVM, pp): pp 0 = conv3x3_ring_kernel<bf16, ntile, res, out_bf16, WVM>,
-    pp 1 = conv3x3_ring_pp_kernel<bf16, ntile, res, out_bf16> (the 8-wave ping-pong kernel)."""
+    ("ring", bf16, ntile, res, out_bf16, WVM, pp, G): pp 0 = conv3x3_ring_kernel<bf16, ntile, res, out_bf16, WVM>,
+    pp 1, G 0 = conv3x3_ring_pp_kernel<bf16, ntile, res, out_bf16, false> (the 8-wave ping-pong kernel), G > 0 =
+    conv3x3_ring_pp2_kernel<ntile, res, out_bf16, G> (G k-tiles per ping-pong slot)."""
     bf = x.dtype == torch.bfloat16
     flags = (1 if bf else 0) | (2 if out.dtype == torch.bfloat16 else 0) | (4 if (resid is not None and resid.dtype == torch.bfloat16) else 0)
     fn = lib().cadre_conv3x3_ring
@@ -242,7 +243,7 @@ def conv3x3_ring(x, w_ring, scale, shift, resid, out, F, H, W, Cin, N, act):
     e1.record()
     M, esz = F * H * W, (2 if bf else 4)
     nbytes = M * Cin * esz + N * 9 * Cin * esz + M * N * out.element_size() + (M * N * resid.element_size() if resid is not None else 0)
-    code = lib().cadre_conv3x3_ring_ntile(F, H, W, N, 1 if bf else 0)      # ntile + 1000 * WVM + 100000 * ping-pong
+    code = lib().cadre_conv3x3_ring_ntile(F, H, W, Cin, N, 1 if bf else 0)      # ntile + 1000 * WVM + 100000 * ping-pong + 1000000 * G
     res = 0 if resid is None else (2 if resid.dtype == torch.bfloat16 else 1)
-    key = ("ring", bf, code % 1000, res, out.dtype == torch.bfloat16, code // 1000 % 100, code // 100000)
+    key = ("ring", bf, code % 1000, res, out.dtype == torch.bfloat16, code // 1000 % 100, code // 100000 % 10, code // 1000000)
     PROFILE.append((key, 2.0 * M * N * 9 * Cin, e0, e1, (M, N, 9 * Cin, 1, 1, 0), nbytes))

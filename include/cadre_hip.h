@@ -15,7 +15,7 @@
 extern "C" {
 #endif
 
-#define CADRE_ABI_VERSION 7
+#define CADRE_ABI_VERSION 8
 int cadre_abi_version(void);
 /* human-readable last argument error of the calling thread ("" if none) */
 const char* cadre_last_error(void);
@@ -100,9 +100,10 @@ int cadre_conv3x3_ring(const void* x, const void* w, const float* scale, const f
                        int32_t flags, void* stream);
 int cadre_conv3x3_ring_supported(int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t flags);
 /* tile configuration as ntile (64 / 128) + 1000 * WVM (waves along the positions: 4 = 256-position tile on 8 waves, one
- * workgroup per CU) + 100000 when the 8-wave ping-pong kernel runs (bf16): names the instantiation
- * conv3x3_ring_kernel<bf16, ntile, res, out_bf16, WVM> / conv3x3_ring_pp_kernel<bf16, ntile, res, out_bf16> */
-int cadre_conv3x3_ring_ntile(int32_t F, int32_t H, int32_t W, int32_t N, int32_t bf16);
+ * workgroup per CU) + 100000 when an 8-wave ping-pong kernel runs + 1000000 * G when it is the G-k-tiles-per-slot form
+ * (bf16): names the instantiation conv3x3_ring_kernel<bf16, ntile, res, out_bf16, WVM> /
+ * conv3x3_ring_pp_kernel<bf16, ntile, res, out_bf16, false> / conv3x3_ring_pp2_kernel<ntile, res, out_bf16, G> */
+int cadre_conv3x3_ring_ntile(int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t bf16);
 /* Sustained matrix-pipe rate of this device (peaks.hip; SURVEY.md 8d asks for the measured peak next to the datasheet
  * one): workgroups x 4 waves, each iters x 8 register-operand MFMAs on independent accumulators (fp32:
  * v_mfma_f32_32x32x2_f32 = 4096 FLOP, bf16: v_mfma_f32_32x32x16_bf16 = 32768 FLOP).  The caller times the launch. */

@@ -20,10 +20,12 @@ def test_cabi_exports_every_declared_symbol():
     L = ctypes.CDLL(hip.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert hip.lib().cadre_abi_version() == hip.ABI_VERSION == 7
+    assert hip.lib().cadre_abi_version() == hip.ABI_VERSION == 8
     # the default library exports only entry points the product dispatches: the superseded kernels live in the A/B build
     if os.path.basename(hip.LIB_PATH) == "libcadre_hip.so":
         assert not hip.has_ab_kernels()
+        for name in hip.AB_SYMBOLS:              # (cadre_lstm_seq_fwd moved there in round 4: measured slower, opt-in only)
+            assert not hasattr(L, name), name
     assert ctypes.sizeof(hip.GemmDesc) == 264      # static_assert-ed in gemm_f32.hip
 
 
@@ -205,11 +207,17 @@ def test_window_conv_policy_is_host_logic():
     trunk = [(72, 64, 64), (36, 128, 128), (18, 256, 256), (9, 512, 512), (9, 512, 128), (9, 128, 128)]
     for hw, cin, n in trunk:
         assert L.cadre_conv3x3_ring_supported(F, hw, hw, cin, n, 1 | 2 | 8 | 4) == 1, (hw, cin, n)
-        code = L.cadre_conv3x3_ring_ntile(F, hw, hw, n, 1)            # ntile + 1000 * waves-along-positions + 100000 * ping-pong
-        assert code == (64 if n < 128 else 128) + 4000 + 100000
+        # ntile + 1000 * waves-along-positions + 100000 * ping-pong + 1000000 * G: G = 9 names the weight-stationary
+        # 64 -> 64 stage (conv3x3_c64s_kernel, one 128-byte chunk of input channels); the 128-channel tiles run the
+        # one-k-tile-per-slot ping-pong kernel (the G-k-tiles-per-slot form lives in the A/B build: measured slower)
+        code = L.cadre_conv3x3_ring_ntile(F, hw, hw, cin, n, 1)
+        assert code == (64 + 9000000 if (n == 64 and cin == 64) else 128) + 4000 + 100000, (hw, cin, n, code)
+    assert L.cadre_conv3x3_ring_ntile(F, 36, 36, 64, 128, 1) == 128 + 4000 + 100000
+    assert L.cadre_conv3x3_ring_ntile(F, 72, 72, 128, 64, 1) == 64 + 4000 + 100000      # two chunks: the ping-pong kernel
+    assert L.cadre_conv3x3_ring_ntile(F, 80, 80, 64, 64, 1) == 64 + 4000 + 100000       # W = 80: three windows do not fit LDS
     assert L.cadre_conv3x3_ring_supported(F, 72, 72, 64, 64, 0) == 1
-    assert L.cadre_conv3x3_ring_ntile(F, 72, 72, 64, 0) == 64 + 4000 + 100000      # fp32 64-channel stage: ping-pong too
-    assert L.cadre_conv3x3_ring_ntile(F, 36, 36, 128, 0) == 128 + 4000             # (a forced fp32 128-channel tile: lockstep)
+    assert L.cadre_conv3x3_ring_ntile(F, 72, 72, 64, 64, 0) == 64 + 4000 + 100000      # fp32 64-channel stage: ping-pong, one k-tile per slot
+    assert L.cadre_conv3x3_ring_ntile(F, 36, 36, 128, 128, 0) == 128 + 4000             # (a forced fp32 128-channel tile: lockstep)
     for hw, cin, n in trunk[1:4]:
         assert L.cadre_conv3x3_ring_supported(F, hw, hw, cin, n, 0) == 0  # fp32 N >= 128: the tile kernels
     assert L.cadre_conv3x3_ring_supported(1, 144, 144, 64, 64, 1) == 0    # W > 95: two windows do not fit LDS

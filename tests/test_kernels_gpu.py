@@ -1193,7 +1193,8 @@ def test_div255_arithmetic_is_the_reference_table(hip):
 @pytest.mark.parametrize("F,H,W,Cin,N,use_resid,act", [
     (2, 18, 22, 64, 64, False, 1), (1, 72, 72, 64, 64, True, 1), (2, 36, 36, 128, 128, True, 1), (3, 18, 18, 256, 256, True, 1),
     (5, 9, 9, 512, 512, False, 1), (5, 9, 9, 512, 128, False, 1), (7, 9, 9, 128, 128, True, 1 | 16), (2, 21, 21, 64, 96, True, 0),
-    (40, 9, 9, 128, 256, True, 1)])
+    (40, 9, 9, 128, 256, True, 1), (260, 9, 9, 256, 128, True, 1), (9, 30, 26, 64, 64, True, 1), (3, 50, 50, 128, 128, False, 1),
+    (3, 60, 60, 128, 128, True, 1), (2, 36, 36, 64, 128, True, 1), (2, 30, 30, 128, 64, True, 1), (2, 20, 20, 128, 192, False, 0)])
 def test_conv3x3_ring(hip, dtype, F, H, W, Cin, N, use_resid, act):
     """cadre_conv3x3_ring (window of pixels resident in LDS, nine taps as row offsets, weights streamed by LDS-DMA)
     vs torch fp32 conv2d on the same operands: every trunk / head shape class, residual before and after the ReLU,

@@ -76,7 +76,7 @@ def test_c3_bf16_goldens_inside_2048_frame_joint_chunk(golden):
     workers; the sliding-window gather rides on the packing pass).  The two reference golden frames
     (tests/golden/enc_288.npz, danet.py:216-238) sit at positions 0 and 2047: latent within the bf16 bar of the
     golden AND bit-identical to the 2-frame bf16 run; every stride-1 3x3 conv must have run on the ping-pong window
-    kernel conv3x3_ring_pp_kernel<true, ...> (asserted from the launch profile) — 1.36 GB bf16 activations per
+    kernels conv3x3_c64s_kernel / conv3x3_ring_pp_kernel<true, ...> (asserted from the launch profile) — 1.36 GB bf16 activations per
     layer-1 tensor, next to the 2 GiB buffer window, 5-6 persistent items per CU."""
     from cadre_amd import hip
     from cadre_amd.encoder import DANetEncoderHIP
@@ -113,7 +113,7 @@ def test_c3_bf16_goldens_inside_2048_frame_joint_chunk(golden):
         hip.PROFILE = None
     ring = [k for k, *_ in prof if k[0] == "ring"]
     # 4 (layer1) + 3 + 3 + 3 (layer2-4: the first conv of each is stride 2) + conv5a/5c/51/52 = 17 stride-1 3x3 convs
-    assert len(ring) == 17 and all(k[1] and k[6] == 1 for k in ring), ring
+    assert len(ring) == 17 and all(k[1] and k[6] == 1 and k[7] == (9 if k[2] == 64 else 0) for k in ring), ring      # conv3x3_c64s_kernel (layer1) / conv3x3_ring_pp_kernel
     conv3 = [(k, shp) for k, _f, _a, _b, shp, _nb in prof if k[0] == "bf16" and k[2] == 2]
     assert len(conv3) == 3 + 3, conv3                                      # only the stride-2 3x3 and 1x1-s2 convs stay on tiles
     got = torch.stack([lat[0, :512], lat[F - 1, :512]])

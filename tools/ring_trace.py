@@ -51,7 +51,7 @@ def main():
     flags = (1 | 2 | (4 if res is not None else 0)) if bf else 0
     a = (x.data_ptr(), wr.data_ptr(), sc.data_ptr(), sh.data_ptr(), res.data_ptr() if res is not None else None, out.data_ptr(),
          F, H, W, Cin, N, 1, flags, None)
-    for _ in range(3):
+    for _ in range(3 if args.mode != 4 else 400):            # (mode 4: the clock the chip holds after ~0.5 s of back-to-back launches)
         assert lib.cadre_conv3x3_ring(*a) == 0
     torch.cuda.synchronize()
     lib.cadre_ring_set_trace(vp(trace.data_ptr()))
@@ -60,7 +60,28 @@ def main():
     assert lib.cadre_conv3x3_ring(*a) == 0
     e1.record()
     torch.cuda.synchronize()
+    if args.mode == 4:                                       # in-kernel clock of the untouched schedule
+        c = trace.cpu().numpy()[:1024].reshape(256, 4)
+        c = c[c[:, 3] != 0]
+        clk = (c[:, 2] - c[:, 0]) / np.maximum(1, (c[:, 3] - c[:, 1])) * 100e6
+        print("%s F=%d %dx%d %d->%d resid=%d G=%s: %.3f ms; in-kernel clock median %.3f GHz (min %.3f, max %.3f) over %d workgroups; "
+              "cycles per workgroup median %.0f" % (args.dtype, F, H, W, Cin, N, args.resid, os.environ.get("CADRE_RING_G", "auto"), e0.elapsed_time(e1),
+                                                    np.median(clk) / 1e9, clk.min() / 1e9, clk.max() / 1e9, len(clk), np.median(c[:, 2] - c[:, 0])))
+        return
     t = trace.cpu().numpy().reshape(512, 64, 8)
+    if args.mode == 1 and t[:, :, 7].any():                  # G-k-tiles-per-slot kernel (conv3x3_ring_pp2_kernel): 8 stamps per item
+        for gname, sel in (("group 0 (wave 0)", slice(0, None, 2)), ("group 1 (wave 4)", slice(1, None, 2))):
+            tt = t[sel]
+            live = tt[:, :, 7] != 0
+            live[:, 0] = False
+            d = np.diff(tt, axis=2)[live]
+            item = (tt[:, 1:, 0] - tt[:, :-1, 0])[live[:, 1:] & (tt[:, :-1, 0] != 0)]
+            print("%s %s F=%d %dx%d %d->%d resid=%d: %.3f ms, %d items (pp2)" % (gname, args.dtype, F, H, W, Cin, N, args.resid, e0.elapsed_time(e1), d.shape[0]))
+            for i, n in enumerate(["epilogue+clear", "rest of R(0), M(0)", "R(1): reads + DMA issue", "R(1): lgkm wait + barrier", "M(1): MFMAs + reads",
+                                   "M(1): vmcnt wait", "M(1): barrier"]):
+                print("  %-28s mean %7.0f  median %7.0f  p90 %7.0f" % (n, d[:, i].mean(), np.median(d[:, i]), np.percentile(d[:, i], 90)))
+            print("  %-28s mean %7.0f" % ("item", item.mean()))
+        return
     if args.mode == 1 and t[:, :, 6].any():                  # ping-pong kernel: wave 0 (group 0) of even workgroups, wave 4 (group 1) of odd
         for gname, sel in (("group 0 (wave 0)", slice(0, None, 2)), ("group 1 (wave 4)", slice(1, None, 2))):
             tt = t[sel]
