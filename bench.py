@@ -320,6 +320,8 @@ def kname(k):
     """Exact kernel symbol as rocprofv3 prints it, from a hip.PROFILE key."""
     if k[0] == "ring":
         tf = ("true" if k[1] else "false", k[2], k[3], "true" if k[4] else "false")
+        if len(k) > 7 and k[7] == 8:             # one wave per SIMD, streamed weights (128-channel tile)
+            return "conv3x3_ring1w_kernel<%d, %s>" % (k[3], tf[3])
         if len(k) > 7 and k[7] == 9:             # the weight-stationary 64 -> 64 stage
             return "conv3x3_c64s_kernel<%d, %s>" % (k[3], tf[3])
         if len(k) > 7 and k[7]:                  # G k-tiles per ping-pong slot (bf16)

@@ -1807,14 +1807,357 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64s_kernel(ring_args a) {
   }
 }
 
+
+#ifdef CADRE_AB_KERNELS
+// ---------------------------------------------------------------------------------------------------------------
+// ONE WAVE PER SIMD, STREAMED WEIGHTS (bf16, 128-channel tile; round 4) — A/B BUILD ONLY (CADRE_BUILD_AB=1, CADRE_RING_1W=1):
+// parity-green; without a residual it TIES the ping-pong kernel (same box, 2048 frames: 0.663 / 0.621 / 0.614 vs 0.658 /
+// 0.616 / 0.624 ms on layer2 / 3 / 4 — both at 64-65 % matrix-pipe duty and the same 1.65-1.69 GHz sustained clock: the
+// chip is power-limited on these layers), with one it spills (16 residual pieces held in registers).
+// conv3x3_ring1w_kernel — the layers whose weights
+// do not fit registers (resnet.py:26-55 layer2-4, danet.py:21-41 conv5a/5c/51) on the scheme of conv3x3_c64s_kernel:
+//   * 4 waves per workgroup, one per SIMD, up to 512 registers: wave w owns 64 positions x ALL 128 channels of a
+//     256-position x 128-channel item (accumulator 128 registers): per k-tile 16 weight + 8 pixel fragment reads feed 32
+//     MFMAs (0.75 ds_read_b128 per MFMA; the 8-wave ping-pong kernel: 1.0) and nothing is read twice by a SIMD;
+//   * weights [128 rows][128 B] per k-tile stream through FOUR LDS stages by LDS-DMA, three k-tiles ahead; pixels: two
+//     windows (the current chunk's and the next one's), as in the ping-pong kernels;
+//   * ONE barrier per k-tile: behind it the stage of k-tile t + 1 is complete (every wave waited for its own pieces by
+//     counted vmcnt: in-order completion) and nobody reads the stage the DMA of k-tile t + 3 is about to overwrite.  The
+//     fragments of k-tile t + 1 are read behind the MFMAs of k-tile t, k-step by k-step into the registers just released:
+//     a wave comes out of the barrier with 32 MFMAs to issue;
+//   * the epilogue needs no LDS (lane-half exchange -> 16-byte stores, conv3x3_ring_pp2_kernel); the folded-BN SHIFT
+//     is the accumulator's initial value, read from an LDS table in accumulator layout; the SCALE must be folded into the
+//     weights by the caller (scale = NULL; cadre_amd/encoder.py does) — otherwise the ping-pong kernel runs;
+//   * the residual of an item is requested during its last chunk (two pieces per k-tile), a chunk ahead of the epilogue.
+// Same k order and epilogue arithmetic as the ping-pong kernel on folded weights: bit-identical outputs.
+template <int RES, bool OUTB>
+__global__ __launch_bounds__(256, 1) void conv3x3_ring1w_kernel(ring_args a) {
+  static_assert(RES == 0 || RES == 2, "bf16 operands take a bf16 residual");
+  constexpr int NTILE = 128, RG_BM = 256, NWAVES = 4, NSTG = 4, LEAD = 3;
+  constexpr int STG_B = NTILE * 128, NBPW = 4;              // weight pieces (8 rows x 128 B) per wave and stage
+  constexpr unsigned OOB = 0x80000000u;
+  constexpr int ESZ = OUTB ? 2 : 4;
+  constexpr int NPC = 16;                                   // epilogue pieces per item and lane: (rb, cb, h)
+  constexpr int NST = OUTB ? NPC : 2 * NPC;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int win_bytes = a.WPX * 128;
+  char* win0 = smem;
+  char* wst = smem + 2 * win_bytes;
+  char* dump = wst + NSTG * STG_B;
+  float* sh_lds = reinterpret_cast<float*>(dump + 1024);   // shift in accumulator layout: [nt][cb][lh][16]
+  const int i_begin = blockIdx.x * a.ipw, i_end = min(a.items, i_begin + a.ipw);
+  const int nitems = i_end - i_begin;
+  if (nitems <= 0) return;
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.M * a.Cin * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.N * a.NC * 9 * 128, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.M * a.N * ESZ, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? a.resid : a.x), 0, RES ? a.M * a.N * 2 : 0, 0x00020000);
+  const int cin_b = a.Cin * 2;
+  const int PA = a.WPX >> 3;
+  for (int i = tid; i < 256; i += 256) reinterpret_cast<unsigned*>(dump)[i] = 0u;      // the ZERO ROW and the dummy DMA target
+  for (int i = tid; i < a.ntiles * 128; i += 256) {         // i = ((nt*4 + cb)*2 + lh)*16 + r -> channel nt*128 + 32 cb + 8 (r >> 2) + 4 lh + (r & 3)
+    const int r = i & 15, lh_ = (i >> 4) & 1, cb = (i >> 5) & 3, nt_ = i >> 7;
+    const int n = nt_ * NTILE + 32 * cb + 8 * (r >> 2) + 4 * lh_ + (r & 3);
+    sh_lds[i] = (a.shift && n < a.N) ? a.shift[n] : 0.f;
+  }
+  auto swz = [](int idx) constexpr -> int { return (idx >> 1) & 7; };
+  const int a_lane = (lane >> 3) * cin_b + ((((lane & 7) ^ (lane >> 4) ^ (4 * (wave & 1)))) << 4);      // window piece j = 4 n + wave
+  int b_lane[NBPW];
+#pragma unroll
+  for (int k = 0; k < NBPW; ++k) {
+    const int r = (wave * NBPW + k) * 8 + (lane >> 3);
+    b_lane[k] = r * a.NC * 9 * 128 + (((lane & 7) ^ swz(r)) << 4);
+  }
+  bool abl_pro = true;
+  auto send_a = [&](int mt_n, int c_n, int buf, int n, bool live) {
+    const int j = 4 * n + wave;
+    const bool ok = live && j < PA;
+    unsigned voff = ok ? (unsigned)((mt_n * RG_BM - a.W - 1 + 8 * j) * cin_b + c_n * 128 + a_lane) : OOB;
+    char* dst = ok ? win0 + buf * win_bytes + j * 1024 : dump;
+    if ((RING_ABL & 4) && !abl_pro) { voff = OOB; dst = dump; }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)dst, 16, (int)voff, 0, 0, 0);
+  };
+  auto send_b = [&](int nt_b, int c, int tap, int stg, bool live) {      // this wave's four pieces of one weight stage
+#pragma unroll
+    for (int k = 0; k < NBPW; ++k) {
+      unsigned voff = live ? (unsigned)(nt_b * (NTILE * a.NC * 9 * 128) + (c * 9 + tap) * 128 + b_lane[k]) : OOB;
+      char* dst = wst + stg * STG_B + (wave * NBPW + k) * 1024;
+      if ((RING_ABL & 8) && !abl_pro) { voff = OOB; dst = dump; }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)dst, 16, (int)voff, 0, 0, 0);
+    }
+  };
+  typedef const __attribute__((address_space(3))) char* lds_cptr;
+  typedef const __attribute__((address_space(3))) f32x4* lds_f4;
+  const lds_cptr lds0 = (lds_cptr)smem;
+  const unsigned zrow_off = (unsigned)(dump - smem);
+  const unsigned wst_off = (unsigned)(wst - smem);
+  const int base_idx = 64 * wave + l31;
+  const unsigned lhb = (unsigned)lh << 4;
+  int boff[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) boff[s] = l31 * 128 + (((2 * s + lh) ^ swz(l31)) << 4);
+  const float inv_w = 1.0f / (float)a.W, inv_h = 1.0f / (float)a.H;
+  int ph[2], pw[2];
+  int mt = i_begin / a.ntiles, nt = i_begin - mt * a.ntiles;
+  {
+    const int HW = a.H * a.W;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int m = mt * RG_BM + 64 * wave + 32 * rb + l31;
+      const int rem = m % HW;
+      ph[rb] = rem / a.W;
+      pw[rb] = rem - ph[rb] * a.W;
+    }
+  }
+  auto advance_mtile = [&]() {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int x = pw[rb] + RG_BM;
+      const int q1 = (int)(((float)x + 0.5f) * inv_w);
+      pw[rb] = x - q1 * a.W;
+      const int y = ph[rb] + q1;
+      const int q2 = (int)(((float)y + 0.5f) * inv_h);
+      ph[rb] = y - q2 * a.H;
+    }
+  };
+  auto masks_of = [&](int mt_i, unsigned* mk) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int m = mt_i * RG_BM + 64 * wave + 32 * rb + l31;
+      unsigned colm = 0, v = 0;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) colm |= ((unsigned)(pw[rb] - 1 + kw) < (unsigned)a.W) ? (1u << kw) : 0u;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) v |= ((unsigned)(ph[rb] - 1 + kh) < (unsigned)a.H) ? (colm << (3 * kh)) : 0u;
+      mk[rb] = m < a.M ? v : 0u;
+    }
+  };
+  auto frag_addr = [&](int tap, int win_off, int bi, const unsigned* mk, int Wx, lds_cptr (*out)[4]) {
+    const int toff = (tap / 3) * Wx + (tap % 3);
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int idx = bi + 32 * rb + toff;
+      const unsigned row = ((mk[rb] >> tap) & 1u) ? (unsigned)(win_off + (idx << 7)) : zrow_off;
+      const unsigned rsw = row ^ (unsigned)(swz(idx) << 4) ^ lhb;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) out[rb][s] = lds0 + (rsw ^ (unsigned)(s << 5));
+    }
+  };
+  // ---- epilogue piece p = (rb = p >> 3, cb = (p >> 1) & 3, h = p & 1): position 64 wave + 32 rb + l31, channels
+  // nt * 128 + 32 cb + 16 h + 8 lh .. + 7
+  f32x16 acc[2][4];
+  u32x4 rq[NPC];
+  const float act_floor = (a.act & 15) == 1 ? 0.f : -__builtin_inff();
+  auto vadd = [](float x, float y) -> float { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+  auto vmax = [](float x, float y) -> float { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+  auto ebyte = [&](int mt_e, int nt_e, int p, int esz) -> int {
+    const int rb = p >> 3, cb = (p >> 1) & 3, h = p & 1;
+    const int pos = mt_e * RG_BM + 64 * wave + 32 * rb + l31;
+    const int ch = nt_e * NTILE + 32 * cb + 16 * h + 8 * lh;
+    return ch < a.N ? (pos * a.N + ch) * esz : (int)OOB;      // (pos >= M lies past num_records; N % 32 == 0)
+  };
+  auto rq_load = [&](int mt_e, int nt_e, int p) {
+    if constexpr (RES != 0 && (RING_ABL & 64) == 0)
+      rq[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, ebyte(mt_e, nt_e, p, 2), 0, 0));
+  };
+  auto epi_piece = [&](int mt_e, int nt_e, int p) {
+    const int rb = p >> 3, cb = (p >> 1) & 3, h = p & 1;
+    if constexpr ((RING_ABL & 32) != 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float t = acc[rb][cb][8 * h + e]; asm volatile("" :: "v"(t)); }
+    } else {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = acc[rb][cb][8 * h + e]; v[4 + e] = acc[rb][cb][8 * h + 4 + e]; }
+      asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %4\n\tv_permlane32_swap_b32 %1, %5\n\tv_permlane32_swap_b32 %2, %6\n\t"
+          "v_permlane32_swap_b32 %3, %7\n\ts_nop 1"
+          : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+      if constexpr (RES != 0) {
+        const u32x4 t = rq[p];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const unsigned rbits = (e & 1) ? (t[e >> 1] & 0xffff0000u) : (t[e >> 1] << 16);
+          v[e] = vmax(vadd(v[e], __builtin_bit_cast(float, rbits)), act_floor);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = vmax(v[e], act_floor);
+      }
+      const int bo = ebyte(mt_e, nt_e, p, ESZ);
+      if constexpr ((RING_ABL & 16) != 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) asm volatile("" :: "v"(v[e]), "v"(bo));
+      } else if constexpr (OUTB) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsC, bo, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[0], v[1], v[2], v[3]}), rsC, bo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[4], v[5], v[6], v[7]}), rsC, bo == (int)OOB ? bo : bo + 16, 0, 0);
+      }
+    }
+  };
+
+  // window slices of the next phase per tap slot (11 per wave: 44 pieces of 8 pixels >= WPX / 8 for W <= 47)
+  auto sl_n = [](int tap) constexpr -> int { return tap < 5 ? 2 : (tap == 5 ? 1 : 0); };
+  auto sl_0 = [](int tap) constexpr -> int { return tap < 5 ? 2 * tap : 10; };
+  // residual loads per tap slot of an item's LAST chunk: pieces 2 (tap - 1), 2 (tap - 1) + 1 for taps 1 .. 8
+  auto rq_n = [](int tap) constexpr -> int { return (RES != 0 && (RING_ABL & 64) == 0 && tap >= 1) ? 2 : 0; };
+
+  // ---- prologue: first window (all 11 slices), weights of k-tiles 0 .. LEAD - 1 into stages 0 .. LEAD - 1
+#pragma unroll 1
+  for (int n = 0; n < 11; ++n) send_a(mt, 0, 0, n, true);
+#pragma unroll
+  for (int t = 0; t < LEAD; ++t) send_b(nt, 0, t, t, true);
+  wait_vm<0>();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  abl_pro = false;
+  RG_CLK(0);
+  unsigned mk[2];
+  masks_of(mt, mk);
+  f32x4 wfr[4][4], pfr[2][4];                               // fragments of the current k-tile: weights [cb][s], pixels [rb][s]
+  {
+    lds_cptr p_addr[2][4];
+    frag_addr(0, 0, base_idx, mk, a.W, p_addr);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) wfr[cb][s] = *reinterpret_cast<lds_f4>(lds0 + wst_off + boff[s] + 4096 * cb);
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) pfr[rb][s] = *reinterpret_cast<lds_f4>(p_addr[rb][s]);
+    }
+  }
+  int g = 0;                                                // k-tiles this workgroup has started (stage of k-tile g: g & 3)
+  int prev_tail = 0;                                        // VMEM operations the previous slot issued after its weight pieces
+  int prev2_tail = 0;
+
+  for (int li = 0; li < nitems; ++li) {
+    int mt1 = mt, nt1 = nt + 1;
+    if (nt1 == a.ntiles) { nt1 = 0; ++mt1; }
+    const bool more = li + 1 < nitems;
+    unsigned mkn[2] = {mk[0], mk[1]};                       // masks of the next item's M tile
+    if (mt1 != mt) { advance_mtile(); masks_of(mt1, mkn); }
+    // the accumulator starts from the folded-BN shift (LDS table in accumulator layout)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const float* tb = sh_lds + ((nt * 4 + cb) * 2 + lh) * 16;
+      f32x16 c0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(tb + 4 * q);
+        c0[4 * q] = t[0]; c0[4 * q + 1] = t[1]; c0[4 * q + 2] = t[2]; c0[4 * q + 3] = t[3];
+      }
+      acc[0][cb] = c0;
+      acc[1][cb] = c0;
+    }
+    for (int c = 0; c < a.NC; ++c) {
+      const int phg = li * a.NC + c;
+      const int wb = phg & 1;
+      const bool last_c = c + 1 == a.NC;
+      const bool has_next = !last_c || more;
+      const int mt_n = last_c ? mt1 : mt, c_n = last_c ? 0 : c + 1;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        int bi = base_idx, Wx = a.W;
+        asm volatile("" : "+v"(bi), "+s"(Wx));
+        // ---- the k-tile's barrier: this wave's pieces of stage g + 1 (issued two slots ago) have landed — everything it
+        // issued since stays in flight: the two slots' tails and the last slot's four weight pieces
+        wait_vm_n(prev2_tail + NBPW + prev_tail);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // weights of k-tile g + LEAD into the stage k-tile g - 1 occupied (its fragments were read two slots ago)
+        {
+          const int stg = (g + LEAD) & (NSTG - 1);
+          if (tap + LEAD < 9) send_b(nt, c, tap + LEAD, stg, true);
+          else if (!last_c) send_b(nt, c + 1, tap + LEAD - 9, stg, true);
+          else send_b(nt1, 0, tap + LEAD - 9, stg, more);
+        }
+        int tail = 0;
+#pragma unroll
+        for (int i = 0; i < sl_n(tap); ++i) send_a(mt_n, c_n, wb ^ 1, sl_0(tap) + i, has_next);
+        tail += sl_n(tap);
+        if constexpr (RES != 0) {
+          if (last_c && tap >= 1) {
+            rq_load(mt, nt, 2 * (tap - 1));
+            rq_load(mt, nt, 2 * (tap - 1) + 1);
+            tail += rq_n(tap);
+          }
+        }
+        // fragments of the next k-tile: addresses (tap 8: tap 0 of the next chunk / item)
+        lds_cptr n_addr[2][4];
+        if (tap < 8) frag_addr(tap + 1, wb * win_bytes, bi, mk, Wx, n_addr);
+        else frag_addr(0, (wb ^ 1) * win_bytes, bi, last_c ? mkn : mk, Wx, n_addr);
+        const unsigned wnext = wst_off + (unsigned)(((g + 1) & (NSTG - 1)) * STG_B);
+        f32x4 nwf[4][4], npf[2][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+              if constexpr ((RING_ABL & 1) != 0) asm volatile("" :: "v"(wfr[cb][s]), "v"(pfr[rb][s]));
+              else acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wfr[cb][s]), __builtin_bit_cast(bf16x8, pfr[rb][s]),
+                                                                         acc[rb][cb], 0, 0, 0);
+            }
+          if constexpr ((RING_ABL & 2) == 0) {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) nwf[cb][s] = *reinterpret_cast<lds_f4>(lds0 + wnext + boff[s] + 4096 * cb);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) npf[rb][s] = *reinterpret_cast<lds_f4>(n_addr[rb][s]);
+          } else {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) nwf[cb][s] = f32x4{0.01f * lane, -2.5f + cb, 0.125f * s, 1.f + tap};
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) npf[rb][s] = f32x4{(float)(lane * 3 + s), 1.5f + rb, -0.75f * lane, 0.3f + tap};
+          }
+        }
+        // issue order per k-step: its eight MFMAs, then the six reads into the registers they released
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb) wfr[cb][s] = nwf[cb][s];
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb) pfr[rb][s] = npf[rb][s];
+        }
+        prev2_tail = prev_tail;
+        prev_tail = tail;
+        ++g;
+      }
+    }
+    // ---- the item's epilogue (16 pieces; its stores count in the next two slots' waits)
+#pragma unroll
+    for (int p = 0; p < NPC; ++p) epi_piece(mt, nt, p);
+    if ((RING_ABL & 48) == 0) prev_tail += NST;
+    if (mt1 != mt) { mk[0] = mkn[0]; mk[1] = mkn[1]; }
+    mt = mt1; nt = nt1;
+  }
+  RG_CLK(1);
+}
+
+#endif      // CADRE_AB_KERNELS
+
 // Tile configuration (host logic): 256 positions x 64 / 128 channels on 8 waves, one persistent workgroup per CU.
 // Channel tile 128 unless N < 128 (CADRE_RING_NTILE forces one for A/B runs).  (A 128-position / 4-wave shape with two
 // workgroups per CU existed until the ping-pong kernel beat it on every shape it was picked for: layer3 bf16 1134 vs
 // 990 TFLOP/s; the kernel template still takes WVM = 2.)
 struct ring_cfg { int wvm, ntile, bm, wpx, wgs, pp, g; size_t lds; long long items; };
-static void ring_pick(long long M, int W, int N, int bf16, int NC_, ring_cfg* c) {
-  const int NC = NC_ < 0 ? -NC_ : NC_;                     // NC_ < 0: the caller rules out conv3x3_c64s_kernel (act | 16)
-  const bool no_c64s = NC_ < 0;
+// pflags: 1 = residual after the activation (act | 16), 2 = a folded-BN scale vector is present — either keeps the launch
+// on the ping-pong kernels (the weight-stationary / one-wave kernels add the residual before the activation; the one-wave
+// kernel wants the scale folded into the weights)
+static void ring_pick(long long M, int W, int N, int bf16, int NC, ring_cfg* c, int pflags = 0) {
+  const bool no_c64s = (pflags & 1) != 0;
   static const int force_nt = [] { const char* e = getenv("CADRE_RING_NTILE"); return e ? atoi(e) : 0; }();
   static const int force_pp = [] { const char* e = getenv("CADRE_RING_PP"); return e ? atoi(e) : 1; }();
   int ntile = N >= 128 ? 128 : 64;
@@ -1851,6 +2194,14 @@ static void ring_pick(long long M, int W, int N, int bf16, int NC_, ring_cfg* c)
   if (bf16 && N == 64 && NC == 1 && c64s_on && force_pp > 0 && !no_c64s) {
     const int wpx3 = (bm + 2 * W + 2 + 7) & ~7;
     if (wpx3 <= 416) { c->g = 9; c->pp = 1; c->wpx = wpx3; c->lds = (size_t)3 * wpx3 * 128 + 1024; }
+  }
+  // the 128-channel tile in bf16 with the scale folded into the weights: conv3x3_ring1w_kernel — one wave per SIMD, four
+  // weight stages, two windows (A/B build + CADRE_RING_1W=1 only: ties the ping-pong kernel); reported as g = 8
+  static const int r1w_on = [] { const char* e = getenv("CADRE_RING_1W"); return e ? atoi(e) : 0; }();
+  if (pp2_built && bf16 && ntile == 128 && NC >= 1 && r1w_on && force_pp > 0 && pflags == 0 && c->g == 1) {
+    const int wpx2 = (bm + 2 * W + 2 + 7) & ~7;
+    const size_t lds1 = (size_t)2 * wpx2 * 128 + (size_t)4 * 128 * 128 + 1024 + (size_t)((N + 127) / 128) * 512;
+    if (wpx2 <= 352 && lds1 <= 160 * 1024) { c->g = 8; c->pp = 1; c->wpx = wpx2; c->lds = lds1; }
   }
   c->items = ((M + bm - 1) / bm) * ((N + ntile - 1) / ntile);
   c->wgs = (int)(c->items < 256 ? c->items : 256);                  // persistent workgroups: one per CU
@@ -1928,7 +2279,7 @@ extern "C" int cadre_conv3x3_ring(const void* x, const void* w, const float* sca
   a.M = F * H * W; a.H = H; a.W = W; a.Cin = Cin; a.N = N; a.NC = Cin * (bf16 ? 2 : 4) / 128;
   a.act = act; a.out_bf16 = out_bf16; a.resid_bf16 = resid_bf16;
   ring_cfg cfg;
-  ring_pick(a.M, W, N, bf16, (act & 16) ? -a.NC : a.NC, &cfg);      // (residual after the activation: not on the weight-stationary kernel)
+  ring_pick(a.M, W, N, bf16, a.NC, &cfg, ((act & 16) ? 1 : 0) | (scale ? 2 : 0));
   const int ntile = cfg.ntile;
   a.mtiles = (a.M + cfg.bm - 1) / cfg.bm;
   a.ntiles = (N + ntile - 1) / ntile;
@@ -1971,7 +2322,21 @@ extern "C" int cadre_conv3x3_ring(const void* x, const void* w, const float* sca
     (void)hipFuncSetAttribute((const void*)conv3x3_c64s_kernel<RS_, OB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
     hipLaunchKernelGGL((conv3x3_c64s_kernel<RS_, OB_>), dim3(grid), dim3(256), lds, st, a);                     \
   } while (0)
-  if (bf16 && cfg.g == 9) {
+#ifdef CADRE_AB_KERNELS
+#define RG_R1W(RS_, OB_)                                                                                         \
+  do {                                                                                                           \
+    (void)hipFuncSetAttribute((const void*)conv3x3_ring1w_kernel<RS_, OB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL((conv3x3_ring1w_kernel<RS_, OB_>), dim3(grid), dim3(256), lds, st, a);                   \
+  } while (0)
+#endif
+  if (false) {
+#ifdef CADRE_AB_KERNELS
+  } else if (bf16 && cfg.g == 8) {
+    if (resid && !resid_bf16) return cadre_fail("cadre_conv3x3_ring: bf16 operands take a bf16 residual");
+    if (resid) { if (out_bf16) RG_R1W(2, true); else RG_R1W(2, false); }
+    else { if (out_bf16) RG_R1W(0, true); else RG_R1W(0, false); }
+#endif
+  } else if (bf16 && cfg.g == 9) {
     if (resid && !resid_bf16) return cadre_fail("cadre_conv3x3_ring: bf16 operands take a bf16 residual");
     if (resid) { if (out_bf16) RG_C64S(2, true); else RG_C64S(2, false); }
     else { if (out_bf16) RG_C64S(0, true); else RG_C64S(0, false); }
@@ -1994,6 +2359,9 @@ extern "C" int cadre_conv3x3_ring(const void* x, const void* w, const float* sca
     if (out_bf16 || (resid && resid_bf16)) return cadre_fail("cadre_conv3x3_ring: fp32 operands take fp32 residual / output");
     if (resid) RG_NT(false, 1, false); else RG_NT(false, 0, false);
   }
+#ifdef CADRE_AB_KERNELS
+#undef RG_R1W
+#endif
 #undef RG_C64S
 #ifdef CADRE_AB_KERNELS
 #undef RG_PP2

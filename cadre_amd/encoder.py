@@ -77,14 +77,23 @@ def _ring_w(w, cpc):
 
 
 class _Conv:
-    __slots__ = ("w", "w_ring", "scale", "shift", "cin", "cout", "k", "stride", "pad", "act")
+    __slots__ = ("w", "w_ring", "ring_folded", "scale", "shift", "cin", "cout", "k", "stride", "pad", "act")
 
     def __init__(self, w, scale, shift, k, stride, pad, act, dev, wdtype=torch.float32):
         self.w = _khwc(w).to(dev).to(wdtype)
         cpc = 64 if wdtype == torch.bfloat16 else 32
         self.w_ring = None
+        self.ring_folded = False
         if k == 3 and stride == 1 and pad == 1 and w.shape[1] % cpc == 0:
-            self.w_ring = _ring_w(w, cpc).to(dev).to(wdtype)
+            wr = w
+            if wdtype == torch.bfloat16 and scale is not None:
+                # bf16 model: the folded-BN scale of an output channel goes INTO its window-kernel weight row (fp32 product,
+                # ONE rounding to bf16), the kernels then get scale = NULL: their epilogue has no multiply and the
+                # weight-stationary / one-wave kernels take the shift as the accumulator's initial value.  (fp32 model:
+                # weights untouched, scale applied in fp32 — rounding within 1 ulp of conv -> BN)
+                wr = w * scale.reshape(-1, 1, 1, 1).to(w.dtype)
+                self.ring_folded = True
+            self.w_ring = _ring_w(wr, cpc).to(dev).to(wdtype)
         self.scale = None if scale is None else scale.contiguous().to(dev)
         self.shift = None if shift is None else shift.contiguous().to(dev)
         self.cout, self.cin = w.shape[0], w.shape[1]
@@ -248,7 +257,7 @@ class DANetEncoderHIP:
             hip.conv3x3_c64_bf16(x, c.w, c.scale, c.shift, resid, out, F, H, W, 1 if act == 1 else 0)
         elif use_ring:
             # stride-1 3x3 convs: each pixel through LDS once per channel chunk, weights streamed (conv3x3_ring.hip)
-            hip.conv3x3_ring(x, c.w_ring, c.scale, c.shift, resid, out, F, H, W, c.cin, c.cout, act)
+            hip.conv3x3_ring(x, c.w_ring, None if c.ring_folded else c.scale, c.shift, resid, out, F, H, W, c.cin, c.cout, act)
         elif c.k == 1 and c.stride == 1:
             hip.gemm(x, c.w, out, M, c.cout, K, K, K, c.cout, scale=c.scale, shift=c.shift, resid=resid,
                      ldr=c.cout, act=act, bf16=wbf, flags=flags)

@@ -1,0 +1,25 @@
+"""The window-conv variants that round 4 built, measured and left in the A/B library (csrc/conv3x3_ring.hip under
+CADRE_AB_KERNELS): the G-k-tiles-per-slot ping-pong kernel (CADRE_RING_G=2) and the one-wave-per-SIMD
+streamed-weights kernel (CADRE_RING_1W=1).  Both stay parity-green against torch on every shape class of
+test_conv3x3_ring — each in its own process: the switches are read once, when the library loads.
+Reference layers: carla_perception/Networks/danet_blocks/resnet.py:26-55, danet.py:21-41."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+AB = os.path.join(ROOT, "cadre_amd", "csrc", "libcadre_hip_ab.so")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.skipif(not os.path.exists(AB), reason="A/B library not built (CADRE_BUILD_AB=1 python -m cadre_amd.build)")
+@pytest.mark.parametrize("switch", ["CADRE_RING_G=2", "CADRE_RING_1W=1"])
+def test_ab_window_conv_variants_match_torch(switch):
+    k, v = switch.split("=")
+    env = dict(os.environ, CADRE_HIP_LIB=AB, CADRE_RING_C64S="0", **{k: v})
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_kernels_gpu.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "test_conv3x3_ring and bf16"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert " passed" in p.stdout
