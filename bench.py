@@ -175,7 +175,7 @@ def learner_round(agent, workers, cfg, shared, timers=None, joint=None, losses_t
         host.append(("encode enqueued", time.perf_counter() - t0))
     if timers is not None:
         torch.cuda.synchronize(); t1 = time.perf_counter()
-    if len(workers) == 1 and not cfg.get("grad_buckets"):
+    if len(workers) == 1:
         # ONE worker per GPU (C1 / C2): the learner section is the function train() itself runs
         # (cadre_amd/ppo_agent/train.py:learner_section = reference train.py:76-110) — bootstrap values, GAE,
         # 4 epochs x 2 minibatches of update_policy + hand-off + in-process chief_step; nothing bench-specific
@@ -208,10 +208,7 @@ def learner_round(agent, workers, cfg, shared, timers=None, joint=None, losses_t
         host.append(("GAE enqueued", time.perf_counter() - t0))
     nW = len(workers)
     dev_losses = []
-    hook = None
-    if cfg.get("grad_buckets") and shared.dist_world():       # MLP-tower gradients out beside the LSTM backward
-        P0 = agent.arena.P0
-        hook = lambda: shared.reduce_bucket_async(P0)
+    hook = shared.overlap_hook()       # several ranks: MLP and steer-LSTM gradient buckets out beside the rest of the backward
     evs = []
     for _ in range(PPO_EPOCH):
         idx = [(wk.stor[0].sample_indices(), wk.stor[1].sample_indices()) for wk in workers]
@@ -382,7 +379,8 @@ def run_config(name, args, rank, local_rank, world, use_dist, steps, warmup, epi
     from ppo_agent.agent import CadreAgent
     from ppo_agent.models import Shared_grad_buffers
     cfg = dict(CONFIGS[name]); cfg["dedup"] = args.dedup
-    cfg["grad_buckets"] = args.grad_buckets
+    if args.no_grad_buckets:
+        os.environ["CADRE_GRAD_BUCKETS"] = "0"
     # windows per encoder launch chain: 128 (1024 frames) per worker; with several workers per GPU their windows form
     # one stream cut into chunks of 256 (2048 frames: every activation tensor stays below the 2 GiB buffer window)
     joint_ok = cfg["workers"] > 1 and not args.dedup and not episodes_dir and not args.no_joint_encode
@@ -536,7 +534,8 @@ def run_config(name, args, rank, local_rank, world, use_dist, steps, warmup, epi
         sync()
         shared.reset(zero=True)
         out["rccl_ranks"] = world
-        out["grad_exchange"] = mode + (" + MLP bucket beside the LSTM backward" if cfg.get("grad_buckets") and mode == "allreduce" else "")
+        out["grad_exchange"] = mode + (" in 3 buckets (MLP towers, steer LSTMs, throttle LSTMs), the first two beside the backward"
+                                        if shared.overlap_hook() is not None else "")
         out["allreduce_ms_per_step"] = round(e0.elapsed_time(e1) / reps, 4)
         out["allreduce_bytes"] = int(g.numel() * 4)
         out["exchanges_in_timed_region"] = n_ex          # one per optimiser step: 8 per round
@@ -631,8 +630,10 @@ def main():
     ap.add_argument("--grad-exchange", default=None, choices=["allreduce", "sharded"],
                     help="N > 1: one all-reduce(SUM) of the gradient arena + replicated clip/Adam (default), or reduce-scatter + "
                          "clip/Adam on the rank's shard + all-gather of the parameters (same wire bytes, 1/N optimiser traffic)")
-    ap.add_argument("--grad-buckets", action="store_true",
-                    help="N > 1, all-reduce mode: the MLP-tower gradients (6 MB) go out as their own bucket beside the LSTM backward")
+    ap.add_argument("--no-grad-buckets", action="store_true",
+                    help="N > 1, all-reduce mode: ONE blocking all-reduce of the 80 MB arena per optimiser step instead of three "
+                         "buckets of which two leave beside the backward (the default)")
+    ap.add_argument("--grad-buckets", action="store_true", help=argparse.SUPPRESS)      # (round-3 flag: now the default)
     ap.add_argument("--spawn-selftest", action="store_true",
                     help="launcher check (no GPU): every rank prints its RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* and exits")
     ap.add_argument("--c3-steps", type=int, default=10, help="timed rounds of the C3 section (>= 10 by default)")

@@ -178,14 +178,25 @@ class PPOLearnerHIP:
         losses[3] = (value_loss*vc, action_loss*cc, ent_loss*ec) (agent.py:226-237).
         The launch sequence has fixed shapes and pointers, so after one eager run it is captured
         into a hipGraph per (B, inv_b) and replayed (launch-bound otherwise: ~2 ms of host time).
-        With `mlp_grads_ready` the sequence is cut in two graphs where the gradients of the MLP towers
-        (arena[P0:]) are final — before the backward through time — and the callable runs in between
-        (the data-parallel exchange starts that bucket's all-reduce beside the LSTM backward)."""
-        parts = ("front", "back") if mlp_grads_ready is not None else ("all",)
-        for part in parts:
+        With `mlp_grads_ready` (a callable taking an arena range) the sequence is cut where gradient buckets become
+        FINAL, and the callable runs at each cut with that bucket's element range — the data-parallel exchange starts the
+        bucket's all-reduce there, beside the kernels that follow (Shared_grad_buffers.reduce_bucket_async):
+          after the MLP-tower backward            arena[P0:]            (6 MB)   — beside the backward through time
+          after the steer nets' weight gradients  arena[:4 size_L]      (37 MB)  — beside the throttle nets' lstm_dw
+        the throttle nets' bucket arena[4 size_L:P0] is final when the step ends (the chief's all_reduce takes it)."""
+        a = self.a
+        if mlp_grads_ready is None:
+            self._run("all", B, inv_b, sorted_rows)
+            return self.workspace(B)["losses"]
+        half = (a.Z // 2) * a.size_L
+        for part, rng in (("front", (a.P0, a.total)), ("mid", (0, half)), ("back", None)):
             self._run(part, B, inv_b, sorted_rows)
-            if part == "front":
-                mlp_grads_ready()
+            if rng is not None:
+                try:
+                    mlp_grads_ready(*rng)
+                except TypeError:                            # (a round-3 style hook without arguments: the MLP bucket only)
+                    if part == "front":
+                        mlp_grads_ready()
         return self.workspace(B)["losses"]
 
     def _run(self, part, B, inv_b, sorted_rows):
@@ -225,8 +236,9 @@ class PPOLearnerHIP:
         return g
 
     def _update_body(self, B, inv_b, sorted_rows=False, part="all"):
-        """part: "all", or "front" (forward, loss, MLP-tower backward, dh_S) / "back" (backward through time and the
-        LSTM weight gradients) — the two halves of the same launch sequence."""
+        """part: "all", or the three cuts of the same launch sequence: "front" (forward, loss, MLP-tower backward, dh_S),
+        "mid" (backward through time + the weight gradients of the steer nets, arena nets 0 .. Z/2 - 1), "back" (the weight
+        gradients of the throttle nets)."""
         a, S = self.a, self.S
         w = self.workspace(B)
         Z, C = a.Z, a.C
@@ -238,7 +250,7 @@ class PPOLearnerHIP:
         sgM2 = None if seg is None else (1, seg, B, 2)  # M tiles, z = 2*net + tower
         sgK1 = None if seg is None else (2, seg, B, 1)  # k tiles (rows), z = net
         sgK2 = None if seg is None else (2, seg, B, 2)
-        front, back = part in ("all", "front"), part in ("all", "back")
+        front, back = part in ("all", "front"), part in ("all", "mid", "back")
         O3, dO3 = w["O3"], w["dO3"]
         if front:
             self._forward(w, B, (0, 1, Z), C, seg=seg, fused_mlp=True)
@@ -292,19 +304,24 @@ class PPOLearnerHIP:
         sgp = None if seg is None else hip.ptr(seg)
         dGp = w["dGp"]                                      # dG of a step in fragment order: ping-pong pair
         gps = dGp.stride(1)
-        for t in range(S, 0, -1):
-            # t == S: dh_{S-1} = dH (MLP towers), no product; else dh_{t-1} = dG_t W_hh.  Then the cell backward of step
-            # t-1 in the same launch: dG_{t-1} (row-major for the weight gradients, fragment order for the next step), dc_{t-2}
-            src = None if t == S else hip.ptr(dGp[t & 1])
-            hip.check(L.cadre_lstm_step_bwd(hip.ptr(self._wp[1]), self._wp[1].stride(0), src, hip.ptr(dGp[(t - 1) & 1]), gps,
-                                            hip.ptr(dG[:, t - 1]), hip.ptr(G[:, t - 1]), H4P, S * B * H4P,
-                                            hip.ptr(dH) if t == S else None, hip.ptr(dC), B * DP, hip.ptr(TC[:, t]),
-                                            hip.ptr(Cs[:, t - 1]), DP, (S + 1) * B * DP, B, a.D, Z, cmd, C, sgp, t & 1, st),
-                      "cadre_lstm_step_bwd")
-        # dW_hh = sum_t dG_t^T h_{t-1} ; dW_ih = sum_t dG_t^T x_t ; db_ih = db_hh = colsum(dG): one launch for all nets
-        hip.check(L.cadre_lstm_dw(hip.ptr(dG), H4P, S * B * H4P, hip.ptr(Hs), hip.ptr(X), DP, (S + 1) * B * DP, S * B * DP, C,
-                                  hip.ptr(gL[a.o_whh:]), hip.ptr(gL[a.o_wih:]), hip.ptr(gL[a.o_bih:]), hip.ptr(gL[a.o_bhh:]),
-                                  DP, sL, B, S, H4, DP, Z, sgp, st), "cadre_lstm_dw")
+        if part != "back":
+            for t in range(S, 0, -1):
+                # t == S: dh_{S-1} = dH (MLP towers), no product; else dh_{t-1} = dG_t W_hh.  Then the cell backward of step
+                # t-1 in the same launch: dG_{t-1} (row-major for the weight gradients, fragment order for the next step), dc_{t-2}
+                src = None if t == S else hip.ptr(dGp[t & 1])
+                hip.check(L.cadre_lstm_step_bwd(hip.ptr(self._wp[1]), self._wp[1].stride(0), src, hip.ptr(dGp[(t - 1) & 1]), gps,
+                                                hip.ptr(dG[:, t - 1]), hip.ptr(G[:, t - 1]), H4P, S * B * H4P,
+                                                hip.ptr(dH) if t == S else None, hip.ptr(dC), B * DP, hip.ptr(TC[:, t]),
+                                                hip.ptr(Cs[:, t - 1]), DP, (S + 1) * B * DP, B, a.D, Z, cmd, C, sgp, t & 1, st),
+                          "cadre_lstm_step_bwd")
+        # dW_hh = sum_t dG_t^T h_{t-1} ; dW_ih = sum_t dG_t^T x_t ; db_ih = db_hh = colsum(dG): one launch for all nets, or —
+        # when the exchange overlaps — one per head: nets [z0, z0 + nz) of the arena (X: one input block per head, x_div = C)
+        z0, nz = {"all": (0, Z), "mid": (0, Z // 2), "back": (Z // 2, Z - Z // 2)}[part]
+        gz = gL[z0 * sL:]
+        hip.check(L.cadre_lstm_dw(hip.ptr(dG[z0:]), H4P, S * B * H4P, hip.ptr(Hs[z0:]), hip.ptr(X[z0 // C:]), DP, (S + 1) * B * DP,
+                                  S * B * DP, C, hip.ptr(gz[a.o_whh:]), hip.ptr(gz[a.o_wih:]), hip.ptr(gz[a.o_bih:]),
+                                  hip.ptr(gz[a.o_bhh:]), DP, sL, B, S, H4, DP, nz, None if seg is None else hip.ptr(seg[z0:]), st),
+                  "cadre_lstm_dw")
         return w["losses"]
 
     # ------------------------------------------------------------------ optimiser (chief.py:13-21)

@@ -339,23 +339,41 @@ class Shared_grad_buffers(object):
         self._mark()
         if not self.dist_world():
             return
-        done = getattr(self, "_bucket_done", None)
-        if done is not None:                               # MLP bucket went out while the LSTM backward ran
-            lo, work = done
-            self._bucket_done = None
-            dist.all_reduce(self.arena.grads[:lo], op=dist.ReduceOp.SUM)
-            work.wait()
+        buckets = getattr(self, "_buckets", None) or []
+        self._buckets = []
+        if buckets:                                        # buckets that went out beside the backward: reduce what they left
+            covered = sorted((lo, hi) for lo, hi, _w in buckets)
+            pos, g = 0, self.arena.grads
+            for lo, hi in covered + [(self.arena.total, self.arena.total)]:
+                if lo > pos:
+                    dist.all_reduce(g[pos:lo], op=dist.ReduceOp.SUM)
+                pos = max(pos, hi)
+            for _lo, _hi, work in buckets:
+                work.wait()
         else:
             dist.all_reduce(self.arena.grads, op=dist.ReduceOp.SUM)
         self._n_exchange.increment()
 
-    def reduce_bucket_async(self, lo):
-        """Start the all-reduce of grads[lo:] (the MLP towers, final before the LSTM backward starts) as an
-        async collective; `all_reduce` later reduces grads[:lo] and waits for this one."""
+    def reduce_bucket_async(self, lo, hi=None):
+        """Start the all-reduce of grads[lo:hi] — a bucket whose gradients are final while the backward still runs (the
+        MLP towers before the backward through time, the steer nets' LSTM gradients before the throttle nets' lstm_dw) —
+        as an async collective on the backend's stream; `all_reduce` later reduces what the buckets left and waits for
+        them.  No-op outside the all-reduce exchange."""
         import torch.distributed as dist
         if not self.dist_world() or self.exchange_mode() != "allreduce":
             return
-        self._bucket_done = (lo, dist.all_reduce(self.arena.grads[lo:], op=dist.ReduceOp.SUM, async_op=True))
+        hi = self.arena.total if hi is None else hi
+        if getattr(self, "_buckets", None) is None:
+            self._buckets = []
+        self._buckets.append((lo, hi, dist.all_reduce(self.arena.grads[lo:hi], op=dist.ReduceOp.SUM, async_op=True)))
+
+    def overlap_hook(self):
+        """The callable `CadreAgent.update_policy_from_storages(mlp_grads_ready=...)` takes, or None when no exchange runs
+        or bucketing is off (CADRE_GRAD_BUCKETS=0; the sharded exchange reduce-scatters the whole arena at once).
+        Default ON whenever ranks exchange gradients: 43 of the 80 MB leave while the backward still computes."""
+        if not self.dist_world() or self.exchange_mode() != "allreduce" or os.environ.get("CADRE_GRAD_BUCKETS", "1") == "0":
+            return None
+        return self.reduce_bucket_async
 
     def reduce_scatter(self):
         """Sharded exchange, step 1: this rank's shard of the gradient arena receives the SUM over ranks
@@ -396,10 +414,9 @@ class Shared_grad_buffers(object):
         """models.py:255-258.  `zero=False` (chief_step, when only nets of this arena handed in): the next
         update_policy WRITES every gradient element of the arena (it does not accumulate), so the 80 MB fill would
         be overwritten unread; a foreign arena accumulated with `add_` always gets the fill."""
-        done = getattr(self, "_bucket_done", None)
-        if done is not None:        # a bucket started by reduce_bucket_async that no all_reduce() collected (nothing was
-            self._bucket_done = None        # handed in afterwards): its collective must not outlive the buffers' reset
-            done[1].wait()
+        for _lo, _hi, work in (getattr(self, "_buckets", None) or []):
+            work.wait()             # a bucket started by reduce_bucket_async that no all_reduce() collected (nothing was
+        self._buckets = []          # handed in afterwards): its collective must not outlive the buffers' reset
         self.counter.reset()
         self._reduced_at.reset()
         if zero or getattr(self, "_accumulated", False):

@@ -49,6 +49,9 @@ def learner_section(agent, steer_rollout, throttle_rollout, done, train_cfg, sha
     throttle_adv = throttle_rollout.compute_returns(nv_t.detach(), normalise=use_adv_norm)
     dev_losses = []
     vl, pl, el = [], [], []
+    # several ranks: gradient buckets leave as soon as they are final, beside the rest of the backward (default; see
+    # Shared_grad_buffers.overlap_hook) — only with the in-process chief, which collects them in chief_step
+    hook = shared_grad_buffers.overlap_hook() if in_process_chief else None
     for _ in range(train_cfg["ppo_epoch"]):
         if fused_gather:
             idx_s, idx_t = steer_rollout.sample_indices(), throttle_rollout.sample_indices()   # steer draws first
@@ -61,7 +64,7 @@ def learner_section(agent, steer_rollout, throttle_rollout, done, train_cfg, sha
                 step_events.append(torch.cuda.Event(enable_timing=True)); step_events[-1].record()
             if kind == "idx":
                 dev_losses.append(agent.update_policy_from_storages(
-                    [(steer_rollout, a, steer_adv, throttle_rollout, b, throttle_adv)], sync=False))
+                    [(steer_rollout, a, steer_adv, throttle_rollout, b, throttle_adv)], sync=False, mlp_grads_ready=hook))
             else:
                 v, p, e = agent.update_policy(a, b)
                 vl.append(v); pl.append(p); el.append(e)

@@ -50,7 +50,8 @@ def rank_main(out_dir, mode):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        cfg = dict(CFG, grad_buckets=(mode == "buckets"))
+        os.environ["CADRE_GRAD_BUCKETS"] = "1" if mode == "buckets" else "0"      # (default on; "allreduce" = the one blocking exchange)
+        cfg = dict(CFG)
         agent = agent_for(rank)
         dist.broadcast(agent.arena.params, 0)
         workers = [bench.Worker(cfg, 1234 + 1000 * rank + w, agent.device) for w in range(cfg["workers"])]

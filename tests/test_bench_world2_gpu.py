@@ -31,8 +31,8 @@ def test_bench_main_at_world_two_on_one_gpu(mode):
     extra = ["--config", "C1", "--no-c3"]
     if mode == "sharded":
         extra += ["--grad-exchange", "sharded"]
-    if mode == "buckets":
-        extra += ["--grad-buckets"]
+    if mode == "allreduce":
+        extra += ["--no-grad-buckets"]                       # (three buckets, two of them beside the backward, are the default)
     d = _run(extra)
     assert d["n_gpus"] == 2 and d["metric"] == "ppo_update_samples_per_sec" and d["scaling"] == "weak"
     assert d["rccl_ranks"] == 2 and d["backend"] == "gloo" and d["one_device"] is True
@@ -41,6 +41,7 @@ def test_bench_main_at_world_two_on_one_gpu(mode):
     assert d["value"] > 0 and abs(d["value"] - 2 * 32 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
     assert d["allreduce_ms_per_step"] > 0 and d["allreduce_bytes"] == 4 * 19998848
     assert d["grad_exchange"].startswith("sharded" if mode == "sharded" else "allreduce")
+    assert ("3 buckets" in d["grad_exchange"]) == (mode == "buckets")
     assert "cpu_baseline" not in d and "measured_peaks" not in d           # rank 0 at N = 1 only
     assert all(abs(x) < 1e3 for x in d["last_losses"])
 

@@ -111,6 +111,22 @@ def _sharded_worker(rank, world, port, q):
         shared.add_gradient(md)
         shared.all_reduce()
         ok &= bool(torch.equal(arena.grads, want)) and shared.n_allreduce == 2
+        # three buckets, as the learner cuts them: MLP towers, then the steer nets' LSTM block; all_reduce takes the rest
+        arena.grads.copy_(base * (rank + 1))
+        half = (arena.Z // 2) * arena.size_L
+        shared.reduce_bucket_async(arena.P0, arena.total)
+        shared.reduce_bucket_async(0, half)
+        shared.add_gradient(md)
+        shared.all_reduce()
+        ok &= bool(torch.equal(arena.grads, want)) and shared.n_allreduce == 3
+        # a bucket nobody collects (no hand-in afterwards) is waited for by reset()
+        shared.reduce_bucket_async(arena.P0)
+        shared.reset()
+        ok &= not shared._buckets
+        ok &= shared.overlap_hook() is not None
+        os.environ["CADRE_GRAD_BUCKETS"] = "0"
+        ok &= shared.overlap_hook() is None
+        os.environ.pop("CADRE_GRAD_BUCKETS")
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
