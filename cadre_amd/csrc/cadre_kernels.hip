@@ -1498,6 +1498,135 @@ __global__ void adam_dev_kernel(float* p, const float* g, float* m, float* v, co
   }
 }
 
+// ---- Adam with the recurrent weights' fragment-order copies written in the same pass (round 4).  The update's LSTM kernels
+// read W_hh of the 8 nets in MFMA fragment order (ppo_update.hip: cadre_pack_lstm_weights: forward [slice][gate][k-block]
+// [lane][4], backward the transpose); packing them was its own launch after every optimiser step — 37 MB read twice and 76 MB
+// written, 30 us.  Here the thread that steps a 4 x 4 block of a W_hh matrix (rows n .. n+3, columns k .. k+3) also stores
+// its four rows into the forward copy and its four columns into the backward copy: 16-byte stores, nothing read twice.
+// adam_dev_kernel<true> steps everything else (it skips the W_hh region of the first n_lstm models).
+struct whh_pack_t {
+  int32_t n_lstm;       // models 0 .. n_lstm-1 are LSTM blocks of lstm_str floats
+  int64_t lstm_str;     // (= seg_off[1] - seg_off[0])
+  int64_t o_whh;        // offset of W_hh inside a block: [H4][ldw] row-major
+  int32_t H4, ldw, D;   // 4 * D gate rows, row pitch (D zero padded to a multiple of 16), hidden width
+  float* fwd;           // cadre_pack_lstm_weights' two outputs, net stride p_str
+  float* bwd;
+  int64_t p_str;
+};
+
+__global__ __launch_bounds__(256) void adam_whh_pack_kernel(float* p, const float* g, float* m, float* v, const double* norms2,
+                                                            int n_models, float max_norm, float w1, float beta2, float w2, float eps,
+                                                            whh_pack_t k) {
+  const int z = blockIdx.y;
+  const int cb = k.ldw / 4, rbk = k.H4 / 4;                 // 4 x 4 blocks per row / per column of blocks
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= cb * rbk) return;
+  const int n = (id / cb) * 4, kk = (id % cb) * 4;          // consecutive lanes: consecutive column blocks of one row block
+  const float total = (float)sqrt(norms2[z]);
+  const float coef = fminf(max_norm / (total + 1e-6f), 1.f);
+  const float step_size = (float)norms2[n_models], bc2_sqrt = (float)norms2[n_models + 1];
+  const int64_t base = (int64_t)z * k.lstm_str + k.o_whh;
+  float4 np[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t e = base + (int64_t)(n + i) * k.ldw + kk;
+    float4 pp = *reinterpret_cast<float4*>(p + e), gg = *reinterpret_cast<const float4*>(g + e);
+    float4 mm = *reinterpret_cast<float4*>(m + e), vv = *reinterpret_cast<float4*>(v + e);
+    float* pe = &pp.x; float* ge = &gg.x; float* me = &mm.x; float* ve = &vv.x;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {                           // (the arithmetic of adam_dev_kernel, same order)
+      const float gi = ge[c] * coef;
+      me[c] = me[c] + w1 * (gi - me[c]);
+      ve[c] = ve[c] * beta2 + w2 * (gi * gi);
+      pe[c] = pe[c] - step_size * (me[c] / (sqrtf(ve[c]) / bc2_sqrt + eps));
+    }
+    *reinterpret_cast<float4*>(p + e) = pp;
+    *reinterpret_cast<float4*>(m + e) = mm;
+    *reinterpret_cast<float4*>(v + e) = vv;
+    np[i] = pp;
+  }
+  const int NB = k.ldw / 16;
+  // forward copy: row r = gate * D + u -> [slice u / 16][gate][k-block kk / 16][lane (q = (kk % 16) / 4, c = u % 16)][4]
+  float* fz = k.fwd + (int64_t)z * k.p_str;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = n + i, gate = r / k.D, u = r - gate * k.D;
+    const int64_t blk = (int64_t)((u >> 4) * 4 + gate) * NB + (kk >> 4);
+    *reinterpret_cast<float4*>(fz + (blk * 64 + ((kk & 15) >> 2) * 16 + (u & 15)) * 4) = np[i];
+  }
+  // backward copy: column u = kk + c (a hidden unit; columns past D hold zeros in W and are not part of the copy), rows
+  // n .. n+3 = 16 (NB w + j) + 4 q + i -> [slice u / 16][quarter w][k-block j][lane (q, c = u % 16)][4]
+  float* bz = k.bwd + (int64_t)z * k.p_str;
+  const int nb16 = n >> 4, w = nb16 / NB, j = nb16 - w * NB, q = (n & 15) >> 2;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int u = kk + c;
+    if (u < k.D) {
+      const float* a0 = &np[0].x; const float* a1 = &np[1].x; const float* a2 = &np[2].x; const float* a3 = &np[3].x;
+      const int64_t blk = (int64_t)((u >> 4) * 4 + w) * NB + j;
+      *reinterpret_cast<float4*>(bz + (blk * 64 + q * 16 + (u & 15)) * 4) = float4{a0[c], a1[c], a2[c], a3[c]};
+    }
+  }
+}
+
+// adam_dev_kernel on everything but the W_hh regions of the LSTM models (those: adam_whh_pack_kernel)
+__global__ void adam_dev_skip_kernel(float* p, const float* g, float* m, float* v, const int64_t* seg_off, const double* norms2,
+                                     int n_models, float max_norm, float w1, float beta2, float w2, float eps, int n_lstm,
+                                     int64_t o_whh, int64_t whh_len) {
+  const int mdl = blockIdx.y;
+  const float total = (float)sqrt(norms2[mdl]);
+  const float coef = fminf(max_norm / (total + 1e-6f), 1.f);
+  const float step_size = (float)norms2[n_models], bc2_sqrt = (float)norms2[n_models + 1];
+  for (int part = 0; part < 2; ++part) {
+    int64_t lo = seg_off[mdl], hi = seg_off[mdl + 1];
+    if (mdl < n_lstm) {
+      if (part == 0) hi = lo + o_whh; else lo = lo + o_whh + whh_len;
+    } else if (part == 1) break;
+    const int64_t n4 = (hi - lo) >> 2;                      // (every bound is a multiple of 4 floats: arena layout)
+    float4* p4 = reinterpret_cast<float4*>(p + lo);
+    const float4* g4 = reinterpret_cast<const float4*>(g + lo);
+    float4* m4 = reinterpret_cast<float4*>(m + lo);
+    float4* v4 = reinterpret_cast<float4*>(v + lo);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+      float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+      float* pe = &pp.x; float* ge = &gg.x; float* me = &mm.x; float* ve = &vv.x;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float gi = ge[e] * coef;
+        me[e] = me[e] + w1 * (gi - me[e]);
+        ve[e] = ve[e] * beta2 + w2 * (gi * gi);
+        pe[e] = pe[e] - step_size * (me[e] / (sqrtf(ve[e]) / bc2_sqrt + eps));
+      }
+      p4[i] = pp; m4[i] = mm; v4[i] = vv;
+    }
+  }
+}
+
+extern "C" int cadre_clip_adam_pack_graph(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                                          const int64_t* seg_off, int32_t n_models, double* norms2, double max_norm, double lr,
+                                          double beta1, double beta2, double eps, int32_t* step_dev, int32_t n_lstm,
+                                          int64_t lstm_str, int64_t o_whh, int32_t H4, int32_t ldw, int32_t D, float* fwd,
+                                          float* bwd, int64_t p_str, void* stream) {
+  FAIL_IF(!params || !grads || !exp_avg || !exp_avg_sq || !seg_off || !norms2 || !step_dev || !fwd || !bwd || n_models < 1 ||
+              n_models > 254 || n_lstm < 1 || n_lstm > n_models,
+          "cadre_clip_adam_pack_graph: bad argument");
+  FAIL_IF(ldw != 544 || D < 1 || D > ldw || H4 != 4 * D || (H4 & 3) || (o_whh & 3) || (lstm_str & 3) || (p_str & 3) ||
+              o_whh + (int64_t)H4 * ldw > lstm_str || p_str < (int64_t)((D + 15) / 16) * 4 * 34 * 256 ||
+              (((uintptr_t)params | (uintptr_t)fwd | (uintptr_t)bwd) & 15),
+          "cadre_clip_adam_pack_graph: built for W_hh [4 D][544] inside an LSTM block, 16-byte aligned (see cadre_pack_lstm_weights)");
+  hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(256), 0, ST(stream), norms2, n_models, step_dev, lr, beta1, beta2);
+  const int64_t all = (int64_t)1 << 62;
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(64, n_models), dim3(256), 0, ST(stream), grads, seg_off, norms2, (int64_t)0, all);
+  const float w1 = (float)(1.0 - beta1), b2 = (float)beta2, w2 = (float)(1.0 - beta2);
+  hipLaunchKernelGGL(adam_dev_skip_kernel, dim3(256, n_models), dim3(256), 0, ST(stream), params, grads, exp_avg, exp_avg_sq, seg_off,
+                     norms2, n_models, (float)max_norm, w1, b2, w2, (float)eps, n_lstm, o_whh, (int64_t)H4 * ldw);
+  whh_pack_t k{n_lstm, lstm_str, o_whh, H4, ldw, D, fwd, bwd, p_str};
+  const int blocks = ((H4 / 4) * (ldw / 4) + 255) / 256;
+  hipLaunchKernelGGL(adam_whh_pack_kernel, dim3(blocks, n_lstm), dim3(256), 0, ST(stream), params, grads, exp_avg, exp_avg_sq,
+                     norms2, n_models, (float)max_norm, w1, b2, w2, (float)eps, k);
+  return (int)hipGetLastError();
+}
+
 extern "C" int cadre_clip_adam_graph(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                                      const int64_t* seg_off, int32_t n_models, double* norms2, double max_norm,
                                      double lr, double beta1, double beta2, double eps, int32_t* step_dev,

@@ -83,6 +83,7 @@ SYMBOLS = {
     "cadre_categorical_dist": [vp, i64, i32, i32, vp, vp, vp, vp],
     "cadre_clip_adam": [vp, vp, vp, vp, vp, i32, vp, f64, f64, f64, f64, f64, i32, vp],
     "cadre_clip_adam_graph": [vp, vp, vp, vp, vp, i32, vp, f64, f64, f64, f64, f64, vp, vp],
+    "cadre_clip_adam_pack_graph": [vp, vp, vp, vp, vp, i32, vp, f64, f64, f64, f64, f64, vp, i32, i64, i64, i32, i32, i32, vp, vp, i64, vp],
     "cadre_clip_adam_norms": [vp, vp, i32, vp, f64, f64, f64, vp, i64, i64, vp],
     "cadre_clip_adam_apply": [vp, vp, vp, vp, vp, i32, vp, f64, f64, f64, f64, i64, i64, vp],
 }

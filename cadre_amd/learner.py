@@ -47,6 +47,13 @@ class PPOLearnerHIP:
         # MLP towers of the update as three fused launches (cadre_mlp_fwd / _bwd / _dw) instead of 17 GEMM / column-sum /
         # mask launches; CADRE_FUSED_MLP=0 keeps the GEMM chain (A/B)
         self.fused_mlp = os.environ.get("CADRE_FUSED_MLP", "1") != "0"
+        # CADRE_ADAM_PACK=1: the optimiser step writes the fragment-order copies of W_hh itself (cadre_clip_adam_pack_graph)
+        # and the update that follows an in-process clip_adam() carries no packing launch.  Opt-in: bit-identical, one kernel
+        # fewer (23 vs 24 per step) and 110 MB less traffic, but NOT faster — same box, C3: 0.987 / 0.992 vs 0.988 / 0.980 ms
+        # per step: the 4 x 4-block thread mapping scatters its 16-byte stores into both copies
+        self.fused_pack = os.environ.get("CADRE_ADAM_PACK", "0") != "0"
+        self._adam_fresh = None    # _pkey() right after a fused optimiser step of THIS learner: the copies are current
+        self._skip_pack = False
         self._mlp_offs = None
         hip.lib()
 
@@ -85,19 +92,29 @@ class PPOLearnerHIP:
         parameters changed: the optimiser step count and `params._version` (in-place loads) key the copy.  Returns
         (forward copy of net g0, net stride gs nets)."""
         a = self.a
-        key = (a.step, a.params._version, a.params.data_ptr())
-        if self._wp is None:
-            n = ((a.D + 15) // 16) * 4 * (a.DP // 16) * 256
-            self._wp = torch.zeros(2, a.Z, n, device=a.device)
+        key = self._pkey()
+        self._alloc_wp()
         capturing = torch.cuda.is_current_stream_capturing()
         if capturing and self.pack_outside_capture:
             return self._wp[0, g0:], gs * self._wp.stride(1)     # (the caller refreshed the copies before the replay)
+        if self._skip_pack:                                      # (update() checked: the last optimiser step left them current)
+            return self._wp[0, g0:], gs * self._wp.stride(1)
         if key != self._wp_key or capturing:
             hip.check(hip.lib().cadre_pack_lstm_weights(hip.ptr(a.params[a.o_whh:]), a.size_L, a.DP, a.D, a.Z, hip.ptr(self._wp[0]),
                                                         hip.ptr(self._wp[1]), self._wp.stride(1), hip.stream()),
                       "cadre_pack_lstm_weights")
             self._wp_key = None if torch.cuda.is_current_stream_capturing() else key
         return self._wp[0, g0:], gs * self._wp.stride(1)
+
+    def _pkey(self):
+        a = self.a
+        return (a.step, a.params._version, a.params.data_ptr())
+
+    def _alloc_wp(self):
+        a = self.a
+        if self._wp is None:
+            n = ((a.D + 15) // 16) * 4 * (a.DP // 16) * 256
+            self._wp = torch.zeros(2, a.Z, n, device=a.device)
 
     # ------------------------------------------------------------------ forward
     def _forward(self, w, B, nets, x_div, S=None, mlp=True, seg=None, fused_mlp=False):
@@ -185,29 +202,36 @@ class PPOLearnerHIP:
           after the steer nets' weight gradients  arena[:4 size_L]      (37 MB)  — beside the throttle nets' lstm_dw
         the throttle nets' bucket arena[4 size_L:P0] is final when the step ends (the chief's all_reduce takes it)."""
         a = self.a
-        if mlp_grads_ready is None:
-            self._run("all", B, inv_b, sorted_rows)
+        # The packed W_hh copies are current iff this learner's own fused optimiser step produced the parameters that are
+        # in the arena now (a chief in another process, a broadcast or a checkpoint load change them behind our back: then
+        # the update's graph carries the packing launch, as in round 3).
+        self._skip_pack = bool(self.fused_pack and self._adam_fresh is not None and self._adam_fresh == self._pkey())
+        try:
+            if mlp_grads_ready is None:
+                self._run("all", B, inv_b, sorted_rows)
+                return self.workspace(B)["losses"]
+            half = (a.Z // 2) * a.size_L
+            for part, rng in (("front", (a.P0, a.total)), ("mid", (0, half)), ("back", None)):
+                self._run(part, B, inv_b, sorted_rows)
+                if rng is not None:
+                    try:
+                        mlp_grads_ready(*rng)
+                    except TypeError:                        # (a round-3 style hook without arguments: the MLP bucket only)
+                        if part == "front":
+                            mlp_grads_ready()
             return self.workspace(B)["losses"]
-        half = (a.Z // 2) * a.size_L
-        for part, rng in (("front", (a.P0, a.total)), ("mid", (0, half)), ("back", None)):
-            self._run(part, B, inv_b, sorted_rows)
-            if rng is not None:
-                try:
-                    mlp_grads_ready(*rng)
-                except TypeError:                            # (a round-3 style hook without arguments: the MLP bucket only)
-                    if part == "front":
-                        mlp_grads_ready()
-        return self.workspace(B)["losses"]
+        finally:
+            self._skip_pack = False                          # (act / get_value outside an update always check the copies)
 
     def _run(self, part, B, inv_b, sorted_rows):
         if not self.use_graphs:
             return self._update_body(B, inv_b, sorted_rows, part)
-        key = (part, B, inv_b, sorted_rows)
+        key = (part, B, inv_b, sorted_rows, self._skip_pack)
         g = self._graphs.get(key)
         if g is None:
             n0 = hip.N_CALLS
             self._update_body(B, inv_b, sorted_rows, part)          # eager warm-up (func attributes, lazy init)
-            self.launches[(part, B)] = hip.N_CALLS - n0             # kernel launches of this part of the step
+            self.launches[(part, B)] = hip.N_CALLS - n0             # kernel launches of this part of the step (latest variant)
             if self._graphs.get(("warm",) + key):
                 torch.cuda.synchronize()
                 self._graphs[key] = self._capture(lambda: self._update_body(B, inv_b, sorted_rows, part))
@@ -331,15 +355,30 @@ class PPOLearnerHIP:
         a = self.a
         a.ensure_adam()
         a.step += 1
-        key = ("adam", float(lr), float(max_grad_norm), float(betas[0]), float(betas[1]), float(eps))
+        fused = self.fused_pack
+        key = ("adam", float(lr), float(max_grad_norm), float(betas[0]), float(betas[1]), float(eps), fused)
+        if fused:
+            self._alloc_wp()
 
         def body():
-            hip.check(hip.lib().cadre_clip_adam_graph(
-                hip.ptr(a.params), hip.ptr(a.grads), hip.ptr(a.exp_avg), hip.ptr(a.exp_avg_sq), hip.ptr(a.seg_off),
-                2 * a.Z, hip.ptr(a.norms2), key[2], key[1], key[3], key[4], key[5], hip.ptr(a.step_dev),
-                hip.stream()), "cadre_clip_adam_graph")
+            if fused:
+                hip.check(hip.lib().cadre_clip_adam_pack_graph(
+                    hip.ptr(a.params), hip.ptr(a.grads), hip.ptr(a.exp_avg), hip.ptr(a.exp_avg_sq), hip.ptr(a.seg_off),
+                    2 * a.Z, hip.ptr(a.norms2), key[2], key[1], key[3], key[4], key[5], hip.ptr(a.step_dev),
+                    a.Z, a.size_L, a.o_whh, a.H4, a.DP, a.D, hip.ptr(self._wp[0]), hip.ptr(self._wp[1]), self._wp.stride(1),
+                    hip.stream()), "cadre_clip_adam_pack_graph")
+            else:
+                hip.check(hip.lib().cadre_clip_adam_graph(
+                    hip.ptr(a.params), hip.ptr(a.grads), hip.ptr(a.exp_avg), hip.ptr(a.exp_avg_sq), hip.ptr(a.seg_off),
+                    2 * a.Z, hip.ptr(a.norms2), key[2], key[1], key[3], key[4], key[5], hip.ptr(a.step_dev),
+                    hip.stream()), "cadre_clip_adam_graph")
+
+        def done():
+            self._adam_fresh = self._pkey() if fused else None      # (the copies now match the stepped parameters)
+            self._wp_key = self._adam_fresh if fused else self._wp_key
         if not self.use_graphs:
-            return body()
+            body()
+            return done()
         g = self._graphs.get(key)
         if g is None:
             if self._graphs.get(("warm",) + key):
@@ -347,10 +386,12 @@ class PPOLearnerHIP:
                 g = self._capture(body)
                 self._graphs[key] = g
                 g.replay()
-                return
+                return done()
             self._graphs[("warm",) + key] = True
-            return body()
+            body()
+            return done()
         g.replay()
+        done()
 
     def clip_adam_sharded(self, lo, hi, all_reduce_norms, lr=3e-4, max_grad_norm=250.0, betas=(0.9, 0.999), eps=1e-8):
         """The same step on arena elements [lo, hi) only (data-parallel ranks after a reduce-scatter of the

@@ -355,6 +355,17 @@ int cadre_clip_adam_graph(float* params, const float* grads, float* exp_avg, flo
                           void* stream);
 
 
+/* cadre_clip_adam_graph that ALSO maintains the fragment-order copies of the recurrent weights (cadre_pack_lstm_weights'
+ * `fwd` / `bwd`, net stride p_str): models 0 .. n_lstm-1 are LSTM blocks of lstm_str floats whose W_hh [H4 = 4 D][ldw = 544]
+ * starts o_whh floats into the block.  The thread that steps a 4 x 4 block of W_hh stores it into both copies, so the
+ * update needs no packing launch after an optimiser step (chief.py:13-21 + models.py:139-152's weights for the next step).
+ * Same parameters, bit for bit, as cadre_clip_adam_graph followed by cadre_pack_lstm_weights. */
+int cadre_clip_adam_pack_graph(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                               const int64_t* seg_off, int32_t n_models, double* norms2, double max_norm, double lr,
+                               double beta1, double beta2, double eps, int32_t* step_dev, int32_t n_lstm,
+                               int64_t lstm_str, int64_t o_whh, int32_t H4, int32_t ldw, int32_t D, float* fwd,
+                               float* bwd, int64_t p_str, void* stream);
+
 /* Data-parallel ranks with a reduce-scattered gradient arena (reference semantics chief.py:13-21: SUM
  * over workers, per-model clip, Adam): this rank owns arena elements [rlo, rhi) (multiples of 4).
  * cadre_clip_adam_norms: increments *step_dev, stores the step's bias-correction scalars in norms2[n_models..+2) and

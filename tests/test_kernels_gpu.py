@@ -810,6 +810,49 @@ def test_clip_adam(hip):
         assert float((pd.cpu() - want).abs().max()) < 2e-7
 
 
+def test_clip_adam_with_weight_packing_equals_adam_then_pack(hip):
+    """cadre_clip_adam_pack_graph (the optimiser step writes the fragment-order copies of W_hh itself) against
+    cadre_clip_adam_graph followed by cadre_pack_lstm_weights on the real arena layout: parameters, both Adam moments and
+    both packed copies bit-identical over three steps (chief.py:13-21; models.py:139-152's weights of the next update)."""
+    from cadre_amd.arena import PPOArena
+    L = hip.lib()
+    arenas = [PPOArena("cuda:0", 530, {"steer": 33, "throttle": 3}, 4) for _ in range(2)]
+    g = torch.Generator(device="cuda").manual_seed(5)
+    p0 = torch.randn(arenas[0].total, device="cuda", generator=g) * 0.05
+    a0 = arenas[0]
+    # zero padding of the arena stays zero: columns D..DP-1 of the LSTM matrices
+    for z in range(a0.Z):
+        for o in (a0.o_wih, a0.o_whh):
+            p0[z * a0.size_L + o: z * a0.size_L + o + a0.H4 * a0.DP].view(a0.H4, a0.DP)[:, a0.D:] = 0
+    n_pack = ((a0.D + 15) // 16) * 4 * (a0.DP // 16) * 256
+    packs = [torch.zeros(2, a0.Z, n_pack, device="cuda") for _ in range(2)]
+    for a in arenas:
+        a.params.copy_(p0)
+        a.ensure_adam()
+    for step in range(3):
+        gr = torch.randn(a0.total, device="cuda", generator=g) * (40.0 if step == 1 else 0.3)      # step 1: the clip bites
+        for z in range(a0.Z):
+            for o in (a0.o_wih, a0.o_whh):
+                gr[z * a0.size_L + o: z * a0.size_L + o + a0.H4 * a0.DP].view(a0.H4, a0.DP)[:, a0.D:] = 0
+        for a in arenas:
+            a.grads.copy_(gr)
+        a, wp = arenas[0], packs[0]
+        hip.check(L.cadre_clip_adam_graph(hip.ptr(a.params), hip.ptr(a.grads), hip.ptr(a.exp_avg), hip.ptr(a.exp_avg_sq), hip.ptr(a.seg_off),
+                                          2 * a.Z, hip.ptr(a.norms2), 250.0, 3e-4, 0.9, 0.999, 1e-8, hip.ptr(a.step_dev), hip.stream()), "adam")
+        hip.check(L.cadre_pack_lstm_weights(hip.ptr(a.params[a.o_whh:]), a.size_L, a.DP, a.D, a.Z, hip.ptr(wp[0]), hip.ptr(wp[1]),
+                                            wp.stride(1), hip.stream()), "pack")
+        a, wp = arenas[1], packs[1]
+        hip.check(L.cadre_clip_adam_pack_graph(hip.ptr(a.params), hip.ptr(a.grads), hip.ptr(a.exp_avg), hip.ptr(a.exp_avg_sq),
+                                               hip.ptr(a.seg_off), 2 * a.Z, hip.ptr(a.norms2), 250.0, 3e-4, 0.9, 0.999, 1e-8,
+                                               hip.ptr(a.step_dev), a.Z, a.size_L, a.o_whh, a.H4, a.DP, a.D, hip.ptr(wp[0]), hip.ptr(wp[1]),
+                                               wp.stride(1), hip.stream()), "adam+pack")
+        torch.cuda.synchronize()
+        assert torch.equal(arenas[0].params, arenas[1].params), step
+        assert torch.equal(arenas[0].exp_avg, arenas[1].exp_avg) and torch.equal(arenas[0].exp_avg_sq, arenas[1].exp_avg_sq)
+        assert torch.equal(packs[0], packs[1]), step
+    assert float(packs[1].abs().max()) > 0 and int(arenas[1].step_dev.item()) == 3
+
+
 # ----------------------------------------------------------------------------- bf16 GEMM (config C3)
 def _bf(x):
     return x.to(torch.bfloat16)

@@ -486,6 +486,41 @@ def test_row_sorted_update_equals_unsorted(Bw, nW):
         assert int(a_p.learner.workspace(Bw * nW)["sync"][-1]) == 0      # no bounded spin ran out
 
 
+def test_optimiser_step_that_writes_the_weight_copies_is_bit_identical():
+    """CADRE_ADAM_PACK=1 (opt-in): clip_adam() writes the fragment-order W_hh copies itself and the next update carries
+    no packing launch.  Several update -> optimiser-step rounds, plus a parameter write from outside in between (which
+    must bring the separate packing launch back), against the default path: same losses, gradients, parameters."""
+    from ppo_agent.storage import RolloutStorage
+    a_f, a_d = make_agent(84, 84), make_agent(84, 84)
+    a_f.learner.fused_pack = True
+    assert not a_d.learner.fused_pack
+    T, Bw = 128, 64
+    data = fill_storages(T, 913)
+    pair = []
+    for hd in ("steer", "throttle"):
+        s = RolloutStorage(T, 2, 530, 8, 530, True, 0.99, 0.95)
+        for k, v in data[hd].items():
+            getattr(s, k).copy_(torch.from_numpy(v))
+        s.to("cuda:0")
+        s.compute_returns(torch.tensor([0.1]))
+        pair.append(s)
+    g = torch.Generator().manual_seed(5)
+    for it in range(6):
+        idx = [torch.randperm(T, generator=g)[:Bw] for _ in range(2)]
+        batches = [(pair[0], idx[0], pair[0].advantages, pair[1], idx[1], pair[1].advantages)]
+        l_f, l_d = a_f.update_policy_from_storages(batches), a_d.update_policy_from_storages(batches)
+        assert torch.equal(torch.as_tensor(l_f).cpu(), torch.as_tensor(l_d).cpu()), it
+        assert torch.equal(a_f.arena.grads, a_d.arena.grads), it
+        if it >= 1:
+            assert a_f.learner._adam_fresh is not None       # the step before this update left the copies current
+        a_f.learner.clip_adam(3e-3, 250.0)
+        a_d.learner.clip_adam(3e-3, 250.0)
+        assert torch.equal(a_f.arena.params, a_d.arena.params), it
+        if it == 3:                                          # parameters replaced behind the learner's back (load / broadcast)
+            for a in (a_f, a_d):
+                a.arena.params.mul_(0.5)
+
+
 def test_full_size_learner_section_vs_oracle():
     """BASELINE C2 sizes (T=128, mini_batch_num=2 -> minibatch 64, fused-gather + hipGraph path):
     get_value, GAE, advantage normalisation and one epoch of updates + clip + Adam vs the oracle."""
