@@ -44,10 +44,16 @@ def _khwc(w):
     return k.reshape(o, -1).contiguous()
 
 
-def _stem_taps(w, ntaps):
-    """OIHW Cin=4 stem weights -> tap-major [O][ntaps][4] (tap = ky*KW + kx, zero taps appended): the B operand of
-    the fused front (cadre_stem_pool): K = 4*ntaps instead of the row formulation's KH*32."""
+def _stem_taps(w, ntaps, row8=False):
+    """OIHW Cin=4 stem weights -> tap-major [O][ntaps][4], the B operand of the fused front (cadre_stem_pool).
+    fp32: tap = ky*KW + kx, zero taps appended (K = 4*50).  bf16 (row8): tap = ky*8 + kx with zero weights at kx = 7
+    (K = 4*56): no pair of adjacent taps straddles a kernel row (stem_pool.hip, second form)."""
     o, i, kh, kw = w.shape
+    if row8:
+        assert kw <= 8 and ntaps == kh * 8
+        out = torch.zeros(o, kh, 8, i, dtype=torch.float32)
+        out[:, :, :kw] = w.permute(0, 2, 3, 1)
+        return out.reshape(o, ntaps * i).contiguous()
     out = torch.zeros(o, ntaps, i, dtype=torch.float32)
     out[:, :kh * kw] = w.permute(0, 2, 3, 1).reshape(o, kh * kw, i)
     return out.reshape(o, ntaps * i).contiguous()
@@ -141,7 +147,10 @@ class DANetEncoderHIP:
         # fused front (pack -> LUT -> stem conv + BN + ReLU -> max-pool in one kernel, stem_pool.hip)
         self.fused_stem = bool(hip.lib().cadre_stem_pool_supported(H, W)) and os.environ.get("CADRE_FUSED_STEM", "1") != "0"
         if self.fused_stem:
-            wt = _stem_taps(sd["backbone.conv1.weight"], 52 if self.bf16 else 50)
+            w1 = torch.as_tensor(sd["backbone.conv1.weight"]).float()
+            if self.bf16:                            # BN scale folded into the bf16 weights (the kernel starts its sums at the shift)
+                w1 = w1 * self.stem.scale.detach().cpu().float().view(-1, 1, 1, 1)
+            wt = _stem_taps(w1, 56 if self.bf16 else 50, row8=self.bf16)
             self.stem_taps = wt.to(dev).to(torch.bfloat16 if self.bf16 else torch.float32)
         if self.bf16:
             # bf16 stem on a zero-padded NHWC4 image (3 px halo; row pitch padded so every 8-pixel tap
@@ -305,7 +314,7 @@ class DANetEncoderHIP:
             Hs, Ws = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
             Hp, Wp = (Hs + 2 - 3) // 2 + 1, (Ws + 2 - 3) // 2 + 1
             p = self._buf("pool", (F, Hp, Wp, 64), torch.bfloat16 if self.bf16 else torch.float32)
-            hip.check(L.cadre_stem_pool(hip.ptr(x), hip.ptr(self.stem_taps), hip.ptr(self.stem.scale), hip.ptr(self.stem.shift),
+            hip.check(L.cadre_stem_pool(hip.ptr(x), hip.ptr(self.stem_taps), None if self.bf16 else hip.ptr(self.stem.scale), hip.ptr(self.stem.shift),
                                         hip.ptr(p), F, H, W, 1 if self.bf16 else 0,
                                         Hp * Wp * 64, Wp * 64, 64, 0, st), "cadre_stem_pool")
             return self._trunk(p, F, Hp, Wp, out, ldo, taps)

@@ -150,7 +150,9 @@ int cadre_pack_obs(const uint8_t* rgb, const uint8_t* route, uint32_t* out, uint
  * u32 scratch of n_src entries; without it n_src is ignored and frame_max holds F entries.) */
 /* Fused encoder front: packed observation -> /255 -> conv1 7x7/s2/p3 (4 -> 64) + folded BN + ReLU ->
  * MaxPool2d(3,2,1)  (agent.py:46, resnet.py:111-115,168-172) in one kernel; the stem map never reaches HBM.
- * wt: tap-major weights [64][taps][4] (tap = ky*7 + kx; fp32: 50 taps, bf16: 52 taps, zero padded).
+ * wt: tap-major weights [64][taps][4]; fp32: tap = ky*7 + kx, 50 taps (one zero tap), BN scale in `scale`;
+ *     bf16: tap = ky*8 + kx, 56 taps (kx = 7: zeros), ALREADY multiplied by the BN scale and `scale` = NULL
+ *     (the kernel starts its sums at the shift).
  * out: pooled map, element (f, p, c, ch) at out_off + f*out_frame + p*out_row + c*out_px + ch (f32, or bf16 when
  * bf16 != 0, which also selects bf16 MFMA).  Geometries: cadre_stem_pool_supported(H, W) (host logic). */
 int cadre_stem_pool(const uint32_t* img, const void* wt, const float* scale, const float* shift,

@@ -9,12 +9,19 @@ import sys
 
 import pytest
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 AB = os.path.join(ROOT, "cadre_amd", "csrc", "libcadre_hip_ab.so")
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.skipif(not os.path.exists(AB), reason="A/B library not built (CADRE_BUILD_AB=1 python -m cadre_amd.build)")
+def _ab_current():
+    from cadre_amd import build as b
+    return os.path.exists(AB) and not b.needs_build(ab=True)
+
+
+@pytest.mark.skipif(not _ab_current(), reason="A/B library missing or older than its sources (CADRE_BUILD_AB=1 python -m cadre_amd.build)")
 @pytest.mark.parametrize("switch", ["CADRE_RING_G=2", "CADRE_RING_1W=1"])
 def test_ab_window_conv_variants_match_torch(switch):
     k, v = switch.split("=")

@@ -17,8 +17,8 @@ for dt in ("f32", "bf16"):
     L = hip.lib()
     p = enc._buf("pool", (F, 72, 72, 64), torch.bfloat16 if dt == "bf16" else torch.float32)
     def run():
-        hip.check(L.cadre_stem_pool(hip.ptr(x), hip.ptr(enc.stem_taps), hip.ptr(enc.stem.scale), hip.ptr(enc.stem.shift), hip.ptr(p),
+        hip.check(L.cadre_stem_pool(hip.ptr(x), hip.ptr(enc.stem_taps), (None if dt == 'bf16' else hip.ptr(enc.stem.scale)), hip.ptr(enc.stem.shift), hip.ptr(p),
                                     F, H, W, 1 if dt == "bf16" else 0, 72 * 72 * 64, 72 * 64, 64, 0, hip.stream()), "stem")
     t = timeit(run)
     fl = 2.0 * F * 144 * 144 * 64 * 196
-    print("stem_pool %s CH=%s: %.3f ms  %.1f TFLOP/s (algorithmic K=196)" % (dt, os.environ.get("CADRE_STEM_CH", "3"), t * 1e3, fl / t / 1e12), flush=True)
+    print("stem_pool %s: %.3f ms  %.1f TFLOP/s (algorithmic K=196)" % (dt, t * 1e3, fl / t / 1e12), flush=True)
