@@ -504,6 +504,8 @@ def run_config(name, args, rank, local_rank, world, use_dist, steps, warmup, epi
         "t_encode_ms": round(t_enc * 1e3, 3), "t_update_ms": round(t_upd * 1e3, 3),
         "encoder_frames_per_sec": round(frames / t_enc, 1),
         "encoder_tflops": round(frames * flops_frame / t_enc / 1e12, 2),
+        "encoder_flops_per_round": {"algorithmic_direct_conv": float(frames * flops_frame),
+                                    "executed": float(frames * agent.vae_model.flops_per_frame(executed=True))},
         "update_only_samples_per_sec": round(nW * T * PPO_EPOCH / t_upd, 1),
         "encoder_fwd_GBps": round(enc_bytes / t_enc / 1e9, 1) if not args.dedup else None,
         "encoder_fwd_hbm_frac": round(enc_bytes / t_enc / 1e9 / PEAK_HBM_GBPS, 4) if not args.dedup else None,
@@ -620,6 +622,7 @@ def main():
     ap.add_argument("--no-joint-encode", action="store_true", help="encode each worker's windows separately (chunks of 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-peaks", action="store_true", help="skip the measured-peaks microbenchmarks (HBM copy, MFMA chains; ~2 s)")
+    ap.add_argument("--no-winograd", action="store_true", help="skip the exploratory c2_winograd section (N = 1, C2 headline)")
     ap.add_argument("--no-c3", "--no-nested", dest="no_c3", action="store_true",
                     help="skip the nested section of the line (C3 next to a C2 headline, C2 next to a C3 headline)")
     ap.add_argument("--encoder-dtype", default=None, choices=["f32", "bf16"],
@@ -714,6 +717,27 @@ def main():
         sec, _c, _e, _p = run_config(other, args, rank, dev_index, world, use_dist, n_other, 2)
         sec["metric"], sec["unit"], sec["n_gpus"] = "ppo_update_samples_per_sec", "samples/s", world
         out[other.lower()] = sec
+    # EXPLORATORY: the C2 round again with the >= 256-channel stride-1 3x3 convs of the fp32
+    # model in Winograd F(2x2, 3x3) — same box, same process, under its own key; `value` above is the direct-convolution path
+    if head == "C2" and world == 1 and not args.no_winograd and not args.replay and not args.dedup and args.encoder_dtype is None:
+        os.environ["CADRE_WINOGRAD"] = "1"
+        try:
+            sec, _c, _e, _p = run_config("C2", args, rank, dev_index, world, use_dist, args.steps, 2)
+        finally:
+            os.environ.pop("CADRE_WINOGRAD", None)
+        fl = sec["encoder_flops_per_round"]
+        out["c2_winograd"] = {
+            "value": sec["value"], "unit": "samples/s", "ms_per_step": sec["ms_per_step"], "steps": sec["steps"],
+            "t_encode_ms": sec["t_encode_ms"], "t_update_ms": sec["t_update_ms"], "vs_direct_conv": round(sec["value"] / out["value"], 4),
+            "encoder_flops_per_round": fl,
+            "encoder_tflops_executed": round(fl["executed"] / (sec["t_encode_ms"] * 1e-3) / 1e12, 2),
+            "encoder_tflops_direct_conv_equivalent": sec["encoder_tflops"],
+            "per_kernel": sec["roofline"]["per_kernel"] if sec.get("roofline") else None,
+            "last_losses": sec["last_losses"],
+            "note": "CADRE_WINOGRAD=1 (off by default): layer3 / layer4 / head stride-1 3x3 convs as input transform -> batched "
+                    "fp32 GEMM over 16 planes -> inverse transform; exact fp32 arithmetic in a different order (goldens <= 2e-4, "
+                    "tests/test_encoder_gpu.py); per_kernel rates count EXECUTED FLOPs, the direct-conv-equivalent rate is "
+                    "stated apart and may exceed the fp32 MFMA peak"}
     if rank == 0:
         if not args.no_peaks and world == 1:
             # the datasheet peaks re-measured on this box (stream copy, register-operand MFMA chains): the

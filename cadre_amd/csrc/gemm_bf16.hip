@@ -408,8 +408,9 @@ extern "C" int cadre_gemm_bf16(const cadre_gemm_t* pp, void* stream) {
 #ifdef CADRE_AB_KERNELS
   if (tile == 12) return cadre_conv_stream_bf16_launch(p, stream);       // 64x64 conv, several M-tiles per workgroup
 #endif
-  static const int BMS[12] = {0, 128, 128, 64, 256, 128, 256, 256, 0, 0, 128, 256}, BNS[12] = {0, 128, 64, 64, 128, 256, 64, 256, 0, 0, 64, 64};
-  BCHECK(tile == 1 || tile == 2 || tile == 3 || tile == 4 || tile == 7 || tile == 10 || tile == 11, "bad tile");
+  // 13: 256x128 on 8 waves (4x2, each wave 64x64, two register sets) — N = 128 layers: a quarter less operand traffic per FLOP than 128x128
+  static const int BMS[14] = {0, 128, 128, 64, 256, 128, 256, 256, 0, 0, 128, 256, 0, 256}, BNS[14] = {0, 128, 64, 64, 128, 256, 64, 256, 0, 0, 64, 64, 0, 128};
+  BCHECK(tile == 1 || tile == 2 || tile == 3 || tile == 4 || tile == 7 || tile == 10 || tile == 11 || tile == 13, "bad tile");
   const int bm = BMS[tile], bn = BNS[tile];
   dim3 grid(((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn), p.split_k, p.batch), block(tile == 7 || tile >= 10 ? 512 : 256);
   hipStream_t st = (hipStream_t)stream;
@@ -425,6 +426,7 @@ extern "C" int cadre_gemm_bf16(const cadre_gemm_t* pp, void* stream) {
   else if (tile == 4) LB(4, 2, 2, 1, 2);
   else if (tile == 10) LB(1, 1, 2, BF16_NS_SMALL, 4);
   else if (tile == 11) LB(2, 1, 2, BF16_NS_SMALL, 4);
+  else if (tile == 13) LB(2, 2, 2, 2, 4);
   else LB(4, 2, 4, 1, 2);          // 256 x 256, 8 waves (2 x 4), each wave 128 x 64
   return (int)hipGetLastError();
 }

@@ -82,8 +82,24 @@ def _ring_w(w, cpc):
     return w.permute(0, 2, 3, 1).reshape(o, kh * kw, i // cpc, cpc).permute(0, 2, 1, 3).contiguous()
 
 
+# EXPLORATORY: Winograd F(2x2, 3x3) for the fp32 model's stride-1 3x3 convs with >= WINOGRAD_MIN_C input channels
+def _winograd_min_c():
+    """0 = off (default); CADRE_WINOGRAD=1: convs with >= CADRE_WINOGRAD_MIN_C (256) input channels.  Read when an encoder is built."""
+    if os.environ.get("CADRE_WINOGRAD", "0") in ("", "0"):
+        return 0
+    return int(os.environ.get("CADRE_WINOGRAD_MIN_C", "256"))
+
+
+def _winograd_u(w):
+    """OIHW 3x3 weights -> U[16][O][I] = (G g G^T)[xi], xi = 4i + j (float64 product, one rounding to fp32): the B operands of
+    the batched GEMM between cadre_winograd_in and cadre_winograd_out (csrc/winograd.hip)."""
+    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
+    u = torch.einsum("ik,ockl,jl->ijoc", G, w.double(), G)             # [4][4][O][I]
+    return u.reshape(16, w.shape[0], w.shape[1]).float().contiguous()
+
+
 class _Conv:
-    __slots__ = ("w", "w_ring", "ring_folded", "scale", "shift", "cin", "cout", "k", "stride", "pad", "act")
+    __slots__ = ("w", "w_ring", "ring_folded", "scale", "shift", "cin", "cout", "k", "stride", "pad", "act", "w_wino")
 
     def __init__(self, w, scale, shift, k, stride, pad, act, dev, wdtype=torch.float32):
         self.w = _khwc(w).to(dev).to(wdtype)
@@ -104,6 +120,11 @@ class _Conv:
         self.shift = None if shift is None else shift.contiguous().to(dev)
         self.cout, self.cin = w.shape[0], w.shape[1]
         self.k, self.stride, self.pad, self.act = k, stride, pad, act
+        self.w_wino = None
+        wmin = _winograd_min_c()
+        if (wmin and wdtype == torch.float32 and k == 3 and stride == 1 and pad == 1 and w.shape[1] >= wmin
+                and w.shape[0] >= 128 and w.shape[1] % 4 == 0 and w.shape[0] % 4 == 0):
+            self.w_wino = _winograd_u(w).to(dev)
 
 
 class DANetEncoderHIP:
@@ -212,6 +233,7 @@ class DANetEncoderHIP:
             if int(bad.item()) != 0:
                 self.fused_stem = False
         self._ws = {}
+        self._ws_flat = {}
         self.ws_generation = 0
         self.n_weights = sum(t.numel() for t in self._all_weight_tensors())
 
@@ -242,6 +264,15 @@ class DANetEncoderHIP:
             self.ws_generation += 1
         return t
 
+    def _flat(self, key, n):
+        """First n elements of a flat fp32 workspace that only grows (layers of different shapes share it, one after another)."""
+        t = self._ws_flat.get(key)
+        if t is None or t.numel() < n:
+            t = torch.empty(n, dtype=torch.float32, device=self.device)
+            self._ws_flat[key] = t
+            self.ws_generation += 1
+        return t[:n]
+
     # ------------------------------------------------------------------ layers
     def _conv(self, c, x, F, H, W, key, resid=None, act=None, out_f32=False):
         Ho = (H + 2 * c.pad - c.k) // c.stride + 1
@@ -260,7 +291,18 @@ class DANetEncoderHIP:
                       | (0 if resid is None else (8 | (4 if resid.dtype == torch.bfloat16 else 0))))
         use_ring = (c.w_ring is not None and self.ring_conv and x.dtype == c.w_ring.dtype and (act & 15) <= 1
                     and bool(hip.lib().cadre_conv3x3_ring_supported(F, H, W, c.cin, c.cout, ring_flags)))
-        if use_c64 and (self.c64_kernel == 2 or not use_ring):
+        if c.w_wino is not None and x.dtype == torch.float32 and odt == torch.float32 and (act & 15) <= 1:
+            # EXPLORATORY: input transform -> one batched GEMM over the 16 transform planes -> inverse transform + BN + residual + ReLU
+            T = F * ((H + 1) // 2) * ((W + 1) // 2)
+            V = self._flat("wino_v", 16 * T * c.cin).view(16, T, c.cin)
+            Mx = self._flat("wino_m", 16 * T * c.cout).view(16, T, c.cout)
+            L = hip.lib()
+            hip.check(L.cadre_winograd_in(hip.ptr(x), hip.ptr(V), F, H, W, c.cin, hip.stream()), "cadre_winograd_in")
+            hip.gemm(V, c.w_wino, Mx, T, c.cout, c.cin, c.cin, c.cin, c.cout, batch=16,
+                     a_z=(1, 16, T * c.cin), b_z=(1, 16, c.cout * c.cin), c_z=(1, 16, T * c.cout))
+            hip.check(L.cadre_winograd_out(hip.ptr(Mx), hip.ptr(c.scale), hip.ptr(c.shift), hip.ptr(resid), hip.ptr(out),
+                                           F, H, W, c.cout, act, hip.stream()), "cadre_winograd_out")
+        elif use_c64 and (self.c64_kernel == 2 or not use_ring):
             # stage-1 convs of the bf16 encoder with the weights resident in LDS (bit-identical to cadre_gemm_bf16);
             # the window kernel below measures 3 % faster on them and takes precedence unless CADRE_C64_KERNEL=2
             hip.conv3x3_c64_bf16(x, c.w, c.scale, c.shift, resid, out, F, H, W, 1 if act == 1 else 0)
@@ -439,12 +481,16 @@ class DANetEncoderHIP:
         act += 2 * Np * 512 + 3072 + 6 * 256 + 512                               # inter-task inputs/outputs
         return e * act * frames + e * self.n_weights
 
-    def flops_per_frame(self):
+    def flops_per_frame(self, executed=False):
+        """Direct-convolution (algorithmic) FLOPs of one frame; executed=True: what the launches multiply — differs only
+        under CADRE_WINOGRAD=1 (16 planes x ceil(H/2) x ceil(W/2) tiles x Cin x Cout per Winograd conv)."""
         H, W = self.H, self.W
         total = 0
         def conv(c, H, W):
             Ho = (H + 2 * c.pad - c.k) // c.stride + 1
             Wo = (W + 2 * c.pad - c.k) // c.stride + 1
+            if executed and c.w_wino is not None:
+                return 2 * 16 * ((H + 1) // 2) * ((W + 1) // 2) * c.cout * c.cin, Ho, Wo
             return 2 * Ho * Wo * c.cout * c.cin * c.k * c.k, Ho, Wo
         f, H, W = conv(self.stem, H, W); total += f
         H, W = (H - 1) // 2 + 1, (W - 1) // 2 + 1

@@ -52,7 +52,11 @@ def main(out_dir):
         pass
     res = {}
     snaps = {}
+    keep = []          # earlier modes' shared tensors stay allocated: a block that was exported over HIP IPC is never handed out
+                       # again inside this process (re-exporting a reused block has failed with hipIpcGetMemHandle: invalid
+                       # argument on some boxes of the pool, once in ~10 runs)
     for mode in ("spawned", "spawned_dist", "in_process"):
+        torch.cuda.ipc_collect()
         work = os.path.join(out_dir, mode)
         os.makedirs(work, exist_ok=True)
         train_cfg, agent_cfg, env_cfg, rollout_cfg = topology_cfgs(work)
@@ -64,6 +68,7 @@ def main(out_dir):
             plist += list(shared[name].parameters())
         device = torch.device("cuda:" + str(agent_cfg.model_cfg.device_num))
         bufs = Shared_grad_buffers(shared, device)
+        keep.append((shared, bufs))
         if mode in ("spawned", "spawned_dist"):
             light, counter, sons = TrafficLight(), Counter(), Counter()
             opt = optim.Adam(plist, lr=train_cfg.lr)

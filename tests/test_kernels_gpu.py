@@ -1142,6 +1142,50 @@ def test_conv_decode_random_geometries(hip):
             assert rel(out.permute(0, 3, 1, 2), want16) < 1e-4, (cases[ci], tile, "bf16")
 
 
+@pytest.mark.parametrize("F,H,W,Cin,N,use_resid,act", [(3, 9, 9, 64, 128, True, 1), (2, 18, 18, 32, 64, False, 1), (2, 7, 10, 16, 32, True, 17),
+                                                     (1, 1, 1, 8, 8, False, 0), (5, 6, 5, 12, 20, True, 0)])
+def test_winograd_conv3x3_matches_torch(hip, F, H, W, Cin, N, use_resid, act):
+    """cadre_winograd_in -> batched cadre_gemm_f32 over the 16 transform planes -> cadre_winograd_out (EXPLORATORY,
+    CADRE_WINOGRAD=1) vs torch conv2d fp32 on the reference layer's formulation (resnet.py:26-55: conv3x3 / s1 / p1 +
+    folded BN + residual + ReLU), odd sizes (the last tile row / column is half outside the map) and a 1x1 map; and the
+    same frames inside a larger batch give the same bits."""
+    from cadre_amd.encoder import _winograd_u
+    g = torch.Generator().manual_seed(F * 100 + H)
+    x = torch.randn(F, H, W, Cin, generator=g)
+    w = torch.randn(N, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5
+    sc, sh = 0.5 + torch.rand(N, generator=g), torch.randn(N, generator=g)
+    res = torch.randn(F, H, W, N, generator=g) if use_resid else None
+    want = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1) * sc + sh
+    if res is not None and not (act & 16):
+        want = want + res
+    if (act & 15) == 1:
+        want = torch.relu(want)
+    if res is not None and (act & 16):
+        want = want + res
+
+    def run(xd, rd, Fb):
+        T = Fb * ((H + 1) // 2) * ((W + 1) // 2)
+        V = torch.full((16, T, Cin), 7.0, device="cuda")
+        Mx = torch.full((16, T, N), 7.0, device="cuda")
+        out = torch.full((Fb, H, W, N), 7.0, device="cuda")
+        L = hip.lib()
+        hip.check(L.cadre_winograd_in(hip.ptr(xd), hip.ptr(V), Fb, H, W, Cin, hip.stream()), "in")
+        hip.gemm(V, u, Mx, T, N, Cin, Cin, Cin, N, batch=16, a_z=(1, 16, T * Cin), b_z=(1, 16, N * Cin), c_z=(1, 16, T * N))
+        hip.check(L.cadre_winograd_out(hip.ptr(Mx), hip.ptr(scd), hip.ptr(shd), hip.ptr(rd), hip.ptr(out), Fb, H, W, N, act, hip.stream()), "out")
+        return out
+    u, scd, shd = dev(_winograd_u(w)), dev(sc), dev(sh)
+    got = run(dev(x), None if res is None else dev(res), F)
+    assert rel(got.cpu(), want) < 2e-5, float((got.cpu() - want).abs().max())
+    big = 7
+    xb = torch.randn(big, H, W, Cin, generator=g)
+    rb = torch.randn(big, H, W, N, generator=g) if use_resid else None
+    xb[2:2 + F] = x
+    if rb is not None:
+        rb[2:2 + F] = res
+    gb = run(dev(xb), None if rb is None else dev(rb), big)
+    assert torch.equal(gb[2:2 + F], got) or F + 2 > big
+
+
 @pytest.mark.parametrize("H,W,F", [(84, 84, 3), (144, 256, 2), (288, 288, 2)])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_fused_stem_pool(hip, H, W, F, dtype):
