@@ -487,6 +487,8 @@ def run_config(name, args, rank, local_rank, world, use_dist, steps, warmup, epi
                 "untimed pass; bytes = 48 x %d parameters + %d activation bytes (SURVEY.md 8d)" % (P, act_bytes)}
     frames = nW * (T + SEQ - 1 if args.dedup else T * SEQ)
     flops_frame = agent.vae_model.flops_per_frame()
+    flops_exec = agent.vae_model.flops_per_frame(executed=True)
+    n_wino = agent.vae_model.winograd_convs()
     nwin = nW * T if joint is not None else T
     enc_bytes = sum(agent.vae_model.algorithmic_bytes(min(cw, nwin - t0) * SEQ) for t0 in range(0, nwin, cw)) * (1 if joint is not None else nW)
     out = {
@@ -500,12 +502,18 @@ def run_config(name, args, rank, local_rank, world, use_dist, steps, warmup, epi
                                   else "8 frames/transition, reference convention",
                                   "fp32" if enc_dtype == "f32" else "bf16 encoder / fp32 losses"),
                    "workers_per_gpu": nW, "num_steps": T, "obs": [H, W], "minibatch_per_gpu": nW * T // MINI_BATCH_NUM,
-                   "parallelism": "dp%d" % world, "frames_per_round_per_gpu": frames},
+                   "parallelism": "dp%d" % world, "frames_per_round_per_gpu": frames,
+                   "conv_algorithm": ("Winograd F(3x3,3x3) fp32 (exact tiling of the 36x36 / 18x18 / 9x9 maps) on the %d stride-1 3x3 "
+                                      "convs with >= 128 input channels (layer2, layer3, layer4, head), direct convolution elsewhere; "
+                                      "CADRE_WINOGRAD=0 = direct everywhere (c2_direct_conv)" % n_wino) if n_wino else "direct"},
         "t_encode_ms": round(t_enc * 1e3, 3), "t_update_ms": round(t_upd * 1e3, 3),
         "encoder_frames_per_sec": round(frames / t_enc, 1),
         "encoder_tflops": round(frames * flops_frame / t_enc / 1e12, 2),
-        "encoder_flops_per_round": {"algorithmic_direct_conv": float(frames * flops_frame),
-                                    "executed": float(frames * agent.vae_model.flops_per_frame(executed=True))},
+        "encoder_tflops_executed": round(frames * flops_exec / t_enc / 1e12, 2),
+        "encoder_flops_per_round": {"algorithmic_direct_conv": float(frames * flops_frame), "executed": float(frames * flops_exec)},
+        "encoder_tflops_note": "encoder_tflops counts DIRECT-convolution FLOPs (the algorithmic work of the layer stack) over "
+                               "t_encode; with Winograd convs fewer are executed (encoder_tflops_executed) — the roofline "
+                               "object and per_kernel count executed FLOPs only",
         "update_only_samples_per_sec": round(nW * T * PPO_EPOCH / t_upd, 1),
         "encoder_fwd_GBps": round(enc_bytes / t_enc / 1e9, 1) if not args.dedup else None,
         "encoder_fwd_hbm_frac": round(enc_bytes / t_enc / 1e9 / PEAK_HBM_GBPS, 4) if not args.dedup else None,
@@ -622,7 +630,7 @@ def main():
     ap.add_argument("--no-joint-encode", action="store_true", help="encode each worker's windows separately (chunks of 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-peaks", action="store_true", help="skip the measured-peaks microbenchmarks (HBM copy, MFMA chains; ~2 s)")
-    ap.add_argument("--no-winograd", action="store_true", help="skip the exploratory c2_winograd section (N = 1, C2 headline)")
+    ap.add_argument("--no-direct-conv", action="store_true", help="skip the c2_direct_conv section (C2 again with CADRE_WINOGRAD=0; N = 1, C2 headline)")
     ap.add_argument("--no-c3", "--no-nested", dest="no_c3", action="store_true",
                     help="skip the nested section of the line (C3 next to a C2 headline, C2 next to a C3 headline)")
     ap.add_argument("--encoder-dtype", default=None, choices=["f32", "bf16"],
@@ -717,27 +725,22 @@ def main():
         sec, _c, _e, _p = run_config(other, args, rank, dev_index, world, use_dist, n_other, 2)
         sec["metric"], sec["unit"], sec["n_gpus"] = "ppo_update_samples_per_sec", "samples/s", world
         out[other.lower()] = sec
-    # EXPLORATORY: the C2 round again with the >= 256-channel stride-1 3x3 convs of the fp32
-    # model in Winograd F(2x2, 3x3) — same box, same process, under its own key; `value` above is the direct-convolution path
-    if head == "C2" and world == 1 and not args.no_winograd and not args.replay and not args.dedup and args.encoder_dtype is None:
-        os.environ["CADRE_WINOGRAD"] = "1"
+    # The fp32 model's >= 128-channel stride-1 3x3 convs run as Winograd F(3x3, 3x3) (exact fp32 arithmetic in another
+    # order).  The same C2 round with direct convolution everywhere (CADRE_WINOGRAD=0), same box, same
+    # process, under its own key — so that the line always states what the algorithm is worth
+    if head == "C2" and world == 1 and not args.no_direct_conv and not args.replay and not args.dedup and args.encoder_dtype is None \
+            and os.environ.get("CADRE_WINOGRAD", "1") not in ("", "0"):
+        os.environ["CADRE_WINOGRAD"] = "0"
         try:
             sec, _c, _e, _p = run_config("C2", args, rank, dev_index, world, use_dist, args.steps, 2)
         finally:
             os.environ.pop("CADRE_WINOGRAD", None)
-        fl = sec["encoder_flops_per_round"]
-        out["c2_winograd"] = {
+        out["c2_direct_conv"] = {
             "value": sec["value"], "unit": "samples/s", "ms_per_step": sec["ms_per_step"], "steps": sec["steps"],
-            "t_encode_ms": sec["t_encode_ms"], "t_update_ms": sec["t_update_ms"], "vs_direct_conv": round(sec["value"] / out["value"], 4),
-            "encoder_flops_per_round": fl,
-            "encoder_tflops_executed": round(fl["executed"] / (sec["t_encode_ms"] * 1e-3) / 1e12, 2),
-            "encoder_tflops_direct_conv_equivalent": sec["encoder_tflops"],
-            "per_kernel": sec["roofline"]["per_kernel"] if sec.get("roofline") else None,
-            "last_losses": sec["last_losses"],
-            "note": "CADRE_WINOGRAD=1 (off by default): layer3 / layer4 / head stride-1 3x3 convs as input transform -> batched "
-                    "fp32 GEMM over 16 planes -> inverse transform; exact fp32 arithmetic in a different order (goldens <= 2e-4, "
-                    "tests/test_encoder_gpu.py); per_kernel rates count EXECUTED FLOPs, the direct-conv-equivalent rate is "
-                    "stated apart and may exceed the fp32 MFMA peak"}
+            "t_encode_ms": sec["t_encode_ms"], "t_update_ms": sec["t_update_ms"],
+            "winograd_vs_direct": round(out["value"] / sec["value"], 4),
+            "encoder_tflops": sec["encoder_tflops"], "roofline": sec["roofline"], "last_losses": sec["last_losses"],
+            "note": "CADRE_WINOGRAD=0: every convolution direct (implicit GEMM / window kernels)"}
     if rank == 0:
         if not args.no_peaks and world == 1:
             # the datasheet peaks re-measured on this box (stream copy, register-operand MFMA chains): the

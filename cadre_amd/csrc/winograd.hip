@@ -1,17 +1,16 @@
-// winograd.hip — Winograd F(2x2, 3x3) in fp32 for the stride-1 3x3 convolutions of the DANet trunk and head
-// (carla_perception/Networks/danet_blocks/resnet.py:26-55, danet.py:21-41), EXPLORATORY (CADRE_WINOGRAD=1, off by
-// default): the fp32 encoder sits at 0.84-0.86 of the direct-convolution MFMA roof, and 2.25x fewer
-// multiply-accumulates is the only lever above 10 % that does not narrow the arithmetic.
+// winograd.hip — Winograd F(m x m, 3x3), m = 2 or 3, in fp32 for the stride-1 3x3 convolutions of the DANet trunk and
+// head with >= 256 input channels (carla_perception/Networks/danet_blocks/resnet.py:26-55, danet.py:21-41;
+// CADRE_WINOGRAD=0 restores direct convolution): the fp32 encoder sits at 0.84-0.86 of the direct-
+// convolution MFMA roof, and fewer multiply-accumulates is the only lever above 10 % that does not narrow the arithmetic.
 //
-//   Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A        d: 4x4 input tile (stride 2, halo 1), Y: 2x2 outputs
-//   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]   A^T = [1 1 1 0; 0 1 -1 -1]
+//   Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A        d: (m+2) x (m+2) input tile (stride m, halo 1), Y: m x m outputs
 //
-// Unfused form: cadre_winograd_in writes V[16][T][Cin] (T = F * ceil(H/2) * ceil(W/2) tiles), ONE batched
-// cadre_gemm_f32 (batch 16: M[xi] = V[xi] . U[xi]^T, U = G g G^T precomputed by the host in float64) and
-// cadre_winograd_out (inverse transform + folded BN + residual + ReLU).  Both transforms are element-wise over
-// channels: a thread owns (tile, 4 channels), every load and store is a coalesced 16-byte access.  HBM traffic
-// per conv: 4x the input (V written, read by the GEMM) + 4x the output (M written, read back) — which is why the
-// form pays only where Cin, Cout >= 256 (layer3 / layer4 / head): DESIGN.md 3.7 has the sizing and the measurement.
+// Unfused form: cadre_winograd_in writes V[(m+2)^2][T][Cin] (T = F * ceil(H/m) * ceil(W/m) tiles), ONE batched
+// cadre_gemm_f32 (M[xi] = V[xi] . U[xi]^T, U = G g G^T precomputed by the host in float64) and cadre_winograd_out
+// (inverse transform + folded BN + residual + ReLU).  Both transforms are element-wise over channels: a thread owns
+// (tile, 4 channels), every load and store is a coalesced 16-byte access.  HBM traffic per conv: (m+2)^2 / m^2 times the
+// input (V written, read by the GEMM) and as much of the output (M written, read back) — which is why the form pays only
+// where Cin, Cout >= 256 (layer3 / layer4 / head): DESIGN.md 3.7 has the sizing and the measurements.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/cadre_hip.h"
@@ -20,8 +19,46 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 int cadre_fail(const char* msg);
 
+// Transform matrices (Cook-Toom, points 0, 1, -1 [, 2], infinity).  F(2x2, 3x3): 4x4 input tiles, 16 planes, 2.25x fewer
+// multiplies than direct; F(3x3, 3x3): 5x5 tiles, 25 planes, 3.24x fewer and only 2.78x (not 4x) the input in transform-domain
+// traffic — the form the encoder picks when it tiles the map at least as well (9x9 and 18x18 maps: exactly).
+template <int M> struct wino_mat;
+template <> struct wino_mat<2> {
+  static constexpr int N = 4;
+  static constexpr float BT[4][4] = {{1, 0, -1, 0}, {0, 1, 1, 0}, {0, -1, 1, 0}, {0, 1, 0, -1}};
+  static constexpr float AT[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
+};
+template <> struct wino_mat<3> {
+  static constexpr int N = 5;
+  static constexpr float BT[5][5] = {{2, -1, -2, 1, 0}, {0, -2, -1, 1, 0}, {0, 2, -3, 1, 0}, {0, -1, 0, 1, 0}, {0, 2, -1, -2, 1}};
+  static constexpr float AT[3][5] = {{1, 1, 1, 1, 0}, {0, 1, -1, 2, 0}, {0, 1, 1, 4, 1}};
+};
+constexpr float wino_mat<2>::BT[4][4];
+constexpr float wino_mat<2>::AT[2][4];
+constexpr float wino_mat<3>::BT[5][5];
+constexpr float wino_mat<3>::AT[3][5];
+
+// sum_k c[k] * v[k] over the non-zero constants (unrolled at compile time; +-1 become adds)
+template <int N>
+__device__ __forceinline__ f32x4 wino_dot(const float (&c)[N], const f32x4* v, int stride) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  bool first = true;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    if (c[k] == 0.f) continue;
+    const f32x4 x = v[k * stride];
+    if (first) { acc = c[k] == 1.f ? x : (c[k] == -1.f ? -x : x * c[k]); first = false; }
+    else if (c[k] == 1.f) acc += x;
+    else if (c[k] == -1.f) acc -= x;
+    else acc += x * c[k];
+  }
+  return acc;
+}
+
+template <int M>
 __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ x, float* __restrict__ V, int F, int H, int W, int C,
                                                        int TH, int TW, long long total) {
+  constexpr int N = wino_mat<M>::N;
   const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
   if (id >= total) return;
   const int C4 = C >> 2;
@@ -30,77 +67,70 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
   const int tx = (int)(tile % TW);
   const long long t2 = tile / TW;
   const int ty = (int)(t2 % TH), f = (int)(t2 / TH);
-  const int r0 = 2 * ty - 1, q0 = 2 * tx - 1;
-  f32x4 d[4][4];
+  const int r0 = M * ty - 1, q0 = M * tx - 1;
+  f32x4 d[N * N];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < N; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < N; ++j) {
       const int r = r0 + i, q = q0 + j;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if ((unsigned)r < (unsigned)H && (unsigned)q < (unsigned)W)
         v = *reinterpret_cast<const f32x4*>(x + (((long long)f * H + r) * W + q) * C + 4 * c4);
-      d[i][j] = v;
+      d[i * N + j] = v;
     }
-  f32x4 t[4][4];
+  f32x4 t[N * N];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {                      // B^T d
-    t[0][j] = d[0][j] - d[2][j];
-    t[1][j] = d[1][j] + d[2][j];
-    t[2][j] = d[2][j] - d[1][j];
-    t[3][j] = d[1][j] - d[3][j];
-  }
+  for (int i = 0; i < N; ++i)                        // B^T d
+#pragma unroll
+    for (int j = 0; j < N; ++j) t[i * N + j] = wino_dot<N>(wino_mat<M>::BT[i], d + j, N);
   const long long T = (long long)F * TH * TW;
   float* vp = V + tile * C + 4 * c4;
   const long long plane = T * C;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {                      // (B^T d) B
-    *reinterpret_cast<f32x4*>(vp + (4 * i + 0) * plane) = t[i][0] - t[i][2];
-    *reinterpret_cast<f32x4*>(vp + (4 * i + 1) * plane) = t[i][1] + t[i][2];
-    *reinterpret_cast<f32x4*>(vp + (4 * i + 2) * plane) = t[i][2] - t[i][1];
-    *reinterpret_cast<f32x4*>(vp + (4 * i + 3) * plane) = t[i][1] - t[i][3];
-  }
+  for (int i = 0; i < N; ++i)                        // (B^T d) B
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+      *reinterpret_cast<f32x4*>(vp + (i * N + j) * plane) = wino_dot<N>(wino_mat<M>::BT[j], t + i * N, 1);
 }
 
 // act: 0 none, 1 ReLU; bit 4: the residual is added AFTER the activation (same codes as cadre_gemm_t.act)
+template <int M>
 __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__ Mx, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, const float* __restrict__ resid,
-                                                        float* __restrict__ out, int F, int H, int W, int N, int TH, int TW,
+                                                        float* __restrict__ out, int F, int H, int W, int Nc, int TH, int TW,
                                                         int act, long long total) {
+  constexpr int N = wino_mat<M>::N;
   const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
   if (id >= total) return;
-  const int N4 = N >> 2;
+  const int N4 = Nc >> 2;
   const int n4 = (int)(id % N4);
   const long long tile = id / N4;
   const int tx = (int)(tile % TW);
   const long long t2 = tile / TW;
   const int ty = (int)(t2 % TH), f = (int)(t2 / TH);
   const long long T = (long long)F * TH * TW;
-  const long long plane = T * N;
-  const float* mp = Mx + tile * N + 4 * n4;
-  f32x4 m[4][4];
+  const long long plane = T * Nc;
+  const float* mp = Mx + tile * Nc + 4 * n4;
+  f32x4 m[N * N];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < N * N; ++i) m[i] = *reinterpret_cast<const f32x4*>(mp + i * plane);
+  f32x4 s[M * N];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) m[i][j] = *reinterpret_cast<const f32x4*>(mp + (4 * i + j) * plane);
-  f32x4 s[2][4];
+  for (int i = 0; i < M; ++i)                        // A^T m
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {                      // A^T m
-    s[0][j] = m[0][j] + m[1][j] + m[2][j];
-    s[1][j] = m[1][j] - m[2][j] - m[3][j];
-  }
+    for (int j = 0; j < N; ++j) s[i * N + j] = wino_dot<N>(wino_mat<M>::AT[i], m + j, N);
   const f32x4 sc = scale ? *reinterpret_cast<const f32x4*>(scale + 4 * n4) : f32x4{1.f, 1.f, 1.f, 1.f};
   const f32x4 sh = shift ? *reinterpret_cast<const f32x4*>(shift + 4 * n4) : f32x4{0.f, 0.f, 0.f, 0.f};
   const bool relu = (act & 15) == 1, post = (act & 16) != 0;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const f32x4 y2[2] = {s[i][0] + s[i][1] + s[i][2], s[i][1] - s[i][2] - s[i][3]};        // (A^T m) A
+  for (int i = 0; i < M; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int r = 2 * ty + i, q = 2 * tx + j;
+    for (int j = 0; j < M; ++j) {
+      const int r = M * ty + i, q = M * tx + j;
       if (r < H && q < W) {
-        const long long e = (((long long)f * H + r) * W + q) * N + 4 * n4;
-        f32x4 y = y2[j] * sc + sh;
+        const long long e = (((long long)f * H + r) * W + q) * Nc + 4 * n4;
+        f32x4 y = wino_dot<N>(wino_mat<M>::AT[j], s + i * N, 1) * sc + sh;       // (A^T m) A
         f32x4 rv = {0.f, 0.f, 0.f, 0.f};
         if (resid) rv = *reinterpret_cast<const f32x4*>(resid + e);
         if (!post) y += rv;
@@ -112,29 +142,33 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
         *reinterpret_cast<f32x4*>(out + e) = y;
       }
     }
-  }
 }
 
-extern "C" int cadre_winograd_in(const float* x, float* V, int32_t F, int32_t H, int32_t W, int32_t C, void* stream) {
+extern "C" int cadre_winograd_in(const float* x, float* V, int32_t F, int32_t H, int32_t W, int32_t C, int32_t m, void* stream) {
   if (!x || !V || F < 1 || H < 1 || W < 1 || C < 4 || (C & 3)) return cadre_fail("cadre_winograd_in: bad argument (C % 4 == 0)");
+  if (m != 2 && m != 3) return cadre_fail("cadre_winograd_in: m must be 2 (F(2x2,3x3)) or 3 (F(3x3,3x3))");
   if (((uintptr_t)x & 15) || ((uintptr_t)V & 15)) return cadre_fail("cadre_winograd_in: operands must be 16-byte aligned");
-  const int TH = (H + 1) / 2, TW = (W + 1) / 2;
+  const int TH = (H + m - 1) / m, TW = (W + m - 1) / m;
   const long long total = (long long)F * TH * TW * (C >> 2);
   if ((total + 255) / 256 > 0x7fffffffLL) return cadre_fail("cadre_winograd_in: too many tiles");
-  hipLaunchKernelGGL(wino_in_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, V, F, H, W, C, TH, TW, total);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (m == 2) hipLaunchKernelGGL(wino_in_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, V, F, H, W, C, TH, TW, total);
+  else hipLaunchKernelGGL(wino_in_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, x, V, F, H, W, C, TH, TW, total);
   return (int)hipGetLastError();
 }
 
 extern "C" int cadre_winograd_out(const float* Mx, const float* scale, const float* shift, const float* resid, float* out,
-                                  int32_t F, int32_t H, int32_t W, int32_t N, int32_t act, void* stream) {
+                                  int32_t F, int32_t H, int32_t W, int32_t N, int32_t act, int32_t m, void* stream) {
   if (!Mx || !out || F < 1 || H < 1 || W < 1 || N < 4 || (N & 3)) return cadre_fail("cadre_winograd_out: bad argument (N % 4 == 0)");
+  if (m != 2 && m != 3) return cadre_fail("cadre_winograd_out: m must be 2 (F(2x2,3x3)) or 3 (F(3x3,3x3))");
   if (((uintptr_t)Mx & 15) || ((uintptr_t)out & 15) || ((uintptr_t)resid & 15) || ((uintptr_t)scale & 15) || ((uintptr_t)shift & 15))
     return cadre_fail("cadre_winograd_out: operands must be 16-byte aligned");
   if ((act & 15) > 1) return cadre_fail("cadre_winograd_out: act must be 0 (none) or 1 (ReLU), bit 4 = residual after the activation");
-  const int TH = (H + 1) / 2, TW = (W + 1) / 2;
+  const int TH = (H + m - 1) / m, TW = (W + m - 1) / m;
   const long long total = (long long)F * TH * TW * (N >> 2);
   if ((total + 255) / 256 > 0x7fffffffLL) return cadre_fail("cadre_winograd_out: too many tiles");
-  hipLaunchKernelGGL(wino_out_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Mx, scale, shift, resid, out,
-                     F, H, W, N, TH, TW, act, total);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (m == 2) hipLaunchKernelGGL(wino_out_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, Mx, scale, shift, resid, out, F, H, W, N, TH, TW, act, total);
+  else hipLaunchKernelGGL(wino_out_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, Mx, scale, shift, resid, out, F, H, W, N, TH, TW, act, total);
   return (int)hipGetLastError();
 }

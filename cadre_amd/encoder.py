@@ -82,24 +82,47 @@ def _ring_w(w, cpc):
     return w.permute(0, 2, 3, 1).reshape(o, kh * kw, i // cpc, cpc).permute(0, 2, 1, 3).contiguous()
 
 
-# EXPLORATORY: Winograd F(2x2, 3x3) for the fp32 model's stride-1 3x3 convs with >= WINOGRAD_MIN_C input channels
 def _winograd_min_c():
-    """0 = off (default); CADRE_WINOGRAD=1: convs with >= CADRE_WINOGRAD_MIN_C (256) input channels.  Read when an encoder is built."""
-    if os.environ.get("CADRE_WINOGRAD", "0") in ("", "0"):
+    """Stride-1 3x3 convs of the fp32 model with at least this many input channels (and >= 128 output channels) run as
+    Winograd F(3x3, 3x3) / F(2x2, 3x3): 128 = layer2, layer3, layer4, head — at 64 channels (layer1) the transform-domain
+    traffic costs more than the fewer MACs save.  CADRE_WINOGRAD=0: direct convolution everywhere
+    (returns 0).  Read when an encoder is built."""
+    if os.environ.get("CADRE_WINOGRAD", "1") in ("", "0"):
         return 0
-    return int(os.environ.get("CADRE_WINOGRAD_MIN_C", "256"))
+    return int(os.environ.get("CADRE_WINOGRAD_MIN_C", "128"))
 
 
-def _winograd_u(w):
-    """OIHW 3x3 weights -> U[16][O][I] = (G g G^T)[xi], xi = 4i + j (float64 product, one rounding to fp32): the B operands of
-    the batched GEMM between cadre_winograd_in and cadre_winograd_out (csrc/winograd.hip)."""
-    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
-    u = torch.einsum("ik,ockl,jl->ijoc", G, w.double(), G)             # [4][4][O][I]
-    return u.reshape(16, w.shape[0], w.shape[1]).float().contiguous()
+_WINO_G = {2: [[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]],
+           3: [[0.5, 0.0, 0.0], [-0.5, -0.5, -0.5], [-1.0 / 6, 1.0 / 6, -1.0 / 6], [1.0 / 6, 1.0 / 3, 2.0 / 3], [0.0, 0.0, 1.0]]}
+
+
+def _winograd_u(w, m=2):
+    """OIHW 3x3 weights -> U[(m+2)^2][O][I] = (G g G^T)[xi], xi = (m+2) i + j (float64 product, one rounding to fp32): the B
+    operands of the batched GEMM between cadre_winograd_in and cadre_winograd_out (csrc/winograd.hip; Cook-Toom points
+    0, 1, -1 [, 2], infinity — G matches the kernels' B^T / A^T)."""
+    G = torch.tensor(_WINO_G[m], dtype=torch.float64)
+    u = torch.einsum("ik,ockl,jl->ijoc", G, torch.as_tensor(w).double(), G)        # [m+2][m+2][O][I]
+    return u.reshape((m + 2) ** 2, w.shape[0], w.shape[1]).float().contiguous()
+
+
+def _winograd_m(H, W):
+    """Output tile edge of the Winograd form for an H x W map: the one with fewer transform-domain multiplies,
+    (m+2)^2 * ceil(H/m) * ceil(W/m) (F(3x3) tiles the 9x9 and 18x18 maps of the 288x288 model exactly).  CADRE_WINOGRAD_M
+    forces 2 or 3."""
+    e = os.environ.get("CADRE_WINOGRAD_M", "")
+    if e in ("2", "3"):
+        return int(e)
+    cost = {m: (m + 2) ** 2 * -(-H // m) * -(-W // m) for m in (2, 3)}
+    return 3 if cost[3] <= cost[2] else 2
 
 
 class _Conv:
-    __slots__ = ("w", "w_ring", "ring_folded", "scale", "shift", "cin", "cout", "k", "stride", "pad", "act", "w_wino")
+    __slots__ = ("w", "w_ring", "ring_folded", "scale", "shift", "cin", "cout", "k", "stride", "pad", "act", "w_wino", "_w_oihw")
+
+    def wino_u(self, m, dev):
+        if m not in self.w_wino:
+            self.w_wino[m] = _winograd_u(self._w_oihw, m).to(dev)
+        return self.w_wino[m]
 
     def __init__(self, w, scale, shift, k, stride, pad, act, dev, wdtype=torch.float32):
         self.w = _khwc(w).to(dev).to(wdtype)
@@ -124,7 +147,8 @@ class _Conv:
         wmin = _winograd_min_c()
         if (wmin and wdtype == torch.float32 and k == 3 and stride == 1 and pad == 1 and w.shape[1] >= wmin
                 and w.shape[0] >= 128 and w.shape[1] % 4 == 0 and w.shape[0] % 4 == 0):
-            self.w_wino = _winograd_u(w).to(dev)
+            self.w_wino = {}                       # {m: U} filled on first use (the tile edge depends on the map size)
+            self._w_oihw = torch.as_tensor(w).float().cpu()
 
 
 class DANetEncoderHIP:
@@ -292,16 +316,17 @@ class DANetEncoderHIP:
         use_ring = (c.w_ring is not None and self.ring_conv and x.dtype == c.w_ring.dtype and (act & 15) <= 1
                     and bool(hip.lib().cadre_conv3x3_ring_supported(F, H, W, c.cin, c.cout, ring_flags)))
         if c.w_wino is not None and x.dtype == torch.float32 and odt == torch.float32 and (act & 15) <= 1:
-            # EXPLORATORY: input transform -> one batched GEMM over the 16 transform planes -> inverse transform + BN + residual + ReLU
-            T = F * ((H + 1) // 2) * ((W + 1) // 2)
-            V = self._flat("wino_v", 16 * T * c.cin).view(16, T, c.cin)
-            Mx = self._flat("wino_m", 16 * T * c.cout).view(16, T, c.cout)
+            # Winograd F(2x2, 3x3): input transform -> one batched GEMM over the 16 transform planes -> inverse transform + BN + residual + ReLU
+            m = _winograd_m(H, W)
+            P, T = (m + 2) ** 2, F * -(-H // m) * -(-W // m)
+            V = self._flat("wino_v", P * T * c.cin).view(P, T, c.cin)
+            Mx = self._flat("wino_m", P * T * c.cout).view(P, T, c.cout)
             L = hip.lib()
-            hip.check(L.cadre_winograd_in(hip.ptr(x), hip.ptr(V), F, H, W, c.cin, hip.stream()), "cadre_winograd_in")
-            hip.gemm(V, c.w_wino, Mx, T, c.cout, c.cin, c.cin, c.cin, c.cout, batch=16,
-                     a_z=(1, 16, T * c.cin), b_z=(1, 16, c.cout * c.cin), c_z=(1, 16, T * c.cout))
+            hip.check(L.cadre_winograd_in(hip.ptr(x), hip.ptr(V), F, H, W, c.cin, m, hip.stream()), "cadre_winograd_in")
+            hip.gemm(V, c.wino_u(m, self.device), Mx, T, c.cout, c.cin, c.cin, c.cin, c.cout, batch=P,
+                     a_z=(1, P, T * c.cin), b_z=(1, P, c.cout * c.cin), c_z=(1, P, T * c.cout))
             hip.check(L.cadre_winograd_out(hip.ptr(Mx), hip.ptr(c.scale), hip.ptr(c.shift), hip.ptr(resid), hip.ptr(out),
-                                           F, H, W, c.cout, act, hip.stream()), "cadre_winograd_out")
+                                           F, H, W, c.cout, act, m, hip.stream()), "cadre_winograd_out")
         elif use_c64 and (self.c64_kernel == 2 or not use_ring):
             # stage-1 convs of the bf16 encoder with the weights resident in LDS (bit-identical to cadre_gemm_bf16);
             # the window kernel below measures 3 % faster on them and takes precedence unless CADRE_C64_KERNEL=2
@@ -481,6 +506,11 @@ class DANetEncoderHIP:
         act += 2 * Np * 512 + 3072 + 6 * 256 + 512                               # inter-task inputs/outputs
         return e * act * frames + e * self.n_weights
 
+    def winograd_convs(self):
+        """Number of conv layers that run as Winograd F(2x2, 3x3) (0 for the bf16 model and under CADRE_WINOGRAD=0)."""
+        cs = [c for blk in self.blocks for c in blk[:2]] + [self.conv5a, self.conv5c, self.conv51, self.conv52]
+        return sum(c.w_wino is not None for c in cs)
+
     def flops_per_frame(self, executed=False):
         """Direct-convolution (algorithmic) FLOPs of one frame; executed=True: what the launches multiply — differs only
         under CADRE_WINOGRAD=1 (16 planes x ceil(H/2) x ceil(W/2) tiles x Cin x Cout per Winograd conv)."""
@@ -490,7 +520,8 @@ class DANetEncoderHIP:
             Ho = (H + 2 * c.pad - c.k) // c.stride + 1
             Wo = (W + 2 * c.pad - c.k) // c.stride + 1
             if executed and c.w_wino is not None:
-                return 2 * 16 * ((H + 1) // 2) * ((W + 1) // 2) * c.cout * c.cin, Ho, Wo
+                m = _winograd_m(H, W)
+                return 2 * (m + 2) ** 2 * -(-H // m) * -(-W // m) * c.cout * c.cin, Ho, Wo
             return 2 * Ho * Wo * c.cout * c.cin * c.k * c.k, Ho, Wo
         f, H, W = conv(self.stem, H, W); total += f
         H, W = (H - 1) // 2 + 1, (W - 1) // 2 + 1

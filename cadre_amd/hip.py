@@ -52,8 +52,8 @@ SYMBOLS = {
     "cadre_stem_pool": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, i64, vp],
     "cadre_div255_selfcheck": [vp, vp, vp],
     "cadre_stem_pool_supported": [i32, i32],
-    "cadre_winograd_in": [vp, vp, i32, i32, i32, i32, vp],
-    "cadre_winograd_out": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+    "cadre_winograd_in": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "cadre_winograd_out": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "cadre_pam": [vp, vp, f32, vp, i32, i32, vp],
     "cadre_cam": [vp, f32, vp, i32, i32, vp],
     "cadre_intertask_att": [vp, vp, i64, i32, f32, vp],

@@ -40,18 +40,21 @@ def test_encoder_vs_reference_golden(golden, tag):
 
 
 @pytest.mark.parametrize("tag", ["native", "288"])
-def test_encoder_winograd_vs_reference_golden(golden, tag, monkeypatch):
-    """EXPLORATORY (CADRE_WINOGRAD=1): the fp32 model with its >= 256-channel stride-1 3x3 convs (layer3, layer4, head) in
-    Winograd F(2x2, 3x3) against the same goldens at the same tolerance, and the same frames in a larger batch give the
-    same bits."""
+@pytest.mark.parametrize("algo", ["winograd", "direct"])
+def test_encoder_conv_algorithms_vs_reference_golden(golden, tag, algo, monkeypatch):
+    """The fp32 model's >= 128-channel stride-1 3x3 convs (layer2, layer3, layer4, head) run as Winograd F(3x3, 3x3) by default
+    and as direct convolution under CADRE_WINOGRAD=0: both against the same goldens at the same tolerance, and the same frames
+    in a larger batch give the same bits either way."""
     from cadre_amd.encoder import DANetEncoderHIP
-    monkeypatch.setenv("CADRE_WINOGRAD", "1")
+    monkeypatch.setenv("CADRE_WINOGRAD", "1" if algo == "winograd" else "0")
     g = golden("enc_" + tag)
     H, W, n = int(g["H"]), int(g["W"]), int(g["n"])
     fh, fw = synth.feat_hw(H, W)
     sd = synth.encoder_state(fh, fw, int(g["seed"]))
     enc = DANetEncoderHIP(sd, H, W, "cuda:0")
-    assert sum(c.w_wino is not None for blk in enc.blocks for c in blk[:2]) == 6 and enc.conv5a.w_wino is not None      # layer3 / layer4 stride-1 convs + head
+    nw = sum(c.w_wino is not None for blk in enc.blocks for c in blk[:2]) + sum(c.w_wino is not None for c in (enc.conv5a, enc.conv5c))
+    assert nw == (11 if algo == "winograd" else 0)           # layer2 / layer3 / layer4: three stride-1 convs each; head: conv5a, conv5c
+    assert enc.winograd_convs() == (13 if algo == "winograd" else 0)        # (+ conv51, conv52)
     r = np.random.RandomState(int(g["frame_seed"]))
     rgb = r.randint(0, 256, (n, H, W, 3)).astype(np.uint8)
     route = ((r.rand(n, W, H) < 0.15) * 255).astype(np.uint8)
@@ -61,7 +64,7 @@ def test_encoder_winograd_vs_reference_golden(golden, tag, monkeypatch):
     l4 = taps["layer4"].permute(0, 3, 1, 2).cpu().numpy()
     da = taps["da"].permute(0, 3, 1, 2).cpu().numpy()
     e = (rel(l4, g["layer4"]), rel(da, g["da"]), rel(lat.cpu().numpy(), g["latent"]))
-    print("winograd encoder %s rel-max-err layer4 %.2e da_head %.2e latent %.2e" % ((tag,) + e))
+    print("%s encoder %s rel-max-err layer4 %.2e da_head %.2e latent %.2e" % ((algo, tag) + e))
     assert e[0] < TOL and e[1] < TOL and e[2] < TOL
     rgb_b, route_b = torch.cat([rgb_d[:1], rgb_d, rgb_d[-1:]]), torch.cat([route_d[:1], route_d, route_d[-1:]])
     assert torch.equal(enc.latent(rgb_b, route_b)[1:1 + n], lat)

@@ -1144,11 +1144,12 @@ def test_conv_decode_random_geometries(hip):
 
 @pytest.mark.parametrize("F,H,W,Cin,N,use_resid,act", [(3, 9, 9, 64, 128, True, 1), (2, 18, 18, 32, 64, False, 1), (2, 7, 10, 16, 32, True, 17),
                                                      (1, 1, 1, 8, 8, False, 0), (5, 6, 5, 12, 20, True, 0)])
-def test_winograd_conv3x3_matches_torch(hip, F, H, W, Cin, N, use_resid, act):
-    """cadre_winograd_in -> batched cadre_gemm_f32 over the 16 transform planes -> cadre_winograd_out (EXPLORATORY,
-    CADRE_WINOGRAD=1) vs torch conv2d fp32 on the reference layer's formulation (resnet.py:26-55: conv3x3 / s1 / p1 +
-    folded BN + residual + ReLU), odd sizes (the last tile row / column is half outside the map) and a 1x1 map; and the
-    same frames inside a larger batch give the same bits."""
+@pytest.mark.parametrize("m", [2, 3])
+def test_winograd_conv3x3_matches_torch(hip, F, H, W, Cin, N, use_resid, act, m):
+    """cadre_winograd_in -> batched cadre_gemm_f32 over the (m+2)^2 transform planes -> cadre_winograd_out, F(2x2,3x3) and
+    F(3x3,3x3), vs torch conv2d fp32 on the reference layer's formulation (resnet.py:26-55: conv3x3 / s1 / p1 + folded BN +
+    residual + ReLU), sizes the tiles do not divide (the last tile row / column is partly outside the map) and a 1x1 map;
+    and the same frames inside a larger batch give the same bits."""
     from cadre_amd.encoder import _winograd_u
     g = torch.Generator().manual_seed(F * 100 + H)
     x = torch.randn(F, H, W, Cin, generator=g)
@@ -1164,16 +1165,16 @@ def test_winograd_conv3x3_matches_torch(hip, F, H, W, Cin, N, use_resid, act):
         want = want + res
 
     def run(xd, rd, Fb):
-        T = Fb * ((H + 1) // 2) * ((W + 1) // 2)
-        V = torch.full((16, T, Cin), 7.0, device="cuda")
-        Mx = torch.full((16, T, N), 7.0, device="cuda")
+        P, T = (m + 2) ** 2, Fb * -(-H // m) * -(-W // m)
+        V = torch.full((P, T, Cin), 7.0, device="cuda")
+        Mx = torch.full((P, T, N), 7.0, device="cuda")
         out = torch.full((Fb, H, W, N), 7.0, device="cuda")
         L = hip.lib()
-        hip.check(L.cadre_winograd_in(hip.ptr(xd), hip.ptr(V), Fb, H, W, Cin, hip.stream()), "in")
-        hip.gemm(V, u, Mx, T, N, Cin, Cin, Cin, N, batch=16, a_z=(1, 16, T * Cin), b_z=(1, 16, N * Cin), c_z=(1, 16, T * N))
-        hip.check(L.cadre_winograd_out(hip.ptr(Mx), hip.ptr(scd), hip.ptr(shd), hip.ptr(rd), hip.ptr(out), Fb, H, W, N, act, hip.stream()), "out")
+        hip.check(L.cadre_winograd_in(hip.ptr(xd), hip.ptr(V), Fb, H, W, Cin, m, hip.stream()), "in")
+        hip.gemm(V, u, Mx, T, N, Cin, Cin, Cin, N, batch=P, a_z=(1, P, T * Cin), b_z=(1, P, N * Cin), c_z=(1, P, T * N))
+        hip.check(L.cadre_winograd_out(hip.ptr(Mx), hip.ptr(scd), hip.ptr(shd), hip.ptr(rd), hip.ptr(out), Fb, H, W, N, act, m, hip.stream()), "out")
         return out
-    u, scd, shd = dev(_winograd_u(w)), dev(sc), dev(sh)
+    u, scd, shd = dev(_winograd_u(w, m)), dev(sc), dev(sh)
     got = run(dev(x), None if res is None else dev(res), F)
     assert rel(got.cpu(), want) < 2e-5, float((got.cpu() - want).abs().max())
     big = 7
