@@ -283,3 +283,26 @@ def test_arena_pickle_drops_process_local_state():
     #  torch.multiprocessing's HIP-IPC reductions: tests/test_topology_gpu.py checks it on the device)
     a2.attach_grads()
     assert m2.rnn.weight_hh.grad is not None and tuple(m2.rnn.weight_hh.grad.shape) == (2120, 530)
+
+
+def test_bench_kernel_names_are_keys_of_the_hbm_traffic_file():
+    """Every kernel name the committed round-4 bench line prints (roofline.kernel, per_kernel of the headline, the C3 section and
+    the direct-conv section) is a key of profiles/hbm_traffic.json — the rocprofv3 PMC passes of the same command — so that
+    `roofline.traffic` is never null because of a naming drift between bench.kname() and the profiler."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    line = open(os.path.join(root, "profiles", "r04_bench_c2_c3.json")).read().strip().splitlines()[-1]
+    bench = json.loads(line)
+    traffic = json.load(open(os.path.join(root, "profiles", "hbm_traffic.json")))
+    names = set()
+    for sect in (bench, bench.get("c3"), bench.get("c2_direct_conv")):
+        assert sect and sect.get("roofline"), "the committed line carries the headline, c3 and c2_direct_conv sections"
+        r = sect["roofline"]
+        names.add(r["kernel"])
+        names |= set(r["per_kernel"])
+        assert r["traffic"] is not None and r["traffic"] > 0
+    assert len(names) >= 10
+    missing = sorted(n for n in names if n not in traffic)
+    assert not missing, missing
+    for n in names:
+        assert traffic[n]["hbm_bytes_per_launch"] > 0 and traffic[n]["launches"] > 0
