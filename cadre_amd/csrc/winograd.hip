@@ -19,7 +19,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 int cadre_fail(const char* msg);
 
-// Transform matrices (Cook-Toom, points 0, 1, -1 [, 2], infinity).  F(2x2, 3x3): 4x4 input tiles, 16 planes, 2.25x fewer
+// Transform matrices (Cook-Toom; F(2x2): points 0, 1, -1, infinity; F(3x3): 0, 3/4, -3/4, 2, infinity).  F(2x2, 3x3): 4x4 input tiles, 16 planes, 2.25x fewer
 // multiplies than direct; F(3x3, 3x3): 5x5 tiles, 25 planes, 3.24x fewer and only 2.78x (not 4x) the input in transform-domain
 // traffic — the form the encoder picks when it tiles the map at least as well (9x9 and 18x18 maps: exactly).
 template <int M> struct wino_mat;
@@ -30,8 +30,11 @@ template <> struct wino_mat<2> {
 };
 template <> struct wino_mat<3> {
   static constexpr int N = 5;
-  static constexpr float BT[5][5] = {{2, -1, -2, 1, 0}, {0, -2, -1, 1, 0}, {0, 2, -3, 1, 0}, {0, -1, 0, 1, 0}, {0, 2, -1, -2, 1}};
-  static constexpr float AT[3][5] = {{1, 1, 1, 1, 0}, {0, 1, -1, 2, 0}, {0, 1, 1, 4, 1}};
+  // points 0, 3/4, -3/4, 2, infinity: 30 % less rounding error than 0, 1, -1, 2 (rms 2.2e-7 against 3.2e-7 of the tensor's max
+  // at K = 512; the direct conv: 1.6e-7) — every coefficient is a dyadic rational, exact in fp32
+  static constexpr float BT[5][5] = {{1.125f, -0.5625f, -2.f, 1.f, 0.f}, {0.f, -1.5f, -1.25f, 1.f, 0.f}, {0.f, 1.5f, -2.75f, 1.f, 0.f},
+                                     {0.f, -0.5625f, 0.f, 1.f, 0.f}, {0.f, 1.125f, -0.5625f, -2.f, 1.f}};
+  static constexpr float AT[3][5] = {{1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 0.75f, -0.75f, 2.f, 0.f}, {0.f, 0.5625f, 0.5625f, 4.f, 1.f}};
 };
 constexpr float wino_mat<2>::BT[4][4];
 constexpr float wino_mat<2>::AT[2][4];

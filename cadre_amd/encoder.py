@@ -93,13 +93,14 @@ def _winograd_min_c():
 
 
 _WINO_G = {2: [[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]],
-           3: [[0.5, 0.0, 0.0], [-0.5, -0.5, -0.5], [-1.0 / 6, 1.0 / 6, -1.0 / 6], [1.0 / 6, 1.0 / 3, 2.0 / 3], [0.0, 0.0, 1.0]]}
+           3: [[8.0 / 9, 0.0, 0.0], [-32.0 / 45, -8.0 / 15, -2.0 / 5], [-32.0 / 99, 8.0 / 33, -2.0 / 11], [8.0 / 55, 16.0 / 55, 32.0 / 55],
+               [0.0, 0.0, 1.0]]}
 
 
 def _winograd_u(w, m=2):
     """OIHW 3x3 weights -> U[(m+2)^2][O][I] = (G g G^T)[xi], xi = (m+2) i + j (float64 product, one rounding to fp32): the B
     operands of the batched GEMM between cadre_winograd_in and cadre_winograd_out (csrc/winograd.hip; Cook-Toom points
-    0, 1, -1 [, 2], infinity — G matches the kernels' B^T / A^T)."""
+    0, 1, -1, infinity for m = 2 and 0, 3/4, -3/4, 2, infinity for m = 3 — G matches the kernels' B^T / A^T)."""
     G = torch.tensor(_WINO_G[m], dtype=torch.float64)
     u = torch.einsum("ik,ockl,jl->ijoc", G, torch.as_tensor(w).double(), G)        # [m+2][m+2][O][I]
     return u.reshape((m + 2) ** 2, w.shape[0], w.shape[1]).float().contiguous()
@@ -258,6 +259,7 @@ class DANetEncoderHIP:
                 self.fused_stem = False
         self._ws = {}
         self._ws_flat = {}
+        self._pass_frames = 0
         self.ws_generation = 0
         self.n_weights = sum(t.numel() for t in self._all_weight_tensors())
 
@@ -272,10 +274,13 @@ class DANetEncoderHIP:
 
     # ------------------------------------------------------------------ workspace
     def _buf(self, key, shape, dtype=torch.float32, zero=False):
-        """Workspace tensor `key` of the given shape: the two most recent shapes of a key stay alive (act() alternates
-        between 1-frame and 8-frame passes; hipGraphs captured over these tensors hold their addresses), a third one
-        replaces the older and bumps `ws_generation` — holders of captured graphs re-capture when it moved."""
-        slot = self._ws.setdefault(key, [])
+        """Workspace tensor `key` of the given shape.  Slots are kept per use: the two most recent SMALL shapes (<= 64 frames:
+        act() alternates between 1-frame and 8-frame passes, and hipGraphs captured over these tensors hold their addresses)
+        and the two most recent LARGE ones (a learner's full chunk and its remainder chunk) — an agent that acts and learns
+        on one encoder no longer evicts its act() tensors every round.  Replacing a small slot bumps
+        `ws_generation`: holders of captured graphs re-capture when it moved."""
+        small = self._pass_frames <= 64                      # (set by preprocess / forward_nhwc from the pass's frame count)
+        slot = self._ws.setdefault((key, small), [])
         for i, t in enumerate(slot):
             if t.shape == torch.Size(shape) and t.dtype == dtype:
                 if i:
@@ -285,7 +290,8 @@ class DANetEncoderHIP:
         slot.insert(0, t)
         if len(slot) > 2:
             slot.pop()
-            self.ws_generation += 1
+            if small:
+                self.ws_generation += 1
         return t
 
     def _flat(self, key, n):
@@ -349,6 +355,7 @@ class DANetEncoderHIP:
         if frame_idx is not None and not self.fused_stem:
             rgb_d, route_d, frame_idx = rgb_d.index_select(0, frame_idx), route_d.index_select(0, frame_idx), None
         F = rgb_d.shape[0] if frame_idx is None else frame_idx.numel()
+        self._pass_frames = int(F)
         n_src = int(rgb_d.shape[0])
         fmax = self._buf("fmax", (max(F, n_src),), torch.int32)
         L = hip.lib()
@@ -374,6 +381,7 @@ class DANetEncoderHIP:
         L = hip.lib()
         st = hip.stream()
         F = x.shape[0]
+        self._pass_frames = int(F)
         H, W = self.H, self.W
         if x.dtype == torch.int32:              # packed observation from preprocess(): fused front
             if not self.fused_stem or tuple(x.shape[1:]) != (H, W):

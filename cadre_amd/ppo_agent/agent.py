@@ -171,7 +171,12 @@ class CadreAgent(object):
         shifted = self._window_shifted(tick_data)
         first = S - 1 if shifted else 0
         raw_rgb, raw_route = rgb.copy(), route_np.copy()
-        # inputs: numpy -> pinned staging -> static device buffers (only the newest frame when the window shifted)
+        # inputs: numpy -> pinned staging -> static device buffers (only the newest frame when the window shifted).  The
+        # pinned buffers are rewritten only after the previous call's asynchronous H2D copies have left them (a caller
+        # that has not read the last action yet may call act() again)
+        ev = st.get("h2d_done")
+        if ev is not None:
+            ev.synchronize()
         st["h_rgb"][first:].copy_(torch.from_numpy(np.ascontiguousarray(rgb[first:])))
         st["h_route"][first:].copy_(torch.from_numpy(np.ascontiguousarray(route_np[first:])))
         st["h_meas"].copy_(torch.from_numpy(np.ascontiguousarray(tick_data["measurements"], dtype=np.float64)))
@@ -182,6 +187,9 @@ class CadreAgent(object):
         st["d_route"][first:].copy_(st["h_route"][first:], non_blocking=True)
         st["d_meas"].copy_(st["h_meas"], non_blocking=True)
         st["d_q"].copy_(st["h_q"], non_blocking=True)
+        if ev is None:
+            ev = st["h2d_done"] = torch.cuda.Event()
+        ev.record()
         lrn = self.learner
         lrn.packed_weights(0, 1, self.arena.Z)                    # refreshed here when the parameters changed, not in the graph
         key = (shifted, command)

@@ -162,7 +162,8 @@ int cadre_stem_pool_supported(int32_t H, int32_t W);
 
 /* Winograd F(m x m, 3x3) transforms, m = 2 or 3, fp32, NHWC (csrc/winograd.hip).  A stride-1 / pad-1 3x3 convolution
  * (resnet.py:26-55) = cadre_winograd_in -> ONE cadre_gemm_f32 with batch (m+2)^2 (M[xi] = V[xi] . U[xi]^T,
- * U[xi][cout][cin] = (G g G^T)[xi] prepared by the host; Cook-Toom points 0, 1, -1 [, 2], infinity) -> cadre_winograd_out.
+ * U[xi][cout][cin] = (G g G^T)[xi] prepared by the host; Cook-Toom points 0, 1, -1, inf (m = 2) / 0, 3/4, -3/4, 2, inf (m = 3):
+ * cadre_amd/encoder.py _WINO_G) -> cadre_winograd_out.
  * T = F * ceil(H/m) * ceil(W/m) tiles.  V: [(m+2)^2][T][C], Mx: [(m+2)^2][T][N], x / resid / out: [F][H][W][C or N].
  * out = act(M . scale + shift (+ resid)) with cadre_gemm_t's act codes (0 none, 1 ReLU, bit 4: residual after act). */
 int cadre_winograd_in(const float* x, float* V, int32_t F, int32_t H, int32_t W, int32_t C, int32_t m, void* stream);

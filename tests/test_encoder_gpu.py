@@ -106,3 +106,27 @@ def test_encoder_bf16_close_to_fp32_reference(golden, tag):
     e = (rel(l4, g["layer4"]), rel(lat.cpu().numpy(), g["latent"]))
     print("bf16 encoder %s rel-max-err layer4 %.2e latent %.2e" % ((tag,) + e))
     assert e[0] < BF16_TOL and e[1] < BF16_TOL
+
+
+def test_workspace_slots_survive_alternating_act_and_learner_shapes():
+    """An agent that acts (1-frame and 8-frame passes) and learns (a full chunk and a remainder chunk) on ONE encoder cycles
+    through four batch shapes per round; the act() tensors (over which hipGraphs are captured) must keep their addresses
+    and `ws_generation` must stand still (slots are kept per use, two small + two large shapes)."""
+    from cadre_amd.encoder import DANetEncoderHIP
+    H = W = 84
+    enc = DANetEncoderHIP(synth.encoder_state(3, 3, 7), H, W, "cuda:0", max_frames=128)
+    r = np.random.RandomState(1)
+    rgb = torch.from_numpy(r.randint(0, 256, (128, H, W, 3)).astype(np.uint8)).cuda()
+    route = torch.from_numpy(((r.rand(128, W, H) < 0.15) * 255).astype(np.uint8)).cuda()
+    want, ptr = {}, {}
+    for F in (1, 8, 128, 72):
+        taps = {}
+        want[F] = enc.latent(rgb[:F], route[:F], taps=taps).clone()
+        ptr[F] = taps["pool"].data_ptr()
+    gen = enc.ws_generation
+    for _ in range(3):
+        for F in (128, 72, 1, 8, 1):
+            taps = {}
+            assert torch.equal(enc.latent(rgb[:F], route[:F], taps=taps), want[F])
+            assert taps["pool"].data_ptr() == ptr[F]
+    assert enc.ws_generation == gen
