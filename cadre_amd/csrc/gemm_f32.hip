@@ -578,6 +578,10 @@ int cadre_gemm_f32_skinny_launch(const cadre_gemm_t& p, void* stream);
 // Auto tile: estimated efficiency = (measured steady-state factor of the tile shape) x (wave
 // quantisation over 256 CUs x resident workgroups per CU).  Factors from tools/gemm_bench.py on
 // MI355X (profiles/r01_gemm_tile_sweep.txt).
+#ifdef CADRE_AB_KERNELS
+int cadre_gemm_stream_f32_launch(const cadre_gemm_t& p, void* stream);   // ab/gemm_stream_f32.hip (tile 13)
+#endif
+
 static int pick_tile(const cadre_gemm_t& p) {
   const int batch = p.batch < 1 ? 1 : p.batch, sk = p.split_k < 1 ? 1 : p.split_k;
   struct Cand { int id, bm, bn, per_cu; double base; };
@@ -684,13 +688,14 @@ extern "C" int cadre_gemm_f32(const cadre_gemm_t* pp, void* stream) {
     GEMM_CHECK(p.batch == 1 && p.split_k == 1 && ((p.N | p.ldc) & 3) == 0 && !p.resid, "bf16 output needs the vector epilogue, no batch/split/resid");
   int tile = p.tile ? p.tile : pick_tile(p);
 #ifdef CADRE_AB_KERNELS
+  if (tile == 13) return cadre_gemm_stream_f32_launch(p, stream);      // short-K dense NT product, several M-tiles per workgroup
   if (tile == 12) return cadre_conv_stream_f32_launch(p, stream);      // 64x64 conv, several M-tiles per workgroup
   if (tile == 11) {                                                    // skinny products of the PPO update
     if (!cadre_gemm_f32_skinny_ok(p)) return cadre_fail("cadre_gemm_f32: tile 11 (skinny) does not take this descriptor");
     return cadre_gemm_f32_skinny_launch(p, stream);
   }
 #else
-  if (tile == 11 || tile == 12) return cadre_fail("cadre_gemm_f32: tiles 11 / 12 exist only in the A/B build (CADRE_BUILD_AB=1)");
+  if (tile >= 11 && tile <= 13) return cadre_fail("cadre_gemm_f32: tiles 11 / 12 / 13 exist only in the A/B build (CADRE_BUILD_AB=1)");
 #endif
   hipStream_t st = (hipStream_t)stream;
   if (tile < 1 || tile > 10 || tile == 7) return cadre_fail("cadre_gemm_f32: bad tile");

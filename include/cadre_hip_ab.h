@@ -4,6 +4,7 @@
  * libcadre_hip.so neither compiles nor exports them.
  *   conv_stream_f32.hip / conv_stream_bf16.hip  cadre_gemm_t.tile 12: 64x64 conv, several M-tiles per workgroup
  *   gemm_f32_skinny.hip                         cadre_gemm_t.tile 11 (fp32): register-direct skinny GEMM
+ *   gemm_stream_f32.hip                         cadre_gemm_t.tile 13 (fp32): short-K dense NT product, several M-tiles per workgroup
  *   conv3x3_c64_bf16.hip                        cadre_conv3x3_c64_bf16 below
  *   ppo_update.hip (under CADRE_AB_KERNELS)     cadre_lstm_seq_fwd below: the persistent forward LSTM (208 vs 110 us)
  *   conv3x3_ring.hip (under CADRE_AB_KERNELS)   the 16x16x32-MFMA instantiations of the window conv (CADRE_RING_M16=1)

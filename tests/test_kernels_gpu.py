@@ -95,6 +95,36 @@ def test_gemm_batched_and_splitk(hip):
     assert rel(out2, want2) < 2e-5
 
 
+@pytest.mark.parametrize("Z,M,N,K,use_resid,act", [(5, 1000, 128, 128, False, 0), (3, 517, 200, 96, True, 2), (1, 64, 64, 64, True, 1),
+                                                  (25, 700, 256, 256, False, 0), (2, 130, 52, 68, True, 0)])
+@needs_ab
+def test_gemm_streamed_short_k_tile(hip, Z, M, N, K, use_resid, act):
+    """Tile 13 (ab/gemm_stream_f32.hip, A/B build: several M-tiles per workgroup, prefetch across tile boundaries; the batched GEMMs of the
+    Winograd convs): vs torch, and BIT-IDENTICAL to the one-tile 64x64 kernel (tile 3) — same k order, same epilogue —
+    on batches, ragged M / N edges, a K that is not a multiple of the 32-wide k-tile, residual + activation."""
+    g = torch.Generator().manual_seed(Z * 1000 + M)
+    A = torch.randn(Z, M, K, generator=g)
+    B = torch.randn(Z, N, K, generator=g) * 0.1
+    sc, sh = torch.rand(Z, N, generator=g) + 0.5, torch.randn(Z, N, generator=g)
+    res = torch.randn(Z, M, N, generator=g) if use_resid else None
+    want = torch.einsum("zmk,znk->zmn", A, B) * sc[:, None, :] + sh[:, None, :]
+    if res is not None:
+        want = want + res
+    if act == 1:
+        want = torch.relu(want)
+    if act == 2:
+        want = F.leaky_relu(want, 0.1)
+    Ad, Bd, scd, shd, rd = dev(A), dev(B), dev(sc), dev(sh), (None if res is None else dev(res))
+    outs = {}
+    for tile in (13, 3):
+        out = torch.full((Z, M, N), 7.0, device="cuda")
+        hip.gemm(Ad, Bd, out, M, N, K, K, K, N, scale=scd, shift=shd, resid=rd, ldr=N, act=act, slope=0.1, batch=Z,
+                 a_z=(1, Z, M * K), b_z=(1, Z, N * K), c_z=(1, Z, M * N), s_z=(1, Z, N), r_z=(1, Z, M * N), tile=tile)
+        outs[tile] = out
+    assert rel(outs[13], want) < 2e-5
+    assert torch.equal(outs[13], outs[3])
+
+
 def test_gemm_batched_splitk(hip):
     """dh_{t-1} = dG_t . W_hh shape: tiny [B, 544] outputs, K = 2120, 8 nets, b_mode 1, split-K slabs."""
     g = torch.Generator().manual_seed(8)
