@@ -700,6 +700,143 @@ __global__ __launch_bounds__(256, TM == 1 ? DW_OCC : 1) void lstm_dw_kernel(dw_a
   }
 }
 
+#ifdef CADRE_AB_KERNELS
+// The same products with the operands of a workgroup's four wave tiles SHARED through LDS: the
+// workgroup owns a 128 x 128 output tile (2 x 2 waves of 64 x 64); per k-step (4 rows) the two dG blocks (4 rows x 64
+// gate columns = 1 KiB each) and the two h / x blocks come in ONCE by LDS-DMA — a wave issues all loads of one block
+// kind, lane-linear: lane (c, q) of a DMA instruction writes exactly the 16 bytes lane (c, q) of a consumer reads — and
+// each is read by two waves: half the L2 traffic of lstm_dw_kernel<1> (1.3 GB per launch at minibatch 256, 66 % of its
+// wave cycles waiting on loads).  KS k-steps per stage, two stages, counted vmcnt + two barriers per stage.
+// MEASURED AND NOT ADOPTED (A/B build, CADRE_DW_LDS=4|8): bit-level parity with the tests, 243-253 vs 218 us at minibatch
+// 256 and 92-99 vs 84 us at 64 (profiles/r04_lstm_dw_lds_sharing.txt) — like the 128 x 64 wave tile before it: operand
+// BYTES are not what the launch waits for; the barriers and one wave less per SIMD cost more than the halved traffic saves.
+template <int KS>
+__global__ __launch_bounds__(256, 2) void lstm_dw_lds_kernel(dw_args p, int MG2, int NG2) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * KS * 4096];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int c = lane & 15, q = lane >> 4;
+  const int z = blockIdx.x % p.Z;
+  const int t2 = blockIdx.x / p.Z;                        // (kind, mg2, ng2), ng2 fastest
+  const int per_kind = MG2 * NG2;
+  const int kind = t2 / per_kind, tk = t2 - kind * per_kind;
+  const int mg2 = tk / NG2, ng2 = tk - mg2 * NG2;
+  const int mg = 2 * mg2 + wm, ng = 2 * ng2 + wn;
+  const bool live = mg < p.MG && ng < p.NG;               // (a wave tile past the matrix: takes part in staging and barriers only)
+  int lo = 0, hi = p.B;
+  if (p.row_seg) {
+    const int beg = p.row_seg[2 * z], cnt = p.row_seg[2 * z + 1];
+    lo = beg;
+    hi = cnt > 0 ? min(p.B, beg + cnt) : lo;
+  }
+  const int nb = (hi - lo + 3) >> 2;
+  const int KT = nb * p.S;
+  const int m0 = 128 * mg2, n0 = 128 * ng2;
+  // this wave stages block kind `wave`: 0 / 1 = dG columns m0 + 64*{0,1}, 2 / 3 = h|x columns n0 + 64*{0,1}
+  const bool stage_g = wave < 2;
+  const int half = wave & 1;
+  const float* gbase = p.dG + (int64_t)z * p.g_str + m0;
+  const float* ybase = (kind == 0 ? p.Hs + (int64_t)z * p.h_str : p.X + (int64_t)(z / p.x_div) * p.x_str) + n0;
+  const unsigned g_bytes = (unsigned)((int64_t)p.S * p.B * p.ldg * 4 - (int64_t)m0 * 4);
+  const unsigned y_bytes = (unsigned)((int64_t)p.S * p.B * p.ldh * 4 - (int64_t)n0 * 4);
+  const __amdgpu_buffer_rsrc_t rsS = stage_g ? __builtin_amdgcn_make_buffer_rsrc((void*)gbase, 0, (int)g_bytes, 0x00020000)
+                                             : __builtin_amdgcn_make_buffer_rsrc((void*)ybase, 0, (int)y_bytes, 0x00020000);
+  const int ld_s = stage_g ? p.ldg : p.ldh;
+  // column chunk past the row pitch (last n-half of h / x): a valid chunk instead, its products are never stored
+  const int col = 64 * half + 4 * c;
+  const int colv = (!stage_g && n0 + col >= p.ldh) ? 4 * c : col;
+  const int voff = (q * ld_s + colv) * 4;
+  int t_n = 0, b_n = 0, ks_n = 0;                         // producer side: next k-step to request
+  auto issue_stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      const int row = t_n * p.B + lo + 4 * b_n;
+      const int so = ks_n < KT ? row * ld_s * 4 : 0x7fffffff;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (__attribute__((address_space(3))) void*)(lds + (buf * KS + i) * 4096 + wave * 1024), 16, voff, so, 0, 0);
+      ++ks_n;
+      const int b1 = b_n + 1;
+      const int wrap = b1 == nb ? 1 : 0;
+      b_n = wrap ? 0 : b1;
+      t_n += wrap;
+    }
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  const bool MASK = ((hi - lo) & 3) != 0;
+  int b_c = 0;
+  const int NS = (KT + KS - 1) / KS;
+  issue_stage(0);
+  for (int s = 0; s < NS; ++s) {
+    issue_stage((s + 1) & 1);                             // (past the end: out-of-bounds requests, zeros)
+    // raw barriers + this wave's own counted vmcnt (a __syncthreads() fence would drain vmcnt to 0 and with it the prefetch)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KS) : "memory");       // this wave's loads of stage s have landed
+    __builtin_amdgcn_s_barrier();                         // ... and everybody else's
+    asm volatile("" ::: "memory");
+    const char* sb = lds + (s & 1) * KS * 4096;
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < KS; ++i) {
+        f32x4 av = *reinterpret_cast<const f32x4*>(sb + i * 4096 + wm * 1024 + lane * 16);
+        f32x4 yv = *reinterpret_cast<const f32x4*>(sb + i * 4096 + 2048 + wn * 1024 + lane * 16);
+        if (MASK) {
+          const bool dead = lo + 4 * b_c + q >= hi;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { av[e] = dead ? 0.f : av[e]; yv[e] = dead ? 0.f : yv[e]; }
+        }
+        const int b1 = b_c + 1;
+        b_c = b1 == nb ? 0 : b1;
+        bsum += av;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], yv[j], acc[a][j], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (fragment reads done: they fed the MFMAs above)
+    __builtin_amdgcn_s_barrier();                         // buffer s & 1 is free: the next iteration refills it
+    asm volatile("" ::: "memory");
+  }
+  if (!live) return;
+  const int mw = m0 + 64 * wm, nw = n0 + 64 * wn;
+  float* out = (kind == 0 ? p.dWhh : p.dWih) + (int64_t)z * p.w_str;
+  if (nw + 4 * c < p.N) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = mw + 16 * q + 4 * r + i;
+        if (m < p.H4)
+          *reinterpret_cast<f32x4*>(out + (int64_t)m * p.ldw + nw + 4 * c) = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+      }
+  }
+  if (kind == 0 && ng == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = bsum[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      bsum[i] = v;
+    }
+    if (q == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = mw + 4 * c + i;
+        if (m < p.H4) {
+          p.dbih[(int64_t)z * p.w_str + m] = bsum[i];
+          p.dbhh[(int64_t)z * p.w_str + m] = bsum[i];
+        }
+      }
+    }
+  }
+}
+
+#endif
+
 // Recurrent weights W [4*D][ldw] (k contiguous) of `Z` nets -> fragment order for both directions, NB = ldw / 16:
 //   fwd[z][slice][gate g][k-block j][lane (q, c)][i] = W[g*D + 16*slice + c][16j + 4q + i]          (0 past unit D)
 //   bwd[z][slice][quarter w][k-block j][lane (q, c)][i] = W[n = 16*(NB*w + j) + 4q + i][16*slice + c]  (0 past 4*D / D)
@@ -1212,6 +1349,15 @@ extern "C" int cadre_lstm_dw(const float* dG, int32_t ldg, int64_t g_str, const 
   const int TM = (tm_env == 2 && ldg >= ((H4 + 127) & ~127)) ? 2 : 1;
   const int MG = (H4 + 64 * TM - 1) / (64 * TM), NG = (N + 63) / 64;
   dw_args a{dG, Hs, X, dWhh, dWih, dbih, dbhh, row_seg, g_str, h_str, x_str, w_str, ldg, ldh, ldw, B, S, H4, N, Z, x_div, MG, NG};
+#ifdef CADRE_AB_KERNELS
+  static const int lds_env = [] { const char* e = getenv("CADRE_DW_LDS"); return e ? atoi(e) : 0; }();     // operands shared through LDS (A/B build)
+  if (lds_env && TM == 1) {
+    const int MG2 = (MG + 1) / 2, NG2 = (NG + 1) / 2;
+    if (lds_env == 4) hipLaunchKernelGGL(lstm_dw_lds_kernel<4>, dim3(Z * 2 * MG2 * NG2), dim3(256), 0, ST(stream), a, MG2, NG2);
+    else hipLaunchKernelGGL(lstm_dw_lds_kernel<8>, dim3(Z * 2 * MG2 * NG2), dim3(256), 0, ST(stream), a, MG2, NG2);
+    return (int)hipGetLastError();
+  }
+#endif
   const int wgs = (2 * MG * NG + 3) / 4;
   if (TM == 1) hipLaunchKernelGGL(lstm_dw_kernel<1>, dim3(Z * wgs), dim3(256), 0, ST(stream), a);
   else hipLaunchKernelGGL(lstm_dw_kernel<2>, dim3(Z * wgs), dim3(256), 0, ST(stream), a);

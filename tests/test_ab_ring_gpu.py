@@ -30,3 +30,15 @@ def test_ab_window_conv_variants_match_torch(switch):
                         "-k", "test_conv3x3_ring and bf16"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert " passed" in p.stdout
+
+
+@pytest.mark.skipif(not _ab_current(), reason="A/B library missing or older than its sources (CADRE_BUILD_AB=1 python -m cadre_amd.build)")
+@pytest.mark.parametrize("ks", ["4", "8"])
+def test_ab_lstm_dw_with_operands_shared_through_lds(ks):
+    """lstm_dw_lds_kernel<KS> (measured slower, A/B build, CADRE_DW_LDS=4|8) stays parity-green on the
+    weight-gradient test (float64 reference, NaN in foreign rows, bit-identical on repeat)."""
+    env = dict(os.environ, CADRE_HIP_LIB=AB, CADRE_DW_LDS=ks)
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_kernels_gpu.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "test_lstm_dw_fused"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert " passed" in p.stdout
