@@ -13,7 +13,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 INCLUDE = os.path.join(os.path.dirname(CSRC), "..", "include")
 SOURCES = ["gemm_f32.hip", "gemm_bf16.hip", "stem_pool.hip", "conv3x3_ring.hip", "ppo_update.hip", "peaks.hip", "winograd.hip",
            "cadre_kernels.hip"]
-AB_SOURCES = ["ab/gemm_f32_skinny.hip", "ab/gemm_stream_f32.hip", "ab/conv_stream_f32.hip", "ab/conv_stream_bf16.hip", "ab/conv3x3_c64_bf16.hip"]
+AB_SOURCES = ["ab/winograd_c64.hip", "ab/gemm_f32_skinny.hip", "ab/gemm_stream_f32.hip", "ab/conv_stream_f32.hip", "ab/conv_stream_bf16.hip", "ab/conv3x3_c64_bf16.hip"]
 LIB = os.path.join(CSRC, "libcadre_hip.so")
 LIB_AB = os.path.join(CSRC, "libcadre_hip_ab.so")
 

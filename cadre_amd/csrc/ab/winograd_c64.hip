@@ -1,0 +1,301 @@
+// winograd_c64.hip — FUSED Winograd F(2x2, 3x3) for the fp32 model's 64 -> 64 stride-1 3x3 convs (layer1:
+// carla_perception/Networks/danet_blocks/resnet.py:26-55 — conv3x3 + folded BN (+ residual) + ReLU), gfx950.
+//
+// The unfused form (winograd.hip) does not pay at 64 channels: the transform-domain planes are 4x (F(2x2)) / 2.78x
+// (F(3x3)) the activations and a 64-channel layer has too few FLOPs per byte to carry them through HBM.  Here nothing
+// of the transform domain leaves the CU:
+//   * workgroup = 4 waves, ONE per SIMD with 512 registers each; a wave owns 16 tiles (2x2 outputs each) x all 64 output
+//     channels x all 16 transform planes = 16 x 4 v_mfma_f32_16x16x4_f32 accumulator blocks = 256 registers (the AGPR
+//     file) — the inverse transform is register-local: a lane holds every plane of its (tile, channel);
+//   * the 64 input channels go by in eight chunks of 8: a lane loads the 4x4 input patch of ITS tile for ITS two
+//     channels (16 loads of 8 bytes; the four k-lanes of a tile read 32 contiguous bytes), transforms it in registers
+//     (B^T d B: 32 adds per channel) and feeds the MFMAs' A operand directly;
+//   * the transformed weights U = G g G^T (host, float64 -> fp32; [chunk][plane][cout][8 cin], 32 KB per chunk) stream
+//     through two LDS buffers by LDS-DMA, one chunk ahead, shared by the four waves; a B fragment is one
+//     ds_read_b64 of 512 contiguous bytes (conflict-free);
+//   * loads for step t+1 (weights chunk + patch) are issued before the MFMAs of step t: one s_waitcnt vmcnt(0) +
+//     one raw barrier per 512 MFMAs (128 per wave).
+// 2.25x fewer multiplies than the direct conv, rounding error BELOW the direct conv's.
+//
+// STATUS (round 4): parity-green, NOT adopted — A/B build only (CADRE_WINOGRAD_C64=1 with libcadre_hip_ab.so).  1024 frames
+// of 72 x 72: 3.10 ms (3.39 with the residual) against 2.97 for the direct window kernel; the MFMAs with their LDS
+// fragment reads alone run 1.45 ms (tools/wino_c64_ablate.py, profiles/r04_wino_c64_ablation.txt), i.e. the schedule is worth
+// 2x once the rest hides.  What does not hide yet: the epilogue (0.9-1.1 ms: hipcc spills ~50 VGPRs around it, and a
+// scratch reload behind 64 stores waits for every one of them — vmcnt completes in order), the patch loads (0.3-0.4 ms
+// of memory latency behind a two-step prefetch) and the weight DMA (0.2 ms).  Lessons already in the code: separate LDS
+// objects per DMA buffer (one object = s_waitcnt vmcnt(0) before every fragment read), no branch around loads (PHI copies
+// wait for memory on the spot), scheduling fences around the MFMA block (the next step's transform is otherwise hoisted
+// to its loads), contiguous item ranges per workgroup (halo rows come from the workgroup's own L1 / L2).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../../include/cadre_hip_ab.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+int cadre_fail(const char* msg);
+
+#ifndef W2_ABL
+#define W2_ABL 0      // tools/wino_c64_ablate.py: 1 no MFMA, 2 no patch loads, 4 no weight DMA, 8 no epilogue, 16 no wait + barrier
+#endif
+
+struct w2_args {
+  const float* x;        // [F][H][W][64]
+  const float* U;        // [8 chunks][16 planes][64 cout][8 cin]
+  const float* scale;    // [64] folded BN (may be null: 1)
+  const float* shift;    // [64] (may be null: 0)
+  const float* resid;    // [F][H][W][64] or null: added before the activation
+  float* out;            // [F][H][W][64]
+  int F, H, W, TH, TW;
+  int ntiles;            // F * TH * TW
+  int ngroups;           // ceil(ntiles / 16)
+  int relu;
+};
+
+template <bool RES>
+__global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
+  // two 32 KB weight-chunk buffers as SEPARATE objects: hipcc then knows that the LDS-DMA into one does not alias the
+  // fragment reads of the other and does not put s_waitcnt vmcnt(0) in front of every step's first ds_read
+  __shared__ __attribute__((aligned(16))) char ubuf0[32768];
+  __shared__ __attribute__((aligned(16))) char ubuf1[32768];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, q = lane >> 4;
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((long long)a.F * a.H * a.W * 256), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc((void*)a.U, 0, 8 * 32768, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, (int)((long long)a.F * a.H * a.W * 256), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? a.resid : a.x), 0, (int)((long long)a.F * a.H * a.W * 256), 0x00020000);
+  // a workgroup walks a CONTIGUOUS range of items (64 tiles each): the input rows its tiles share with the tile row above
+  // were fetched by itself half an item earlier — they come from its own L1 / its XCD's L2, not from HBM again
+  const int nitems = (a.ngroups + 3) >> 2;
+  const int per_wg = (nitems + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int item0 = (int)blockIdx.x * per_wg;
+  const int my_items = min(per_wg, nitems - item0);
+  if (my_items <= 0) return;
+  const int thw = a.TH * a.TW;
+
+  // ---- per-item lane state of the A side: tile = group * 16 + n, patch origin (2ty-1, 2tx-1), channel slice 4q of a chunk
+  int a_base = 0;                 // byte offset of patch pixel (0, 0), channel 4q of chunk 0 (may be negative: masked pixels only)
+  unsigned a_rows = 0, a_cols = 0;
+  auto plan_a = [&](int item_l) {
+    const int item = item0 + item_l;
+    const int tile = (item * 4 + wave) * 16 + n;
+    a_rows = a_cols = 0;
+    a_base = 0;
+    if (item_l < my_items && tile < a.ntiles) {
+      const int f = tile / thw, rem = tile - f * thw;
+      const int ty = rem / a.TW, tx = rem - ty * a.TW;
+      const int r0 = 2 * ty - 1, c0 = 2 * tx - 1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if ((unsigned)(r0 + i) < (unsigned)a.H) a_rows |= 1u << i;
+        if ((unsigned)(c0 + i) < (unsigned)a.W) a_cols |= 1u << i;
+      }
+      a_base = ((f * a.H + r0) * a.W + c0) * 256 + 8 * q;
+    }
+  };
+  // patches are requested TWO steps ahead (a step is ~2 us of MFMAs, an HBM round trip under load is longer): two register
+  // sets by step parity — step t transforms set t & 1, then refills it with the patch of step t + 2
+  f32x2 dn2[2][16];
+  auto request_d = [&](int chunk, f32x2* dn) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned okm = (a_rows >> i) & (a_cols >> j) & 1u;          // (bitwise: no control flow around the loads)
+        unsigned off = okm ? (unsigned)(a_base + (i * a.W + j) * 256 + chunk * 32) : OOB;
+        if constexpr ((W2_ABL & 32) != 0) off = (unsigned)(((i * 4 + j) * 256 + chunk * 32 + 8 * q) + n * 4096);    // (ablation: always the same few KB)
+        if constexpr ((W2_ABL & 2) == 0) dn[4 * i + j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsX, (int)off, 0, 0));
+        else dn[4 * i + j] = f32x2{(float)off, (float)chunk};
+      }
+  };
+  auto request_u = [&](int chunk, int buf) {      // this wave's quarter (8 KB) of the chunk
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int piece = wave * 8 + i;              // 32 pieces of 1 KB
+      if constexpr ((W2_ABL & 4) == 0)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (__attribute__((address_space(3))) void*)((buf ? ubuf1 : ubuf0) + piece * 1024), 16,
+                                               lane * 16, chunk * 32768 + piece * 1024, 0, 0);
+    }
+  };
+
+  f32x4 acc[16][4];               // [plane][16-channel block]: rows = tiles 4q + r, column = channel 16*blk + n
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  float sc[4], sh[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    sc[b] = a.scale ? a.scale[16 * b + n] : 1.f;
+    sh[b] = a.shift ? a.shift[16 * b + n] : 0.f;
+  }
+
+  // ---- prologue: weights chunk 0 and the first item's first two patches
+  plan_a(0);
+  request_u(0, 0);
+  request_d(0, dn2[0]);
+  request_d(1, dn2[1]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  for (int item_l = 0; item_l < my_items; ++item_l) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {                 // (unrolled: chunk, LDS buffer c & 1 and "first chunk" are compile-time)
+      // ---- input transform of this step's patch: V = B^T d B (per channel), 16 planes x 4 channels
+      f32x2 V[16];
+      f32x2* dn = dn2[c & 1];
+      {
+        f32x2 tt[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          tt[0 + j] = dn[0 + j] - dn[8 + j];
+          tt[4 + j] = dn[4 + j] + dn[8 + j];
+          tt[8 + j] = dn[8 + j] - dn[4 + j];
+          tt[12 + j] = dn[4 + j] - dn[12 + j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          V[4 * i + 0] = tt[4 * i + 0] - tt[4 * i + 2];
+          V[4 * i + 1] = tt[4 * i + 1] + tt[4 * i + 2];
+          V[4 * i + 2] = tt[4 * i + 2] - tt[4 * i + 1];
+          V[4 * i + 3] = tt[4 * i + 1] - tt[4 * i + 3];
+        }
+      }
+      // (scheduling fences: hipcc otherwise hoists the NEXT step's transform up to its loads — in front of this step's
+      // MFMAs — and waits for memory there, and sinks the B-fragment reads down to their first use)
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- requests of step t+1: weights chunk into the other buffer (its readers finished at the last barrier), patch
+      // (unconditional — past the workgroup's last step the weights land in a buffer nobody reads and the patch offsets
+      // are out of bounds: a branch around the loads would put register copies, and with them a wait for memory, right here)
+      request_u((c + 1) & 7, (c + 1) & 1);
+      if (c == 6) plan_a(item_l + 1);            // (steps t+2, t+3 of chunks 0, 1 belong to the next item)
+      if (c != 7) request_d((c + 2) & 7, dn);    // (last chunk: after the epilogue — one patch set less live across it)
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- 16 planes x 4 channel blocks x 4 k-steps of MFMAs; B fragments one plane ahead
+      const char* ub = ((c & 1) ? ubuf1 : ubuf0) + (n * 32 + q * 8);
+      f32x2 bf[2][4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bf[0][b] = *reinterpret_cast<const f32x2*>(ub + b * 512);
+#pragma unroll
+      for (int p = 0; p < 16; ++p) {
+        if (p + 1 < 16) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) bf[(p + 1) & 1][b] = *reinterpret_cast<const f32x2*>(ub + (p + 1) * 2048 + b * 512);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            if constexpr ((W2_ABL & 1) == 0)
+              acc[p][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[p][s], bf[p & 1][b][s], (c == 0 && s == 0) ? zero4 : acc[p][b], 0, 0, 0);
+            else acc[p][b][s] = ((c == 0 && s == 0) ? 0.f : acc[p][b][s]) + V[p][s] * bf[p & 1][b][s];
+        __builtin_amdgcn_sched_barrier(0);          // plane p+1's fragment reads stay in front of plane p's MFMAs
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- end of an item: inverse transform (register-local), BN, residual, ReLU, stores
+      if (c == 7) request_d(1, dn);               // chunk 1 of the next item (chunk 0 went out two steps ago); ahead of the stores below
+      __builtin_amdgcn_sched_barrier(0);
+      if (c == 7 && (W2_ABL & 8) != 0) {
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float kv = acc[p][b][r]; asm volatile("" :: "v"(kv)); }
+      }
+      if (c == 7 && (W2_ABL & 8) == 0) {
+        // lane (n, q): tiles 4q + r of the wave's 16, channel 16*b + n.  Residuals of tile r+1 are requested before tile r's
+        // outputs are formed (32-bit offsets into per-launch buffer descriptors; pixels outside the map: out of bounds)
+        const int item = item0 + item_l;
+        const int tile0 = (item * 4 + wave) * 16 + 4 * q;
+        auto offsets = [&](int r, unsigned (&eo)[4]) {       // byte offsets of tile r's four pixels, channel n (or out of bounds)
+          const int tile = tile0 + r;
+          const int f = tile / thw, rem = tile - f * thw;
+          const int ty = rem / a.TW, tx = rem - ty * a.TW;
+          const int y0 = 2 * ty, x0 = 2 * tx;
+          const bool tv = tile < a.ntiles;
+          const unsigned e00 = (unsigned)((((f * a.H + y0) * a.W + x0) * 64 + n) * 4);
+#pragma unroll
+          for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx)
+              eo[2 * dy + dx] = (tv && y0 + dy < a.H && x0 + dx < a.W) ? e00 + (unsigned)((dy * a.W + dx) * 256) : OOB;
+        };
+        unsigned eo[2][4];
+        float rv[2][16];
+        auto req_res = [&](int r) {
+          offsets(r, eo[r & 1]);
+          if constexpr (RES) {
+#pragma unroll
+            for (int px = 0; px < 4; ++px)
+#pragma unroll
+              for (int b = 0; b < 4; ++b)
+                rv[r & 1][4 * px + b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)eo[r & 1][px], 64 * b, 0));
+          }
+        };
+        req_res(0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (r + 1 < 4) req_res(r + 1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            float m[16];
+#pragma unroll
+            for (int p = 0; p < 16; ++p) m[p] = acc[p][b][r];
+            float s0[4], s1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              s0[j] = m[0 + j] + m[4 + j] + m[8 + j];
+              s1[j] = m[4 + j] - m[8 + j] - m[12 + j];
+            }
+            float y[4];
+            y[0] = s0[0] + s0[1] + s0[2]; y[1] = s0[1] - s0[2] - s0[3];
+            y[2] = s1[0] + s1[1] + s1[2]; y[3] = s1[1] - s1[2] - s1[3];
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+              float v = y[px] * sc[b] + sh[b];
+              if constexpr (RES) v += rv[r & 1][4 * px + b];
+              if (a.relu) v = fmaxf(v, 0.f);
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsO, (int)eo[r & 1][px], 64 * b, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);     // (one (tile, channel block) at a time: the 256 accumulators are not all read up front)
+          }
+        }
+      }
+      if constexpr ((W2_ABL & 16) == 0) {
+        // in-order completion: step t+1's weights (issued first) and patch (issued a step ago) have landed once at most the
+        // 16 patch loads of step t+2 — and, at the end of an item, the epilogue's stores behind them — are still in flight
+        if (c == 7) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                       // ... everybody's; and everybody is done reading buffer c & 1
+        asm volatile("" ::: "memory");
+      }
+    }
+  }
+}
+
+// U must be laid out [8][16][64][8] (chunk of 8 input channels, plane xi = 4i + j, output channel, channel in chunk):
+// cadre_amd/encoder.py _winograd_u_c64.  out = act(conv * scale + shift (+ resid)), act: 0 none, 1 ReLU.
+extern "C" int cadre_winograd_c64(const float* x, const float* U, const float* scale, const float* shift, const float* resid, float* out,
+                                  int32_t F, int32_t H, int32_t W, int32_t act, void* stream) {
+  if (!x || !U || !out || F < 1 || H < 1 || W < 1) return cadre_fail("cadre_winograd_c64: bad argument");
+  if (act != 0 && act != 1) return cadre_fail("cadre_winograd_c64: act must be 0 (none) or 1 (ReLU after the residual)");
+  if ((((uintptr_t)x | (uintptr_t)U | (uintptr_t)out | (uintptr_t)resid) & 15) || (((uintptr_t)scale | (uintptr_t)shift) & 3))
+    return cadre_fail("cadre_winograd_c64: operands must be 16-byte aligned");
+  if ((long long)F * H * W * 256 >= (1ll << 31)) return cadre_fail("cadre_winograd_c64: the activation tensor must stay below the 2 GiB buffer window: chunk the batch");
+  w2_args a;
+  a.x = x; a.U = U; a.scale = scale; a.shift = shift; a.resid = resid; a.out = out;
+  a.F = F; a.H = H; a.W = W; a.TH = (H + 1) / 2; a.TW = (W + 1) / 2;
+  const long long nt = (long long)F * a.TH * a.TW;
+  if (nt > 0x7fffffff - 64) return cadre_fail("cadre_winograd_c64: too many tiles");
+  a.ntiles = (int)nt;
+  a.ngroups = (int)((nt + 15) / 16);
+  a.relu = act;
+  const int nitems = (a.ngroups + 3) / 4;
+  const int grid = nitems < 256 ? nitems : 256;
+  if (resid) hipLaunchKernelGGL(wino2_c64_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(wino2_c64_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}

@@ -106,6 +106,12 @@ def _winograd_u(w, m=2):
     return u.reshape((m + 2) ** 2, w.shape[0], w.shape[1]).float().contiguous()
 
 
+def _winograd_u_c64(w):
+    """OIHW 64 x 64 x 3 x 3 -> the fused kernel's layout [8 chunks of 8 cin][16 planes][64 cout][8 cin] (csrc/winograd_c64.hip)."""
+    u = _winograd_u(w, 2)                                          # [16][O = 64][I = 64]
+    return u.reshape(16, 64, 8, 8).permute(2, 0, 1, 3).contiguous()
+
+
 def _winograd_m(H, W):
     """Output tile edge of the Winograd form for an H x W map: the one with fewer transform-domain multiplies,
     (m+2)^2 * ceil(H/m) * ceil(W/m) (F(3x3) tiles the 9x9 and 18x18 maps of the 288x288 model exactly).  CADRE_WINOGRAD_M
@@ -118,7 +124,7 @@ def _winograd_m(H, W):
 
 
 class _Conv:
-    __slots__ = ("w", "w_ring", "ring_folded", "scale", "shift", "cin", "cout", "k", "stride", "pad", "act", "w_wino", "_w_oihw")
+    __slots__ = ("w", "w_ring", "ring_folded", "scale", "shift", "cin", "cout", "k", "stride", "pad", "act", "w_wino", "_w_oihw", "w_wino_c64")
 
     def wino_u(self, m, dev):
         if m not in self.w_wino:
@@ -145,6 +151,11 @@ class _Conv:
         self.cout, self.cin = w.shape[0], w.shape[1]
         self.k, self.stride, self.pad, self.act = k, stride, pad, act
         self.w_wino = None
+        self.w_wino_c64 = None
+        if (_winograd_min_c() and os.environ.get("CADRE_WINOGRAD_C64", "0") != "0" and hip.has_ab_kernels() and wdtype == torch.float32
+                and k == 3 and stride == 1 and pad == 1 and tuple(w.shape[:2]) == (64, 64)):
+            # fused F(2x2) kernel of the 64 -> 64 stage: A/B build only, measured 3.1 / 3.4 vs 2.97 ms (csrc/ab/winograd_c64.hip)
+            self.w_wino_c64 = _winograd_u_c64(torch.as_tensor(w).float()).to(dev)
         wmin = _winograd_min_c()
         if (wmin and wdtype == torch.float32 and k == 3 and stride == 1 and pad == 1 and w.shape[1] >= wmin
                 and w.shape[0] >= 128 and w.shape[1] % 4 == 0 and w.shape[0] % 4 == 0):
@@ -321,7 +332,12 @@ class DANetEncoderHIP:
                       | (0 if resid is None else (8 | (4 if resid.dtype == torch.bfloat16 else 0))))
         use_ring = (c.w_ring is not None and self.ring_conv and x.dtype == c.w_ring.dtype and (act & 15) <= 1
                     and bool(hip.lib().cadre_conv3x3_ring_supported(F, H, W, c.cin, c.cout, ring_flags)))
-        if c.w_wino is not None and x.dtype == torch.float32 and odt == torch.float32 and (act & 15) <= 1:
+        if (c.w_wino_c64 is not None and x.dtype == torch.float32 and odt == torch.float32 and act in (0, 1)
+                and F * H * W * 256 < 2 ** 31 and (resid is None or resid.dtype == torch.float32)):
+            # fused Winograd F(2x2, 3x3) of the 64 -> 64 stage: transforms and the 16 plane products in one kernel
+            hip.check(hip.lib().cadre_winograd_c64(hip.ptr(x), hip.ptr(c.w_wino_c64), hip.ptr(c.scale), hip.ptr(c.shift), hip.ptr(resid),
+                                                   hip.ptr(out), F, H, W, act, hip.stream()), "cadre_winograd_c64")
+        elif c.w_wino is not None and x.dtype == torch.float32 and odt == torch.float32 and (act & 15) <= 1:
             # Winograd F(2x2, 3x3): input transform -> one batched GEMM over the 16 transform planes -> inverse transform + BN + residual + ReLU
             m = _winograd_m(H, W)
             P, T = (m + 2) ** 2, F * -(-H // m) * -(-W // m)

@@ -92,6 +92,7 @@ SYMBOLS = {
 # entry points of the A/B build only (include/cadre_hip_ab.h; CADRE_BUILD_AB=1 python -m cadre_amd.build, then
 # CADRE_HIP_LIB=.../libcadre_hip_ab.so): bound when the loaded library has them
 AB_SYMBOLS = {
+    "cadre_winograd_c64": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "cadre_lstm_pointwise_fwd": [vp, i64, i64, vp, i64, i32, vp, vp, vp, i64, i64, i32, i32, i32, vp, vp],
     "cadre_lstm_pointwise_bwd": [vp, vp, i64, i64, vp, vp, i64, vp, vp, i64, i32, i64, i64, i32, i32, i32, vp, i32, vp, vp],
     "cadre_colsum2": [vp, i64, i64, vp, vp, i64, i32, i32, i32, vp, i32, vp],

@@ -1172,6 +1172,42 @@ def test_conv_decode_random_geometries(hip):
             assert rel(out.permute(0, 3, 1, 2), want16) < 1e-4, (cases[ci], tile, "bf16")
 
 
+@pytest.mark.parametrize("F,H,W,use_resid,act", [(3, 72, 72, True, 1), (2, 21, 21, False, 1), (5, 7, 10, True, 0), (1, 1, 1, False, 1),
+                                                 (40, 9, 13, True, 1), (300, 6, 6, False, 1)])
+@needs_ab
+def test_winograd_c64_fused_matches_torch(hip, F, H, W, use_resid, act):
+    """cadre_winograd_c64 (A/B build; fused F(2x2,3x3): transforms + 16 plane products in one kernel, layer1 of the fp32 model) vs torch
+    conv2d + folded BN + residual + ReLU (resnet.py:26-55) on maps the 2x2 tiles divide and do not divide, fewer tiles
+    than one workgroup takes and many items per workgroup; same frames in a larger batch: same bits."""
+    from cadre_amd.encoder import _winograd_u_c64
+    g = torch.Generator().manual_seed(F * 100 + H)
+    x = torch.randn(F, H, W, 64, generator=g)
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24.0
+    sc, sh = 0.5 + torch.rand(64, generator=g), torch.randn(64, generator=g)
+    res = torch.randn(F, H, W, 64, generator=g) if use_resid else None
+    want = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1) * sc + sh
+    if res is not None:
+        want = want + res
+    if act == 1:
+        want = torch.relu(want)
+    u, scd, shd = dev(_winograd_u_c64(w)), dev(sc), dev(sh)
+
+    def run(xd, rd, Fb):
+        out = torch.full((Fb, H, W, 64), 7.0, device="cuda")
+        hip.check(hip.lib().cadre_winograd_c64(hip.ptr(xd), hip.ptr(u), hip.ptr(scd), hip.ptr(shd), hip.ptr(rd), hip.ptr(out), Fb, H, W, act,
+                                               hip.stream()), "cadre_winograd_c64")
+        return out
+    got = run(dev(x), None if res is None else dev(res), F)
+    assert rel(got.cpu(), want) < 2e-5, float((got.cpu() - want).abs().max())
+    xb = torch.randn(F + 3, H, W, 64, generator=g)
+    rb = torch.randn(F + 3, H, W, 64, generator=g) if use_resid else None
+    xb[2:2 + F] = x
+    if rb is not None:
+        rb[2:2 + F] = res
+    gb = run(dev(xb), None if rb is None else dev(rb), F + 3)
+    assert torch.equal(gb[2:2 + F], got)
+
+
 @pytest.mark.parametrize("F,H,W,Cin,N,use_resid,act", [(3, 9, 9, 64, 128, True, 1), (2, 18, 18, 32, 64, False, 1), (2, 7, 10, 16, 32, True, 17),
                                                      (1, 1, 1, 8, 8, False, 0), (5, 6, 5, 12, 20, True, 0)])
 @pytest.mark.parametrize("m", [2, 3])
