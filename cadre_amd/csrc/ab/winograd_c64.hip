@@ -18,9 +18,9 @@
 // 2.25x fewer multiplies than the direct conv, rounding error BELOW the direct conv's.
 //
 // STATUS (round 4): parity-green, NOT adopted — A/B build only (CADRE_WINOGRAD_C64=1 with libcadre_hip_ab.so).  1024 frames
-// of 72 x 72: 3.10 ms (3.39 with the residual) against 2.97 for the direct window kernel; the MFMAs with their LDS
+// of 72 x 72: 3.09 ms (3.20 with the residual) against 2.97 for the direct window kernel; the MFMAs with their LDS
 // fragment reads alone run 1.45 ms (tools/wino_c64_ablate.py, profiles/r04_wino_c64_ablation.txt), i.e. the schedule is worth
-// 2x once the rest hides.  What does not hide yet: the epilogue (0.9-1.1 ms: hipcc spills ~50 VGPRs around it, and a
+// 2x once the rest hides.  What does not hide yet: the epilogue (0.8-0.9 ms: hipcc spills ~45 VGPRs around it, and a
 // scratch reload behind 64 stores waits for every one of them — vmcnt completes in order), the patch loads (0.3-0.4 ms
 // of memory latency behind a two-step prefetch) and the weight DMA (0.2 ms).  Lessons already in the code: separate LDS
 // objects per DMA buffer (one object = s_waitcnt vmcnt(0) before every fragment read), no branch around loads (PHI copies
@@ -193,8 +193,6 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
       }
       __builtin_amdgcn_sched_barrier(0);
       // ---- end of an item: inverse transform (register-local), BN, residual, ReLU, stores
-      if (c == 7) request_d(1, dn);               // chunk 1 of the next item (chunk 0 went out two steps ago); ahead of the stores below
-      __builtin_amdgcn_sched_barrier(0);
       if (c == 7 && (W2_ABL & 8) != 0) {
 #pragma unroll
         for (int p = 0; p < 16; ++p)
@@ -264,6 +262,8 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
           }
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      if (c == 7) request_d(1, dn);               // chunk 1 of the next item, BEHIND the epilogue: one patch set less live across it
       if constexpr ((W2_ABL & 16) == 0) {
         // in-order completion: step t+1's weights (issued first) and patch (issued a step ago) have landed once at most the
         // 16 patch loads of step t+2 — and, at the end of an item, the epilogue's stores behind them — are still in flight
