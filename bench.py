@@ -315,6 +315,8 @@ AM = {0: "dense A[M][K]", 1: "dense A[K][M]", 2: "NHWC implicit-GEMM conv", 3: "
 
 def kname(k):
     """Exact kernel symbol as rocprofv3 prints it, from a hip.PROFILE key."""
+    if k[0] == "wino_c64":
+        return "wino2_c64_kernel<%s>" % ("true" if k[1] else "false")
     if k[0] == "ring":
         tf = ("true" if k[1] else "false", k[2], k[3], "true" if k[4] else "false")
         if len(k) > 7 and k[7] == 8:             # one wave per SIMD, streamed weights (128-channel tile)
@@ -356,7 +358,10 @@ def roofline_of(prof, steps):
     peak_tf = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
     t_mfma, t_hbm = fl / (peak_tf * 1e12), nb / (PEAK_HBM_GBPS * 1e9)
     tile, am = (65, 2) if dom[0] == "ring" else ((dom[1], dom[2]) if bf16 else (dom[0], dom[1]))
-    r = {"kernel": kname(dom), "kernel_desc": "%s tile, %s%s" % (TILE.get(tile, tile), AM.get(am, am), ", bf16" if bf16 else ""),
+    desc = "%s tile, %s%s" % (TILE.get(tile, tile), AM.get(am, am), ", bf16" if bf16 else "")
+    if dom[0] == "wino_c64":
+        desc = "fused Winograd F(2x2,3x3) of the fp32 64 -> 64 stage (executed FLOPs)"
+    r = {"kernel": kname(dom), "kernel_desc": desc,
          "flops_per_launch": round(fl / n, 1), "bytes_per_launch": round(nb / n, 1), "launches": n,
          "avg_launch_us": round(t / n * 1e6, 2),
          "mfma_frac": round(t_mfma / t, 4), "hbm_frac": round(t_hbm / t, 4),

@@ -17,18 +17,17 @@
 //     one raw barrier per 512 MFMAs (128 per wave).
 // 2.25x fewer multiplies than the direct conv, rounding error BELOW the direct conv's.
 //
-// STATUS (round 4): parity-green, NOT adopted — A/B build only (CADRE_WINOGRAD_C64=1 with libcadre_hip_ab.so).  1024 frames
-// of 72 x 72: 3.09 ms (3.20 with the residual) against 2.97 for the direct window kernel; the MFMAs with their LDS
-// fragment reads alone run 1.45 ms (tools/wino_c64_ablate.py, profiles/r04_wino_c64_ablation.txt), i.e. the schedule is worth
-// 2x once the rest hides.  What does not hide yet: the epilogue (0.8-0.9 ms: hipcc spills ~45 VGPRs around it, and a
-// scratch reload behind 64 stores waits for every one of them — vmcnt completes in order), the patch loads (0.3-0.4 ms
-// of memory latency behind a two-step prefetch) and the weight DMA (0.2 ms).  Lessons already in the code: separate LDS
-// objects per DMA buffer (one object = s_waitcnt vmcnt(0) before every fragment read), no branch around loads (PHI copies
-// wait for memory on the spot), scheduling fences around the MFMA block (the next step's transform is otherwise hoisted
-// to its loads), contiguous item ranges per workgroup (halo rows come from the workgroup's own L1 / L2).
+// Built with -mllvm -enable-misched=0 (cadre_amd/build.py EXTRA_FLAGS): the source is written in issue order and the machine
+// scheduler's reordering cost 40-100 VGPR spills, whose scratch reloads behind the epilogue's stores wait for every one of
+// them (vmcnt completes in order) — 3.09 / 3.20 ms with the scheduler, 2.50 / 2.62 ms without, against 2.97 ms for the direct
+// window kernel (1024 frames of 72 x 72; without / with residual).  The MFMAs with their LDS fragment reads alone run
+// 1.45 ms (tools/wino_c64_ablate.py, profiles/r04_wino_c64_ablation.txt): what does not hide yet is memory latency behind
+// the per-step wait (0.65 ms) and the weight DMA (0.25 ms).  Lessons in the code: separate LDS objects per DMA buffer (one
+// object = s_waitcnt vmcnt(0) before every fragment read), no branch around loads (PHI copies wait for memory on the spot),
+// scheduling fences around the MFMA block, contiguous item ranges per workgroup (halo rows from the workgroup's own L1 / L2).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "../../../include/cadre_hip_ab.h"
+#include "../../include/cadre_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));

@@ -152,9 +152,9 @@ class _Conv:
         self.k, self.stride, self.pad, self.act = k, stride, pad, act
         self.w_wino = None
         self.w_wino_c64 = None
-        if (_winograd_min_c() and os.environ.get("CADRE_WINOGRAD_C64", "0") != "0" and hip.has_ab_kernels() and wdtype == torch.float32
+        if (_winograd_min_c() and os.environ.get("CADRE_WINOGRAD_C64", "1") != "0" and wdtype == torch.float32
                 and k == 3 and stride == 1 and pad == 1 and tuple(w.shape[:2]) == (64, 64)):
-            # fused F(2x2) kernel of the 64 -> 64 stage: A/B build only, measured 3.1 / 3.4 vs 2.97 ms (csrc/ab/winograd_c64.hip)
+            # fused F(2x2) kernel of the 64 -> 64 stage (csrc/winograd_c64.hip): 2.50 / 2.62 vs 2.97 ms per 1024 frames of 72 x 72
             self.w_wino_c64 = _winograd_u_c64(torch.as_tensor(w).float()).to(dev)
         wmin = _winograd_min_c()
         if (wmin and wdtype == torch.float32 and k == 3 and stride == 1 and pad == 1 and w.shape[1] >= wmin
@@ -335,8 +335,7 @@ class DANetEncoderHIP:
         if (c.w_wino_c64 is not None and x.dtype == torch.float32 and odt == torch.float32 and act in (0, 1)
                 and F * H * W * 256 < 2 ** 31 and (resid is None or resid.dtype == torch.float32)):
             # fused Winograd F(2x2, 3x3) of the 64 -> 64 stage: transforms and the 16 plane products in one kernel
-            hip.check(hip.lib().cadre_winograd_c64(hip.ptr(x), hip.ptr(c.w_wino_c64), hip.ptr(c.scale), hip.ptr(c.shift), hip.ptr(resid),
-                                                   hip.ptr(out), F, H, W, act, hip.stream()), "cadre_winograd_c64")
+            hip.winograd_c64(x, c.w_wino_c64, c.scale, c.shift, resid, out, F, H, W, act)
         elif c.w_wino is not None and x.dtype == torch.float32 and odt == torch.float32 and (act & 15) <= 1:
             # Winograd F(2x2, 3x3): input transform -> one batched GEMM over the 16 transform planes -> inverse transform + BN + residual + ReLU
             m = _winograd_m(H, W)
@@ -533,7 +532,7 @@ class DANetEncoderHIP:
     def winograd_convs(self):
         """Number of conv layers that run as Winograd F(2x2, 3x3) (0 for the bf16 model and under CADRE_WINOGRAD=0)."""
         cs = [c for blk in self.blocks for c in blk[:2]] + [self.conv5a, self.conv5c, self.conv51, self.conv52]
-        return sum(c.w_wino is not None for c in cs)
+        return sum(c.w_wino is not None or c.w_wino_c64 is not None for c in cs)
 
     def flops_per_frame(self, executed=False):
         """Direct-convolution (algorithmic) FLOPs of one frame; executed=True: what the launches multiply — differs only
@@ -543,6 +542,8 @@ class DANetEncoderHIP:
         def conv(c, H, W):
             Ho = (H + 2 * c.pad - c.k) // c.stride + 1
             Wo = (W + 2 * c.pad - c.k) // c.stride + 1
+            if executed and c.w_wino_c64 is not None:
+                return 2 * 16 * -(-H // 2) * -(-W // 2) * c.cout * c.cin, Ho, Wo
             if executed and c.w_wino is not None:
                 m = _winograd_m(H, W)
                 return 2 * (m + 2) ** 2 * -(-H // m) * -(-W // m) * c.cout * c.cin, Ho, Wo

@@ -52,6 +52,7 @@ SYMBOLS = {
     "cadre_stem_pool": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, i64, vp],
     "cadre_div255_selfcheck": [vp, vp, vp],
     "cadre_stem_pool_supported": [i32, i32],
+    "cadre_winograd_c64": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "cadre_winograd_in": [vp, vp, i32, i32, i32, i32, i32, vp],
     "cadre_winograd_out": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "cadre_pam": [vp, vp, f32, vp, i32, i32, vp],
@@ -92,7 +93,6 @@ SYMBOLS = {
 # entry points of the A/B build only (include/cadre_hip_ab.h; CADRE_BUILD_AB=1 python -m cadre_amd.build, then
 # CADRE_HIP_LIB=.../libcadre_hip_ab.so): bound when the loaded library has them
 AB_SYMBOLS = {
-    "cadre_winograd_c64": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "cadre_lstm_pointwise_fwd": [vp, i64, i64, vp, i64, i32, vp, vp, vp, i64, i64, i32, i32, i32, vp, vp],
     "cadre_lstm_pointwise_bwd": [vp, vp, i64, i64, vp, vp, i64, vp, vp, i64, i32, i64, i64, i32, i32, i32, vp, i32, vp, vp],
     "cadre_colsum2": [vp, i64, i64, vp, vp, i64, i32, i32, i32, vp, i32, vp],
@@ -227,6 +227,23 @@ def conv3x3_c64_bf16(x, w, scale, shift, resid, out, F, H, W, relu):
     M = F * H * W
     nbytes = M * 64 * 2 * (3 if resid is not None else 2) + 64 * 576 * 2
     PROFILE.append((("bf16", 64, 2), 2.0 * M * 64 * 576, e0, e1, (M, 64, 576, 1, 1, 0), nbytes))
+
+
+def winograd_c64(x, u, scale, shift, resid, out, F, H, W, act):
+    """cadre_winograd_c64 (fused Winograd F(2x2,3x3) of the fp32 64 -> 64 stage) with the profiling hook of gemm():
+    key ("wino_c64", residual); FLOPs = the EXECUTED ones (16 planes x tiles x 64 x 64)."""
+    fn = lib().cadre_winograd_c64
+    args = (ptr(x), ptr(u), ptr(scale), ptr(shift), ptr(resid), ptr(out), F, H, W, act, stream())
+    if PROFILE is None or torch.cuda.is_current_stream_capturing():
+        check(fn(*args), "cadre_winograd_c64")
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(fn(*args), "cadre_winograd_c64")
+    e1.record()
+    T = F * ((H + 1) // 2) * ((W + 1) // 2)
+    nbytes = F * H * W * 64 * 4 * (3 if resid is not None else 2) + 16 * 64 * 64 * 4
+    PROFILE.append((("wino_c64", resid is not None), 2.0 * 16 * T * 64 * 64, e0, e1, (T, 64, 64 * 16, 1, 1, 0), nbytes))
 
 
 def conv3x3_ring(x, w_ring, scale, shift, resid, out, F, H, W, Cin, N, act):

@@ -160,6 +160,14 @@ int cadre_stem_pool(const uint32_t* img, const void* wt, const float* scale, con
                     int64_t out_frame, int64_t out_row, int32_t out_px, int64_t out_off, void* stream);
 int cadre_stem_pool_supported(int32_t H, int32_t W);
 
+/* FUSED Winograd F(2x2, 3x3) for 64 -> 64 stride-1 / pad-1 3x3 convs in fp32 (csrc/winograd_c64.hip; the fp32 model's layer1,
+ * resnet.py:26-55): input transform, 16 plane products and inverse transform in one kernel, nothing of the transform
+ * domain leaves the CU.  U: the transformed weights (G g G^T)[xi][cout][cin] laid out [8 chunks of 8 cin][16 planes][64][8]
+ * (cadre_amd/encoder.py _winograd_u_c64).  out = act(conv * scale + shift (+ resid)), act 0 none / 1 ReLU; x, resid, out
+ * [F][H][W][64] below 2 GiB. */
+int cadre_winograd_c64(const float* x, const float* U, const float* scale, const float* shift, const float* resid, float* out,
+                       int32_t F, int32_t H, int32_t W, int32_t act, void* stream);
+
 /* Winograd F(m x m, 3x3) transforms, m = 2 or 3, fp32, NHWC (csrc/winograd.hip).  A stride-1 / pad-1 3x3 convolution
  * (resnet.py:26-55) = cadre_winograd_in -> ONE cadre_gemm_f32 with batch (m+2)^2 (M[xi] = V[xi] . U[xi]^T,
  * U[xi][cout][cin] = (G g G^T)[xi] prepared by the host; Cook-Toom points 0, 1, -1, inf (m = 2) / 0, 3/4, -3/4, 2, inf (m = 3):

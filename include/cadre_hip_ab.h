@@ -4,7 +4,6 @@
  * libcadre_hip.so neither compiles nor exports them.
  *   conv_stream_f32.hip / conv_stream_bf16.hip  cadre_gemm_t.tile 12: 64x64 conv, several M-tiles per workgroup
  *   gemm_f32_skinny.hip                         cadre_gemm_t.tile 11 (fp32): register-direct skinny GEMM
- *   winograd_c64.hip                            cadre_winograd_c64: fused Winograd F(2x2,3x3) of the fp32 64 -> 64 stage
  *   gemm_stream_f32.hip                         cadre_gemm_t.tile 13 (fp32): short-K dense NT product, several M-tiles per workgroup
  *   conv3x3_c64_bf16.hip                        cadre_conv3x3_c64_bf16 below
  *   ppo_update.hip (under CADRE_AB_KERNELS)     cadre_lstm_seq_fwd below: the persistent forward LSTM (208 vs 110 us)
@@ -64,14 +63,6 @@ int cadre_colsum2(const float* X, int64_t ldx, int64_t x_str, float* out, float*
 int cadre_lstm_seq_fwd(const float* Wp, int64_t wp_str, const float* bias, int64_t b_str, float* G, int32_t ldg,
                        int64_t g_str, float* Hs, float* Cs, float* TC, int32_t ldh, int64_t h_str, int32_t B, int32_t D,
                        int32_t S, int32_t Z, const int32_t* row_seg, int32_t* sync_ws, void* stream);
-/* FUSED Winograd F(2x2, 3x3) for 64 -> 64 stride-1 / pad-1 3x3 convs in fp32 (csrc/ab/winograd_c64.hip; measured 3.09 / 3.20 ms against 2.97 of the direct kernel: not adopted; the fp32 model's layer1,
- * resnet.py:26-55): input transform, 16 plane products and inverse transform in one kernel, nothing of the transform
- * domain leaves the CU.  U: the transformed weights (G g G^T)[xi][cout][cin] laid out [8 chunks of 8 cin][16 planes][64][8]
- * (cadre_amd/encoder.py _winograd_u_c64).  out = act(conv * scale + shift (+ resid)), act 0 none / 1 ReLU; x, resid, out
- * [F][H][W][64] below 2 GiB. */
-int cadre_winograd_c64(const float* x, const float* U, const float* scale, const float* shift, const float* resid, float* out,
-                       int32_t F, int32_t H, int32_t W, int32_t act, void* stream);
-
 #ifdef __cplusplus
 }
 #endif

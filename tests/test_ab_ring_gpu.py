@@ -42,14 +42,3 @@ def test_ab_lstm_dw_with_operands_shared_through_lds(ks):
                         "-k", "test_lstm_dw_fused"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert " passed" in p.stdout
-
-
-@pytest.mark.skipif(not _ab_current(), reason="A/B library missing or older than its sources (CADRE_BUILD_AB=1 python -m cadre_amd.build)")
-def test_ab_fused_winograd_of_the_64_channel_stage():
-    """cadre_winograd_c64 (fused F(2x2,3x3) of the fp32 64 -> 64 stage: built, parity-green, slower than the direct window kernel
-    — DESIGN.md 3.7) stays green against torch on every shape class of its kernel test."""
-    env = dict(os.environ, CADRE_HIP_LIB=AB)
-    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_kernels_gpu.py"), "-q", "-x", "-m", "gpu",
-                        "-k", "test_winograd_c64_fused_matches_torch"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
-    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
-    assert " passed" in p.stdout

@@ -54,7 +54,7 @@ def test_encoder_conv_algorithms_vs_reference_golden(golden, tag, algo, monkeypa
     enc = DANetEncoderHIP(sd, H, W, "cuda:0")
     nw = sum(c.w_wino is not None for blk in enc.blocks for c in blk[:2]) + sum(c.w_wino is not None for c in (enc.conv5a, enc.conv5c))
     assert nw == (11 if algo == "winograd" else 0)           # layer2 / layer3 / layer4: three stride-1 convs each; head: conv5a, conv5c
-    assert enc.winograd_convs() == (13 if algo == "winograd" else 0)        # (+ conv51, conv52)
+    assert enc.winograd_convs() == (17 if algo == "winograd" else 0)        # (+ conv51, conv52 and layer1's four fused 64 -> 64 convs)
     r = np.random.RandomState(int(g["frame_seed"]))
     rgb = r.randint(0, 256, (n, H, W, 3)).astype(np.uint8)
     route = ((r.rand(n, W, H) < 0.15) * 255).astype(np.uint8)

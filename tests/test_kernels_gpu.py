@@ -1174,9 +1174,8 @@ def test_conv_decode_random_geometries(hip):
 
 @pytest.mark.parametrize("F,H,W,use_resid,act", [(3, 72, 72, True, 1), (2, 21, 21, False, 1), (5, 7, 10, True, 0), (1, 1, 1, False, 1),
                                                  (40, 9, 13, True, 1), (300, 6, 6, False, 1)])
-@needs_ab
 def test_winograd_c64_fused_matches_torch(hip, F, H, W, use_resid, act):
-    """cadre_winograd_c64 (A/B build; fused F(2x2,3x3): transforms + 16 plane products in one kernel, layer1 of the fp32 model) vs torch
+    """cadre_winograd_c64 (fused F(2x2,3x3): transforms + 16 plane products in one kernel, layer1 of the fp32 model) vs torch
     conv2d + folded BN + residual + ReLU (resnet.py:26-55) on maps the 2x2 tiles divide and do not divide, fewer tiles
     than one workgroup takes and many items per workgroup; same frames in a larger batch: same bits."""
     from cadre_amd.encoder import _winograd_u_c64

@@ -11,8 +11,8 @@ NAMES = {0: "full kernel", 1: "no MFMA", 2: "no patch loads", 4: "no weight DMA"
 so = lambda a: os.path.join(ROOT, "tools", "_trace", "libw64_abl%d.so" % a)
 if "--build-only" in sys.argv:
     os.makedirs(os.path.dirname(so(0)), exist_ok=True)
-    srcs = [os.path.join(ROOT, "cadre_amd", "csrc", f) for f in ("ab/winograd_c64.hip", "cadre_kernels.hip")]
-    ps = [subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DW2_ABL=%d" % a, "-o", so(a)] + srcs,
+    srcs = [os.path.join(ROOT, "cadre_amd", "csrc", f) for f in ("winograd_c64.hip", "cadre_kernels.hip")]
+    ps = [subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-mllvm", "-enable-misched=0", "-DW2_ABL=%d" % a, "-o", so(a)] + srcs,
                            stderr=subprocess.DEVNULL) for a in ABLS]
     assert all(p.wait() == 0 for p in ps)
     sys.exit(0)
