@@ -56,12 +56,14 @@ def test_c2_encoder_goldens_inside_1024_frame_chunk(golden):
         torch.cuda.synchronize()
     finally:
         hip.PROFILE = None
-    tiles = {(65 if k[0] == "ring" else k[0]) for k, *_ in prof}
-    launched = {((65 if k[0] == "ring" else k[0]), shape[0], shape[1]) for k, _f, _a, _b, shape, _nb in prof}
-    # the timed run's kernels: fused front (stem_pool.hip, no GEMM launch for the stem), the stage-1 convs on the full
-    # 1024-frame M (64x64 tile 3, or the ring kernel 65 where it is enabled), 8-wave 128x128 tile (8) for layer2.0
+    code = lambda k: {"ring": 65, "wino_c64": 66}.get(k[0], k[0])
+    tiles = {code(k) for k, *_ in prof}
+    launched = {(code(k), shape[0], shape[1]) for k, _f, _a, _b, shape, _nb in prof}
+    # the timed run's kernels: fused front (stem_pool.hip, no GEMM launch for the stem), the four stage-1 convs as the fused
+    # Winograd kernel (66) on all 1024 x 36 x 36 tiles of the chunk, 8-wave 128x128 tile (8) for layer2.0 and for the
+    # Winograd convs' batched GEMMs
     assert enc.fused_stem and 8 in tiles, sorted(tiles)
-    assert any(t in (3, 65) and m == F * 72 * 72 for t, m, _n in launched), sorted(launched)[:8]
+    assert sum(1 for k, *_ in prof if k[0] == "wino_c64") == 4 and (66, F * 36 * 36, 64) in launched, sorted(launched)[:8]
     got = torch.stack([lat[0], lat[F - 1]])
     e = rel(got.cpu().numpy(), g["latent"])
     print("288x288 goldens inside a 1024-frame chunk: latent rel-max-err %.2e, tiles %s" % (e, sorted(tiles)))
