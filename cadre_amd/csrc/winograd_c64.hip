@@ -34,6 +34,15 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 int cadre_fail(const char* msg);
 
+#ifndef W2_ILV
+#define W2_ILV 1      // 1: the step's patch loads and weight-DMA pieces are issued one per plane BETWEEN the MFMAs (0: a burst in front of them)
+#endif
+#ifndef W2_EPD
+#define W2_EPD 1      // residual form: the next item's chunk-1 patch is requested beside the epilogue's tiles 2, 3 (0: behind the epilogue)
+#endif
+#ifndef W2_ASM_MFMA
+#define W2_ASM_MFMA 1
+#endif
 #ifndef W2_ABL
 #define W2_ABL 0      // tools/wino_c64_ablate.py: 1 no MFMA, 2 no patch loads, 4 no weight DMA, 8 no epilogue, 16 no wait + barrier
 #endif
@@ -51,12 +60,41 @@ struct w2_args {
   int relu;
 };
 
+// The 64 accumulator blocks are pinned to the AGPR file ("+a"): left to the register allocator, hipcc moved blocks between
+// AGPRs and VGPRs inside the steps around the epilogue (v_accvgpr_read + s_nop 8 behind every second MFMA, the patch
+// registers spilled to make room).  Inline asm hides the MFMA from the hazard recognizer: the only read of an accumulator by
+// the vector ALU is the epilogue's, behind mfma_drain().
+__device__ __forceinline__ void mfma_acc(f32x4& acc, float av, float bv, bool first) {
+#if W2_ASM_MFMA && defined(__HIP_DEVICE_COMPILE__)
+  if (first) asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=a"(acc) : "v"(av), "v"(bv));
+  else asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(av), "v"(bv));
+#else
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, first ? zero4 : acc, 0, 0, 0);
+#endif
+}
+// (an empty asm that "rewrites" the block right where a group reads it: hipcc otherwise moves ~150 v_accvgpr_read of LATER
+// groups to the top of the epilogue — and spills patch registers, whose spill stores wait for the loads that fill them)
+__device__ __forceinline__ void acc_pin(f32x4& acc) {
+#if W2_ASM_MFMA && defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+a"(acc));
+#endif
+}
+__device__ __forceinline__ void mfma_drain() {
+#if W2_ASM_MFMA && defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // (an 8-pass MFMA's result is readable by the vector ALU 18 wait states later at most)
+#endif
+}
+
 template <bool RES>
 __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
-  // two 32 KB weight-chunk buffers as SEPARATE objects: hipcc then knows that the LDS-DMA into one does not alias the
-  // fragment reads of the other and does not put s_waitcnt vmcnt(0) in front of every step's first ds_read
+  // four 32 KB weight-chunk buffers as SEPARATE objects: hipcc then knows that the LDS-DMA into one does not alias the
+  // fragment reads of another and does not put s_waitcnt vmcnt(0) in front of every step's first ds_read.  The chunk of
+  // step t+2 is requested at step t (a step is 128 MFMAs per wave = 1.8 us: less than an L2 round trip under load)
   __shared__ __attribute__((aligned(16))) char ubuf0[32768];
   __shared__ __attribute__((aligned(16))) char ubuf1[32768];
+  __shared__ __attribute__((aligned(16))) char ubuf2[32768];
+  __shared__ __attribute__((aligned(16))) char ubuf3[32768];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, q = lane >> 4;
@@ -109,18 +147,30 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
         else dn[4 * i + j] = f32x2{(float)off, (float)chunk};
       }
   };
+  auto request_d1 = [&](int chunk, f32x2* dn, int i, int j) {      // one pixel of the patch
+    const unsigned okm = (a_rows >> i) & (a_cols >> j) & 1u;
+    unsigned off = okm ? (unsigned)(a_base + (i * a.W + j) * 256 + chunk * 32) : OOB;
+    if constexpr ((W2_ABL & 32) != 0) off = (unsigned)(((i * 4 + j) * 256 + chunk * 32 + 8 * q) + n * 4096);
+    if constexpr ((W2_ABL & 2) == 0) dn[4 * i + j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsX, (int)off, 0, 0));
+    else dn[4 * i + j] = f32x2{(float)off, (float)chunk};
+  };
+  auto request_u1 = [&](int chunk, int buf, int i) {      // one 1 KB piece of this wave's quarter of the chunk
+    const int piece = wave * 8 + i;
+    if constexpr ((W2_ABL & 4) == 0)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (__attribute__((address_space(3))) void*)((buf == 0 ? ubuf0 : buf == 1 ? ubuf1 : buf == 2 ? ubuf2 : ubuf3) + piece * 1024), 16,
+                                             lane * 16, chunk * 32768 + piece * 1024, 0, 0);
+  };
   auto request_u = [&](int chunk, int buf) {      // this wave's quarter (8 KB) of the chunk
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int piece = wave * 8 + i;              // 32 pieces of 1 KB
       if constexpr ((W2_ABL & 4) == 0)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (__attribute__((address_space(3))) void*)((buf ? ubuf1 : ubuf0) + piece * 1024), 16,
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (__attribute__((address_space(3))) void*)((buf == 0 ? ubuf0 : buf == 1 ? ubuf1 : buf == 2 ? ubuf2 : ubuf3) + piece * 1024), 16,
                                                lane * 16, chunk * 32768 + piece * 1024, 0, 0);
     }
   };
 
   f32x4 acc[16][4];               // [plane][16-channel block]: rows = tiles 4q + r, column = channel 16*blk + n
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   float sc[4], sh[4];
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
@@ -131,6 +181,7 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
   // ---- prologue: weights chunk 0 and the first item's first two patches
   plan_a(0);
   request_u(0, 0);
+  request_u(1, 1);
   request_d(0, dn2[0]);
   request_d(1, dn2[1]);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -166,12 +217,34 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
       // ---- requests of step t+1: weights chunk into the other buffer (its readers finished at the last barrier), patch
       // (unconditional — past the workgroup's last step the weights land in a buffer nobody reads and the patch offsets
       // are out of bounds: a branch around the loads would put register copies, and with them a wait for memory, right here)
-      request_u((c + 1) & 7, (c + 1) & 1);
       if (c == 6) plan_a(item_l + 1);            // (steps t+2, t+3 of chunks 0, 1 belong to the next item)
-      if (c != 7) request_d((c + 2) & 7, dn);    // (last chunk: after the epilogue — one patch set less live across it)
+      // (epilogue state of the item's last step: byte offsets of tile r's four pixels at channel n, residual values)
+      unsigned eo[4][4];
+      float rv[8][4];                            // residuals by (tile, channel block) group g = 4r + b: ring of 8 groups, pixel
+      auto offsets = [&](int r, unsigned (&o)[4]) {
+        const int tile = ((item0 + item_l) * 4 + wave) * 16 + 4 * q + r;
+        const int f = tile / thw, rem = tile - f * thw;
+        const int ty = rem / a.TW, tx = rem - ty * a.TW;
+        const int y0 = 2 * ty, x0 = 2 * tx;
+        const bool tv = tile < a.ntiles;
+        const unsigned e00 = (unsigned)((((f * a.H + y0) * a.W + x0) * 64 + n) * 4);
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx)
+            o[2 * dy + dx] = (tv && y0 + dy < a.H && x0 + dx < a.W) ? e00 + (unsigned)((dy * a.W + dx) * 256) : OOB;
+      };
+      auto req_res1 = [&](int r, int k) {        // residual of tile r: pixel k >> 2, channel block k & 3
+        rv[(4 * r + (k & 3)) & 7][k >> 2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)eo[r][k >> 2], 64 * (k & 3), 0));
+      };
+      if (c == 7 && W2_ILV && RES && (W2_ABL & 8) == 0) { offsets(0, eo[0]); offsets(1, eo[1]); }
+      if constexpr (!W2_ILV) {
+        request_u((c + 2) & 7, (c + 2) & 3);
+        if (c != 7) request_d((c + 2) & 7, dn);    // (last chunk: after the epilogue — one patch set less live across it)
+      }
       __builtin_amdgcn_sched_barrier(0);
       // ---- 16 planes x 4 channel blocks x 4 k-steps of MFMAs; B fragments one plane ahead
-      const char* ub = ((c & 1) ? ubuf1 : ubuf0) + (n * 32 + q * 8);
+      const char* ub = ((c & 3) == 0 ? ubuf0 : (c & 3) == 1 ? ubuf1 : (c & 3) == 2 ? ubuf2 : ubuf3) + (n * 32 + q * 8);
       f32x2 bf[2][4];
 #pragma unroll
       for (int b = 0; b < 4; ++b) bf[0][b] = *reinterpret_cast<const f32x2*>(ub + b * 512);
@@ -181,12 +254,19 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
 #pragma unroll
           for (int b = 0; b < 4; ++b) bf[(p + 1) & 1][b] = *reinterpret_cast<const f32x2*>(ub + (p + 1) * 2048 + b * 512);
         }
+        if constexpr (W2_ILV) {
+          // one memory request per plane, between the MFMAs: a burst of 24 per wave in front of the block keeps all four
+          // waves of the CU in the address queue — not issuing MFMAs — while the texture addresser works through 96 requests
+          if (p < 8) request_u1((c + 2) & 7, (c + 2) & 3, p);
+          if (c != 7) request_d1((c + 2) & 7, dn, p >> 2, p & 3);
+          if (c == 7 && RES && (W2_ABL & 8) == 0) { req_res1(p >> 3, 4 * (2 * (p & 1)) + ((p >> 1) & 3)); req_res1(p >> 3, 4 * (2 * (p & 1) + 1) + ((p >> 1) & 3)); }
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
           for (int b = 0; b < 4; ++b)
             if constexpr ((W2_ABL & 1) == 0)
-              acc[p][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[p][s], bf[p & 1][b][s], (c == 0 && s == 0) ? zero4 : acc[p][b], 0, 0, 0);
+              mfma_acc(acc[p][b], V[p][s], bf[p & 1][b][s], c == 0 && s == 0);
             else acc[p][b][s] = ((c == 0 && s == 0) ? 0.f : acc[p][b][s]) + V[p][s] * bf[p & 1][b][s];
         __builtin_amdgcn_sched_barrier(0);          // plane p+1's fragment reads stay in front of plane p's MFMAs
       }
@@ -199,48 +279,32 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
           for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { const float kv = acc[p][b][r]; asm volatile("" :: "v"(kv)); }
+        request_d(1, dn);
       }
+      if (c == 7) mfma_drain();
       if (c == 7 && (W2_ABL & 8) == 0) {
-        // lane (n, q): tiles 4q + r of the wave's 16, channel 16*b + n.  Residuals of tile r+1 are requested before tile r's
-        // outputs are formed (32-bit offsets into per-launch buffer descriptors; pixels outside the map: out of bounds)
-        const int item = item0 + item_l;
-        const int tile0 = (item * 4 + wave) * 16 + 4 * q;
-        auto offsets = [&](int r, unsigned (&eo)[4]) {       // byte offsets of tile r's four pixels, channel n (or out of bounds)
-          const int tile = tile0 + r;
-          const int f = tile / thw, rem = tile - f * thw;
-          const int ty = rem / a.TW, tx = rem - ty * a.TW;
-          const int y0 = 2 * ty, x0 = 2 * tx;
-          const bool tv = tile < a.ntiles;
-          const unsigned e00 = (unsigned)((((f * a.H + y0) * a.W + x0) * 64 + n) * 4);
-#pragma unroll
-          for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx)
-              eo[2 * dy + dx] = (tv && y0 + dy < a.H && x0 + dx < a.W) ? e00 + (unsigned)((dy * a.W + dx) * 256) : OOB;
-        };
-        unsigned eo[2][4];
-        float rv[2][16];
-        auto req_res = [&](int r) {
-          offsets(r, eo[r & 1]);
-          if constexpr (RES) {
-#pragma unroll
-            for (int px = 0; px < 4; ++px)
-#pragma unroll
-              for (int b = 0; b < 4; ++b)
-                rv[r & 1][4 * px + b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)eo[r & 1][px], 64 * b, 0));
-          }
-        };
-        req_res(0);
-        __builtin_amdgcn_sched_barrier(0);
+        // lane (n, q): tiles 4q + r of the wave's 16, channel 16*b + n.  Memory requests ride one or a few at a time between
+        // the (tile, channel block) groups: the residuals of tiles 0, 1 were requested inside the MFMA block, those of tiles
+        // 2, 3 go out beside tiles 0, 1, the next item's chunk-1 patch (into the set this step's transform freed) beside
+        // tiles 2, 3 — no group waits for a request issued right in front of it
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if (r + 1 < 4) req_res(r + 1);
+          if (!W2_ILV || !RES) offsets(r, eo[r]);
+          if (!W2_ILV && RES) for (int k = 0; k < 16; ++k) req_res1(r, k);
+          if (W2_ILV && RES && r < 2) offsets(r + 2, eo[r + 2]);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int b = 0; b < 4; ++b) {
+            if constexpr (W2_ILV) {
+              if (RES && W2_EPD && r >= 2) {
+                const int g = 4 * (r - 2) + b;         // 0..7: two patch pixels each
+                request_d1(1, dn, (2 * g) >> 2, (2 * g) & 3);
+                request_d1(1, dn, (2 * g + 1) >> 2, (2 * g + 1) & 3);
+              }
+            }
             float m[16];
 #pragma unroll
-            for (int p = 0; p < 16; ++p) m[p] = acc[p][b][r];
+            for (int p = 0; p < 16; ++p) { acc_pin(acc[p][b]); m[p] = acc[p][b][r]; }
             float s0[4], s1[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -253,21 +317,25 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
 #pragma unroll
             for (int px = 0; px < 4; ++px) {
               float v = y[px] * sc[b] + sh[b];
-              if constexpr (RES) v += rv[r & 1][4 * px + b];
+              if constexpr (RES) v += rv[(4 * r + b) & 7][px];
               if (a.relu) v = fmaxf(v, 0.f);
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsO, (int)eo[r & 1][px], 64 * b, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsO, (int)eo[r][px], 64 * b, 0);
+            }
+            if (W2_ILV && RES && r < 2) {           // this group's ring slot is free: the residuals of group g + 8 (tile r + 2)
+#pragma unroll
+              for (int px = 0; px < 4; ++px) req_res1(r + 2, 4 * px + b);
             }
             __builtin_amdgcn_sched_barrier(0);     // (one (tile, channel block) at a time: the 256 accumulators are not all read up front)
           }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (c == 7) request_d(1, dn);               // chunk 1 of the next item, BEHIND the epilogue: one patch set less live across it
+      if (c == 7 && !(W2_ILV && RES && W2_EPD) && (W2_ABL & 8) == 0) request_d(1, dn);   // chunk 1 of the next item, BEHIND the epilogue: one patch set less live across it
       if constexpr ((W2_ABL & 16) == 0) {
         // in-order completion: step t+1's weights (issued first) and patch (issued a step ago) have landed once at most the
         // 16 patch loads of step t+2 — and, at the end of an item, the epilogue's stores behind them — are still in flight
         if (c == 7) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");      // (8 weight pieces + 16 patch loads of step t+2 stay in flight)
         __builtin_amdgcn_s_barrier();                       // ... everybody's; and everybody is done reading buffer c & 1
         asm volatile("" ::: "memory");
       }

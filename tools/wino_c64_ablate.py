@@ -12,7 +12,7 @@ so = lambda a: os.path.join(ROOT, "tools", "_trace", "libw64_abl%d.so" % a)
 if "--build-only" in sys.argv:
     os.makedirs(os.path.dirname(so(0)), exist_ok=True)
     srcs = [os.path.join(ROOT, "cadre_amd", "csrc", f) for f in ("winograd_c64.hip", "cadre_kernels.hip")]
-    ps = [subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-mllvm", "-enable-misched=0", "-DW2_ABL=%d" % a, "-o", so(a)] + srcs,
+    ps = [subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-mllvm", "-enable-misched=0", "-mllvm", "-pragma-unroll-threshold=262144", "-DW2_ABL=%d" % a, "-o", so(a)] + srcs,
                            stderr=subprocess.DEVNULL) for a in ABLS]
     assert all(p.wait() == 0 for p in ps)
     sys.exit(0)
