@@ -27,11 +27,14 @@ for name, H, W, ci, co, k, s, p in cases:
     out = torch.empty(F, Ho, Wo, co, device="cuda", dtype=torch.bfloat16)
     sc = torch.rand(co, device="cuda"); sh = torch.randn(co, device="cuda")
     K, M = k * k * ci, F * Ho * Wo
-    row = []
+    row = []; ref = None
     for tl in tiles:
-        if (tl == 7 and co < 256):
+        if (tl in (7, 14) and co < 256):
             row.append("     --     "); continue
         t = timeit(lambda: hip.gemm(x, w, out, M, co, K, 0, K, co, a_mode=2, scale=sc, shift=sh, act=1,
                                     conv=(H, W, ci, Ho, Wo, k, k, s, p), bf16=True, flags=2, tile=tl))
-        row.append("%5.0f us %4.0f" % (t * 1e6, 2.0 * M * co * K / t / 1e12))
+        if ref is None:
+            ref = out.clone()
+        same = "" if bool((out == ref).all()) else " DIFF %.3g" % float((out.float() - ref.float()).abs().max())
+        row.append("%5.0f us %4.0f%s" % (t * 1e6, 2.0 * M * co * K / t / 1e12, same))
     print("%-30s M=%-8d us / TFLOP/s by tile %s: %s" % (name, M, tiles, " | ".join(row)), flush=True)
