@@ -31,15 +31,10 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 int cadre_fail(const char* msg);
 
-#ifndef W2_ILV
-#define W2_ILV 1      // 1: the step's patch loads and weight-DMA pieces are issued one per plane BETWEEN the MFMAs (0: a burst in front of them)
-#endif
-#ifndef W2_EPD
-#define W2_EPD 1      // residual form: the next item's chunk-1 patch is requested beside the epilogue's tiles 2, 3 (0: behind the epilogue)
-#endif
 #ifndef W2_ASM_MFMA
 #define W2_ASM_MFMA 1
 #endif
@@ -174,8 +169,8 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
   float sc[4], sh[4];
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
-    sc[b] = a.scale ? a.scale[16 * b + n] : 1.f;
-    sh[b] = a.shift ? a.shift[16 * b + n] : 0.f;
+    sc[b] = a.scale ? a.scale[4 * n + b] : 1.f;
+    sh[b] = a.shift ? a.shift[4 * n + b] : 0.f;
   }
 
   // ---- prologue: weights chunk 0 and the first item's first two patches
@@ -218,30 +213,29 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
       // (unconditional — past the workgroup's last step the weights land in a buffer nobody reads and the patch offsets
       // are out of bounds: a branch around the loads would put register copies, and with them a wait for memory, right here)
       if (c == 6) plan_a(item_l + 1);            // (steps t+2, t+3 of chunks 0, 1 belong to the next item)
-      // (epilogue state of the item's last step: byte offsets of tile r's four pixels at channel n, residual values)
+      // (epilogue state of the item's last step: byte offsets of tile r's four pixels at channel 4n, residual values.  MFMA
+      // block b, column n is output channel 4n + b — the host lays U out that way, cadre_amd/encoder.py _winograd_u_c64 — so a
+      // lane ends up with FOUR CONSECUTIVE channels of a pixel: 16-byte stores and residual loads, 16 of each per lane and
+      // item instead of 64.  The epilogue was bound by the address path: 512 four-byte requests per item and CU)
       unsigned eo[4][4];
-      float rv[8][4];                            // residuals by (tile, channel block) group g = 4r + b: ring of 8 groups, pixel
+      f32x4 rv[4][4];                            // residuals by (tile, pixel): channels 4n .. 4n+3
       auto offsets = [&](int r, unsigned (&o)[4]) {
         const int tile = ((item0 + item_l) * 4 + wave) * 16 + 4 * q + r;
         const int f = tile / thw, rem = tile - f * thw;
         const int ty = rem / a.TW, tx = rem - ty * a.TW;
         const int y0 = 2 * ty, x0 = 2 * tx;
         const bool tv = tile < a.ntiles;
-        const unsigned e00 = (unsigned)((((f * a.H + y0) * a.W + x0) * 64 + n) * 4);
+        const unsigned e00 = (unsigned)((((f * a.H + y0) * a.W + x0) * 64 + 4 * n) * 4);
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
           for (int dx = 0; dx < 2; ++dx)
             o[2 * dy + dx] = (tv && y0 + dy < a.H && x0 + dx < a.W) ? e00 + (unsigned)((dy * a.W + dx) * 256) : OOB;
       };
-      auto req_res1 = [&](int r, int k) {        // residual of tile r: pixel k >> 2, channel block k & 3
-        rv[(4 * r + (k & 3)) & 7][k >> 2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsR, (int)eo[r][k >> 2], 64 * (k & 3), 0));
+      auto req_res1 = [&](int r, int px) {       // residual of tile r, pixel px
+        rv[r][px] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, (int)eo[r][px], 0, 0));
       };
-      if (c == 7 && W2_ILV && RES && (W2_ABL & 8) == 0) { offsets(0, eo[0]); offsets(1, eo[1]); }
-      if constexpr (!W2_ILV) {
-        request_u((c + 2) & 7, (c + 2) & 3);
-        if (c != 7) request_d((c + 2) & 7, dn);    // (last chunk: after the epilogue — one patch set less live across it)
-      }
+      if (c == 7 && RES && (W2_ABL & 8) == 0) { offsets(0, eo[0]); offsets(1, eo[1]); }
       __builtin_amdgcn_sched_barrier(0);
       // ---- 16 planes x 4 channel blocks x 4 k-steps of MFMAs; B fragments one plane ahead
       const char* ub = ((c & 3) == 0 ? ubuf0 : (c & 3) == 1 ? ubuf1 : (c & 3) == 2 ? ubuf2 : ubuf3) + (n * 32 + q * 8);
@@ -254,12 +248,12 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
 #pragma unroll
           for (int b = 0; b < 4; ++b) bf[(p + 1) & 1][b] = *reinterpret_cast<const f32x2*>(ub + (p + 1) * 2048 + b * 512);
         }
-        if constexpr (W2_ILV) {
+        {
           // one memory request per plane, between the MFMAs: a burst of 24 per wave in front of the block keeps all four
           // waves of the CU in the address queue — not issuing MFMAs — while the texture addresser works through 96 requests
           if (p < 8) request_u1((c + 2) & 7, (c + 2) & 3, p);
           if (c != 7) request_d1((c + 2) & 7, dn, p >> 2, p & 3);
-          if (c == 7 && RES && (W2_ABL & 8) == 0) { req_res1(p >> 3, 4 * (2 * (p & 1)) + ((p >> 1) & 3)); req_res1(p >> 3, 4 * (2 * (p & 1) + 1) + ((p >> 1) & 3)); }
+          if (c == 7 && RES && (W2_ABL & 8) == 0 && (p & 1)) req_res1(p >> 3, (p >> 1) & 3);      // (tiles 0, 1: 8 requests)
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -283,24 +277,23 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
       }
       if (c == 7) mfma_drain();
       if (c == 7 && (W2_ABL & 8) == 0) {
-        // lane (n, q): tiles 4q + r of the wave's 16, channel 16*b + n.  Memory requests ride one or a few at a time between
-        // the (tile, channel block) groups: the residuals of tiles 0, 1 were requested inside the MFMA block, those of tiles
-        // 2, 3 go out beside tiles 0, 1, the next item's chunk-1 patch (into the set this step's transform freed) beside
-        // tiles 2, 3 — no group waits for a request issued right in front of it
+        // lane (n, q): tiles 4q + r of the wave's 16, channels 4n .. 4n+3.  Memory requests ride a few at a time between the
+        // (tile, channel block) groups: the residuals of tiles 0, 1 were requested inside the MFMA block, those of tiles 2, 3
+        // go out beside tiles 0, 1, the next item's chunk-1 patch (into the set this step's transform freed) beside tiles
+        // 2, 3 — no group waits for a request issued right in front of it
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if (!W2_ILV || !RES) offsets(r, eo[r]);
-          if (!W2_ILV && RES) for (int k = 0; k < 16; ++k) req_res1(r, k);
-          if (W2_ILV && RES && r < 2) offsets(r + 2, eo[r + 2]);
+          if (!RES) offsets(r, eo[r]);
+          if (RES && r < 2) offsets(r + 2, eo[r + 2]);
           __builtin_amdgcn_sched_barrier(0);
+          float v[4][4];                           // [pixel][channel 4n + b]
 #pragma unroll
           for (int b = 0; b < 4; ++b) {
-            if constexpr (W2_ILV) {
-              if (RES && W2_EPD && r >= 2) {
-                const int g = 4 * (r - 2) + b;         // 0..7: two patch pixels each
-                request_d1(1, dn, (2 * g) >> 2, (2 * g) & 3);
-                request_d1(1, dn, (2 * g + 1) >> 2, (2 * g + 1) & 3);
-              }
+            if (RES && r < 2) req_res1(r + 2, b);
+            if (r >= 2) {
+              const int g = 4 * (r - 2) + b;         // 0..7: two patch pixels each
+              request_d1(1, dn, (2 * g) >> 2, (2 * g) & 3);
+              request_d1(1, dn, (2 * g + 1) >> 2, (2 * g + 1) & 3);
             }
             float m[16];
 #pragma unroll
@@ -315,26 +308,30 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
             y[0] = s0[0] + s0[1] + s0[2]; y[1] = s0[1] - s0[2] - s0[3];
             y[2] = s1[0] + s1[1] + s1[2]; y[3] = s1[1] - s1[2] - s1[3];
 #pragma unroll
-            for (int px = 0; px < 4; ++px) {
-              float v = y[px] * sc[b] + sh[b];
-              if constexpr (RES) v += rv[(4 * r + b) & 7][px];
-              if (a.relu) v = fmaxf(v, 0.f);
-              __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsO, (int)eo[r][px], 64 * b, 0);
-            }
-            if (W2_ILV && RES && r < 2) {           // this group's ring slot is free: the residuals of group g + 8 (tile r + 2)
-#pragma unroll
-              for (int px = 0; px < 4; ++px) req_res1(r + 2, 4 * px + b);
-            }
+            for (int px = 0; px < 4; ++px) v[px][b] = y[px] * sc[b] + sh[b];
             __builtin_amdgcn_sched_barrier(0);     // (one (tile, channel block) at a time: the 256 accumulators are not all read up front)
           }
+#pragma unroll
+          for (int px = 0; px < 4; ++px) {
+            f32x4 o = {v[px][0], v[px][1], v[px][2], v[px][3]};
+            if constexpr (RES) o += rv[r][px];
+            if (a.relu) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsO, (int)eo[r][px], 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (c == 7 && !(W2_ILV && RES && W2_EPD) && (W2_ABL & 8) == 0) request_d(1, dn);   // chunk 1 of the next item, BEHIND the epilogue: one patch set less live across it
       if constexpr ((W2_ABL & 16) == 0) {
         // in-order completion: step t+1's weights (issued first) and patch (issued a step ago) have landed once at most the
         // 16 patch loads of step t+2 — and, at the end of an item, the epilogue's stores behind them — are still in flight
-        if (c == 7) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+        // (end of an item, behind the requests of step t+1: 8 weight pieces, 16 residual loads, 16 stores, 16 patch loads)
+        if (c == 7 && (W2_ABL & 8) != 0) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else if (c == 7 && RES) asm volatile("s_waitcnt vmcnt(56)" ::: "memory");
+        else if (c == 7) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");      // (8 weight pieces + 16 patch loads of step t+2 stay in flight)
         __builtin_amdgcn_s_barrier();                       // ... everybody's; and everybody is done reading buffer c & 1
         asm volatile("" ::: "memory");
@@ -343,7 +340,7 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
   }
 }
 
-// U must be laid out [8][16][64][8] (chunk of 8 input channels, plane xi = 4i + j, output channel, channel in chunk):
+// U must be laid out [8][16][64][8] (chunk of 8 input channels, plane xi = 4i + j, position 16 b + n = output channel 4 n + b, channel in chunk):
 // cadre_amd/encoder.py _winograd_u_c64.  out = act(conv * scale + shift (+ resid)), act: 0 none, 1 ReLU.
 extern "C" int cadre_winograd_c64(const float* x, const float* U, const float* scale, const float* shift, const float* resid, float* out,
                                   int32_t F, int32_t H, int32_t W, int32_t act, void* stream) {

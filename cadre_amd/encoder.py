@@ -107,8 +107,12 @@ def _winograd_u(w, m=2):
 
 
 def _winograd_u_c64(w):
-    """OIHW 64 x 64 x 3 x 3 -> the fused kernel's layout [8 chunks of 8 cin][16 planes][64 cout][8 cin] (csrc/winograd_c64.hip)."""
+    """OIHW 64 x 64 x 3 x 3 -> the fused kernel's layout [8 chunks of 8 cin][16 planes][64 positions][8 cin]
+    (csrc/winograd_c64.hip); position 16 b + n of the cout axis holds output channel 4 n + b: column n of the kernel's MFMA
+    block b — a lane then owns four consecutive channels of a pixel (16-byte stores)."""
     u = _winograd_u(w, 2)                                          # [16][O = 64][I = 64]
+    pos = torch.arange(64)
+    u = u[:, 4 * (pos % 16) + pos // 16, :]
     return u.reshape(16, 64, 8, 8).permute(2, 0, 1, 3).contiguous()
 
 

@@ -101,7 +101,7 @@ AB_SYMBOLS = {
 }
 
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class CadreHipError(RuntimeError):
