@@ -1207,6 +1207,37 @@ def test_winograd_c64_fused_matches_torch(hip, F, H, W, use_resid, act):
     assert torch.equal(gb[2:2 + F], got)
 
 
+@pytest.mark.parametrize("use_resid", [False, True])
+def test_winograd_c64_fused_repeatable_under_load(hip, use_resid):
+    """The fused layer-1 kernel orders its weight DMA and patch loads with hand-counted s_waitcnt vmcnt(N) + raw barriers, issues its
+    MFMAs as inline asm (the hazard recognizer does not see them: the wait states in front of the epilogue's accumulator reads are
+    written by hand) and reads residuals requested inside the last MFMA block.  A miscount is a race: 20 launches with every CU
+    walking several 64-tile items (both forms of the item's last counted wait) must agree bit for bit, and with torch."""
+    from cadre_amd.encoder import _winograd_u_c64
+    F, H, W = 320, 72, 72                                       # 6480 items over 256 workgroups: 25-26 items each
+    g = torch.Generator(device="cuda").manual_seed(11 + int(use_resid))
+    x = torch.randn(F, H, W, 64, device="cuda", generator=g)
+    w = torch.randn(64, 64, 3, 3, device="cuda", generator=g) / 24.0
+    sc = 0.5 + torch.rand(64, device="cuda", generator=g)
+    sh = torch.randn(64, device="cuda", generator=g)
+    res = torch.randn(F, H, W, 64, device="cuda", generator=g) if use_resid else None
+    u = _winograd_u_c64(w.cpu()).cuda()
+    outs = []
+    for rep in range(20):
+        out = torch.empty(F, H, W, 64, device="cuda")
+        hip.check(hip.lib().cadre_winograd_c64(hip.ptr(x), hip.ptr(u), hip.ptr(sc), hip.ptr(sh), hip.ptr(res), hip.ptr(out), F, H, W, 1,
+                                               hip.stream()), "cadre_winograd_c64")
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    for sl in (slice(0, 2), slice(F - 2, F)):                     # first and last items of the launch
+        ref = torch.nn.functional.conv2d(x[sl].permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1) * sc + sh
+        if use_resid:
+            ref = ref + res[sl]
+        ref = torch.relu(ref)
+        assert float((outs[0][sl] - ref).abs().max() / ref.abs().max()) < 2e-5
+
+
 @pytest.mark.parametrize("F,H,W,Cin,N,use_resid,act", [(3, 9, 9, 64, 128, True, 1), (2, 18, 18, 32, 64, False, 1), (2, 7, 10, 16, 32, True, 17),
                                                      (1, 1, 1, 8, 8, False, 0), (5, 6, 5, 12, 20, True, 0)])
 @pytest.mark.parametrize("m", [2, 3])
