@@ -10,21 +10,32 @@
 //   * the 64 input channels go by in eight chunks of 8: a lane loads the 4x4 input patch of ITS tile for ITS two
 //     channels (16 loads of 8 bytes; the four k-lanes of a tile read 32 contiguous bytes), transforms it in registers
 //     (B^T d B: 32 adds per channel) and feeds the MFMAs' A operand directly;
-//   * the transformed weights U = G g G^T (host, float64 -> fp32; [chunk][plane][cout][8 cin], 32 KB per chunk) stream
-//     through two LDS buffers by LDS-DMA, one chunk ahead, shared by the four waves; a B fragment is one
-//     ds_read_b64 of 512 contiguous bytes (conflict-free);
-//   * loads for step t+1 (weights chunk + patch) are issued before the MFMAs of step t: one s_waitcnt vmcnt(0) +
-//     one raw barrier per 512 MFMAs (128 per wave).
+//   * the transformed weights U = G g G^T (host, float64 -> fp32; [chunk][plane][position][8 cin], 32 KB per chunk; position
+//     16 b + n = output channel 4 n + b) stream through four LDS buffers by LDS-DMA, two chunks ahead, shared by the four waves;
+//     a B fragment is one ds_read_b64 of 512 contiguous bytes (conflict-free);
+//   * the memory requests of step t+2 (8 weight pieces, 16 patch pixels per wave) are issued ONE PER PLANE between the MFMAs
+//     of step t: one counted s_waitcnt vmcnt + one raw barrier per 512 MFMAs (128 per wave);
+//   * the epilogue (inverse transform, BN, residual, ReLU) stores 16 bytes per lane: MFMA block b, column n is output
+//     channel 4n + b, so a lane holds four consecutive channels of a pixel.
 // 2.25x fewer multiplies than the direct conv, rounding error BELOW the direct conv's.
 //
-// Built with -mllvm -enable-misched=0 (cadre_amd/build.py EXTRA_FLAGS): the source is written in issue order and the machine
-// scheduler's reordering cost 40-100 VGPR spills, whose scratch reloads behind the epilogue's stores wait for every one of
-// them (vmcnt completes in order) — 3.09 / 3.20 ms with the scheduler, 2.50 / 2.62 ms without, against 2.97 ms for the direct
-// window kernel (1024 frames of 72 x 72; without / with residual).  The MFMAs with their LDS fragment reads alone run
-// 1.45 ms (tools/wino_c64_ablate.py, profiles/r04_wino_c64_ablation.txt): what does not hide yet is memory latency behind
-// the per-step wait (0.65 ms) and the weight DMA (0.25 ms).  Lessons in the code: separate LDS objects per DMA buffer (one
-// object = s_waitcnt vmcnt(0) before every fragment read), no branch around loads (PHI copies wait for memory on the spot),
-// scheduling fences around the MFMA block, contiguous item ranges per workgroup (halo rows from the workgroup's own L1 / L2).
+// Built with -mllvm -enable-misched=0 -mllvm -pragma-unroll-threshold=262144 (cadre_amd/build.py EXTRA_FLAGS): the source is
+// written in issue order (the machine scheduler's reordering cost 40-100 VGPR spills), and the step loop must be unrolled
+// (register sets indexed by step parity).  Measured per 1024 frames of 72 x 72, without / with residual, against 2.97 ms
+// for the direct window kernel (tools/wino_c64_ab.py, tools/wino_c64_ablate.py, profiles/r04_wino_c64_*.txt):
+//   3.09 / 3.20 ms  with the machine scheduler
+//   2.50 / 2.62     without it, requests issued as a burst of 24 per wave in front of the MFMA block
+//   1.92 / 2.33     requests one per plane between the MFMAs: the burst kept all four waves of the CU in the address queue —
+//                   not issuing MFMAs — while the texture addresser worked through 96 requests ("no patch loads" had run 1.65)
+//   1.89 / 1.97     accumulators pinned to the AGPR file (inline-asm MFMAs, pinned epilogue reads): hipcc had moved ~150
+//                   v_accvgpr_read of later epilogue groups to the top of the epilogue and spilled patch registers to make room
+//                   (a spill store waits for the load that fills the register: a memory round trip inside the MFMA block);
+//                   residuals of tiles 0, 1 requested inside the last MFMA block; 256 -> 139 VGPRs, no spills
+//   1.84 / 1.90     16-byte stores and residual loads (the cout permutation above): 128 instead of 512 requests per item and CU
+// The MFMAs with their LDS fragment reads alone run 1.38 ms; what is left: patch requests 0.2, epilogue 0.16, weight DMA 0.1,
+// wait + barrier 0.09.  Lessons in the code: separate LDS objects per DMA buffer (one object = s_waitcnt vmcnt(0) before
+// every fragment read), no branch around loads (PHI copies wait for memory on the spot), scheduling fences around the MFMA
+// block, contiguous item ranges per workgroup (halo rows from the workgroup's own L1 / L2).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/cadre_hip.h"
@@ -44,7 +55,7 @@ int cadre_fail(const char* msg);
 
 struct w2_args {
   const float* x;        // [F][H][W][64]
-  const float* U;        // [8 chunks][16 planes][64 cout][8 cin]
+  const float* U;        // [8 chunks][16 planes][64 positions: 16 b + n = cout 4 n + b][8 cin]
   const float* scale;    // [64] folded BN (may be null: 1)
   const float* shift;    // [64] (may be null: 0)
   const float* resid;    // [F][H][W][64] or null: added before the activation
