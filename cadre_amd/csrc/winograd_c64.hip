@@ -7,9 +7,9 @@
 //   * workgroup = 4 waves, ONE per SIMD with 512 registers each; a wave owns 16 tiles (2x2 outputs each) x all 64 output
 //     channels x all 16 transform planes = 16 x 4 v_mfma_f32_16x16x4_f32 accumulator blocks = 256 registers (the AGPR
 //     file) — the inverse transform is register-local: a lane holds every plane of its (tile, channel);
-//   * the 64 input channels go by in eight chunks of 8: a lane loads the 4x4 input patch of ITS tile for ITS two
-//     channels (16 loads of 8 bytes; the four k-lanes of a tile read 32 contiguous bytes), transforms it in registers
-//     (B^T d B: 32 adds per channel) and feeds the MFMAs' A operand directly;
+//   * the 64 input channels go by in eight chunks (steps) of 8: a lane loads the 4x4 input patch of ITS tile for FOUR
+//     channels every other step (16 loads of 16 bytes; the four k-lanes of a tile read 64 contiguous bytes), transforms two
+//     channels per step in registers (B^T d B: 32 adds per channel) and feeds the MFMAs' A operand directly;
 //   * the transformed weights U = G g G^T (host, float64 -> fp32; [chunk][plane][position][8 cin], 32 KB per chunk; position
 //     16 b + n = output channel 4 n + b) stream through four LDS buffers by LDS-DMA, two chunks ahead, shared by the four waves;
 //     a B fragment is one ds_read_b64 of 512 contiguous bytes (conflict-free);
@@ -32,7 +32,9 @@
 //                   (a spill store waits for the load that fills the register: a memory round trip inside the MFMA block);
 //                   residuals of tiles 0, 1 requested inside the last MFMA block; 256 -> 139 VGPRs, no spills
 //   1.84 / 1.90     16-byte stores and residual loads (the cout permutation above): 128 instead of 512 requests per item and CU
-// The MFMAs with their LDS fragment reads alone run 1.38 ms; what is left: patch requests 0.2, epilogue 0.16, weight DMA 0.1,
+//   1.77 / 1.82     16-byte patch requests (four channels of a pixel = two steps' worth, every other step; U's cin axis permuted to
+//                   match): half the requests and cache lines touched per byte
+// The MFMAs with their LDS fragment reads alone run 1.38 ms; what is left: patch requests, epilogue 0.16, weight DMA 0.1,
 // wait + barrier 0.09.  Lessons in the code: separate LDS objects per DMA buffer (one object = s_waitcnt vmcnt(0) before
 // every fragment read), no branch around loads (PHI copies wait for memory on the spot), scheduling fences around the MFMA
 // block, contiguous item ranges per workgroup (halo rows from the workgroup's own L1 / L2).
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
   const int thw = a.TH * a.TW;
 
   // ---- per-item lane state of the A side: tile = group * 16 + n, patch origin (2ty-1, 2tx-1), channel slice 4q of a chunk
-  int a_base = 0;                 // byte offset of patch pixel (0, 0), channel 4q of chunk 0 (may be negative: masked pixels only)
+  int a_base = 0;                 // byte offset of patch pixel (0, 0), channel 4q of double-step 0 (may be negative: masked pixels only)
   unsigned a_rows = 0, a_cols = 0;
   auto plan_a = [&](int item_l) {
     const int item = item0 + item_l;
@@ -135,30 +137,22 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
         if ((unsigned)(r0 + i) < (unsigned)a.H) a_rows |= 1u << i;
         if ((unsigned)(c0 + i) < (unsigned)a.W) a_cols |= 1u << i;
       }
-      a_base = ((f * a.H + r0) * a.W + c0) * 256 + 8 * q;
+      a_base = ((f * a.H + r0) * a.W + c0) * 256 + 16 * q;
     }
   };
   // patches are requested TWO steps ahead (a step is ~2 us of MFMAs, an HBM round trip under load is longer): two register
   // sets by step parity — step t transforms set t & 1, then refills it with the patch of step t + 2
-  f32x2 dn2[2][16];
-  auto request_d = [&](int chunk, f32x2* dn) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const unsigned okm = (a_rows >> i) & (a_cols >> j) & 1u;          // (bitwise: no control flow around the loads)
-        unsigned off = okm ? (unsigned)(a_base + (i * a.W + j) * 256 + chunk * 32) : OOB;
-        if constexpr ((W2_ABL & 32) != 0) off = (unsigned)(((i * 4 + j) * 256 + chunk * 32 + 8 * q) + n * 4096);    // (ablation: always the same few KB)
-        if constexpr ((W2_ABL & 2) == 0) dn[4 * i + j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsX, (int)off, 0, 0));
-        else dn[4 * i + j] = f32x2{(float)off, (float)chunk};
-      }
-  };
-  auto request_d1 = [&](int chunk, f32x2* dn, int i, int j) {      // one pixel of the patch
+  // patches are requested by DOUBLE-STEP d (16 input channels): a lane asks for the four channels 16d + 4q .. + 3 of each of its
+  // 16 patch pixels at once (16 bytes: half the requests — and cache lines touched — per byte of the 8-byte form, measured
+  // 1.84 / 1.94 -> 1.77 / 1.82 ms); components 2e, 2e + 1 feed step 2d + e (U's cin axis is laid out to match).  Two register sets by
+  // parity of d: the set of d + 1 is requested during step 2d (one request per plane between the MFMAs), a full step ahead of its use
+  f32x4 dq2[2][16];
+  auto request_q1 = [&](int d, f32x4* dq, int i, int j) {
     const unsigned okm = (a_rows >> i) & (a_cols >> j) & 1u;
-    unsigned off = okm ? (unsigned)(a_base + (i * a.W + j) * 256 + chunk * 32) : OOB;
-    if constexpr ((W2_ABL & 32) != 0) off = (unsigned)(((i * 4 + j) * 256 + chunk * 32 + 8 * q) + n * 4096);
-    if constexpr ((W2_ABL & 2) == 0) dn[4 * i + j] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsX, (int)off, 0, 0));
-    else dn[4 * i + j] = f32x2{(float)off, (float)chunk};
+    unsigned off = okm ? (unsigned)(a_base + (i * a.W + j) * 256 + d * 64) : OOB;
+    if constexpr ((W2_ABL & 32) != 0) off = (unsigned)(((i * 4 + j) * 256 + d * 64 + 16 * q) + n * 4096);
+    if constexpr ((W2_ABL & 2) == 0) dq[4 * i + j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)off, 0, 0));
+    else dq[4 * i + j] = f32x4{(float)off, (float)d, (float)off, (float)d};
   };
   auto request_u1 = [&](int chunk, int buf, int i) {      // one 1 KB piece of this wave's quarter of the chunk
     const int piece = wave * 8 + i;
@@ -188,8 +182,8 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
   plan_a(0);
   request_u(0, 0);
   request_u(1, 1);
-  request_d(0, dn2[0]);
-  request_d(1, dn2[1]);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) request_q1(0, dq2[0], k >> 2, k & 3);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -199,7 +193,9 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
     for (int c = 0; c < 8; ++c) {                 // (unrolled: chunk, LDS buffer c & 1 and "first chunk" are compile-time)
       // ---- input transform of this step's patch: V = B^T d B (per channel), 16 planes x 4 channels
       f32x2 V[16];
-      f32x2* dn = dn2[c & 1];
+      f32x2 dn[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) dn[k] = f32x2{dq2[(c >> 1) & 1][k][2 * (c & 1)], dq2[(c >> 1) & 1][k][2 * (c & 1) + 1]};
       {
         f32x2 tt[16];
 #pragma unroll
@@ -263,7 +259,7 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
           // one memory request per plane, between the MFMAs: a burst of 24 per wave in front of the block keeps all four
           // waves of the CU in the address queue — not issuing MFMAs — while the texture addresser works through 96 requests
           if (p < 8) request_u1((c + 2) & 7, (c + 2) & 3, p);
-          if (c != 7) request_d1((c + 2) & 7, dn, p >> 2, p & 3);
+          if ((c & 1) == 0) request_q1(((c >> 1) + 1) & 3, dq2[((c >> 1) + 1) & 1], p >> 2, p & 3);
           if (c == 7 && RES && (W2_ABL & 8) == 0 && (p & 1)) req_res1(p >> 3, (p >> 1) & 3);      // (tiles 0, 1: 8 requests)
         }
 #pragma unroll
@@ -284,7 +280,6 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
           for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { const float kv = acc[p][b][r]; asm volatile("" :: "v"(kv)); }
-        request_d(1, dn);
       }
       if (c == 7) mfma_drain();
       if (c == 7 && (W2_ABL & 8) == 0) {
@@ -301,11 +296,6 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
 #pragma unroll
           for (int b = 0; b < 4; ++b) {
             if (RES && r < 2) req_res1(r + 2, b);
-            if (r >= 2) {
-              const int g = 4 * (r - 2) + b;         // 0..7: two patch pixels each
-              request_d1(1, dn, (2 * g) >> 2, (2 * g) & 3);
-              request_d1(1, dn, (2 * g + 1) >> 2, (2 * g + 1) & 3);
-            }
             float m[16];
 #pragma unroll
             for (int p = 0; p < 16; ++p) { acc_pin(acc[p][b]); m[p] = acc[p][b][r]; }
@@ -337,13 +327,13 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
       }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr ((W2_ABL & 16) == 0) {
-        // in-order completion: step t+1's weights (issued first) and patch (issued a step ago) have landed once at most the
-        // 16 patch loads of step t+2 — and, at the end of an item, the epilogue's stores behind them — are still in flight
-        // (end of an item, behind the requests of step t+1: 8 weight pieces, 16 residual loads, 16 stores, 16 patch loads)
-        if (c == 7 && (W2_ABL & 8) != 0) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        else if (c == 7 && RES) asm volatile("s_waitcnt vmcnt(56)" ::: "memory");
-        else if (c == 7) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");      // (8 weight pieces + 16 patch loads of step t+2 stay in flight)
+        // in-order completion: step t+1's weights and patch (both requested a step ago) have landed once at most THIS step's
+        // requests are still in flight
+        // even steps: 8 weight pieces + the 16 patch requests of the next double-step stay in flight; odd steps: the weight pieces
+        // (+ the epilogue's 16 residual loads and 16 stores at the end of an item)
+        if (c == 7 && (W2_ABL & 8) == 0) { if (RES) asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); }
+        else if (c & 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
         __builtin_amdgcn_s_barrier();                       // ... everybody's; and everybody is done reading buffer c & 1
         asm volatile("" ::: "memory");
       }
@@ -351,7 +341,8 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
   }
 }
 
-// U must be laid out [8][16][64][8] (chunk of 8 input channels, plane xi = 4i + j, position 16 b + n = output channel 4 n + b, channel in chunk):
+// U must be laid out [8][16][64][8] (chunk c = 2d + e of 8 input channels, plane xi = 4i + j, position 16 b + n = output channel 4 n + b,
+// index 2q + s in the chunk = input channel 16 d + 4 q + 2 e + s):
 // cadre_amd/encoder.py _winograd_u_c64.  out = act(conv * scale + shift (+ resid)), act: 0 none, 1 ReLU.
 extern "C" int cadre_winograd_c64(const float* x, const float* U, const float* scale, const float* shift, const float* resid, float* out,
                                   int32_t F, int32_t H, int32_t W, int32_t act, void* stream) {

@@ -106,13 +106,19 @@ def _winograd_u(w, m=2):
     return u.reshape((m + 2) ** 2, w.shape[0], w.shape[1]).float().contiguous()
 
 
-def _winograd_u_c64(w):
+def _winograd_u_c64(w, cin_pairs=True):
     """OIHW 64 x 64 x 3 x 3 -> the fused kernel's layout [8 chunks of 8 cin][16 planes][64 positions][8 cin]
     (csrc/winograd_c64.hip); position 16 b + n of the cout axis holds output channel 4 n + b: column n of the kernel's MFMA
-    block b — a lane then owns four consecutive channels of a pixel (16-byte stores)."""
+    block b — a lane then owns four consecutive channels of a pixel (16-byte stores); chunk c = 2d + e, index k = 2q + s of the
+    cin axis hold input channel 16 d + 4 q + 2 e + s (16-byte patch requests; cin_pairs=False: natural order, older builds)."""
     u = _winograd_u(w, 2)                                          # [16][O = 64][I = 64]
     pos = torch.arange(64)
     u = u[:, 4 * (pos % 16) + pos // 16, :]
+    if cin_pairs:
+        # chunk c = 2d + e, index k = 2q + s in the chunk  <->  input channel 16 d + 4 q + 2 e + s: a lane (q) requests the four
+        # channels 16 d + 4 q .. + 3 of a pixel at once (16 bytes) and feeds steps 2d and 2d + 1 from them
+        c, k = pos // 8, pos % 8
+        u = u[:, :, 16 * (c // 2) + 4 * (k // 2) + 2 * (c % 2) + (k % 2)]
     return u.reshape(16, 64, 8, 8).permute(2, 0, 1, 3).contiguous()
 
 

@@ -101,7 +101,7 @@ AB_SYMBOLS = {
 }
 
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class CadreHipError(RuntimeError):

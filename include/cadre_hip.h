@@ -15,7 +15,7 @@
 extern "C" {
 #endif
 
-#define CADRE_ABI_VERSION 10
+#define CADRE_ABI_VERSION 11
 int cadre_abi_version(void);
 /* human-readable last argument error of the calling thread ("" if none) */
 const char* cadre_last_error(void);
@@ -163,7 +163,8 @@ int cadre_stem_pool_supported(int32_t H, int32_t W);
 /* FUSED Winograd F(2x2, 3x3) for 64 -> 64 stride-1 / pad-1 3x3 convs in fp32 (csrc/winograd_c64.hip; the fp32 model's layer1,
  * resnet.py:26-55): input transform, 16 plane products and inverse transform in one kernel, nothing of the transform
  * domain leaves the CU.  U: the transformed weights (G g G^T)[xi][cout][cin] laid out [8 chunks of 8 cin][16 planes][64 positions][8],
- * position 16 b + n = output channel 4 n + b (cadre_amd/encoder.py _winograd_u_c64).  out = act(conv * scale + shift (+ resid)), act 0 none / 1 ReLU; x, resid, out
+ * position 16 b + n = output channel 4 n + b, cin of chunk 2d + e at index 2q + s = input channel 16 d + 4 q + 2 e + s
+ * (cadre_amd/encoder.py _winograd_u_c64).  out = act(conv * scale + shift (+ resid)), act 0 none / 1 ReLU; x, resid, out
  * [F][H][W][64] below 2 GiB. */
 int cadre_winograd_c64(const float* x, const float* U, const float* scale, const float* shift, const float* resid, float* out,
                        int32_t F, int32_t H, int32_t W, int32_t act, void* stream);
