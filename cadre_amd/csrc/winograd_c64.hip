@@ -172,6 +172,7 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
 
   f32x4 acc[16][4];               // [plane][16-channel block]: rows = tiles 4q + r, column = channel 16*blk + n
   float sc[4], sh[4];
+  const float act_floor = a.relu ? 0.f : -__builtin_inff();
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
     sc[b] = a.scale ? a.scale[4 * n + b] : 1.f;
@@ -189,6 +190,22 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
   asm volatile("" ::: "memory");
 
   for (int item_l = 0; item_l < my_items; ++item_l) {
+    // (byte offsets of the item's output pixels: formed inside step 6's MFMA block — two integer divisions per tile that would
+    // otherwise run in the epilogue, where nothing hides them)
+    unsigned eo[4][4];
+    auto offsets = [&](int r, unsigned (&o)[4]) {
+      const int tile = ((item0 + item_l) * 4 + wave) * 16 + 4 * q + r;
+      const int f = tile / thw, rem = tile - f * thw;
+      const int ty = rem / a.TW, tx = rem - ty * a.TW;
+      const int y0 = 2 * ty, x0 = 2 * tx;
+      const bool tv = tile < a.ntiles;
+      const unsigned e00 = (unsigned)((((f * a.H + y0) * a.W + x0) * 64 + 4 * n) * 4);
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx)
+          o[2 * dy + dx] = (tv && y0 + dy < a.H && x0 + dx < a.W) ? e00 + (unsigned)((dy * a.W + dx) * 256) : OOB;
+    };
 #pragma unroll
     for (int c = 0; c < 8; ++c) {                 // (unrolled: chunk, LDS buffer c & 1 and "first chunk" are compile-time)
       // ---- input transform of this step's patch: V = B^T d B (per channel), 16 planes x 4 channels
@@ -224,25 +241,10 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
       // block b, column n is output channel 4n + b — the host lays U out that way, cadre_amd/encoder.py _winograd_u_c64 — so a
       // lane ends up with FOUR CONSECUTIVE channels of a pixel: 16-byte stores and residual loads, 16 of each per lane and
       // item instead of 64.  The epilogue was bound by the address path: 512 four-byte requests per item and CU)
-      unsigned eo[4][4];
       f32x4 rv[4][4];                            // residuals by (tile, pixel): channels 4n .. 4n+3
-      auto offsets = [&](int r, unsigned (&o)[4]) {
-        const int tile = ((item0 + item_l) * 4 + wave) * 16 + 4 * q + r;
-        const int f = tile / thw, rem = tile - f * thw;
-        const int ty = rem / a.TW, tx = rem - ty * a.TW;
-        const int y0 = 2 * ty, x0 = 2 * tx;
-        const bool tv = tile < a.ntiles;
-        const unsigned e00 = (unsigned)((((f * a.H + y0) * a.W + x0) * 64 + 4 * n) * 4);
-#pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-          for (int dx = 0; dx < 2; ++dx)
-            o[2 * dy + dx] = (tv && y0 + dy < a.H && x0 + dx < a.W) ? e00 + (unsigned)((dy * a.W + dx) * 256) : OOB;
-      };
       auto req_res1 = [&](int r, int px) {       // residual of tile r, pixel px
         rv[r][px] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, (int)eo[r][px], 0, 0));
       };
-      if (c == 7 && RES && (W2_ABL & 8) == 0) { offsets(0, eo[0]); offsets(1, eo[1]); }
       __builtin_amdgcn_sched_barrier(0);
       // ---- 16 planes x 4 channel blocks x 4 k-steps of MFMAs; B fragments one plane ahead
       const char* ub = ((c & 3) == 0 ? ubuf0 : (c & 3) == 1 ? ubuf1 : (c & 3) == 2 ? ubuf2 : ubuf3) + (n * 32 + q * 8);
@@ -259,6 +261,7 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
           // one memory request per plane, between the MFMAs: a burst of 24 per wave in front of the block keeps all four
           // waves of the CU in the address queue — not issuing MFMAs — while the texture addresser works through 96 requests
           if (p < 8) request_u1((c + 2) & 7, (c + 2) & 3, p);
+          if (c == 6 && (p & 3) == 1) offsets(p >> 2, eo[p >> 2]);
           if ((c & 1) == 0) request_q1(((c >> 1) + 1) & 3, dq2[((c >> 1) + 1) & 1], p >> 2, p & 3);
           if (c == 7 && RES && (W2_ABL & 8) == 0 && (p & 1)) req_res1(p >> 3, (p >> 1) & 3);      // (tiles 0, 1: 8 requests)
         }
@@ -289,37 +292,39 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
         // 2, 3 — no group waits for a request issued right in front of it
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if (!RES) offsets(r, eo[r]);
-          if (RES && r < 2) offsets(r + 2, eo[r + 2]);
           __builtin_amdgcn_sched_barrier(0);
           float v[4][4];                           // [pixel][channel 4n + b]
+          // two channel blocks at a time on packed fp32 pairs (no MFMA runs beside the epilogue: v_pk_add_f32 is two adds per slot;
+          // the 256 accumulators are read a group at a time, not all up front)
 #pragma unroll
-          for (int b = 0; b < 4; ++b) {
-            if (RES && r < 2) req_res1(r + 2, b);
-            float m[16];
+          for (int bp = 0; bp < 2; ++bp) {
+            if (RES && r < 2) { req_res1(r + 2, 2 * bp); req_res1(r + 2, 2 * bp + 1); }
+            f32x2 m[16];
 #pragma unroll
-            for (int p = 0; p < 16; ++p) { acc_pin(acc[p][b]); m[p] = acc[p][b][r]; }
-            float s0[4], s1[4];
+            for (int p = 0; p < 16; ++p) { acc_pin(acc[p][2 * bp]); acc_pin(acc[p][2 * bp + 1]); m[p] = f32x2{acc[p][2 * bp][r], acc[p][2 * bp + 1][r]}; }
+            f32x2 s0[4], s1[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               s0[j] = m[0 + j] + m[4 + j] + m[8 + j];
               s1[j] = m[4 + j] - m[8 + j] - m[12 + j];
             }
-            float y[4];
+            f32x2 y[4];
             y[0] = s0[0] + s0[1] + s0[2]; y[1] = s0[1] - s0[2] - s0[3];
             y[2] = s1[0] + s1[1] + s1[2]; y[3] = s1[1] - s1[2] - s1[3];
+            const f32x2 sc2 = {sc[2 * bp], sc[2 * bp + 1]}, sh2 = {sh[2 * bp], sh[2 * bp + 1]};
 #pragma unroll
-            for (int px = 0; px < 4; ++px) v[px][b] = y[px] * sc[b] + sh[b];
-            __builtin_amdgcn_sched_barrier(0);     // (one (tile, channel block) at a time: the 256 accumulators are not all read up front)
+            for (int px = 0; px < 4; ++px) {
+              const f32x2 t = y[px] * sc2 + sh2;
+              v[px][2 * bp] = t[0]; v[px][2 * bp + 1] = t[1];
+            }
+            __builtin_amdgcn_sched_barrier(0);
           }
 #pragma unroll
           for (int px = 0; px < 4; ++px) {
             f32x4 o = {v[px][0], v[px][1], v[px][2], v[px][3]};
             if constexpr (RES) o += rv[r][px];
-            if (a.relu) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
-            }
+            for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], act_floor);      // (no branch: the epilogue stays one basic block per tile)
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsO, (int)eo[r][px], 0, 0);
           }
           __builtin_amdgcn_sched_barrier(0);
