@@ -123,25 +123,24 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
   // ---- per-item lane state of the A side: tile = group * 16 + n, patch origin (2ty-1, 2tx-1), channel slice 4q of a chunk
   int a_base = 0;                 // byte offset of patch pixel (0, 0), channel 4q of double-step 0 (may be negative: masked pixels only)
   unsigned a_rows = 0, a_cols = 0;
-  auto plan_a = [&](int item_l) {
+  auto plan_a = [&](int item_l) {      // (branch-free: it runs in front of step 6's MFMA block)
     const int item = item0 + item_l;
     const int tile = (item * 4 + wave) * 16 + n;
-    a_rows = a_cols = 0;
-    a_base = 0;
-    if (item_l < my_items && tile < a.ntiles) {
-      const int f = tile / thw, rem = tile - f * thw;
-      const int ty = rem / a.TW, tx = rem - ty * a.TW;
-      const int r0 = 2 * ty - 1, c0 = 2 * tx - 1;
+    const bool live = (item_l < my_items) & (tile < a.ntiles);
+    const int tl = live ? tile : 0;
+    const int f = tl / thw, rem = tl - f * thw;
+    const int ty = rem / a.TW, tx = rem - ty * a.TW;
+    const int r0 = 2 * ty - 1, c0 = 2 * tx - 1;
+    unsigned rows = 0, cols = 0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if ((unsigned)(r0 + i) < (unsigned)a.H) a_rows |= 1u << i;
-        if ((unsigned)(c0 + i) < (unsigned)a.W) a_cols |= 1u << i;
-      }
-      a_base = ((f * a.H + r0) * a.W + c0) * 256 + 16 * q;
+    for (int i = 0; i < 4; ++i) {
+      rows |= ((unsigned)(r0 + i) < (unsigned)a.H) ? 1u << i : 0u;
+      cols |= ((unsigned)(c0 + i) < (unsigned)a.W) ? 1u << i : 0u;
     }
+    a_rows = live ? rows : 0u;
+    a_cols = live ? cols : 0u;
+    a_base = ((f * a.H + r0) * a.W + c0) * 256 + 16 * q;
   };
-  // patches are requested TWO steps ahead (a step is ~2 us of MFMAs, an HBM round trip under load is longer): two register
-  // sets by step parity — step t transforms set t & 1, then refills it with the patch of step t + 2
   // patches are requested by DOUBLE-STEP d (16 input channels): a lane asks for the four channels 16d + 4q .. + 3 of each of its
   // 16 patch pixels at once (16 bytes: half the requests — and cache lines touched — per byte of the 8-byte form, measured
   // 1.84 / 1.94 -> 1.77 / 1.82 ms); components 2e, 2e + 1 feed step 2d + e (U's cin axis is laid out to match).  Two register sets by
@@ -204,7 +203,7 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
       for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 2; ++dx)
-          o[2 * dy + dx] = (tv && y0 + dy < a.H && x0 + dx < a.W) ? e00 + (unsigned)((dy * a.W + dx) * 256) : OOB;
+          o[2 * dy + dx] = ((int)tv & (int)(y0 + dy < a.H) & (int)(x0 + dx < a.W)) ? e00 + (unsigned)((dy * a.W + dx) * 256) : OOB;      // (bitwise: no control flow inside the MFMA block)
     };
 #pragma unroll
     for (int c = 0; c < 8; ++c) {                 // (unrolled: chunk, LDS buffer c & 1 and "first chunk" are compile-time)

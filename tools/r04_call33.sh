@@ -3,7 +3,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 O=gpurun_out/r04c33; mkdir -p $O
 timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_encoder_gpu.py tests/test_timed_shapes_gpu.py -q -m gpu -x -k "winograd or conv_algorithms or golden or invariance or timed or chunk" 2>&1 | tail -4
-timeout 300 python tools/wino_c64_ab.py cur:c8 ds2 2>&1 | tail -7 | tee $O/ab.txt
+timeout 300 python tools/wino_c64_ab.py flr nobr 2>&1 | tail -7 | tee $O/ab.txt
 timeout 300 python tools/wino_c64_ablate.py 2>&1 | tee $O/abl.txt
 timeout 900 python bench.py --no-cpu-baseline --no-c3 --no-peaks > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 python3 - <<'PY'
