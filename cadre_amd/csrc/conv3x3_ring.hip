@@ -89,6 +89,17 @@ struct ring_args {
 #define RING_ABL 0
 #endif
 
+// The staging slots' raised wave priority (+1-3 % on every bf16 shape) is a compile-time choice: as the run-time flag
+// a.prio it put two scalar branches into every slot of the ping-pong kernels (RING_PRIO_CONST=0 restores the flag for A/B).
+#ifndef RING_PRIO_CONST
+#define RING_PRIO_CONST 1
+#endif
+#if RING_PRIO_CONST
+#define RING_PRIO_ON true
+#else
+#define RING_PRIO_ON (a.prio)
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void wait_vm_n(int n) {        // wave-uniform n in [0, 40]
@@ -524,18 +535,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
   }
   // The per-lane source offsets of a slot's loads (vector ALU work) are computed apart from their issue (scalar + VMEM
   // only): in the k-loop they are prepared one slot ahead, under the wave's own MFMAs.
+  // (a dead request = bit 31 of the offset set: out of range for the descriptor.  OR-ing a scalar select into the offset keeps
+  // the k-loop free of control flow — as "cond ? offset : OOB" hipcc branches around the offset arithmetic, and a scalar branch
+  // in a staging slot costs more than the arithmetic it skips)
   auto voff_a = [&](int mt_n, int c_n, int j, bool live) -> unsigned {
-    return (live && j < PA) ? (unsigned)((mt_n * RG_BM - a.W - 1 + 8 * j) * cin_b + c_n * 128 + a_lane) : OOB;
+    const unsigned kill = ((int)live & (int)(j < PA)) ? 0u : OOB;
+    return (unsigned)((mt_n * RG_BM - a.W - 1 + 8 * j) * cin_b + c_n * 128 + a_lane) | kill;
   };
   bool abl_pro = true;                                     // (ablation builds: the prologue's loads always go out)
   auto send_a = [&](unsigned voff, int wsel, int j, bool live) {
-    char* dst = (live && j < PA) ? win0 + wsel * win_bytes + j * 1024 : dump;
+    char* dst = ((int)live & (int)(j < PA)) ? win0 + wsel * win_bytes + j * 1024 : dump;
     if ((RING_ABL & 4) && !abl_pro) { voff = OOB; dst = dump; }      // the DMA still issues, nothing is fetched, the window keeps its data
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)dst, 16, (int)voff, 0, 0, 0);
   };
   auto issue_a = [&](int mt_n, int c_n, int wsel, int j, bool live) { send_a(voff_a(mt_n, c_n, j, live), wsel, j, live); };
   auto voff_b = [&](int nt_b, int c, int tap, bool live, int k) -> unsigned {
-    return live ? (unsigned)(nt_b * (NTILE * a.NC * 9 * 128) + (c * 9 + tap) * 128 + b_lane[k]) : OOB;
+    return (unsigned)(nt_b * (NTILE * a.NC * 9 * 128) + (c * 9 + tap) * 128 + b_lane[k]) | (live ? 0u : OOB);
   };
   auto send_b = [&](unsigned voff, int stg, int k) {
     char* dst = bst + stg * STG_B + (wave * NBPW + k) * 1024;
@@ -774,11 +789,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
       }
       mask[rb] = mk;
     }
-    for (int c = 0; c < a.NC; ++c) {
+    // one channel chunk (9 k-tiles).  Whether it is the item's LAST chunk is a compile-time parameter (two instances of the body):
+    // the counted waits, the early residual requests and the closing barrier depend on it, and as run-time conditions they put
+    // half a dozen scalar branches into every staging slot (wait_vm_n alone is a branch tree over the count)
+    auto chunk = [&](auto last_t, const int c) {
+      constexpr int LT = decltype(last_t)::value;            // 0: not the last chunk, 1: the last chunk, 2: decided at run time
+      const bool last_c = LT == 2 ? (c + 1 == a.NC) : (LT != 0);
       const int phg = li * a.NC + c;
       const int win_off = (phg & 1) * win_bytes;
       const bool has_next = phg + 1 < total_ph;
-      const bool last_c = c + 1 == a.NC;
       const int mt_n = last_c ? mt1 : mt, c_n = last_c ? 0 : c + 1;
       auto slot_voff = [&](int tap) {                      // source offsets of the loads staging slot `tap` issues
 #pragma unroll
@@ -791,29 +810,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         // ================= R slot (at raised priority: its few instructions go between the other group's MFMAs)
-        if (a.prio) __builtin_amdgcn_s_setprio(2);
-        if (tap == 0 && c == 0) {
-          RG_STAMP(0);
-          // the previous item's epilogue, both groups side by side: group 0 is in its R(0) slot, group 1 — one slot
-          // behind — still in its M(8) slot, whose closing barrier it takes only now
-          if (have_prev) {
-            epilogue(mt_p, nt_p, phl_p);
-            if (grp == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
-          }
-#pragma unroll
-          for (int rb = 0; rb < PR; ++rb)
-#pragma unroll
-            for (int cb = 0; cb < CT; ++cb)
-#pragma unroll
-              for (int r = 0; r < (M16 ? 4 : 16); ++r) acc[rb][cb][r] = 0.f;
-          RG_STAMP(1);
-        }
+        if (RING_PRIO_ON) __builtin_amdgcn_s_setprio(2);
         if (tap == 4 && c == 0) RG_STAMP(2);
         if (tap == 4 && c == 0) RG_SLOT(0);
         // operations this wave issues in this R slot / issued in its previous one (folds: tap is unrolled)
         // (residual of output blocks 0 and 1: requested at k-tiles 7 and 8 of the item's last chunk — an HBM round trip
         //  ahead of the epilogue that adds them; the later blocks when the epilogue starts, two blocks ahead)
-        auto n_res = [&](int t) -> int { return (RES != 0 && !(RING_ABL & 64) && t >= 7) ? NPASS : 0; };
+        auto n_res = [](int t) constexpr -> int { return (RES != 0 && !(RING_ABL & 64) && t >= 7) ? NPASS : 0; };
         const int n_now = NBPW + sl_of(tap) + (last_c ? n_res(tap) : 0);
         const char* bs = bst + (tap % RG_NSTB) * STG_B;     // 9 k-tiles per chunk, 3 stages: the stage of k-tile `tap` is tap % 3 — static
         f32x4 afr[PR][KS], bfr[CT][KS];
@@ -888,7 +891,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
         // confirm the weights this wave issued in its previous R slot (in-order completion), all fragment reads returned
         // (a slot issues weights first, then window slices / the early residual: those younger operations of the
         //  oldest slot still counted may stay in flight too — the slices are HBM reads, not needed before the next phase)
-        const int young = sl_of((tap + 8) % 9) + (tap == 0 ? ((c == 0 && have_prev) ? n_res(8) : 0) : (last_c ? n_res(tap - 1) : 0));
+        // (tap 0 of an item's first chunk: between the previous slot's weights and this slot's loads lie the previous item's early
+        //  residual requests of tap 8 and its epilogue — the later blocks' residual requests and every store; counting them too
+        //  keeps this wait from draining the epilogue's stores.  In the launch's first item nothing older is in flight.  Every other
+        //  tap: tap is unrolled and last_c a template parameter — the switch folds to one s_waitcnt)
+        constexpr int N_EPI = (RING_ABL & 32) ? 0 : ((RING_ABL & 16) ? 0 : NBLK * NPASS) + ((RES != 0 && !(RING_ABL & 64)) ? (NBLK - 2) * NPASS : 0);
+        const int young = sl_of((tap + 8) % 9) + (tap == 0 ? (c == 0 ? n_res(8) + N_EPI : 0) : (last_c ? n_res(tap - 1) : 0));
         wait_vm_n(n_now + young);
         if (tap == 4 && c == 0) RG_SLOT(2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -897,7 +905,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (tap == 4 && c == 0) RG_STAMP(4);
-        if (a.prio) __builtin_amdgcn_s_setprio(0);
+        if (RING_PRIO_ON) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         // ================= M slot
 #pragma unroll
@@ -942,6 +950,31 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
         asm volatile("" ::: "memory");
         if (tap == 4 && c == 0) RG_STAMP(6);
       }
+    };
+    // ---- head of the item's first staging slot (R(0) of chunk 0; ONE copy, in front of both instances of the chunk body)
+    if (RING_PRIO_ON) __builtin_amdgcn_s_setprio(2);
+    RG_STAMP(0);
+    // the previous item's epilogue, both groups side by side: group 0 is in its R(0) slot, group 1 — one slot
+    // behind — still in its M(8) slot, whose closing barrier it takes only now
+    if (have_prev) {
+      epilogue(mt_p, nt_p, phl_p);
+      if (grp == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+    }
+#pragma unroll
+    for (int rb = 0; rb < PR; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < CT; ++cb)
+#pragma unroll
+        for (int r = 0; r < (M16 ? 4 : 16); ++r) acc[rb][cb][r] = 0.f;
+    RG_STAMP(1);
+    // (two chunks per item: every chunk would alternate between the two instances — measured 2-3 % slower than one body with the
+    //  run-time conditions, 2 x 1152-channel layers; from four chunks on the instance without the end-of-item code repeats: -4..-7 %)
+    if (a.NC == 2) {
+      chunk(int_k<2>{}, 0);
+      chunk(int_k<2>{}, 1);
+    } else {
+      for (int c = 0; c + 1 < a.NC; ++c) chunk(int_k<0>{}, c);
+      chunk(int_k<1>{}, a.NC - 1);
     }
     mt_p = mt; nt_p = nt; phl_p = (li * a.NC + a.NC - 1) & 1; have_prev = true;
     if (mt1 != mt) advance_mtile();
@@ -1321,7 +1354,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp2_kernel(ring_args a) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) { b_ln[q] = b_lane[q]; asm volatile("" : "+v"(b_ln[q])); }
         // ================= R slot (at raised priority: its instructions go between the other group's MFMAs)
-        if (a.prio) __builtin_amdgcn_s_setprio(2);
+        if (RING_PRIO_ON) __builtin_amdgcn_s_setprio(2);
         if (ss == 0 && per == 0) RG_STAMP(0);
         if (ss == 1 && per == 0) RG_STAMP(2);
         if (ss == 0 && per == 0) {
@@ -1389,7 +1422,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp2_kernel(ring_args a) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (ss == 1 && per == 0) RG_STAMP(4);
-        if (a.prio) __builtin_amdgcn_s_setprio(0);
+        if (RING_PRIO_ON) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         // ================= M slot: G k-tiles, k-step outer; behind the MFMAs of k-step s of k-tile j go the reads of k-step s
         // of k-tile j + 1 — into the registers those MFMAs have just released
