@@ -623,7 +623,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
 #pragma unroll
       for (int i = 0; i < NPASS; ++i) {
         const int eo = eb + (32 * rb + RSTEP * i) * a.N + 32 * cb;
-        const int bo = ((chm >> cb) & 1u) ? eo * RSZ : (int)OOB;
+        const int bo = (int)((unsigned)(eo * RSZ) | (((chm >> cb) & 1u) ? 0u : OOB));      // (select of constants + OR: no divergent branch around the offset)
         if constexpr (RES == 2 && !WIDE) dst[i] = __builtin_bit_cast(rq_t, __builtin_amdgcn_raw_buffer_load_b64(rsR, bo, 0, 0));
         else dst[i] = __builtin_bit_cast(rq_t, __builtin_amdgcn_raw_buffer_load_b128(rsR, bo, 0, 0));
       }
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ring_pp_kernel(ring_args a) {
             for (int e = 0; e < 4; ++e) v[h][e] = fmaxf(v[h][e], act_floor);
         }
         const int eo = eb + (32 * rb + RSTEP * i) * a.N + 32 * cb;
-        const int bo = ((chm >> cb) & 1u) ? eo * ESZ : (int)OOB;
+        const int bo = (int)((unsigned)(eo * ESZ) | (((chm >> cb) & 1u) ? 0u : OOB));
         if constexpr ((RING_ABL & 16) != 0) {                 // no global stores: the values stay live
 #pragma unroll
           for (int h = 0; h < NV; ++h) asm volatile("" :: "v"(v[h]), "v"(bo));
@@ -1585,8 +1585,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64s_kernel(ring_args a) {
   bool abl_pro = true;
   auto send_a = [&](int mt_n, int buf, int n, bool live) {
     const int j = 4 * n + wave;
-    const bool ok = live && j < PA;
-    unsigned voff = ok ? (unsigned)((mt_n * RG_BM - a.W - 1 + 8 * j) * 128 + a_lane) : OOB;
+    const bool ok = (int)live & (int)(j < PA);
+    // (a dead request = bit 31 of the offset: OR-ing a scalar select keeps the item loop free of branches, see conv3x3_ring_pp_kernel)
+    unsigned voff = (unsigned)((mt_n * RG_BM - a.W - 1 + 8 * j) * 128 + a_lane) | (ok ? 0u : OOB);
     char* dst = ok ? win0 + buf * win_bytes + j * 1024 : dump;
     if ((RING_ABL & 4) && !abl_pro) { voff = OOB; dst = dump; }
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)dst, 16, (int)voff, 0, 0, 0);
@@ -1654,7 +1655,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64s_kernel(ring_args a) {
   const bool post = (a.act & 16) != 0;
   auto ebyte = [&](int mt_e, int p, bool live, int esz) -> int {      // byte offset of piece p's 8 channels, or out of range
     const int pos = mt_e * RG_BM + 128 * phf + 32 * (p >> 1) + l31;
-    return live ? (pos * 64 + 32 * chh + 16 * (p & 1) + 8 * lh) * esz : (int)OOB;      // (pos >= M lies past num_records)
+    return (int)((unsigned)((pos * 64 + 32 * chh + 16 * (p & 1) + 8 * lh) * esz) | (live ? 0u : OOB));      // (pos >= M lies past num_records)
   };
   auto rq_load = [&](int mt_e, int p, bool live) {
     if constexpr (RES != 0 && (RING_ABL & 64) == 0)
@@ -1789,7 +1790,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64s_kernel(ring_args a) {
             acc[Q][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wfr[tap][s]), __builtin_bit_cast(bf16x8, pfr[rb][s]),
                                                                  acc[Q][rb], 0, 0, 0);
         }
-        if (tap < 8 || more) {
+        {                                                    // (past the last item: stale pixels of a window buffer, never used)
           if constexpr ((RING_ABL & 2) == 0) {
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb) nfr[rb][s] = *reinterpret_cast<lds_f4>(n_addr[rb][s]);
