@@ -1585,9 +1585,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64s_kernel(ring_args a) {
   bool abl_pro = true;
   auto send_a = [&](int mt_n, int buf, int n, bool live) {
     const int j = 4 * n + wave;
-    const bool ok = (int)live & (int)(j < PA);
-    // (a dead request = bit 31 of the offset: OR-ing a scalar select keeps the item loop free of branches, see conv3x3_ring_pp_kernel)
-    unsigned voff = (unsigned)((mt_n * RG_BM - a.W - 1 + 8 * j) * 128 + a_lane) | (ok ? 0u : OOB);
+    const bool ok = live && j < PA;
+    unsigned voff = ok ? (unsigned)((mt_n * RG_BM - a.W - 1 + 8 * j) * 128 + a_lane) : OOB;
     char* dst = ok ? win0 + buf * win_bytes + j * 1024 : dump;
     if ((RING_ABL & 4) && !abl_pro) { voff = OOB; dst = dump; }
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)dst, 16, (int)voff, 0, 0, 0);
@@ -1655,7 +1654,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64s_kernel(ring_args a) {
   const bool post = (a.act & 16) != 0;
   auto ebyte = [&](int mt_e, int p, bool live, int esz) -> int {      // byte offset of piece p's 8 channels, or out of range
     const int pos = mt_e * RG_BM + 128 * phf + 32 * (p >> 1) + l31;
-    return (int)((unsigned)((pos * 64 + 32 * chh + 16 * (p & 1) + 8 * lh) * esz) | (live ? 0u : OOB));      // (pos >= M lies past num_records)
+    return live ? (pos * 64 + 32 * chh + 16 * (p & 1) + 8 * lh) * esz : (int)OOB;      // (pos >= M lies past num_records)
   };
   auto rq_load = [&](int mt_e, int p, bool live) {
     if constexpr (RES != 0 && (RING_ABL & 64) == 0)
@@ -1790,7 +1789,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64s_kernel(ring_args a) {
             acc[Q][rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wfr[tap][s]), __builtin_bit_cast(bf16x8, pfr[rb][s]),
                                                                  acc[Q][rb], 0, 0, 0);
         }
-        {                                                    // (past the last item: stale pixels of a window buffer, never used)
+        if (tap < 8 || more) {
           if constexpr ((RING_ABL & 2) == 0) {
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb) nfr[rb][s] = *reinterpret_cast<lds_f4>(n_addr[rb][s]);
