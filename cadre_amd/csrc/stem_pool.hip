@@ -51,13 +51,14 @@ struct stem_args {
 };
 
 // float32(i / 255.) for an integer-valued float i in [0, 255], EXACTLY the reference's value (agent.py:46 divides in
-// double and stores float32): one multiply by fl(1/255) and one Newton correction — checked against the host table for
-// all 256 inputs by cadre_div255_selfcheck (tests/test_kernels_gpu.py).  4 VALU per value, no table lookup, no LDS.
+// double and stores float32): fl(1/255) split into a high and a low part — checked against the host table for
+// all 256 inputs by cadre_div255_selfcheck (tests/test_kernels_gpu.py).  3 VALU per value (convert, multiply, fma), no table lookup, no LDS.
 __device__ __forceinline__ float div255(float f) {
-  const float r = 0.00392156862745098f;
-  const float q0 = f * r;
-  const float e = __builtin_fmaf(-q0, 255.0f, f);
-  return __builtin_fmaf(e, r, q0);
+  // f / 255 = f * (r_hi + r_lo) with r_hi = fl(1/255), r_lo = fl(1/255 - r_hi): the product f * r_hi is exact inside the fma
+  // (8-bit f), so fma(f, r_hi, fl(f * r_lo)) is the correctly rounded quotient for all 256 inputs — one multiply + one fma
+  // (round 4; until then a multiply and a Newton step: two fmas)
+  const float r_hi = 0x1.010102p-8f, r_lo = -0x1.fdfdfep-33f;
+  return __builtin_fmaf(f, r_hi, f * r_lo);
 }
 
 __global__ void div255_check_kernel(const float* lut, int* bad) {
