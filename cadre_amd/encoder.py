@@ -94,13 +94,16 @@ def _winograd_min_c():
 
 _WINO_G = {2: [[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]],
            3: [[8.0 / 9, 0.0, 0.0], [-32.0 / 45, -8.0 / 15, -2.0 / 5], [-32.0 / 99, 8.0 / 33, -2.0 / 11], [8.0 / 55, 16.0 / 55, 32.0 / 55],
-               [0.0, 0.0, 1.0]]}
+               [0.0, 0.0, 1.0]],
+           # F(4x4): points 0, 3/4, -3/4, 3/2, -3/2, infinity; rows scaled against the powers of two taken out of B^T (winograd.hip)
+           4: [[64.0 / 81, 0.0, 0.0], [128.0 / 243, 128.0 / 324, 128.0 / 432], [128.0 / 243, -128.0 / 324, 128.0 / 432],
+               [32.0 / 243, 32.0 / 162, 32.0 / 108], [32.0 / 243, -32.0 / 162, 32.0 / 108], [0.0, 0.0, 1.0]]}
 
 
 def _winograd_u(w, m=2):
     """OIHW 3x3 weights -> U[(m+2)^2][O][I] = (G g G^T)[xi], xi = (m+2) i + j (float64 product, one rounding to fp32): the B
     operands of the batched GEMM between cadre_winograd_in and cadre_winograd_out (csrc/winograd.hip; Cook-Toom points
-    0, 1, -1, infinity for m = 2 and 0, 3/4, -3/4, 2, infinity for m = 3 — G matches the kernels' B^T / A^T)."""
+    0, 1, -1, infinity for m = 2, 0, 3/4, -3/4, 2, infinity for m = 3, 0, +-3/4, +-3/2, infinity for m = 4 — G matches the kernels' B^T / A^T)."""
     G = torch.tensor(_WINO_G[m], dtype=torch.float64)
     u = torch.einsum("ik,ockl,jl->ijoc", G, torch.as_tensor(w).double(), G)        # [m+2][m+2][O][I]
     return u.reshape((m + 2) ** 2, w.shape[0], w.shape[1]).float().contiguous()
@@ -127,10 +130,16 @@ def _winograd_m(H, W):
     (m+2)^2 * ceil(H/m) * ceil(W/m) (F(3x3) tiles the 9x9 and 18x18 maps of the 288x288 model exactly).  CADRE_WINOGRAD_M
     forces 2 or 3."""
     e = os.environ.get("CADRE_WINOGRAD_M", "")
-    if e in ("2", "3"):
+    if e in ("2", "3", "4"):
         return int(e)
     cost = {m: (m + 2) ** 2 * -(-H // m) * -(-W // m) for m in (2, 3)}
-    return 3 if cost[3] <= cost[2] else 2
+    best = 3 if cost[3] <= cost[2] else 2
+    # F(4x4) only where 4 x 4 tiles cover the map EXACTLY (36 x 36: layer2 of the 288 x 288 model) and beat the others: its
+    # rounding error is 1.6x the F(3x3) set's (CADRE_WINOGRAD_M4=0: never)
+    if (os.environ.get("CADRE_WINOGRAD_M4", "1") != "0" and H % 4 == 0 and W % 4 == 0
+            and 36 * (H // 4) * (W // 4) < cost[best]):
+        return 4
+    return best
 
 
 class _Conv:

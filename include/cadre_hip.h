@@ -169,16 +169,17 @@ int cadre_stem_pool_supported(int32_t H, int32_t W);
 int cadre_winograd_c64(const float* x, const float* U, const float* scale, const float* shift, const float* resid, float* out,
                        int32_t F, int32_t H, int32_t W, int32_t act, void* stream);
 
-/* Winograd F(m x m, 3x3) transforms, m = 2 or 3, fp32, NHWC (csrc/winograd.hip).  A stride-1 / pad-1 3x3 convolution
+/* Winograd F(m x m, 3x3) transforms, m = 2, 3 or 4, fp32, NHWC (csrc/winograd.hip).  A stride-1 / pad-1 3x3 convolution
  * (resnet.py:26-55) = cadre_winograd_in -> ONE cadre_gemm_f32 with batch (m+2)^2 (M[xi] = V[xi] . U[xi]^T,
- * U[xi][cout][cin] = (G g G^T)[xi] prepared by the host; Cook-Toom points 0, 1, -1, inf (m = 2) / 0, 3/4, -3/4, 2, inf (m = 3):
+ * U[xi][cout][cin] = (G g G^T)[xi] prepared by the host; Cook-Toom points 0, 1, -1, inf (m = 2) / 0, 3/4, -3/4, 2, inf (m = 3) /
+ * 0, +-3/4, +-3/2, inf (m = 4):
  * cadre_amd/encoder.py _WINO_G) -> cadre_winograd_out.
  * T = F * ceil(H/m) * ceil(W/m) tiles.  V: [(m+2)^2][T][C], Mx: [(m+2)^2][T][N], x / resid / out: [F][H][W][C or N].
  * out = act(M . scale + shift (+ resid)) with cadre_gemm_t's act codes (0 none, 1 ReLU, bit 4: residual after act). */
 int cadre_winograd_in(const float* x, float* V, int32_t F, int32_t H, int32_t W, int32_t C, int32_t m, void* stream);
 int cadre_winograd_out(const float* Mx, const float* scale, const float* shift, const float* resid, float* out,
                        int32_t F, int32_t H, int32_t W, int32_t N, int32_t act, int32_t m, void* stream);
-/* The fused front converts bytes arithmetically (x * fl(1/255) + one Newton correction) instead of through the
+/* The fused front converts bytes arithmetically (fma(x, r_hi, x * r_lo), r_hi + r_lo = 1/255 split in two floats) instead of through the
  * table: counts, into *mismatches (device int32), the i in 0..255 for which that differs from lut255[i]; must be 0. */
 int cadre_div255_selfcheck(const float* lut255, int32_t* mismatches, void* stream);
 /* nn.MaxPool2d(3,2,1) resnet.py:114 on NHWC [F][H][W][C] (C%4==0) -> [F][Ho][Wo][C] */
