@@ -23,15 +23,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _run(module, args, tag, timeout=900):
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # (this pytest process may hold gigabytes of cached device memory from the tests before: hand it back before the driver and
+    #  its children export and import blocks over HIP IPC)
+    try:
+        import torch
+        if torch.cuda.is_initialized():
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+    except Exception:
+        pass
     for attempt in (0, 1):
         p = subprocess.run([sys.executable, "-m", module] + args, cwd=ROOT, env=env, capture_output=True, text=True,
                            timeout=timeout)
-        # ONE retry, and only for the pool's HIP-IPC flake (`hipIpcGetMemHandle: invalid argument` when a block the
-        # allocator handed out before is exported again — seen in ~1 of 10 full-suite runs, never in the test run alone); any
-        # other failure, and a second IPC failure, fails the test
-        if p.returncode == 0 or attempt == 1 or "hipIpc" not in (p.stdout + p.stderr):
+        # ONE retry, and only for the pool's HIP-IPC export flake (`storage._share_cuda_()` -> hipIpcGetMemHandle:
+        # invalid argument in the driver's second mode — seen on some boxes when the test runs inside the full suite, never in
+        # the test file alone); any other failure, and a second IPC failure, fails the test
+        out = p.stdout + p.stderr
+        if p.returncode == 0 or attempt == 1 or not ("hipIpc" in out or "_share_cuda_" in out):
             break
-        print("HIP-IPC flake, retrying once:\n" + p.stderr[-1500:])
+        print("HIP-IPC export flake, retrying once:\n" + p.stderr[-1500:])
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith(tag + " ")]
     assert p.returncode == 0 and lines, "driver failed rc=%s\nstdout:\n%s\nstderr:\n%s" % (
         p.returncode, p.stdout[-3000:], p.stderr[-6000:])
