@@ -208,7 +208,7 @@ def learner_round(agent, workers, cfg, shared, timers=None, joint=None, losses_t
         host.append(("GAE enqueued", time.perf_counter() - t0))
     nW = len(workers)
     dev_losses = []
-    hook = shared.overlap_hook()       # several ranks: MLP and steer-LSTM gradient buckets out beside the rest of the backward
+    hook = shared.overlap_hook(agent.arena)  # several ranks + --grad-buckets: MLP and steer-LSTM gradient buckets out beside the rest of the backward
     evs = []
     for _ in range(PPO_EPOCH):
         idx = [(wk.stor[0].sample_indices(), wk.stor[1].sample_indices()) for wk in workers]
@@ -376,19 +376,18 @@ def roofline_of(prof, steps):
     return dom, r
 
 
-def run_config(name, args, rank, local_rank, world, use_dist, steps, warmup, episodes_dir=None):
+def run_config(name, args, rank, local_rank, world, use_dist, steps, warmup, episodes_dir=None, dedup=None):
     """Build the agent + workers of BASELINE config `name`, warm up, time `steps` learner rounds (barrier +
     synchronize on both sides, MAX over ranks) and return the result dict (rank 0) plus what cpu_baseline needs."""
     import torch.distributed as dist
     from cadre_amd import hip, synth
     from ppo_agent.agent import CadreAgent
     from ppo_agent.models import Shared_grad_buffers
-    cfg = dict(CONFIGS[name]); cfg["dedup"] = args.dedup
-    if args.no_grad_buckets:
-        os.environ["CADRE_GRAD_BUCKETS"] = "0"
+    dedup = args.dedup if dedup is None else dedup
+    cfg = dict(CONFIGS[name]); cfg["dedup"] = dedup
     # windows per encoder launch chain: 128 (1024 frames) per worker; with several workers per GPU their windows form
     # one stream cut into chunks of 256 (2048 frames: every activation tensor stays below the 2 GiB buffer window)
-    joint_ok = cfg["workers"] > 1 and not args.dedup and not episodes_dir and not args.no_joint_encode
+    joint_ok = cfg["workers"] > 1 and not dedup and not episodes_dir and not args.no_joint_encode
     cw = args.chunk_windows if args.chunk_windows else (256 if joint_ok else 128)
     cfg["chunk_windows"] = cw
     episodes = None
@@ -483,16 +482,31 @@ def run_config(name, args, rank, local_rank, world, use_dist, steps, warmup, epi
     lrn = agent.learner
     n_launch = sum(v for (part, b), v in lrn.launches.items() if b == B_gpu and part == "all") or \
         sum(v for (part, b), v in lrn.launches.items() if b == B_gpu)
+    # FLOPs: the reference evaluates all 4 command nets of a head on every row and masks (agent.py:170-182): 3 x 2 x 0.144 G
+    # per row (forward + backward).  Rows are sorted by command here and each net runs ITS run of rows only: a quarter of
+    # that is executed.  Both roofs are priced on what is executed / moved; the larger time names the bound.
+    flops_ref = 3 * 2 * 0.144e9 * B_gpu
+    flops_exec = flops_ref / 4
+    t_hbm_s, t_mfma_s = upd_bytes / (PEAK_HBM_GBPS * 1e9), flops_exec / (PEAK_F32_MFMA_TFLOPS * 1e12)
+    hbm_frac = t_hbm_s / (med * 1e-3)
+    mfma_frac = t_mfma_s / (med * 1e-3)
     update_roofline = {
-        "bound": "hbm", "bytes_per_step": upd_bytes, "ms_per_step": round(med, 4), "ms_per_step_min": round(step_ms_s[0], 4),
+        "bound": "hbm" if t_hbm_s >= t_mfma_s else "mfma",
+        "frac": round(max(hbm_frac, mfma_frac), 4),
+        "bytes_per_step": upd_bytes, "ms_per_step": round(med, 4), "ms_per_step_min": round(step_ms_s[0], 4),
         "ms_per_step_max": round(step_ms_s[-1], 4), "achieved": round(upd_bytes / (med * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS,
-        "unit": "GB/s", "hbm_frac": round(upd_bytes / (med * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), "minibatch_rows": B_gpu,
+        "unit": "GB/s", "hbm_frac": round(hbm_frac, 4),
+        "achieved_tflops_executed": round(flops_exec / (med * 1e-3) / 1e12, 2), "peak_tflops": PEAK_F32_MFMA_TFLOPS,
+        "mfma_frac": round(mfma_frac, 4), "minibatch_rows": B_gpu,
         "kernels_per_update": n_launch, "kernels_note": "C-ABI launches of update_policy (forward, loss, backward) per "
         "minibatch step; + 3-4 for gather/sort/permute and 3 for clip + Adam; one hipGraph replay each",
-        "flops_per_step": round(3 * 2 * 0.144e9 * B_gpu, 1),
+        "flops_per_step": round(flops_ref, 1), "flops_per_step_executed": round(flops_exec, 1),
         "note": "one minibatch step = gather + update_policy + gradient exchange + per-model clip + Adam, HIP events in an "
-                "untimed pass; bytes = 48 x %d parameters + %d activation bytes (SURVEY.md 8d)" % (P, act_bytes)}
-    frames = nW * (T + SEQ - 1 if args.dedup else T * SEQ)
+                "untimed pass; bytes = 48 x %d parameters + %d activation bytes (SURVEY.md 8d); flops_per_step = the "
+                "reference's command-masked work (every net on every row), flops_per_step_executed = a quarter of it (rows "
+                "sorted by command, each net on its own run); hbm_frac = bytes / 8 TB/s, mfma_frac = executed FLOPs / "
+                "157.3 TFLOP/s (fp32 matrix pipe), bound = the larger time" % (P, act_bytes)}
+    frames = nW * (T + SEQ - 1 if dedup else T * SEQ)
     flops_frame = agent.vae_model.flops_per_frame()
     flops_exec = agent.vae_model.flops_per_frame(executed=True)
     n_wino = agent.vae_model.winograd_convs()
@@ -505,7 +519,7 @@ def run_config(name, args, rank, local_rank, world, use_dist, steps, warmup, epi
         "config": {"workload": "%s: %d worker(s) x %d-step rollout, %dx%dx3 synthetic obs (+route), DANet encoder "
                                "(%s) + PPO update (4 epochs x 2 minibatches), %s"
                                % (name, nW, T, H, W,
-                                  "latent cache: each distinct frame encoded once" if args.dedup
+                                  "latent cache: each distinct frame encoded once" if dedup
                                   else "8 frames/transition, reference convention",
                                   "fp32" if enc_dtype == "f32" else "bf16 encoder / fp32 losses"),
                    "workers_per_gpu": nW, "num_steps": T, "obs": [H, W], "minibatch_per_gpu": nW * T // MINI_BATCH_NUM,
@@ -522,8 +536,14 @@ def run_config(name, args, rank, local_rank, world, use_dist, steps, warmup, epi
                                "t_encode; with Winograd convs fewer are executed (encoder_tflops_executed) — the roofline "
                                "object and per_kernel count executed FLOPs only",
         "update_only_samples_per_sec": round(nW * T * PPO_EPOCH / t_upd, 1),
-        "encoder_fwd_GBps": round(enc_bytes / t_enc / 1e9, 1) if not args.dedup else None,
-        "encoder_fwd_hbm_frac": round(enc_bytes / t_enc / 1e9 / PEAK_HBM_GBPS, 4) if not args.dedup else None,
+        "encoder_fwd_GBps": round(enc_bytes / t_enc / 1e9, 1) if not dedup else None,
+        "encoder_fwd_hbm_frac": round(enc_bytes / t_enc / 1e9 / PEAK_HBM_GBPS, 4) if not dedup else None,
+        # north_star asks for >= 0.70 of the HBM roof on the encoder forward.  The layer stack has 149 (fp32) / 298 (bf16)
+        # FLOP per algorithmic byte: fp32 is MFMA-bound 7x over (a perfect 157 TFLOP/s kernel moves 0.13 of the roof), bf16
+        # sits on the ridge, where 0.70 would need 1.67 PFLOP/s sustained against a MEASURED random-operand MFMA ceiling
+        # of 1.78-1.80 PFLOP/s on this chip.  The reachable figure the build tracks instead: the whole bf16
+        # encoder at 1.2 PFLOP/s = 0.50 of the roof; fp32 at 0.85 of the fp32 MFMA peak on executed FLOPs = 0.23.
+        "encoder_fwd_hbm_frac_target": (0.50 if enc_dtype != "f32" else 0.23) if not dedup else None,
         "encoder_fwd_GBps_note": "algorithmic bytes (SURVEY 8d layer model, weights once per chunk) / t_encode vs HBM peak "
                                  "8000 GB/s; the fp32 conv stack is MFMA-bound (see roofline)",
         "roofline": roof,
@@ -552,7 +572,7 @@ def run_config(name, args, rank, local_rank, world, use_dist, steps, warmup, epi
         shared.reset(zero=True)
         out["rccl_ranks"] = world
         out["grad_exchange"] = mode + (" in 3 buckets (MLP towers, steer LSTMs, throttle LSTMs), the first two beside the backward"
-                                        if shared.overlap_hook() is not None else "")
+                                        if shared.overlap_hook(agent.arena) is not None else "")
         out["allreduce_ms_per_step"] = round(e0.elapsed_time(e1) / reps, 4)
         out["allreduce_bytes"] = int(g.numel() * 4)
         out["exchanges_in_timed_region"] = n_ex          # one per optimiser step: 8 per round
@@ -630,8 +650,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
-                    help="headline config (default: C2 on one GPU; C3 per GPU on several = BASELINE C4, the shape the "
-                         "1 -> 8 scaling target is defined on; the other one rides along as a nested section)")
+                    help="headline config (default: C2 PER GPU at every world size, so that value(N) / value(1) compares like "
+                         "with like; C3 per GPU — BASELINE C4 at N = 8, the shape the 1 -> 8 target is defined on — rides "
+                         "along as the nested \"c3\" section of every line, N = 1 included)")
     ap.add_argument("--chunk-windows", type=int, default=0,
                     help="windows (x8 frames) per encoder launch chain (default: 128, or 256 across the workers of a GPU)")
     ap.add_argument("--no-joint-encode", action="store_true", help="encode each worker's windows separately (chunks of 128)")
@@ -648,13 +669,16 @@ def main():
     ap.add_argument("--grad-exchange", default=None, choices=["allreduce", "sharded"],
                     help="N > 1: one all-reduce(SUM) of the gradient arena + replicated clip/Adam (default), or reduce-scatter + "
                          "clip/Adam on the rank's shard + all-gather of the parameters (same wire bytes, 1/N optimiser traffic)")
-    ap.add_argument("--no-grad-buckets", action="store_true",
-                    help="N > 1, all-reduce mode: ONE blocking all-reduce of the 80 MB arena per optimiser step instead of three "
-                         "buckets of which two leave beside the backward (the default)")
-    ap.add_argument("--grad-buckets", action="store_true", help=argparse.SUPPRESS)      # (round-3 flag: now the default)
+    ap.add_argument("--grad-buckets", action="store_true",
+                    help="N > 1, all-reduce mode: the gradient arena leaves in three buckets, two of them beside the backward "
+                         "(opt-in: no multi-GPU RCCL run of this form exists yet; default = ONE blocking all-reduce of the "
+                         "80 MB arena per optimiser step)")
+    ap.add_argument("--no-grad-buckets", action="store_true", help=argparse.SUPPRESS)    # (round-4 flag: the default again)
     ap.add_argument("--spawn-selftest", action="store_true",
                     help="launcher check (no GPU): every rank prints its RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* and exits")
     ap.add_argument("--c3-steps", type=int, default=10, help="timed rounds of the C3 section (>= 10 by default)")
+    ap.add_argument("--no-latent-cache", action="store_true",
+                    help="skip the c2_latent_cache / c3_latent_cache sections (the same rounds with each distinct frame encoded once)")
     ap.add_argument("--dedup", action="store_true",
                     help="encode each distinct frame once (sliding-window latent cache) instead of the "
                          "reference's 8 frames per transition; NOT the default metric convention")
@@ -662,6 +686,10 @@ def main():
 
     if args.grad_exchange:
         os.environ["CADRE_GRAD_EXCHANGE"] = args.grad_exchange
+    if args.grad_buckets:
+        os.environ["CADRE_GRAD_BUCKETS"] = "1"
+    if args.no_grad_buckets:
+        os.environ["CADRE_GRAD_BUCKETS"] = "0"
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # `python bench.py --gpus N` without a launcher: this process has not touched the GPU (and never will) — it
         # starts N fresh children, one per LOCAL_RANK, relays rank 0's JSON line and exits with their status
@@ -710,9 +738,13 @@ def main():
             log("[bench] rank %d: init_process_group(%s) failed: %r" % (rank, backend, e))
             sys.exit(RC_RENDEZVOUS)
 
-    # headline: C2 on one GPU (BASELINE.json's single-GPU fp32 config); on several GPUs C3 per GPU — BASELINE C4,
-    # num_processes = 4 per GPU, bf16 encoder / fp32 losses, the shape north_star's 1 -> 8 target is defined on
-    head = args.config or ("C3" if world > 1 else "C2")
+    # headline: C2 PER GPU at every world size (BASELINE.json's single-GPU fp32 config, weak scaling: one worker x 128
+    # steps per GPU) — round 4 switched the headline to C3 for N > 1, which made value(N) / value(1) compare a 4-worker
+    # bf16 shape with a 1-worker fp32 one and inflated any efficiency computed from the lines ~4x.  C3 per
+    # GPU (BASELINE C4 at N = 8: num_processes = 4 per GPU, bf16 encoder / fp32 losses, the shape north_star's 1 -> 8
+    # target is defined on) is the nested "c3" section of EVERY line, with the same fields: its scaling is
+    # c3.value(N) / (N * c3.value(1)) from the N = 1 line's c3 section.
+    head = args.config or "C2"
     other = {"C2": "C3", "C3": "C2"}.get(head) if args.config is None else None
     res, cfg, enc_state, ppo_state = run_config(head, args, rank, dev_index, world, use_dist, args.steps, args.warmup,
                                                 args.replay)
@@ -725,13 +757,30 @@ def main():
         out["backend"] = backend if backend != "nccl" else "nccl (RCCL)"
         if one_device:
             out["one_device"] = True
-    # the other BASELINE shape in the same line: next to a C2 headline the C3 section (>= 10 timed rounds), next to a C3
-    # headline (N > 1) the C2 section
+    out["scaling_reference"] = ("value of the N = 1 line (same config, same per-GPU work): efficiency(N) = value(N) / (N x "
+                                "value(1)); the nested c3 section scales against the N = 1 line's c3.value")
+    # the other BASELINE shape in the same line: next to the C2 headline the C3 section (>= 10 timed rounds)
     if other and not args.no_c3 and not args.replay and not args.dedup and args.encoder_dtype is None:
         n_other = max(2, args.c3_steps) if other == "C3" else args.steps
         sec, _c, _e, _p = run_config(other, args, rank, dev_index, world, use_dist, n_other, 2)
         sec["metric"], sec["unit"], sec["n_gpus"] = "ppo_update_samples_per_sec", "samples/s", world
         out[other.lower()] = sec
+    # The round a user of this learner would run: the environment re-sends 7 of the 8 frames of every
+    # window (env_wrapper.py:899-904), so with the sliding-window latent cache each distinct frame is encoded ONCE — T + 7
+    # frames per worker instead of 8 T, bit-identical features (tests/test_encoder_gpu.py) — and the round is ~70 % update.
+    # Own keys; the headline keeps the reference's 8-frames-per-transition convention.
+    if not args.no_latent_cache and not args.replay and not args.dedup and args.encoder_dtype is None and args.config is None:
+        for nm in ("C2", "C3"):
+            sec, _c, _e, _p = run_config(nm, args, rank, dev_index, world, use_dist, max(2, args.c3_steps), 2, dedup=True)
+            out[nm.lower() + "_latent_cache"] = {
+                "value": sec["value"], "unit": "samples/s", "ms_per_step": sec["ms_per_step"], "steps": sec["steps"], "n_gpus": world,
+                "t_encode_ms": sec["t_encode_ms"], "t_update_ms": sec["t_update_ms"],
+                "frames_per_round_per_gpu": sec["config"]["frames_per_round_per_gpu"],
+                "update_share_of_round": round(sec["t_update_ms"] / (sec["t_encode_ms"] + sec["t_update_ms"]), 3),
+                "update_roofline": sec["update_roofline"], "last_losses": sec["last_losses"],
+                "ms_per_step_min_median_max": sec["ms_per_step_min_median_max"],
+                "note": "%s with the sliding-window latent cache (--dedup): each distinct frame encoded once; NOT the headline "
+                        "convention (the reference encodes 8 frames per transition)" % nm}
     # The fp32 model's >= 128-channel stride-1 3x3 convs run as Winograd F(3x3, 3x3) (exact fp32 arithmetic in another
     # order).  The same C2 round with direct convolution everywhere (CADRE_WINOGRAD=0), same box, same
     # process, under its own key — so that the line always states what the algorithm is worth
@@ -756,7 +805,7 @@ def main():
                 from tools.peaks_bench import measure
                 mp = measure()
                 out["measured_peaks"] = mp
-                for sect in (out, out.get("c3"), out.get("c2")):
+                for sect in (out, out.get("c3"), out.get("c2"), out.get("c2_latent_cache"), out.get("c3_latent_cache")):
                     rf = sect.get("roofline") if sect else None
                     if rf and rf.get("bound") == "mfma":
                         pk = mp["mfma_bf16_2wave_TFLOPs"] if rf["peak"] > 1000 else mp["mfma_f32_2wave_TFLOPs"]
@@ -765,7 +814,8 @@ def main():
                         rf["frac_of_measured"] = round(rf["achieved"] / max(mp["hbm_copy_GBps"], mp["hbm_read_GBps"]), 4)
                     ur = sect.get("update_roofline") if sect else None
                     if ur:
-                        ur["frac_of_measured"] = round(ur["achieved"] / max(mp["hbm_copy_GBps"], mp["hbm_read_GBps"]), 4)
+                        ur["hbm_frac_of_measured"] = round(ur["achieved"] / max(mp["hbm_copy_GBps"], mp["hbm_read_GBps"]), 4)
+                        ur["mfma_frac_of_measured"] = round(ur["achieved_tflops_executed"] / mp["mfma_f32_2wave_TFLOPs"], 4)
             except Exception as e:                           # a diagnostic: never fails the bench line
                 log("[bench] measured_peaks skipped: %r" % (e,))
         if not args.no_cpu_baseline and world == 1:          # CPU baseline: rank 0 at N=1 only

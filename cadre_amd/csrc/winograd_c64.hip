@@ -32,10 +32,14 @@
 //                   (a spill store waits for the load that fills the register: a memory round trip inside the MFMA block);
 //                   residuals of tiles 0, 1 requested inside the last MFMA block; 256 -> 139 VGPRs, no spills
 //   1.84 / 1.90     16-byte stores and residual loads (the cout permutation above): 128 instead of 512 requests per item and CU
-//   1.77 / 1.82     16-byte patch requests (four channels of a pixel = two steps' worth, every other step; U's cin axis permuted to
+//   1.74 / 1.80     16-byte patch requests (four channels of a pixel = two steps' worth, every other step; U's cin axis permuted to
 //                   match): half the requests and cache lines touched per byte
-// The MFMAs with their LDS fragment reads alone run 1.38 ms; what is left: patch requests, epilogue 0.16, weight DMA 0.1,
-// wait + barrier 0.09.  Lessons in the code: separate LDS objects per DMA buffer (one object = s_waitcnt vmcnt(0) before
+//   1.66 / 1.75     no control flow in the item loop: max(x, floor) instead of a uniform `if (relu)` per store (32 basic blocks in
+//                   the epilogue), the tile / offset arithmetic on selects, the inverse transform on packed pairs (rocprof in
+//                   the bench: 1.75 / 1.79 ms per launch)
+// The MFMAs with their LDS fragment reads alone run 1.33 ms; what is left (profiles/r04_wino_c64_ablation_branch_free.txt): patch
+// requests 0.18 (every pixel is requested by the four tiles that overlap it: FETCH 1.92 GB against 1.36 algorithmic), epilogue
+// 0.15, weight DMA 0.06, wait + barrier 0.07.  Lessons in the code: separate LDS objects per DMA buffer (one object = s_waitcnt vmcnt(0) before
 // every fragment read), no branch around loads (PHI copies wait for memory on the spot), scheduling fences around the MFMA
 // block, contiguous item ranges per workgroup (halo rows from the workgroup's own L1 / L2).
 #include <hip/hip_runtime.h>

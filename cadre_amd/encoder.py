@@ -127,8 +127,8 @@ def _winograd_u_c64(w, cin_pairs=True):
 
 def _winograd_m(H, W):
     """Output tile edge of the Winograd form for an H x W map: the one with fewer transform-domain multiplies,
-    (m+2)^2 * ceil(H/m) * ceil(W/m) (F(3x3) tiles the 9x9 and 18x18 maps of the 288x288 model exactly).  CADRE_WINOGRAD_M
-    forces 2 or 3."""
+    (m+2)^2 * ceil(H/m) * ceil(W/m) (F(3x3) tiles the 9x9 and 18x18 maps of the 288x288 model exactly; F(4x4) is taken only
+    where 4x4 tiles cover the map exactly and it is the cheapest: the 36x36 maps).  CADRE_WINOGRAD_M forces 2, 3 or 4."""
     e = os.environ.get("CADRE_WINOGRAD_M", "")
     if e in ("2", "3", "4"):
         return int(e)
@@ -173,7 +173,7 @@ class _Conv:
         self.w_wino_c64 = None
         if (_winograd_min_c() and os.environ.get("CADRE_WINOGRAD_C64", "1") != "0" and wdtype == torch.float32
                 and k == 3 and stride == 1 and pad == 1 and tuple(w.shape[:2]) == (64, 64)):
-            # fused F(2x2) kernel of the 64 -> 64 stage (csrc/winograd_c64.hip): 2.50 / 2.62 vs 2.97 ms per 1024 frames of 72 x 72
+            # fused F(2x2) kernel of the 64 -> 64 stage (csrc/winograd_c64.hip): 1.66 / 1.75 vs 2.97 ms per 1024 frames of 72 x 72
             self.w_wino_c64 = _winograd_u_c64(torch.as_tensor(w).float()).to(dev)
         wmin = _winograd_min_c()
         if (wmin and wdtype == torch.float32 and k == 3 and stride == 1 and pad == 1 and w.shape[1] >= wmin

@@ -214,14 +214,26 @@ class PPOLearnerHIP:
             for part, rng in (("front", (a.P0, a.total)), ("mid", (0, half)), ("back", None)):
                 self._run(part, B, inv_b, sorted_rows)
                 if rng is not None:
-                    try:
+                    # the hook's arity is read from its signature — never from a TypeError, which would also swallow one
+                    # raised INSIDE the hook (a failed collective on this rank only: its peers would wait for ever)
+                    if self._hook_takes_range(mlp_grads_ready):
                         mlp_grads_ready(*rng)
-                    except TypeError:                        # (a round-3 style hook without arguments: the MLP bucket only)
-                        if part == "front":
-                            mlp_grads_ready()
+                    elif part == "front":                    # (a round-3 style hook without arguments: the MLP bucket only)
+                        mlp_grads_ready()
             return self.workspace(B)["losses"]
         finally:
             self._skip_pack = False                          # (act / get_value outside an update always check the copies)
+
+    @staticmethod
+    def _hook_takes_range(hook):
+        import inspect
+        try:
+            ps = [q for q in inspect.signature(hook).parameters.values()]
+        except (TypeError, ValueError):
+            return True
+        if any(q.kind == q.VAR_POSITIONAL for q in ps):
+            return True
+        return sum(q.kind in (q.POSITIONAL_ONLY, q.POSITIONAL_OR_KEYWORD) for q in ps) >= 1
 
     def _run(self, part, B, inv_b, sorted_rows):
         if not self.use_graphs:

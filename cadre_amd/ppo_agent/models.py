@@ -367,11 +367,20 @@ class Shared_grad_buffers(object):
             self._buckets = []
         self._buckets.append((lo, hi, dist.all_reduce(self.arena.grads[lo:hi], op=dist.ReduceOp.SUM, async_op=True)))
 
-    def overlap_hook(self):
-        """The callable `CadreAgent.update_policy_from_storages(mlp_grads_ready=...)` takes, or None when no exchange runs
-        or bucketing is off (CADRE_GRAD_BUCKETS=0; the sharded exchange reduce-scatters the whole arena at once).
-        Default ON whenever ranks exchange gradients: 43 of the 80 MB leave while the backward still computes."""
-        if not self.dist_world() or self.exchange_mode() != "allreduce" or os.environ.get("CADRE_GRAD_BUCKETS", "1") == "0":
+    def overlap_hook(self, arena=None):
+        """The callable `CadreAgent.update_policy_from_storages(mlp_grads_ready=...)` takes, or None when no exchange runs,
+        bucketing is off, or the updating agent's arena is NOT the one behind this buffer.
+        `arena`: the parameter arena of the agent whose update will call the hook.  In the reference's topology a worker
+        owns its nets and `add_gradient` ADDS its gradients into the shared arena afterwards: a bucket of the shared arena
+        reduced while the worker's backward still runs would go out before that add (and `add_` would then write into a
+        buffer with a collective in flight) — such an agent gets the single blocking all-reduce of `chief_step`.
+        OPT-IN (CADRE_GRAD_BUCKETS=1 / `bench.py --grad-buckets`): three hipGraph parts per step and async collectives
+        beside the backward have only ever run over gloo and at RCCL world size 1 — no multi-GPU RCCL run of this form
+        exists yet, so the default exchange is the one blocking all-reduce per optimiser step (the sharded exchange
+        reduce-scatters the whole arena at once and never buckets)."""
+        if not self.dist_world() or self.exchange_mode() != "allreduce" or os.environ.get("CADRE_GRAD_BUCKETS", "0") in ("", "0"):
+            return None
+        if arena is not None and arena is not self.arena:
             return None
         return self.reduce_bucket_async
 

@@ -8,7 +8,7 @@ import torch
 
 from .agent import CadreAgent
 from .chief import chief_step
-from .models import get_vae_output
+from .models import arena_of, get_vae_output
 from .storage import RolloutStorage
 from .utils import check_exist
 
@@ -49,9 +49,10 @@ def learner_section(agent, steer_rollout, throttle_rollout, done, train_cfg, sha
     throttle_adv = throttle_rollout.compute_returns(nv_t.detach(), normalise=use_adv_norm)
     dev_losses = []
     vl, pl, el = [], [], []
-    # several ranks: gradient buckets leave as soon as they are final, beside the rest of the backward (default; see
-    # Shared_grad_buffers.overlap_hook) — only with the in-process chief, which collects them in chief_step
-    hook = shared_grad_buffers.overlap_hook() if in_process_chief else None
+    # several ranks, CADRE_GRAD_BUCKETS=1: gradient buckets leave as soon as they are final, beside the rest of the backward
+    # (Shared_grad_buffers.overlap_hook) — only with the in-process chief, which collects them in chief_step, and only
+    # when the agent's nets live in the arena behind `shared_grad_buffers` (a foreign worker arena is ADDED afterwards)
+    hook = shared_grad_buffers.overlap_hook(arena_of(agent.model_dict)) if in_process_chief else None
     for _ in range(train_cfg["ppo_epoch"]):
         if fused_gather:
             idx_s, idx_t = steer_rollout.sample_indices(), throttle_rollout.sample_indices()   # steer draws first

@@ -50,7 +50,7 @@ def rank_main(out_dir, mode):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        os.environ["CADRE_GRAD_BUCKETS"] = "1" if mode == "buckets" else "0"      # (default on; "allreduce" = the one blocking exchange)
+        os.environ["CADRE_GRAD_BUCKETS"] = "1" if mode == "buckets" else "0"      # (opt-in; "allreduce" = the one blocking exchange, the default)
         cfg = dict(CFG)
         agent = agent_for(rank)
         dist.broadcast(agent.arena.params, 0)

@@ -344,11 +344,18 @@ def gen_clip():
          ppo_seed=SEED_PPO, grad_seed=5)
 
 
-def gen_act():
-    """F-act: CadreAgent.act on native-size observations (agent.py:114-141) + sampling rule."""
+def gen_act(name="act", H=144, W=256, n=6, rollout_seed=4321):
+    """F-act: CadreAgent.act on native-size observations (agent.py:114-141) + sampling rule.
+    name="act_288" (H = W = 288, round 5): the same chain at the size bench.py times — the reference agent's encoder is
+    the imported DANet instance with the inter-task first layers re-sized for the 9x9 map (the module surgery of
+    `ref_danet`), every other line of agent.py:97-141 runs unmodified."""
     agent, st0 = ref_agent()
-    steps = synth.synth_rollout(6, 144, 256, seed=4321)
-    mine = synth.encoder_state(5, 8, SEED_ENC)
+    fh, fw = synth.feat_hw(H, W)
+    if (fh, fw) != (5, 8):
+        net, _mine, _sd = ref_danet(fh, fw)
+        agent.vae_model = net
+    steps = synth.synth_rollout(n, H, W, seed=rollout_seed)
+    mine = synth.encoder_state(fh, fw, SEED_ENC)
     o_params = ppo_ref.to_torch_params(st0)
     feats, acts, lps, vals, qs, margins = [], [], [], [], [], []
     torch.manual_seed(99)
@@ -383,7 +390,7 @@ def gen_act():
         lps.append([lp[0].item(), lp[1].item()]); vals.append([v[0].item(), v[1].item()])
         qs.append(np.concatenate([q_s.numpy()[0], q_t.numpy()[0]]))
     print("  act: sampling == argmax(p/q), identical RNG consumption; min margin %.3e" % min(margins))
-    save("act", rollout_seed=4321, torch_seed=99, feats=np.array(feats), actions=np.array(acts),
+    save(name, rollout_seed=rollout_seed, torch_seed=99, feats=np.array(feats), actions=np.array(acts),
          log_probs=np.array(lps), values=np.array(vals), q=np.array(qs), margins=np.array(margins))
 
 
@@ -412,6 +419,7 @@ def gen_insert():
 
 
 SETS = dict(prep=gen_prep, gae=gen_gae, sampler=gen_sampler, insert=gen_insert, act=gen_act,
+            act_288=lambda: gen_act("act_288", 288, 288, 4, 4322),
             update=gen_update, chief=gen_clip,
             enc_native=lambda: gen_enc("native", 144, 256),
             enc_84=lambda: gen_enc("84", 84, 84),

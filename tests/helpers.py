@@ -27,11 +27,14 @@ def fill_storages(T, seed, with_hidden=True):
     return d
 
 
-def oracle_learner_replay(g, max_steps=None):
+def oracle_learner_replay(g, max_steps=None, data=None):
+    """train.py:76-110 on the oracle.  `data`: storage contents {head: {field: array}} to replay instead of the seeded
+    ones of `fill_storages` (the end-to-end contract tests fill them from the oracle's own act path)."""
     T, mbn, epochs = int(g["T"]), int(g["mbn"]), int(g["epochs"])
     st0 = synth.ppo_state(int(g["ppo_seed"]))
     names = [str(n) for n in g["names"]]
-    data = fill_storages(T, int(g["data_seed"]))
+    if data is None:
+        data = fill_storages(T, int(g["data_seed"]))
     params = ppo_ref.to_torch_params(st0, requires_grad=True)
     adam = {m: {k: (torch.zeros_like(p), torch.zeros_like(p)) for k, p in d.items()} for m, d in params.items()}
     stor = {hd: {k: torch.from_numpy(v).clone() for k, v in data[hd].items()} for hd in data}

@@ -123,10 +123,27 @@ def _sharded_worker(rank, world, port, q):
         shared.reduce_bucket_async(arena.P0)
         shared.reset()
         ok &= not shared._buckets
-        ok &= shared.overlap_hook() is not None
-        os.environ["CADRE_GRAD_BUCKETS"] = "0"
+        # bucketing is OPT-IN (no multi-GPU RCCL run of it exists yet) ...
+        os.environ.pop("CADRE_GRAD_BUCKETS", None)
         ok &= shared.overlap_hook() is None
+        os.environ["CADRE_GRAD_BUCKETS"] = "1"
+        ok &= shared.overlap_hook() is not None and shared.overlap_hook(arena) is not None
+        # ... and never handed to an agent whose nets live in ANOTHER arena (reference topology: the worker's gradients are
+        # ADDED to the shared arena after its backward — a bucket of the shared arena reduced during that backward would
+        # leave before the add and never be summed): such a worker gets the one blocking all-reduce
+        arena_w = PPOArena("cpu", 530, {"steer": 33, "throttle": 3}, 4)
+        with _no_orthogonal_init():
+            md_w = {"steer_ppo_0": arena_w.bind("steer_ppo_0", Model(530, 33))}
+        from ppo_agent.models import arena_of
+        hook = shared.overlap_hook(arena_of(md_w))
+        ok &= hook is None
+        arena.grads.zero_()
+        arena_w.grads.copy_(base * (rank + 1))                  # the worker's backward wrote its own arena
+        shared.add_gradient(md_w)                               # models.py:231-239: += into the shared arena
+        shared.all_reduce()
+        ok &= bool(torch.equal(arena.grads, want))              # every range summed over the ranks, MLP towers and steer LSTMs included
         os.environ.pop("CADRE_GRAD_BUCKETS")
+        shared.reset()
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

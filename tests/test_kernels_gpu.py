@@ -1231,11 +1231,12 @@ def test_winograd_c64_fused_repeatable_under_load(hip, use_resid):
     torch.cuda.synchronize()
     assert all(torch.equal(outs[0], o) for o in outs[1:])
     for sl in (slice(0, 2), slice(F - 2, F)):                     # first and last items of the launch
-        ref = torch.nn.functional.conv2d(x[sl].permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1) * sc + sh
+        # reference = torch on the CPU in fp32, like every other kernel test (not MIOpen on the device: HIP vs HIP)
+        ref = torch.nn.functional.conv2d(x[sl].cpu().permute(0, 3, 1, 2), w.cpu(), padding=1).permute(0, 2, 3, 1) * sc.cpu() + sh.cpu()
         if use_resid:
-            ref = ref + res[sl]
+            ref = ref + res[sl].cpu()
         ref = torch.relu(ref)
-        assert float((outs[0][sl] - ref).abs().max() / ref.abs().max()) < 2e-5
+        assert float((outs[0][sl].cpu() - ref).abs().max() / ref.abs().max()) < 2e-5
 
 
 @pytest.mark.parametrize("F,H,W,Cin,N,use_resid,act", [(3, 9, 9, 64, 128, True, 1), (2, 18, 18, 32, 64, False, 1), (2, 7, 10, 16, 32, True, 17),
@@ -1436,9 +1437,10 @@ def test_conv3x3_ring_and_c64_repeatable_under_load(hip, dtype, F, H, W, Cin, N)
         outs.append(out)
     torch.cuda.synchronize()
     assert all(torch.equal(outs[0], o) for o in outs[1:])
-    ref = torch.nn.functional.conv2d(x[:4].float().permute(0, 3, 1, 2), w.float(), padding=1).permute(0, 2, 3, 1) * sc + sh
-    ref = torch.relu(ref + res[:4].float())
-    assert float((outs[0][:4].float() - ref).abs().max() / ref.abs().max()) < (1.5e-2 if bf else 2e-5)
+    # reference = torch on the CPU in fp32 (not MIOpen on the device)
+    ref = torch.nn.functional.conv2d(x[:4].float().cpu().permute(0, 3, 1, 2), w.float().cpu(), padding=1).permute(0, 2, 3, 1) * sc.cpu() + sh.cpu()
+    ref = torch.relu(ref + res[:4].float().cpu())
+    assert float((outs[0][:4].float().cpu() - ref).abs().max() / ref.abs().max()) < (1.5e-2 if bf else 2e-5)
     if bf and Cin == 64 and N == 64 and _has_ab():
         w_khwc = w.permute(0, 2, 3, 1).reshape(N, 576).contiguous()
         outs2 = []
@@ -1448,4 +1450,4 @@ def test_conv3x3_ring_and_c64_repeatable_under_load(hip, dtype, F, H, W, Cin, N)
             outs2.append(out)
         torch.cuda.synchronize()
         assert all(torch.equal(outs2[0], o) for o in outs2[1:])
-        assert float((outs2[0][:4].float() - ref).abs().max() / ref.abs().max()) < 1.5e-2
+        assert float((outs2[0][:4].float().cpu() - ref).abs().max() / ref.abs().max()) < 1.5e-2

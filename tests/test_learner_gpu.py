@@ -149,6 +149,28 @@ def test_act_matches_reference(golden):
         assert len(ctl) == 3
 
 
+def test_act_matches_reference_at_288(golden):
+    """F-act at the size bench.py times (288 x 288: Winograd F(4x4) / F(3x3) / the fused layer-1 kernel are the fp32 defaults
+    exactly here): agent.py:97-141 of the imported reference (tests/golden/act_288.npz, make_golden.py `act_288`) —
+    features within 2e-4, action indices BIT-EXACT (smallest top-2 margin of p/q in the fixture: 1.1e-2, recorded in
+    `margins`), log-probs and values within 1e-3."""
+    g = golden("act_288")
+    agent = make_agent(288, 288)
+    steps = synth.synth_rollout(len(g["actions"]), 288, 288, seed=int(g["rollout_seed"]))
+    torch.manual_seed(int(g["torch_seed"]))
+    worst = 0.0
+    for i, td in enumerate(steps):
+        obs = dict(rgb=td["rgb"], route_fig=td["route_fig"].copy(), measurements=td["measurements"], command=td["command"])
+        feat, a, lp, v, hid = agent.act(obs)
+        e = rel(feat.cpu().numpy(), g["feats"][i])
+        worst = max(worst, e)
+        assert e < 2e-4, (i, e)
+        assert [int(a[0]), int(a[1])] == list(g["actions"][i]), (i, g["margins"][2 * i:2 * i + 2])   # bit-exact
+        assert rel([lp[0].item(), lp[1].item()], g["log_probs"][i]) < 1e-3
+        assert rel([v[0].item(), v[1].item()], g["values"][i]) < 1e-3
+    print("act at 288x288: worst feature error %.2e, min margin of the fixture %.2e" % (worst, float(g["margins"].min())))
+
+
 def test_act_graph_equals_eager_launch_chain():
     """act() captured into one hipGraph per (window mode, command) (reference agent.py:114-141; ~150 launches per env
     step otherwise): identical features, actions, log-probs, values, route mutation and global-RNG consumption as the

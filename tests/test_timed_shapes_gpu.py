@@ -273,3 +273,115 @@ def test_c3_bf16_contract_end_to_end():
     print("C3 contract: losses rel err %.2e (got %s want %s), |grad| %.4f vs %.4f" % (e_loss, got_l, want_l, gn, gn_ref))
     assert e_loss < C3_LOSS_TOL
     assert abs(gn - gn_ref) / gn_ref < C3_LOSS_TOL
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# C2 contract (fp32 end to end AT 288 x 288): observations -> act() (pre_process, DANet encoder, LSTM + heads, sampling)
+# -> RolloutStorage.insert -> learner_section (bootstrap values, GAE, advantage normalisation, update_policy, clip, Adam)
+# against the oracle chain encoder_ref.latent_feature -> ppo_ref act -> ppo_ref learner replay, as ONE chain
+# (reference ppo_agent/agent.py:97-141, storage.py:45-58, train.py:55-110).  Bars = north_star's: action indices and
+# advantage ordering bit-exact, fp32 losses within 1e-4 relative.  Both conv algorithms of the fp32 encoder: the
+# default (Winograd F(4x4) / F(3x3) / fused layer-1 kernel — all ON exactly at this size) and CADRE_WINOGRAD=0.
+C2_T = 16
+_C2_ORACLE = {}
+
+
+def _c2_oracle_chain():
+    """The oracle side, once per session: features of the 16 windows, act outputs with torch's CPU generator seeded per
+    step, storages as train.py:57-72 fills them."""
+    if _C2_ORACLE:
+        return _C2_ORACLE
+    from oracle import encoder_ref, ppo_ref
+    H = W = 288
+    sd = synth.encoder_state(9, 9, 7)
+    st0 = synth.ppo_state(11)
+    params = ppo_ref.to_torch_params(st0)
+    steps = synth.synth_rollout(C2_T, H, W, seed=2024)
+    T = C2_T
+    data = {hd: dict(obs=np.zeros((T + 1, 8, 530), np.float32), action=np.zeros((T + 1, 1), np.int64),
+                     action_log_probs=np.zeros((T + 1, 1), np.float32), value_preds=np.zeros((T + 1, 1), np.float32),
+                     rewards=np.zeros((T + 1, 1), np.float32), masks=np.zeros((T + 1, 1), np.float32),
+                     command=np.zeros((T + 1, 1), np.int32), hn=np.zeros((T + 1, 530), np.float32),
+                     cn=np.zeros((T + 1, 530), np.float32)) for hd in ("steer", "throttle")}
+    margins = []
+    for i, td in enumerate(steps):
+        feat = encoder_ref.latent_feature(td["rgb"], td["route_fig"], td["measurements"], sd)
+        torch.manual_seed(5000 + i)
+        c = td["command"]
+        for hd, K, j in (("steer", 33, 0), ("throttle", 3, 1)):
+            with torch.no_grad():
+                x, _ = ppo_ref.lstm_forward(feat, (torch.zeros(1, 530), torch.zeros(1, 530)), params["%s_lstm_%d" % (hd, c)])
+                logits = ppo_ref.categorical_logits(x, params["%s_ppo_%d" % (hd, c)])
+                val = ppo_ref.mlp3(x, params["%s_ppo_%d" % (hd, c)], "critic")
+            q = torch.empty(1, K).exponential_(1)
+            a = int(ppo_ref.sample_from_logits(logits, q))
+            ratio = (torch.softmax(logits, -1) / q)[0]
+            top2 = torch.topk(ratio, 2).values
+            margins.append(float((top2[0] - top2[1]) / top2[0]))
+            d = data[hd]
+            d["obs"][i] = feat.numpy()
+            d["action"][i, 0] = a
+            d["action_log_probs"][i, 0] = float(logits[0, a])
+            d["value_preds"][i, 0] = float(val)
+            d["rewards"][i, 0] = float(td["reward"][j])
+            d["masks"][i, 0] = 0.0 if bool(td["done"][j]) else 1.0          # train.py:61-62
+            d["command"][i, 0] = c
+    _C2_ORACLE.update(steps=steps, data=data, margins=margins, sd=sd, st0=st0)
+    return _C2_ORACLE
+
+
+@pytest.mark.parametrize("algo", ["default", "direct"])
+def test_c2_fp32_contract_end_to_end(algo, monkeypatch):
+    from ppo_agent.agent import CadreAgent
+    from ppo_agent.models import Shared_grad_buffers
+    from ppo_agent.storage import RolloutStorage
+    from ppo_agent.train import learner_section
+    from tests.helpers import oracle_learner_replay
+    from tests.test_learner_gpu import per_model
+    if algo == "direct":
+        monkeypatch.setenv("CADRE_WINOGRAD", "0")
+    else:
+        monkeypatch.delenv("CADRE_WINOGRAD", raising=False)
+    o = _c2_oracle_chain()
+    T, H, W = C2_T, 288, 288
+    cfg = dict(use_lstm=True, vae_device=0, device_num=0, vae_params="CoPM", measurement_dim=18,
+               num_output=dict(steer=33, throttle=3), command_num=4, obs_hw=(H, W), weights_init="none",
+               vae_state_dict=o["sd"], latent_cache=False)
+    agent = CadreAgent(rank=0, model_cfg=cfg, frame=8, STEER_CONTROL={i: (i - 16) / 16.0 for i in range(33)},
+                       THROTTLE_CONTROL={0: [0, 0], 1: [0, 1], 2: [0.6, 0]}, ent_coeff=0.01, value_coeff=0.1,
+                       clip_coeff=1.0, clip=0.1)
+    assert (agent.vae_model.winograd_convs() > 0) == (algo == "default")
+    agent.arena.load_numpy_state(o["st0"])
+    stor = [RolloutStorage(T, 2, 530, 8, 530, True, 0.99, 0.95) for _ in range(2)]
+    for s in stor:
+        s.to(agent.device)
+    worst_f = worst_v = 0.0
+    for i, td in enumerate(o["steps"]):                      # train.py:55-72
+        torch.manual_seed(5000 + i)
+        obs = dict(rgb=td["rgb"], route_fig=td["route_fig"].copy(), measurements=td["measurements"], command=td["command"])
+        feat, a, lp, v, hid = agent.act(obs)
+        worst_f = max(worst_f, rel(feat.cpu().numpy(), o["data"]["steer"]["obs"][i]))
+        for j, hd in enumerate(("steer", "throttle")):
+            d = o["data"][hd]
+            assert int(a[j]) == int(d["action"][i, 0]), (i, hd, o["margins"][2 * i + j])          # bit-exact indices
+            worst_v = max(worst_v, abs(lp[j].item() - d["action_log_probs"][i, 0]) / max(1.0, abs(d["action_log_probs"][i, 0])),
+                          abs(v[j].item() - d["value_preds"][i, 0]) / max(1.0, abs(d["value_preds"][i, 0])))
+            stor[j].insert(feat, a[j], lp[j], v[j], torch.tensor(float(td["reward"][j])),
+                           torch.tensor([[0.0] if td["done"][j] else [1.0]]), hid, td["command"])
+    assert worst_f < ENC_TOL and worst_v < 1e-4, (worst_f, worst_v)
+    g = dict(T=T, mbn=2, epochs=2, ppo_seed=11, data_seed=0, torch_seed=31, names=np.array(sorted(o["st0"])))
+    want = oracle_learner_replay(g, data=o["data"])
+    shared = Shared_grad_buffers(agent.model_dict, agent.device)
+    torch.manual_seed(31)
+    vl, pl, el = learner_section(agent, stor[0], stor[1], False, dict(use_adv_norm=True, ppo_epoch=2, max_grad_norm=250.0), shared)
+    e_loss = rel(np.array([vl, pl, el]).T, np.array(want["losses"]))
+    for hd, s in zip(("steer", "throttle"), stor):
+        mine = s.advantages.cpu().numpy()[:, 0]
+        assert np.array_equal(np.argsort(mine, kind="stable"), np.argsort(want["adv_" + hd][:, 0], kind="stable")), hd
+    names = [str(n) for n in g["names"]]
+    ps = per_model(agent.arena, agent.arena.params, names, lambda ts: float(sum(t.sum() for t in ts)))
+    e_par = rel(ps, want["param_sums"][-1])
+    print("C2 contract (%s): feature err %.2e, value/log-prob err %.2e, losses rel err %.2e, parameter sums %.2e, min action margin %.2e"
+          % (algo, worst_f, worst_v, e_loss, e_par, min(o["margins"])))
+    assert e_loss < 1e-4                                   # north_star: fp32 losses within 1e-4 relative
+    assert e_par < 1e-5
