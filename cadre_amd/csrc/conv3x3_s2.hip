@@ -1,0 +1,466 @@
+// conv3x3_s2.hip — 3x3 / STRIDE 2 / pad 1 convolution on dense bf16 NHWC for gfx950: the first conv of the three
+// down-sampling BasicBlocks of the DANet trunk (carla_perception/Networks/danet_blocks/resnet.py:26-55 with stride = 2,
+// layer2.0 / layer3.0 / layer4.0: resnet.py:152-158), bf16 model (BASELINE config C3).
+//
+// Until round 5 these three layers ran as an implicit GEMM on the tile kernel (gemm_bf16.hip, a_mode 2): every input pixel
+// gathered once per tap it serves (2.25 times on average) from L2 through VGPRs into LDS under a workgroup barrier per
+// k-tile — 534 / 814 / 924 TFLOP/s, the kernels furthest below either roof.  Here they get what the
+// stride-1 convs have had since round 2 (conv3x3_ring.hip), adapted to the stride:
+//   * PIXEL PLANES.  With H = 2 Ho, W = 2 Wo the input splits into four planes by (row parity, column parity); in plane
+//     coordinates every tap is a CONSTANT offset of the flattened output position p = (f Ho + ho) Wo + wo:
+//         plane (1,1): taps (0,0) (0,2) (2,0) (2,2)  ->  p - Wo - 1, p - Wo, p - 1, p
+//         plane (0,1): taps (1,0) (1,2)              ->  p - 1, p
+//         plane (1,0): taps (0,1) (2,1)              ->  p - Wo, p
+//         plane (0,0): tap  (1,1)                    ->  p
+//     so a tile of 256 output positions needs, per 128-byte channel chunk, four WINDOWS of 256 (+ Wo + 1) consecutive
+//     plane pixels — each input pixel enters LDS once per (M tile, channel chunk, N tile) instead of 2.25 times.  The planes
+//     exist only in LDS: LDS-DMA (buffer_load ... lds) takes a per-lane SOURCE address, the lane computes the NHWC address of
+//     its plane pixel (one exact floor-division by Wo per 8-pixel piece) — no VGPR round trip, hardware zero fill outside
+//     the tensor; halo taps (ho = 0 / wo = 0) read a zero row (one select per fragment row, 9-bit mask per position).
+//   * k ordered (chunk, plane, tap): a chunk's nine k-tiles run plane by plane (4 + 2 + 2 + 1).  The four windows of a
+//     chunk do not fit LDS twice, so windows live in a RING OF THREE buffers (37 KB each): while the taps of one plane are
+//     read, the next plane's window is complete and the one after it is landing.
+//   * the eight waves form two groups of four half a k-tile apart (waves w and w + 4 share a SIMD), two barriers per
+//     k-tile: one group stages (fragment reads + DMA issue) while the other issues its 16 MFMAs — the ping-pong of
+//     conv3x3_ring_pp_kernel.  New here, the two groups have different DMA duties:
+//       group 0 issues ALL weight pieces (k-tile t + 1 at the start of its staging slot R(t), confirmed by its own counted
+//         vmcnt at the end of its MFMA slot M(t): two stages suffice);
+//       group 1 issues ALL window pieces on a static schedule and confirms a window one slot before its first reader.
+//     A wave's vmcnt completes in order: with weights and windows in different waves' queues, an HBM-latency window piece
+//     never stands in front of an L2-latency weight piece that is needed next.
+//   * weights [N][chunk][tap in plane order][128 B] stream through the two stages by LDS-DMA; 128-byte rows XOR-swizzled on
+//     the SOURCE address (chunk ^ ((row >> 1) & 7)), every ds_read_b128 conflict-free;
+//   * persistent workgroups walk contiguous (M tile, N tile) items, N inner; the previous item's epilogue runs in each
+//     group's first staging slot of the next item, without LDS: v_permlane32_swap turns the accumulator's (lane -> position,
+//     register -> channel) into eight consecutive channels per lane = one 16-byte store.
+// Same epilogue contract as the other conv kernels: y = act(conv * scale[n] + shift[n]); bf16 in, fp32 accumulate, bf16 out.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <type_traits>
+#include "../../include/cadre_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+int cadre_fail(const char* msg);
+
+#define S2_BM 256                  // output positions per item
+#define S2_NTILE 128               // output channels per item
+#define S2_PA_MAX 37               // 8-pixel pieces per window buffer: 296 pixels >= 256 + Wo + 1 (Wo <= 39)
+#define S2_WIN_B (S2_PA_MAX * 1024)
+#define S2_STG_B (S2_NTILE * 128)
+
+// -DS2_ABL=<bits>: timing ablations (results wrong by construction, never in the product build): 1 no MFMAs, 2 no fragment
+// reads, 4 no window DMA after the prologue, 8 no weight DMA after the prologue, 16 no epilogue
+#ifndef S2_ABL
+#define S2_ABL 0
+#endif
+
+struct s2_args {
+  const void* x;          // [F][H][W][Cin] bf16, H = 2 Ho, W = 2 Wo
+  const void* w;          // [N][NC][9][128 B]: chunk-major, tap IN PLANE ORDER (0,0) (0,2) (2,0) (2,2) (1,0) (1,2) (0,1) (2,1) (1,1)
+  const float* scale;     // [N] or null
+  const float* shift;     // [N] or null
+  void* out;              // [M][N] bf16
+  int M, Min;             // output positions F * Ho * Wo, input pixels F * H * W
+  int Ho, Wo, W, Cin, N, NC;
+  int act;                // 0 none, 1 ReLU
+  int mtiles, ntiles, items, ipw;
+  int PA;                 // live 8-pixel pieces of a window: ceil((256 + Wo + 1) / 8) <= S2_PA_MAX
+};
+
+template <int N>
+__device__ __forceinline__ void s2_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// NPW: window pieces per wave of group 1 and window (4 waves: 4 * NPW >= PA): 9 (Wo <= 31) or 10
+template <int NPW>
+__global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(s2_args a) {
+  constexpr int NH = (NPW + 1) / 2;                         // a window's pieces go out in two k-tiles: NH, then NPW - NH
+  constexpr int NST = 8;                                   // epilogue stores per wave: 4 blocks of 32 x 32 x two 16-byte halves
+  constexpr unsigned OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;                 // 64-position block, 64-channel half
+  const int grp = wave >> 2, pb = wave & 3;                // ping-pong group (waves w, w + 4 share a SIMD); DMA piece lane of the wave
+  char* win0 = smem;                                       // three window buffers, two weight stages, the zero row / dump, folded BN
+  char* bst = smem + 3 * S2_WIN_B;
+  char* dump = bst + 2 * S2_STG_B;
+  float* sc_lds = reinterpret_cast<float*>(dump + 1024);
+
+  const int i_begin = blockIdx.x * a.ipw, i_end = min(a.items, i_begin + a.ipw);
+  const int nitems = i_end - i_begin;
+  if (nitems <= 0) return;
+  const int cin_b = a.Cin * 2;
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.Min * cin_b, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.N * a.NC * 9 * 128, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.M * a.N * 2, 0x00020000);
+  for (int i = tid; i < 256; i += 512) reinterpret_cast<unsigned*>(dump)[i] = 0u;       // ZERO ROW (halo taps) and dummy DMA target
+  for (int i = tid; i < a.ntiles * S2_NTILE; i += 512) {
+    sc_lds[i] = (a.scale && i < a.N) ? a.scale[i] : 1.f;
+    sc_lds[a.ntiles * S2_NTILE + i] = (a.shift && i < a.N) ? a.shift[i] : 0.f;
+  }
+  auto swz = [](int idx) constexpr -> int { return (idx >> 1) & 7; };
+  const int Wo = a.Wo, Wi = a.W;
+  const float inv_wo = 1.0f / (float)Wo, inv_ho = 1.0f / (float)a.Ho;
+
+  // ---- window DMA (group 1).  Piece j = 4 n + pb of a window: LDS rows 8 j .. 8 j + 7; this lane brings row 8 j + (lane >> 3),
+  // LDS chunk (lane & 7) <- source chunk (lane & 7) ^ swz(row); swz(row) = (lane >> 4) ^ 4 (j & 1), and j has the parity of pb.
+  // Row r of plane ph's window of M tile mt holds plane position pp = mt * 256 + start(ph) + r, i.e. input pixel
+  //   (2 q + pr) * W + 2 (pp - q Wo) + pc = 2 pp + q W + pr W + pc,   q = floor(pp / Wo)   (W = 2 Wo; q counts rows across frames)
+  // Positions before the tensor give a negative offset (as unsigned: beyond num_records), positions past its end lie beyond
+  // num_records: both arrive as zeros.
+  const int sw_lane = (((lane & 7) ^ (lane >> 4) ^ (4 * (pb & 1)))) << 4;
+  bool abl_pro = true;
+  auto send_win = [&](int mt_n, int c_n, auto ph_c, int bufsel, int n, bool live) {
+    constexpr int ph = decltype(ph_c)::value;              // 0: plane (1,1), 1: (0,1), 2: (1,0), 3: (0,0)
+    constexpr int pr = (ph == 0 || ph == 2) ? 1 : 0, pc = (ph == 0 || ph == 1) ? 1 : 0;
+    const int start = ph == 0 ? -(Wo + 1) : (ph == 1 ? -1 : (ph == 2 ? -Wo : 0));
+    const int j = 4 * n + pb;
+    const int pp = mt_n * S2_BM + start + 8 * j + (lane >> 3);
+    int q = (int)((float)pp * inv_wo);                     // exact after one correction step (|pp| < 2^24)
+    const int r = pp - q * Wo;
+    q += (r >= Wo) ? 1 : 0;
+    q -= (r < 0) ? 1 : 0;
+    const int px = 2 * pp + q * Wi + pr * Wi + pc;
+    const bool ok = live && j < a.PA;
+    unsigned voff = (unsigned)(px * cin_b + c_n * 128 + sw_lane) | (ok ? 0u : OOB);
+    char* dst = ok ? win0 + bufsel * S2_WIN_B + j * 1024 : dump;
+    if ((S2_ABL & 4) && !abl_pro) { voff = OOB; dst = dump; }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)dst, 16, (int)voff, 0, 0, 0);
+  };
+  // ---- weight DMA (group 0): stage piece pc4 = 4 pb + k (k = 0 .. 3): rows 8 pc4 .. + 7
+  int b_lane[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = (4 * pb + k) * 8 + (lane >> 3);
+    b_lane[k] = r * a.NC * 9 * 128 + (((lane & 7) ^ swz(r)) << 4);
+  }
+  auto send_wts = [&](int nt_b, int c, int tap, int stg, bool live) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      unsigned voff = (unsigned)(nt_b * (S2_NTILE * a.NC * 9 * 128) + (c * 9 + tap) * 128 + b_lane[k]) | (live ? 0u : OOB);
+      char* dst = bst + stg * S2_STG_B + (4 * pb + k) * 1024;
+      if ((S2_ABL & 8) && !abl_pro) { voff = OOB; dst = dump; }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)dst, 16, (int)voff, 0, 0, 0);
+    }
+  };
+  // ---- lane constants of the fragment reads
+  int kc[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) kc[s] = (2 * s + lh) << 4;
+  int boff[2][4];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const int n = 64 * wn + 32 * cb + l31;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) boff[cb][s] = n * 128 + (((2 * s + lh) ^ swz(n)) << 4);
+  }
+  const unsigned zrow_off = (unsigned)(dump - smem);
+
+  // (ho, wo) of this lane's two fragment rows (positions 64 wm + 32 rb + l31 of the current M tile)
+  int ph_[2], pw_[2];
+  int mt = i_begin / a.ntiles, nt = i_begin - mt * a.ntiles;
+  {
+    const int HW = a.Ho * Wo;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int m = mt * S2_BM + 64 * wm + 32 * rb + l31;
+      const int rem = m % HW;
+      ph_[rb] = rem / Wo;
+      pw_[rb] = rem - ph_[rb] * Wo;
+    }
+  }
+  auto advance_mtile = [&]() {                             // + 256 positions, exact float-reciprocal floors (x < 2^16)
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const int x = pw_[rb] + S2_BM;
+      const int q1 = (int)(((float)x + 0.5f) * inv_wo);
+      pw_[rb] = x - q1 * Wo;
+      const int y = ph_[rb] + q1;
+      const int q2 = (int)(((float)y + 0.5f) * inv_ho);
+      ph_[rb] = y - q2 * a.Ho;
+    }
+  };
+
+  // ---- epilogue of one item, no LDS slab.  Accumulator tile (rb, cb): lane (l31, lh), register r holds position 32 rb + l31,
+  // channel 32 cb + 8 (r >> 2) + 4 lh + (r & 3).  One v_permlane32_swap per register pair leaves lane (l31, lh) with channels
+  // 32 cb + 16 h + 8 lh .. + 7 (h = 0, 1): one 16-byte store per (tile, h).
+  f32x16 acc[2][2];
+  const float act_floor = (a.act & 15) == 1 ? 0.f : -__builtin_inff();
+  auto epilogue = [&](int mt_e, int nt_e) {
+    if constexpr ((S2_ABL & 16) != 0) {
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { const float t = acc[rb][cb][r]; asm volatile("" :: "v"(t)); }
+    } else {
+      const int eb = (mt_e * S2_BM + 64 * wm + l31) * a.N + nt_e * S2_NTILE + 64 * wn + 8 * lh;
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        const bool ch_ok = nt_e * S2_NTILE + 64 * wn + 32 * cb < a.N;          // (N % 32 == 0)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              // v_permlane32_swap x, y: x <- [x.lo, y.lo], y <- [x.hi, y.hi] (inline asm: see conv3x3_ring.hip on the builtin)
+              float fx = acc[rb][cb][8 * h + e], fy = acc[rb][cb][8 * h + 4 + e];
+              asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(fx), "+v"(fy));
+              v[e] = fx;
+              v[4 + e] = fy;
+            }
+            const int nl = nt_e * S2_NTILE + 64 * wn + 32 * cb + 16 * h + 8 * lh;
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc_lds + nl), s1 = *reinterpret_cast<const f32x4*>(sc_lds + nl + 4);
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(sc_lds + a.ntiles * S2_NTILE + nl);
+            const f32x4 t1 = *reinterpret_cast<const f32x4*>(sc_lds + a.ntiles * S2_NTILE + nl + 4);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              o[e] = (__bf16)fmaxf(v[e] * s0[e] + t0[e], act_floor);
+              o[4 + e] = (__bf16)fmaxf(v[4 + e] * s1[e] + t1[e], act_floor);
+            }
+            const int eo = eb + 32 * rb * a.N + 32 * cb + 16 * h;
+            const int bo = (int)((unsigned)(eo * 2) | (ch_ok ? 0u : OOB));      // (a position past M lies past num_records)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsC, bo, 0, 0);
+          }
+        }
+      }
+    }
+  };
+
+  // ---- prologue: group 1 brings window (1,1) and the first half of window (0,1) of the first chunk, group 0 the weights of
+  // k-tile 0; everything landed and published
+  if (grp == 1) {
+#pragma unroll
+    for (int n = 0; n < NPW; ++n) send_win(mt, 0, std::integral_constant<int, 0>{}, 0, n, true);
+#pragma unroll
+    for (int n = 0; n < NH; ++n) send_win(mt, 0, std::integral_constant<int, 1>{}, 1, n, true);
+  } else {
+    send_wts(nt, 0, 0, 0, true);
+  }
+  s2_wait_vm<0>();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (grp == 1) __builtin_amdgcn_s_barrier();              // group 1 runs one slot behind
+  abl_pro = false;
+
+  int b0 = 0, b1 = 1, b2 = 2;                              // window buffers of the current chunk's planes (1,1) / (0,1) / (1,0); (0,0) re-uses b0
+  int kpar = 0;                                            // weight stage of the current chunk's k-tile 0 (9 k-tiles per chunk: flips)
+  int mt_p = 0, nt_p = 0;
+  bool have_prev = false;
+
+  for (int li = 0; li < nitems; ++li) {
+    int mt1 = mt, nt1 = nt + 1;
+    if (nt1 == a.ntiles) { nt1 = 0; ++mt1; }
+    const bool more = li + 1 < nitems;
+    // halo masks in k-tile order: bit t set = the tap's pixel exists (kh = 0 needs ho > 0, kw = 0 needs wo > 0)
+    unsigned mask[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const unsigned top = ph_[rb] > 0 ? 1u : 0u, left = pw_[rb] > 0 ? 1u : 0u;
+      mask[rb] = (top & left) | (top << 1) | (left << 2) | (1u << 3) | (left << 4) | (1u << 5) | (top << 6) | (1u << 7) | (1u << 8);
+    }
+    // ---- head of the item's first staging slot: group 0 requests the weights of k-tile 1 FIRST (its stores then stand
+    // behind them in the queue: the wait at the end of M(0) need not drain them), then the previous item's epilogue, both
+    // groups side by side (group 1 is still in its M slot of the previous item's last k-tile: it takes that slot's closing
+    // barrier only now)
+    __builtin_amdgcn_s_setprio(2);
+    if (grp == 0) send_wts(nt, 0, 1, kpar ^ 1, true);
+    if (have_prev) {
+      epilogue(mt_p, nt_p);
+      if (grp == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+    }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.f;
+
+    for (int c = 0; c < a.NC; ++c) {
+      const bool last_c = c + 1 == a.NC;
+      const int mt_n = last_c ? mt1 : mt, nt_n = last_c ? nt1 : nt, c_n = last_c ? 0 : c + 1;
+      const bool live_n = !last_c || more;
+      const unsigned wb0 = (unsigned)(b0 * S2_WIN_B), wb1 = (unsigned)(b1 * S2_WIN_B), wb2 = (unsigned)(b2 * S2_WIN_B);
+      const unsigned st_even = (unsigned)((bst - smem) + kpar * S2_STG_B), st_odd = (unsigned)((bst - smem) + (kpar ^ 1) * S2_STG_B);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        // ================= R slot: fragment reads of k-tile t, DMA issue (at raised priority: between the other group's MFMAs)
+        if (t > 0 || c > 0) __builtin_amdgcn_s_setprio(2);
+        constexpr int dummy = 0; (void)dummy;
+        // window buffer and row offset of k-tile t (static)
+        const unsigned wbase = t < 4 ? wb0 : (t < 6 ? wb1 : (t < 8 ? wb2 : wb0));
+        const int ro = (t == 1 || t == 5) ? 1 : ((t == 2 || t == 7) ? Wo : (t == 3 ? Wo + 1 : 0));
+        const unsigned sbase = (t & 1) ? st_odd : st_even;
+        f32x4 afr[2][4], bfr[2][4];
+        {
+          unsigned arow_sw[2];
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb) {
+            const int idx = 64 * wm + 32 * rb + l31 + ro;
+            const unsigned row = ((mask[rb] >> t) & 1u) ? wbase + (unsigned)(idx << 7) : zrow_off;
+            arow_sw[rb] = row ^ (unsigned)(swz(idx) << 4);
+          }
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            bfr[0][s] = *reinterpret_cast<const f32x4*>(smem + sbase + boff[0][s]);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) afr[rb][s] = *reinterpret_cast<const f32x4*>(smem + (arow_sw[rb] ^ (unsigned)kc[s]));
+          }
+#pragma unroll
+          for (int s = 0; s < 4; ++s) bfr[1][s] = *reinterpret_cast<const f32x4*>(smem + sbase + boff[1][s]);
+        }
+        if constexpr ((S2_ABL & 2) != 0) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) afr[rb][s] = f32x4{(float)(lane * 3 + s), 1.5f + rb, -0.75f * lane, 0.3f};
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) bfr[cb][s] = f32x4{0.01f * lane, -2.5f + cb, 0.125f * s, 1.f};
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);                 // (the reads go out first: their latency runs under the issue below)
+        if (grp == 0) {
+          // weights of k-tile t + 1 into the stage k-tile t - 1 was read from (its last readers, group 1, finished a slot ago)
+          if (t < 8) { if (t > 0 || c > 0) send_wts(nt, c, t + 1, ((t + 1) & 1) ^ kpar, true); }      // (t == 0 of the item's first chunk: sent in the head)
+          else send_wts(nt_n, c_n, 0, kpar ^ 1, live_n);   // next chunk's k-tile 0: the stage parity flips with the chunk
+        } else {
+          // window pieces, static schedule (the buffer a window goes into was read last two phases ago):
+          //   t0: (0,1) of this chunk, second half | t1, t2: (1,0) of this chunk | t4, t5: (0,0) of this chunk (re-uses b0)
+          //   t6, t7: (1,1) of the NEXT chunk -> b1 | t8: (0,1) of the next chunk, first half -> b2
+          if (t == 0) {
+#pragma unroll
+            for (int n = NH; n < NPW; ++n) send_win(mt, c, std::integral_constant<int, 1>{}, b1, n, true);
+          } else if (t == 1) {
+#pragma unroll
+            for (int n = 0; n < NH; ++n) send_win(mt, c, std::integral_constant<int, 2>{}, b2, n, true);
+          } else if (t == 2) {
+#pragma unroll
+            for (int n = NH; n < NPW; ++n) send_win(mt, c, std::integral_constant<int, 2>{}, b2, n, true);
+          } else if (t == 4) {
+#pragma unroll
+            for (int n = 0; n < NH; ++n) send_win(mt, c, std::integral_constant<int, 3>{}, b0, n, true);
+          } else if (t == 5) {
+#pragma unroll
+            for (int n = NH; n < NPW; ++n) send_win(mt, c, std::integral_constant<int, 3>{}, b0, n, true);
+          } else if (t == 6) {
+#pragma unroll
+            for (int n = 0; n < NH; ++n) send_win(mt_n, c_n, std::integral_constant<int, 0>{}, b1, n, live_n);
+          } else if (t == 7) {
+#pragma unroll
+            for (int n = NH; n < NPW; ++n) send_win(mt_n, c_n, std::integral_constant<int, 0>{}, b1, n, live_n);
+          } else if (t == 8) {
+#pragma unroll
+            for (int n = 0; n < NH; ++n) send_win(mt_n, c_n, std::integral_constant<int, 1>{}, b2, n, live_n);
+          }
+          // a window is confirmed (in-order completion: everything but the pieces issued after its last one) in the slot
+          // before group 0 first reads it: (0,1) at t3, (1,0) at t5, (0,0) at t7, the next chunk's (1,1) at t8
+          if (t == 3) s2_wait_vm<NPW>();                   // younger: t1 + t2
+          if (t == 5) s2_wait_vm<NPW>();                   // younger: t4 + t5
+          if (t == 7) s2_wait_vm<NPW>();                   // younger: t6 + t7
+          if (t == 8) s2_wait_vm<NH>();                    // younger: t8
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        // ================= M slot
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            if constexpr ((S2_ABL & 1) != 0) {
+#pragma unroll
+              for (int rb = 0; rb < 2; ++rb) asm volatile("" :: "v"(bfr[cb][s]), "v"(afr[rb][s]));
+            } else {
+#pragma unroll
+              for (int rb = 0; rb < 2; ++rb)
+                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bfr[cb][s]), __builtin_bit_cast(bf16x8, afr[rb][s]),
+                                                                      acc[rb][cb], 0, 0, 0);
+            }
+          }
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp == 0) {
+          // the weights of k-tile t + 1 (issued in R(t)) have landed; after the item's first k-tile the previous item's
+          // stores (issued behind them) may stay in flight
+          if (t == 0 && c == 0 && have_prev && !(S2_ABL & 16)) s2_wait_vm<NST>();
+          else s2_wait_vm<0>();
+        }
+        if (!(t == 8 && last_c && grp == 1)) __builtin_amdgcn_s_barrier();      // (group 1, end of an item: after its epilogue)
+        asm volatile("" ::: "memory");
+      }
+      // next chunk: planes (1,1) / (0,1) / (1,0) in b1 / b2 / b0
+      { const int t0 = b0; b0 = b1; b1 = b2; b2 = t0; }
+      kpar ^= 1;
+    }
+    mt_p = mt; nt_p = nt; have_prev = true;
+    if (mt1 != mt) advance_mtile();
+    mt = mt1; nt = nt1;
+  }
+  // ---- tail: the last item's epilogue (group 0 one slot before group 1)
+  __builtin_amdgcn_s_setprio(0);
+  epilogue(mt_p, nt_p);
+  __builtin_amdgcn_s_barrier();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+static int s2_capable(int F, int H, int W, int Cin, int N) {
+  if (F < 1 || H < 2 || W < 2 || (H & 1) || (W & 1)) return 0;
+  const int Wo = W / 2;
+  if (Wo < 1 || Wo > 39) return 0;                         // a window is 256 + Wo + 1 <= 296 pixels
+  if (Cin % 64 != 0 || N % 32 != 0 || Cin < 64) return 0;
+  const long long Min = (long long)F * H * W, M = Min / 4, lim = 1ll << 31;
+  if (Min * Cin * 2 >= lim || (long long)N * Cin * 9 * 2 >= lim || M * N * 2 >= lim) return 0;
+  if (M >= (1 << 23)) return 0;                            // the plane-position division runs in fp32
+  const int ntiles = (N + S2_NTILE - 1) / S2_NTILE;
+  if ((size_t)3 * S2_WIN_B + 2 * S2_STG_B + 1024 + (size_t)ntiles * S2_NTILE * 8 > 160 * 1024) return 0;
+  return 1;
+}
+
+static const int g_s2_on = [] { const char* e = getenv("CADRE_S2_CONV"); return e ? atoi(e) : 1; }();
+
+// 1: cadre_conv3x3_s2 takes this geometry (bf16 NHWC, even H and W, Cin % 64 == 0, N % 32 == 0); CADRE_S2_CONV=0: never
+extern "C" int cadre_conv3x3_s2_supported(int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N) {
+  return (g_s2_on && s2_capable(F, H, W, Cin, N)) ? 1 : 0;
+}
+
+extern "C" int cadre_conv3x3_s2(const void* x, const void* w, const float* scale, const float* shift, void* out, int32_t F,
+                                int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t act, void* stream) {
+  if (!x || !w || !out) return cadre_fail("cadre_conv3x3_s2: null operand");
+  if (!s2_capable(F, H, W, Cin, N))
+    return cadre_fail("cadre_conv3x3_s2: unsupported geometry (even H, W; W <= 78; Cin % 64 == 0; N % 32 == 0; every tensor < 2 GiB: chunk the batch)");
+  if ((act & 15) > 1 || (act & 16)) return cadre_fail("cadre_conv3x3_s2: act 0 (none) or 1 (ReLU)");
+  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)out) & 15) return cadre_fail("cadre_conv3x3_s2: operands must be 16-byte aligned");
+  s2_args a;
+  a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.out = out;
+  a.Ho = H / 2; a.Wo = W / 2; a.W = W; a.Cin = Cin; a.N = N; a.NC = Cin / 64; a.act = act;
+  a.Min = F * H * W; a.M = F * a.Ho * a.Wo;
+  a.mtiles = (a.M + S2_BM - 1) / S2_BM;
+  a.ntiles = (N + S2_NTILE - 1) / S2_NTILE;
+  a.items = a.mtiles * a.ntiles;
+  const int wgs = a.items < 256 ? a.items : 256;           // persistent workgroups: one per CU
+  a.ipw = (a.items + wgs - 1) / wgs;
+  const int grid = (a.items + a.ipw - 1) / a.ipw;
+  a.PA = (S2_BM + a.Wo + 1 + 7) / 8;
+  const size_t lds = (size_t)3 * S2_WIN_B + 2 * S2_STG_B + 1024 + (size_t)a.ntiles * S2_NTILE * 8;
+  hipStream_t st = (hipStream_t)stream;
+  if (a.PA <= 36) {
+    (void)hipFuncSetAttribute((const void*)conv3x3_s2_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((conv3x3_s2_kernel<9>), dim3(grid), dim3(512), lds, st, a);
+  } else {
+    (void)hipFuncSetAttribute((const void*)conv3x3_s2_kernel<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((conv3x3_s2_kernel<10>), dim3(grid), dim3(512), lds, st, a);
+  }
+  return (int)hipGetLastError();
+}

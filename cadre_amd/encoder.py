@@ -82,6 +82,18 @@ def _ring_w(w, cpc):
     return w.permute(0, 2, 3, 1).reshape(o, kh * kw, i // cpc, cpc).permute(0, 2, 1, 3).contiguous()
 
 
+S2_TAPS = ((0, 0), (0, 2), (2, 0), (2, 2), (1, 0), (1, 2), (0, 1), (2, 1), (1, 1))
+
+
+def _s2_w(w):
+    """OIHW 3x3 weights -> [O][Cin/64][9][64], the nine taps of a 64-channel chunk in PLANE order (the parity plane of the input
+    pixel a tap reads under stride 2: (odd, odd) x 4, (even, odd) x 2, (odd, even) x 2, (even, even) x 1): cadre_conv3x3_s2's B."""
+    o, i, kh, kw = w.shape
+    assert kh == 3 and kw == 3 and i % 64 == 0
+    taps = torch.stack([w[:, :, a, b] for a, b in S2_TAPS], dim=1)            # [O][9][I]
+    return taps.reshape(o, 9, i // 64, 64).permute(0, 2, 1, 3).contiguous()
+
+
 def _winograd_min_c():
     """Stride-1 3x3 convs of the fp32 model with at least this many input channels (and >= 128 output channels) run as
     Winograd F(3x3, 3x3) / F(2x2, 3x3): 128 = layer2, layer3, layer4, head — at 64 channels (layer1) the transform-domain
@@ -143,7 +155,7 @@ def _winograd_m(H, W):
 
 
 class _Conv:
-    __slots__ = ("w", "w_ring", "ring_folded", "scale", "shift", "cin", "cout", "k", "stride", "pad", "act", "w_wino", "_w_oihw", "w_wino_c64")
+    __slots__ = ("w", "w_ring", "ring_folded", "scale", "shift", "cin", "cout", "k", "stride", "pad", "act", "w_wino", "_w_oihw", "w_wino_c64", "w_s2")
 
     def wino_u(self, m, dev):
         if m not in self.w_wino:
@@ -165,6 +177,12 @@ class _Conv:
                 wr = w * scale.reshape(-1, 1, 1, 1).to(w.dtype)
                 self.ring_folded = True
             self.w_ring = _ring_w(wr, cpc).to(dev).to(wdtype)
+        self.w_s2 = None
+        if k == 3 and stride == 2 and pad == 1 and wdtype == torch.bfloat16 and w.shape[1] % 64 == 0 and w.shape[0] % 32 == 0:
+            # bf16 model, stride-2 3x3 convs (layer2.0 / 3.0 / 4.0 conv1): plane-window kernel (csrc/conv3x3_s2.hip); the folded-BN
+            # scale goes into the weight rows like on the stride-1 window kernels (fp32 product, one rounding to bf16)
+            ws = w if scale is None else w * scale.reshape(-1, 1, 1, 1).to(w.dtype)
+            self.w_s2 = _s2_w(torch.as_tensor(ws).float()).to(dev).to(wdtype)
         self.scale = None if scale is None else scale.contiguous().to(dev)
         self.shift = None if shift is None else shift.contiguous().to(dev)
         self.cout, self.cin = w.shape[0], w.shape[1]
@@ -374,6 +392,10 @@ class DANetEncoderHIP:
         elif use_ring:
             # stride-1 3x3 convs: each pixel through LDS once per channel chunk, weights streamed (conv3x3_ring.hip)
             hip.conv3x3_ring(x, c.w_ring, None if c.ring_folded else c.scale, c.shift, resid, out, F, H, W, c.cin, c.cout, act)
+        elif (c.w_s2 is not None and x.dtype == torch.bfloat16 and odt == torch.bfloat16 and resid is None and act in (0, 1)
+              and bool(hip.lib().cadre_conv3x3_s2_supported(F, H, W, c.cin, c.cout))):
+            # stride-2 3x3 convs of the bf16 model: four parity-plane windows in LDS, each pixel once per channel chunk
+            hip.conv3x3_s2(x, c.w_s2, None, c.shift, out, F, H, W, c.cin, c.cout, act)
         elif c.k == 1 and c.stride == 1:
             hip.gemm(x, c.w, out, M, c.cout, K, K, K, c.cout, scale=c.scale, shift=c.shift, resid=resid,
                      ldr=c.cout, act=act, bf16=wbf, flags=flags)

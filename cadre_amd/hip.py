@@ -41,6 +41,8 @@ SYMBOLS = {
     "cadre_conv3x3_ring": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "cadre_conv3x3_ring_supported": [i32, i32, i32, i32, i32, i32],
     "cadre_conv3x3_ring_ntile": [i32, i32, i32, i32, i32, i32],
+    "cadre_conv3x3_s2": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "cadre_conv3x3_s2_supported": [i32, i32, i32, i32, i32],
     "cadre_maxpool3x3s2_bf16": [vp, vp, i32, i32, i32, i32, vp],
     "cadre_pam_bf16out": [vp, vp, f32, vp, i32, i32, vp],
     "cadre_cam_bf16out": [vp, f32, vp, i32, i32, vp],
@@ -101,7 +103,7 @@ AB_SYMBOLS = {
 }
 
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class CadreHipError(RuntimeError):
@@ -244,6 +246,24 @@ def winograd_c64(x, u, scale, shift, resid, out, F, H, W, act):
     T = F * ((H + 1) // 2) * ((W + 1) // 2)
     nbytes = F * H * W * 64 * 4 * (3 if resid is not None else 2) + 16 * 64 * 64 * 4
     PROFILE.append((("wino_c64", resid is not None), 2.0 * 16 * T * 64 * 64, e0, e1, (T, 64, 64 * 16, 1, 1, 0), nbytes))
+
+
+def conv3x3_s2(x, w_s2, scale, shift, out, F, H, W, Cin, N, act):
+    """cadre_conv3x3_s2 (3x3 / s2 / p1 on bf16 NHWC: four parity-plane windows in LDS); profiling key ("s2", npw):
+    conv3x3_s2_kernel<npw>, npw = window pieces per wave (9 for output rows of <= 31 pixels, else 10)."""
+    fn = lib().cadre_conv3x3_s2
+    args = (ptr(x), ptr(w_s2), ptr(scale), ptr(shift), ptr(out), F, H, W, Cin, N, act, stream())
+    if PROFILE is None or torch.cuda.is_current_stream_capturing():
+        check(fn(*args), "cadre_conv3x3_s2")
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(fn(*args), "cadre_conv3x3_s2")
+    e1.record()
+    M = F * (H // 2) * (W // 2)
+    nbytes = F * H * W * Cin * 2 + N * 9 * Cin * 2 + M * N * 2
+    npw = 9 if (256 + W // 2 + 1 + 7) // 8 <= 36 else 10
+    PROFILE.append((("s2", npw), 2.0 * M * N * 9 * Cin, e0, e1, (M, N, 9 * Cin, 1, 1, 0), nbytes))
 
 
 def conv3x3_ring(x, w_ring, scale, shift, resid, out, F, H, W, Cin, N, act):

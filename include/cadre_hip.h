@@ -15,7 +15,7 @@
 extern "C" {
 #endif
 
-#define CADRE_ABI_VERSION 11
+#define CADRE_ABI_VERSION 12
 int cadre_abi_version(void);
 /* human-readable last argument error of the calling thread ("" if none) */
 const char* cadre_last_error(void);
@@ -104,6 +104,14 @@ int cadre_conv3x3_ring_supported(int32_t F, int32_t H, int32_t W, int32_t Cin, i
  * (bf16): names the instantiation conv3x3_ring_kernel<bf16, ntile, res, out_bf16, WVM> /
  * conv3x3_ring_pp_kernel<bf16, ntile, res, out_bf16, false> / conv3x3_ring_pp2_kernel<ntile, res, out_bf16, G> */
 int cadre_conv3x3_ring_ntile(int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t bf16);
+/* 3x3 / STRIDE 2 / pad 1 convolution on dense bf16 NHWC (resnet.py:26-55 conv1 of layer2.0 / layer3.0 / layer4.0, stride 2:
+ * resnet.py:152-158), bf16 model: x [F][H][W][Cin] with even H, W; w [N][Cin/64][9][64] with the nine taps of a 64-channel
+ * chunk in PLANE order (kh,kw) = (0,0) (0,2) (2,0) (2,2) (1,0) (1,2) (0,1) (2,1) (1,1); y = act(conv*scale[n] + shift[n]) as bf16
+ * [F*(H/2)*(W/2)][N]; act 0 / 1 (ReLU).  The input is staged as four parity planes in LDS, each pixel once per (M tile,
+ * channel chunk, N tile) instead of once per tap (conv3x3_s2.hip).  cadre_conv3x3_s2_supported: host logic, no launch. */
+int cadre_conv3x3_s2(const void* x, const void* w, const float* scale, const float* shift, void* out, int32_t F, int32_t H,
+                     int32_t W, int32_t Cin, int32_t N, int32_t act, void* stream);
+int cadre_conv3x3_s2_supported(int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N);
 /* Sustained matrix-pipe rate of this device (peaks.hip; SURVEY.md 8d asks for the measured peak next to the datasheet
  * one): workgroups x 4 waves, each iters x 8 register-operand MFMAs on independent accumulators (fp32:
  * v_mfma_f32_32x32x2_f32 = 4096 FLOP, bf16: v_mfma_f32_32x32x16_bf16 = 32768 FLOP).  The caller times the launch. */

@@ -1451,3 +1451,57 @@ def test_conv3x3_ring_and_c64_repeatable_under_load(hip, dtype, F, H, W, Cin, N)
         torch.cuda.synchronize()
         assert all(torch.equal(outs2[0], o) for o in outs2[1:])
         assert float((outs2[0][:4].float().cpu() - ref).abs().max() / ref.abs().max()) < 1.5e-2
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# stride-2 plane-window conv (csrc/conv3x3_s2.hip, round 5): resnet.py:26-55 conv1 of the down-sampling blocks
+@pytest.mark.parametrize("Nimg,H,W,Cin,Cout,act", [(3, 18, 18, 64, 128, 1), (2, 36, 36, 128, 256, 1), (5, 8, 12, 64, 64, 0),
+                                                   (1, 2, 2, 64, 32, 1), (7, 10, 6, 256, 160, 1), (2, 72, 72, 64, 128, 1),
+                                                   (9, 6, 4, 192, 512, 0)])
+def test_conv3x3_s2_matches_torch(hip, Nimg, H, W, Cin, Cout, act):
+    """cadre_conv3x3_s2 vs torch-CPU fp32 conv2d(stride 2, pad 1) + folded BN + ReLU on bf16-rounded operands: maps whose
+    rows are shorter / longer than an 8-pixel DMA piece, M tiles that straddle rows and frames (top / left halo masks inside
+    a tile), 1-4 channel chunks, N tiles that are not full (160 = 128 + 32), a single 1 x 1 output map."""
+    from cadre_amd.encoder import _s2_w
+    g = torch.Generator().manual_seed(Nimg * 1000 + H * 10 + Cin + Cout)
+    x = _bf(torch.randn(Nimg, Cin, H, W, generator=g))
+    w = _bf(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
+    scale = torch.rand(Cout, generator=g) + 0.5; shift = torch.randn(Cout, generator=g)
+    y = F.conv2d(x.float(), w.float(), None, 2, 1)
+    want = y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    if act:
+        want = F.relu(want)
+    Ho, Wo = H // 2, W // 2
+    assert tuple(y.shape[2:]) == (Ho, Wo)
+    assert hip.lib().cadre_conv3x3_s2_supported(Nimg, H, W, Cin, Cout) == 1
+    xd = dev(x.permute(0, 2, 3, 1).contiguous())
+    wd = dev(_s2_w(w.float())).to(torch.bfloat16)
+    out = torch.full((Nimg, Ho, Wo, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+    hip.conv3x3_s2(xd, wd, dev(scale), dev(shift), out, Nimg, H, W, Cin, Cout, act)
+    torch.cuda.synchronize()
+    assert not torch.isnan(out.float()).any()
+    assert rel(out.float().permute(0, 3, 1, 2), want) < 6e-3           # bf16 output rounding (2^-9 relative) on exact-input sums
+
+
+def test_conv3x3_s2_full_size_repeatable_under_load(hip):
+    """The three trunk shapes at many frames (several persistent items per workgroup, every CU loaded): 10 launches agree
+    bit for bit (hand-counted vmcnt + raw barriers: a race shows up as run-to-run differences), first and last frames agree
+    with torch-CPU fp32."""
+    from cadre_amd.encoder import _s2_w
+    for F_, H, Cin, Cout in ((192, 72, 64, 128), (256, 36, 128, 256), (512, 18, 256, 512)):
+        g = torch.Generator(device="cuda").manual_seed(H + Cin)
+        x = torch.randn(F_, H, H, Cin, device="cuda", generator=g).to(torch.bfloat16)
+        w = (torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) * (1.5 / np.sqrt(9 * Cin))).to(torch.bfloat16)
+        sh = torch.randn(Cout, device="cuda", generator=g)
+        wd = _s2_w(w.float().cpu()).to(torch.bfloat16).cuda()
+        outs = []
+        for rep in range(10):
+            out = torch.empty(F_, H // 2, H // 2, Cout, device="cuda", dtype=torch.bfloat16)
+            hip.conv3x3_s2(x, wd, None, sh, out, F_, H, H, Cin, Cout, 1)
+            outs.append(out)
+        torch.cuda.synchronize()
+        assert all(torch.equal(outs[0], o) for o in outs[1:]), (H, Cin)
+        for sl in (slice(0, 2), slice(F_ - 2, F_)):
+            ref = F.conv2d(x[sl].float().cpu().permute(0, 3, 1, 2), w.float().cpu(), None, 2, 1).permute(0, 2, 3, 1) + sh.cpu()
+            ref = torch.relu(ref)
+            assert float((outs[0][sl].float().cpu() - ref).abs().max() / ref.abs().max()) < 6e-3, (H, Cin)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """HIP-IPC export probe (round 5): which allocator situations make `storage._share_cuda_()` fail with
 `hipIpcGetMemHandle: invalid argument` on this pool?  Each case exports an 80 MB tensor (the size of the parameter arena),
-optionally imports it in a FRESH child (torch.multiprocessing, spawn) that adds 1 to it, and reports ok / the error.
+and reports ok / the error (export only: `hipIpcGetMemHandle` is the call that failed in the topology driver; the import side is
+exercised by tests/test_topology_gpu.py).
 
     python tools/dbg/ipc_probe.py [hold_gb]
 
@@ -29,7 +30,7 @@ def child(t, q):
     q.put(float(t[0].item()))
 
 
-def export(t, with_child=True):
+def export(t, with_child=False):
     try:
         t.untyped_storage()._share_cuda_()
     except Exception as e:      # noqa: BLE001
