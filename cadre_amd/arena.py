@@ -23,6 +23,30 @@ def _rup(x, m):
 
 
 class PPOArena:
+    # Tensors that travel to other processes as HIP-IPC handles (reference main.py:57-70: the shared nets, the gradient
+    # buffers and this object are pickled to the spawned chief and workers) come from a PRIVATE, never-split memory pool: each
+    # is its own hipMalloc.  The caching allocator would carve them out of segments it shares with unrelated tensors, and
+    # `storage._share_cuda_()` exports the whole SEGMENT: two launch rounds of one parent process then export the same
+    # segment twice, the second time after the first round's importers have opened and closed it — the situation in which
+    # `hipIpcGetMemHandle: invalid argument` was seen on this pool (tests/test_topology_gpu.py; the export alone succeeds in
+    # every allocator layout: profiles/r05_hip_ipc_export_probe.txt).  CADRE_ARENA_POOL=0 restores the shared allocator.
+    _pools = {}
+
+    def _alloc_shared(self, fn):
+        import os
+        if self.device.type != "cuda" or os.environ.get("CADRE_ARENA_POOL", "1") == "0" or not hasattr(torch.cuda, "MemPool"):
+            return fn()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        pool = PPOArena._pools.get(idx)
+        if pool is None:
+            try:
+                pool = torch.cuda.MemPool(no_split=True)
+            except TypeError:                                  # (older torch: no no_split argument)
+                pool = torch.cuda.MemPool()
+            PPOArena._pools[idx] = pool                        # (the pool outlives every tensor allocated from it)
+        with torch.cuda.use_mem_pool(pool, device=idx):
+            return fn()
+
     def __init__(self, device, obs_dim=530, n_out=None, command_num=4, hid=128):
         n_out = n_out or {"steer": 33, "throttle": 3}
         self.device = torch.device(device)
@@ -54,17 +78,17 @@ class PPOArena:
         self.P0 = self.Z * self.size_L
         self.total = self.P0 + self.Z * self.size_P
         assert self.size_L % 4 == 0 and self.size_T % 4 == 0
-        self.params = torch.zeros(self.total, device=self.device)
-        self.grads = torch.zeros(self.total, device=self.device)
+        self.params = self._alloc_shared(lambda: torch.zeros(self.total, device=self.device))
+        self.grads = self._alloc_shared(lambda: torch.zeros(self.total, device=self.device))
         self.exp_avg = None
         self.exp_avg_sq = None
         self._bound = []
         self.step = 0
         # clip segments in reference model order is irrelevant for the math; one segment per model
         offs = [g * self.size_L for g in range(self.Z)] + [self.P0 + g * self.size_P for g in range(self.Z)] + [self.total]
-        self.seg_off = torch.tensor(offs, dtype=torch.int64, device=self.device)
-        self.norms2 = torch.zeros(2 * self.Z + 2, dtype=torch.float64, device=self.device)
-        self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.device)   # Adam step count (graph replay)
+        self.seg_off = self._alloc_shared(lambda: torch.tensor(offs, dtype=torch.int64).to(self.device))
+        self.norms2 = self._alloc_shared(lambda: torch.zeros(2 * self.Z + 2, dtype=torch.float64, device=self.device))
+        self.step_dev = self._alloc_shared(lambda: torch.zeros(1, dtype=torch.int32, device=self.device))   # Adam step count (graph replay)
 
     # ------------------------------------------------------------------ naming
     def net_index(self, head, command):

@@ -33,7 +33,7 @@
 //   * persistent workgroups walk contiguous (M tile, N tile) items, N inner; the previous item's epilogue runs in each
 //     group's first staging slot of the next item, without LDS: v_permlane32_swap turns the accumulator's (lane -> position,
 //     register -> channel) into eight consecutive channels per lane = one 16-byte store.
-// Same epilogue contract as the other conv kernels: y = act(conv * scale[n] + shift[n]); bf16 in, fp32 accumulate, bf16 out.
+// y = act(conv + shift[n]) with the folded-BN scale already in the weight rows (scale = NULL); bf16 in, fp32 accumulate, bf16 out.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -58,12 +58,23 @@ int cadre_fail(const char* msg);
 #ifndef S2_ABL
 #define S2_ABL 0
 #endif
+// L2 warming of the plane windows — built, measured, OFF (S2_TOUCH=1 builds it for A/B runs).  A window can be requested only
+// once its ring buffer is free — one or two k-tiles before its first reader for the windows behind the short phases — and a
+// first-touch line comes from HBM: the ablation of the first build put 17-33 % of a launch on the window DMA.  The idea: group 1
+// TOUCHES a window's lines three k-tiles before it requests them (4-byte LDS-DMA loads, one lane per 64-byte sector, into a
+// junk area).  Measured (profiles/r05_s2_l2_touch_ab.txt, same box, interleaved): 614 / 499 / 456 us with the touches against
+// 515 / 423 / 403 without — the three touch instructions per odd k-tile carry ~15 VALU each (a floor-division by Wo per lane),
+// and vector-ALU work inside a staging slot is starved by the other group's MFMAs (the slot then lasts as long
+// as their MFMA slot); even with NO window DMA the touches alone cost 158 us.  Whatever they save in HBM latency is far less.
+#ifndef S2_TOUCH
+#define S2_TOUCH 0
+#endif
+#define S2_NTOUCH (S2_TOUCH ? 3 : 0)       // touch instructions per window (4 pieces = 64 sectors each)
 
 struct s2_args {
   const void* x;          // [F][H][W][Cin] bf16, H = 2 Ho, W = 2 Wo
   const void* w;          // [N][NC][9][128 B]: chunk-major, tap IN PLANE ORDER (0,0) (0,2) (2,0) (2,2) (1,0) (1,2) (0,1) (2,1) (1,1)
-  const float* scale;     // [N] or null
-  const float* shift;     // [N] or null
+  const float* shift;     // [N] or null (the folded-BN scale belongs in the weights)
   void* out;              // [M][N] bf16
   int M, Min;             // output positions F * Ho * Wo, input pixels F * H * W
   int Ho, Wo, W, Cin, N, NC;
@@ -91,6 +102,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(s2_args a) {
   char* bst = smem + 3 * S2_WIN_B;
   char* dump = bst + 2 * S2_STG_B;
   float* sc_lds = reinterpret_cast<float*>(dump + 1024);
+  char* junk = dump + 1024 + a.ntiles * S2_NTILE * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 256;      // this wave's target of its touch loads
 
   const int i_begin = blockIdx.x * a.ipw, i_end = min(a.items, i_begin + a.ipw);
   const int nitems = i_end - i_begin;
@@ -100,10 +112,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(s2_args a) {
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.N * a.NC * 9 * 128, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.M * a.N * 2, 0x00020000);
   for (int i = tid; i < 256; i += 512) reinterpret_cast<unsigned*>(dump)[i] = 0u;       // ZERO ROW (halo taps) and dummy DMA target
-  for (int i = tid; i < a.ntiles * S2_NTILE; i += 512) {
-    sc_lds[i] = (a.scale && i < a.N) ? a.scale[i] : 1.f;
-    sc_lds[a.ntiles * S2_NTILE + i] = (a.shift && i < a.N) ? a.shift[i] : 0.f;
-  }
+  for (int i = tid; i < a.ntiles * S2_NTILE; i += 512) sc_lds[i] = (a.shift && i < a.N) ? a.shift[i] : 0.f;      // folded-BN shift of every channel
   auto swz = [](int idx) constexpr -> int { return (idx >> 1) & 7; };
   const int Wo = a.Wo, Wi = a.W;
   const float inv_wo = 1.0f / (float)Wo, inv_ho = 1.0f / (float)a.Ho;
@@ -116,22 +125,46 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(s2_args a) {
   // num_records: both arrive as zeros.
   const int sw_lane = (((lane & 7) ^ (lane >> 4) ^ (4 * (pb & 1)))) << 4;
   bool abl_pro = true;
-  auto send_win = [&](int mt_n, int c_n, auto ph_c, int bufsel, int n, bool live) {
+  // (the compiler hoists the plane-position arithmetic of a chunk's 40 pieces out of the k-tile loop: ~40 live registers, two
+  //  VALU per request left in the staging slots.  The touches' offsets are computed in their slot from opaque copies of the lane
+  //  index: hoisted too they pushed the kernel into scratch, and spill traffic would break the hand-counted vmcnt)
+  auto send_win = [&](int mt_n, int c_n, auto ph_c, int bufsel, int n, bool live, int lrow, int swl) {
     constexpr int ph = decltype(ph_c)::value;              // 0: plane (1,1), 1: (0,1), 2: (1,0), 3: (0,0)
     constexpr int pr = (ph == 0 || ph == 2) ? 1 : 0, pc = (ph == 0 || ph == 1) ? 1 : 0;
     const int start = ph == 0 ? -(Wo + 1) : (ph == 1 ? -1 : (ph == 2 ? -Wo : 0));
     const int j = 4 * n + pb;
-    const int pp = mt_n * S2_BM + start + 8 * j + (lane >> 3);
+    const int pp = mt_n * S2_BM + start + 8 * j + lrow;
     int q = (int)((float)pp * inv_wo);                     // exact after one correction step (|pp| < 2^24)
     const int r = pp - q * Wo;
     q += (r >= Wo) ? 1 : 0;
     q -= (r < 0) ? 1 : 0;
     const int px = 2 * pp + q * Wi + pr * Wi + pc;
     const bool ok = live && j < a.PA;
-    unsigned voff = (unsigned)(px * cin_b + c_n * 128 + sw_lane) | (ok ? 0u : OOB);
+    unsigned voff = (unsigned)(px * cin_b + c_n * 128 + swl) | (ok ? 0u : OOB);
     char* dst = ok ? win0 + bufsel * S2_WIN_B + j * 1024 : dump;
     if ((S2_ABL & 4) && !abl_pro) { voff = OOB; dst = dump; }
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)dst, 16, (int)voff, 0, 0, 0);
+  };
+  // touch instruction k of a window (pieces 4 k .. 4 k + 3 of this wave): lane -> (piece 4 k + (lane >> 4), row (lane >> 1) & 7,
+  // 64-byte sector lane & 1)
+  auto touch_win = [&](int mt_n, int c_n, auto ph_c, bool live, int lk) {
+    constexpr int ph = decltype(ph_c)::value;
+    constexpr int pr = (ph == 0 || ph == 2) ? 1 : 0, pc = (ph == 0 || ph == 1) ? 1 : 0;
+    const int start = ph == 0 ? -(Wo + 1) : (ph == 1 ? -1 : (ph == 2 ? -Wo : 0));
+#pragma unroll
+    for (int k = 0; k < S2_NTOUCH; ++k) {
+      const int n = 4 * k + (lk >> 4);
+      const int j = 4 * n + pb;
+      const int pp = mt_n * S2_BM + start + 8 * j + ((lk >> 1) & 7);
+      int q = (int)((float)pp * inv_wo);
+      const int r = pp - __mul24(q, Wo);                   // (full-rate 24-bit multiplies: |pp| < 2^23, q < 2^19)
+      q += (r >= Wo) ? 1 : 0;
+      q -= (r < 0) ? 1 : 0;
+      const int px_nc = __mul24(pp, 2 * a.NC) + __mul24(q, Wi * a.NC) + (pr * Wi + pc) * a.NC;      // pixel index x chunks per pixel
+      const bool ok = live && n < NPW && j < a.PA;
+      const unsigned voff = (unsigned)((px_nc << 7) + c_n * 128 + 64 * (lk & 1)) | (ok ? 0u : OOB);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)junk, 4, (int)voff, 0, 0, 0);
+    }
   };
   // ---- weight DMA (group 0): stage piece pc4 = 4 pb + k (k = 0 .. 3): rows 8 pc4 .. + 7
   int b_lane[4];
@@ -149,17 +182,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(s2_args a) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)dst, 16, (int)voff, 0, 0, 0);
     }
   };
-  // ---- lane constants of the fragment reads
-  int kc[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) kc[s] = (2 * s + lh) << 4;
-  int boff[2][4];
-#pragma unroll
-  for (int cb = 0; cb < 2; ++cb) {
-    const int n = 64 * wn + 32 * cb + l31;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) boff[cb][s] = n * 128 + (((2 * s + lh) ^ swz(n)) << 4);
-  }
+  // ---- lane constants of the fragment reads.  k-step s of this lane half reads the logical 16-byte chunk 2 s + lh = (s << 1) | lh;
+  // with the row swizzle sw the physical chunk is ((s << 1) | lh) ^ sw = (lh ^ sw) ^ (s << 1): ONE base per fragment row with the
+  // lane-half and swizzle bits folded in, XOR-ed with the literal s << 5 (rows start on 128-byte boundaries, so base + x == base ^ x)
+  const unsigned lh4 = (unsigned)lh << 4;
+  const unsigned bbase = (unsigned)((64 * wn + l31) * 128) ^ ((unsigned)swz(64 * wn + l31) << 4) ^ lh4;      // weight row n = 64 wn + 32 cb + l31: swz(n + 32) == swz(n)
   const unsigned zrow_off = (unsigned)(dump - smem);
 
   // (ho, wo) of this lane's two fragment rows (positions 64 wm + 32 rb + l31 of the current M tile)
@@ -187,11 +214,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(s2_args a) {
     }
   };
 
-  // ---- epilogue of one item, no LDS slab.  Accumulator tile (rb, cb): lane (l31, lh), register r holds position 32 rb + l31,
-  // channel 32 cb + 8 (r >> 2) + 4 lh + (r & 3).  One v_permlane32_swap per register pair leaves lane (l31, lh) with channels
-  // 32 cb + 16 h + 8 lh .. + 7 (h = 0, 1): one 16-byte store per (tile, h).
+  // ---- epilogue of one item, no LDS slab and no BN arithmetic: the folded-BN scale is in the weights (the caller folds it:
+  // scale == NULL is part of the contract), the shift is the accumulators' initial value.  Accumulator tile (rb, cb): lane
+  // (l31, lh), register r holds position 32 rb + l31, channel 32 cb + 8 (r >> 2) + 4 lh + (r & 3).  ReLU, pairwise conversion
+  // to bf16 (dword j = channels 8 (j >> 1) + 4 lh + 2 (j & 1) + {0, 1}), then ONE v_permlane32_swap per dword pair leaves lane
+  // (l31, lh) with channels 32 cb + 16 h + 8 lh .. + 7 (h = 0, 1): one 16-byte store per (tile, h), 16 swaps per item.
   f32x16 acc[2][2];
   const float act_floor = (a.act & 15) == 1 ? 0.f : -__builtin_inff();
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  auto acc_init = [&](int nt_i) {
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const float* sh = sc_lds + nt_i * S2_NTILE + 64 * wn + 32 * cb + 4 * lh;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(sh + 8 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[0][cb][4 * g + e] = t[e]; acc[1][cb][4 * g + e] = t[e]; }
+      }
+    }
+  };
   auto epilogue = [&](int mt_e, int nt_e) {
     if constexpr ((S2_ABL & 16) != 0) {
 #pragma unroll
@@ -207,30 +249,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(s2_args a) {
         const bool ch_ok = nt_e * S2_NTILE + 64 * wn + 32 * cb < a.N;          // (N % 32 == 0)
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
+          unsigned d[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const bf16x2 pk = {(__bf16)fmaxf(acc[rb][cb][2 * j], act_floor), (__bf16)fmaxf(acc[rb][cb][2 * j + 1], act_floor)};
+            d[j] = __builtin_bit_cast(unsigned, pk);
+          }
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
-            float v[8];
+            unsigned fx[2], fy[2];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < 2; ++e) {
               // v_permlane32_swap x, y: x <- [x.lo, y.lo], y <- [x.hi, y.hi] (inline asm: see conv3x3_ring.hip on the builtin)
-              float fx = acc[rb][cb][8 * h + e], fy = acc[rb][cb][8 * h + 4 + e];
-              asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(fx), "+v"(fy));
-              v[e] = fx;
-              v[4 + e] = fy;
-            }
-            const int nl = nt_e * S2_NTILE + 64 * wn + 32 * cb + 16 * h + 8 * lh;
-            const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc_lds + nl), s1 = *reinterpret_cast<const f32x4*>(sc_lds + nl + 4);
-            const f32x4 t0 = *reinterpret_cast<const f32x4*>(sc_lds + a.ntiles * S2_NTILE + nl);
-            const f32x4 t1 = *reinterpret_cast<const f32x4*>(sc_lds + a.ntiles * S2_NTILE + nl + 4);
-            bf16x8 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              o[e] = (__bf16)fmaxf(v[e] * s0[e] + t0[e], act_floor);
-              o[4 + e] = (__bf16)fmaxf(v[4 + e] * s1[e] + t1[e], act_floor);
+              fx[e] = d[4 * h + e]; fy[e] = d[4 * h + 2 + e];
+              asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(fx[e]), "+v"(fy[e]));
             }
             const int eo = eb + 32 * rb * a.N + 32 * cb + 16 * h;
             const int bo = (int)((unsigned)(eo * 2) | (ch_ok ? 0u : OOB));      // (a position past M lies past num_records)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsC, bo, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{fx[0], fx[1], fy[0], fy[1]}, rsC, bo, 0, 0);
           }
         }
       }
@@ -241,9 +277,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(s2_args a) {
   // k-tile 0; everything landed and published
   if (grp == 1) {
 #pragma unroll
-    for (int n = 0; n < NPW; ++n) send_win(mt, 0, std::integral_constant<int, 0>{}, 0, n, true);
+    for (int n = 0; n < NPW; ++n) send_win(mt, 0, std::integral_constant<int, 0>{}, 0, n, true, lane >> 3, sw_lane);
 #pragma unroll
-    for (int n = 0; n < NH; ++n) send_win(mt, 0, std::integral_constant<int, 1>{}, 1, n, true);
+    for (int n = 0; n < NH; ++n) send_win(mt, 0, std::integral_constant<int, 1>{}, 1, n, true, lane >> 3, sw_lane);
   } else {
     send_wts(nt, 0, 0, 0, true);
   }
@@ -280,12 +316,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(s2_args a) {
       epilogue(mt_p, nt_p);
       if (grp == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
     }
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.f;
+    acc_init(nt);                                          // the sums start at the folded-BN shift
 
     for (int c = 0; c < a.NC; ++c) {
       const bool last_c = c + 1 == a.NC;
@@ -309,16 +340,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(s2_args a) {
           for (int rb = 0; rb < 2; ++rb) {
             const int idx = 64 * wm + 32 * rb + l31 + ro;
             const unsigned row = ((mask[rb] >> t) & 1u) ? wbase + (unsigned)(idx << 7) : zrow_off;
-            arow_sw[rb] = row ^ (unsigned)(swz(idx) << 4);
+            arow_sw[rb] = row ^ (unsigned)(swz(idx) << 4) ^ lh4;
           }
+          const unsigned bsw = sbase + bbase;                // (stages start on 16 KB boundaries)
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            bfr[0][s] = *reinterpret_cast<const f32x4*>(smem + sbase + boff[0][s]);
+            bfr[0][s] = *reinterpret_cast<const f32x4*>(smem + (bsw ^ (unsigned)(s << 5)));
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) afr[rb][s] = *reinterpret_cast<const f32x4*>(smem + (arow_sw[rb] ^ (unsigned)kc[s]));
+            for (int rb = 0; rb < 2; ++rb) afr[rb][s] = *reinterpret_cast<const f32x4*>(smem + (arow_sw[rb] ^ (unsigned)(s << 5)));
           }
 #pragma unroll
-          for (int s = 0; s < 4; ++s) bfr[1][s] = *reinterpret_cast<const f32x4*>(smem + sbase + boff[1][s]);
+          for (int s = 0; s < 4; ++s) bfr[1][s] = *reinterpret_cast<const f32x4*>(smem + (bsw ^ (unsigned)(s << 5)) + 32 * 128);
         }
         if constexpr ((S2_ABL & 2) != 0) {
 #pragma unroll
@@ -335,40 +367,52 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(s2_args a) {
           if (t < 8) { if (t > 0 || c > 0) send_wts(nt, c, t + 1, ((t + 1) & 1) ^ kpar, true); }      // (t == 0 of the item's first chunk: sent in the head)
           else send_wts(nt_n, c_n, 0, kpar ^ 1, live_n);   // next chunk's k-tile 0: the stage parity flips with the chunk
         } else {
+          int lk = lane;
+          int mt_s = mt, mt_ns = mt_n, c_s = c, c_ns = c_n;
+          asm volatile("" : "+v"(lk), "+s"(mt_s), "+s"(mt_ns), "+s"(c_s), "+s"(c_ns));      // (the touches' offsets are computed here, not hoisted)
           // window pieces, static schedule (the buffer a window goes into was read last two phases ago):
           //   t0: (0,1) of this chunk, second half | t1, t2: (1,0) of this chunk | t4, t5: (0,0) of this chunk (re-uses b0)
           //   t6, t7: (1,1) of the NEXT chunk -> b1 | t8: (0,1) of the next chunk, first half -> b2
           if (t == 0) {
 #pragma unroll
-            for (int n = NH; n < NPW; ++n) send_win(mt, c, std::integral_constant<int, 1>{}, b1, n, true);
+            for (int n = NH; n < NPW; ++n) send_win(mt, c, std::integral_constant<int, 1>{}, b1, n, true, lane >> 3, sw_lane);
           } else if (t == 1) {
 #pragma unroll
-            for (int n = 0; n < NH; ++n) send_win(mt, c, std::integral_constant<int, 2>{}, b2, n, true);
+            for (int n = 0; n < NH; ++n) send_win(mt, c, std::integral_constant<int, 2>{}, b2, n, true, lane >> 3, sw_lane);
           } else if (t == 2) {
 #pragma unroll
-            for (int n = NH; n < NPW; ++n) send_win(mt, c, std::integral_constant<int, 2>{}, b2, n, true);
+            for (int n = NH; n < NPW; ++n) send_win(mt, c, std::integral_constant<int, 2>{}, b2, n, true, lane >> 3, sw_lane);
           } else if (t == 4) {
 #pragma unroll
-            for (int n = 0; n < NH; ++n) send_win(mt, c, std::integral_constant<int, 3>{}, b0, n, true);
+            for (int n = 0; n < NH; ++n) send_win(mt, c, std::integral_constant<int, 3>{}, b0, n, true, lane >> 3, sw_lane);
           } else if (t == 5) {
 #pragma unroll
-            for (int n = NH; n < NPW; ++n) send_win(mt, c, std::integral_constant<int, 3>{}, b0, n, true);
+            for (int n = NH; n < NPW; ++n) send_win(mt, c, std::integral_constant<int, 3>{}, b0, n, true, lane >> 3, sw_lane);
           } else if (t == 6) {
 #pragma unroll
-            for (int n = 0; n < NH; ++n) send_win(mt_n, c_n, std::integral_constant<int, 0>{}, b1, n, live_n);
+            for (int n = 0; n < NH; ++n) send_win(mt_n, c_n, std::integral_constant<int, 0>{}, b1, n, live_n, lane >> 3, sw_lane);
           } else if (t == 7) {
 #pragma unroll
-            for (int n = NH; n < NPW; ++n) send_win(mt_n, c_n, std::integral_constant<int, 0>{}, b1, n, live_n);
+            for (int n = NH; n < NPW; ++n) send_win(mt_n, c_n, std::integral_constant<int, 0>{}, b1, n, live_n, lane >> 3, sw_lane);
           } else if (t == 8) {
 #pragma unroll
-            for (int n = 0; n < NH; ++n) send_win(mt_n, c_n, std::integral_constant<int, 1>{}, b2, n, live_n);
+            for (int n = 0; n < NH; ++n) send_win(mt_n, c_n, std::integral_constant<int, 1>{}, b2, n, live_n, lane >> 3, sw_lane);
           }
-          // a window is confirmed (in-order completion: everything but the pieces issued after its last one) in the slot
-          // before group 0 first reads it: (0,1) at t3, (1,0) at t5, (0,0) at t7, the next chunk's (1,1) at t8
-          if (t == 3) s2_wait_vm<NPW>();                   // younger: t1 + t2
-          if (t == 5) s2_wait_vm<NPW>();                   // younger: t4 + t5
-          if (t == 7) s2_wait_vm<NPW>();                   // younger: t6 + t7
-          if (t == 8) s2_wait_vm<NH>();                    // younger: t8
+          // touches, three k-tiles ahead of the requests (behind this slot's pieces in the queue): t1: (0,0) of this chunk,
+          // t3: (1,1) of the next chunk, t5: (0,1) of the next chunk, t7: (1,0) of the next chunk (requested at its t1, t2)
+          if constexpr (S2_TOUCH != 0) {
+            if (t == 1) touch_win(mt_s, c_s, std::integral_constant<int, 3>{}, true, lk);
+            if (t == 3) touch_win(mt_ns, c_ns, std::integral_constant<int, 0>{}, live_n, lk);
+            if (t == 5) touch_win(mt_ns, c_ns, std::integral_constant<int, 1>{}, live_n, lk);
+            if (t == 7) touch_win(mt_ns, c_ns, std::integral_constant<int, 2>{}, live_n, lk);
+          }
+          // a window is confirmed (in-order completion: everything but the operations issued after its last piece) in the
+          // slot before group 0 first reads it: (0,1) at t3, (1,0) at t5, (0,0) at t7, the next chunk's (1,1) at t8
+          constexpr int NQ = S2_NTOUCH;
+          if (t == 3) s2_wait_vm<NPW + 2 * NQ>();          // younger: t1 (pieces, touches) + t2 + t3 (touches)
+          if (t == 5) s2_wait_vm<NPW + 2 * NQ>();          // younger: t3 (touches) + t4 + t5 (pieces, touches)
+          if (t == 7) s2_wait_vm<NPW + 2 * NQ>();          // younger: t5 (touches) + t6 + t7 (pieces, touches)
+          if (t == 8) s2_wait_vm<NH + NQ>();               // younger: t7 (touches) + t8
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -424,7 +468,7 @@ static int s2_capable(int F, int H, int W, int Cin, int N) {
   if (Min * Cin * 2 >= lim || (long long)N * Cin * 9 * 2 >= lim || M * N * 2 >= lim) return 0;
   if (M >= (1 << 23)) return 0;                            // the plane-position division runs in fp32
   const int ntiles = (N + S2_NTILE - 1) / S2_NTILE;
-  if ((size_t)3 * S2_WIN_B + 2 * S2_STG_B + 1024 + (size_t)ntiles * S2_NTILE * 8 > 160 * 1024) return 0;
+  if ((size_t)3 * S2_WIN_B + 2 * S2_STG_B + 1024 + (size_t)ntiles * S2_NTILE * 4 + 2048 > 160 * 1024) return 0;
   return 1;
 }
 
@@ -438,12 +482,13 @@ extern "C" int cadre_conv3x3_s2_supported(int32_t F, int32_t H, int32_t W, int32
 extern "C" int cadre_conv3x3_s2(const void* x, const void* w, const float* scale, const float* shift, void* out, int32_t F,
                                 int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t act, void* stream) {
   if (!x || !w || !out) return cadre_fail("cadre_conv3x3_s2: null operand");
+  if (scale) return cadre_fail("cadre_conv3x3_s2: fold the BN scale into the weight rows and pass scale = NULL (the kernel has no epilogue multiply)");
   if (!s2_capable(F, H, W, Cin, N))
     return cadre_fail("cadre_conv3x3_s2: unsupported geometry (even H, W; W <= 78; Cin % 64 == 0; N % 32 == 0; every tensor < 2 GiB: chunk the batch)");
   if ((act & 15) > 1 || (act & 16)) return cadre_fail("cadre_conv3x3_s2: act 0 (none) or 1 (ReLU)");
   if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)out) & 15) return cadre_fail("cadre_conv3x3_s2: operands must be 16-byte aligned");
   s2_args a;
-  a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.out = out;
+  a.x = x; a.w = w; a.shift = shift; a.out = out;
   a.Ho = H / 2; a.Wo = W / 2; a.W = W; a.Cin = Cin; a.N = N; a.NC = Cin / 64; a.act = act;
   a.Min = F * H * W; a.M = F * a.Ho * a.Wo;
   a.mtiles = (a.M + S2_BM - 1) / S2_BM;
@@ -453,7 +498,7 @@ extern "C" int cadre_conv3x3_s2(const void* x, const void* w, const float* scale
   a.ipw = (a.items + wgs - 1) / wgs;
   const int grid = (a.items + a.ipw - 1) / a.ipw;
   a.PA = (S2_BM + a.Wo + 1 + 7) / 8;
-  const size_t lds = (size_t)3 * S2_WIN_B + 2 * S2_STG_B + 1024 + (size_t)a.ntiles * S2_NTILE * 8;
+  const size_t lds = (size_t)3 * S2_WIN_B + 2 * S2_STG_B + 1024 + (size_t)a.ntiles * S2_NTILE * 4 + 2048;      // (+ 8 x 256 B of touch targets)
   hipStream_t st = (hipStream_t)stream;
   if (a.PA <= 36) {
     (void)hipFuncSetAttribute((const void*)conv3x3_s2_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -106,8 +106,9 @@ int cadre_conv3x3_ring_supported(int32_t F, int32_t H, int32_t W, int32_t Cin, i
 int cadre_conv3x3_ring_ntile(int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t bf16);
 /* 3x3 / STRIDE 2 / pad 1 convolution on dense bf16 NHWC (resnet.py:26-55 conv1 of layer2.0 / layer3.0 / layer4.0, stride 2:
  * resnet.py:152-158), bf16 model: x [F][H][W][Cin] with even H, W; w [N][Cin/64][9][64] with the nine taps of a 64-channel
- * chunk in PLANE order (kh,kw) = (0,0) (0,2) (2,0) (2,2) (1,0) (1,2) (0,1) (2,1) (1,1); y = act(conv*scale[n] + shift[n]) as bf16
- * [F*(H/2)*(W/2)][N]; act 0 / 1 (ReLU).  The input is staged as four parity planes in LDS, each pixel once per (M tile,
+ * chunk in PLANE order (kh,kw) = (0,0) (0,2) (2,0) (2,2) (1,0) (1,2) (0,1) (2,1) (1,1); y = act(conv + shift[n]) as bf16
+ * [F*(H/2)*(W/2)][N]; scale must be NULL (the caller folds the BN scale into the weight rows: the kernel starts its sums at
+ * the shift and has no epilogue multiply); act 0 / 1 (ReLU).  The input is staged as four parity planes in LDS, each pixel once per (M tile,
  * channel chunk, N tile) instead of once per tap (conv3x3_s2.hip).  cadre_conv3x3_s2_supported: host logic, no launch. */
 int cadre_conv3x3_s2(const void* x, const void* w, const float* scale, const float* shift, void* out, int32_t F, int32_t H,
                      int32_t W, int32_t Cin, int32_t N, int32_t act, void* stream);

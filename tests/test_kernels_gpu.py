@@ -1465,10 +1465,11 @@ def test_conv3x3_s2_matches_torch(hip, Nimg, H, W, Cin, Cout, act):
     from cadre_amd.encoder import _s2_w
     g = torch.Generator().manual_seed(Nimg * 1000 + H * 10 + Cin + Cout)
     x = _bf(torch.randn(Nimg, Cin, H, W, generator=g))
-    w = _bf(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
     scale = torch.rand(Cout, generator=g) + 0.5; shift = torch.randn(Cout, generator=g)
+    # folded BN: the scale goes into the weight rows (one rounding to bf16, as cadre_amd/encoder.py does), the kernel adds the shift
+    w = _bf(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5 * scale.view(-1, 1, 1, 1))
     y = F.conv2d(x.float(), w.float(), None, 2, 1)
-    want = y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    want = y + shift.view(1, -1, 1, 1)
     if act:
         want = F.relu(want)
     Ho, Wo = H // 2, W // 2
@@ -1477,7 +1478,7 @@ def test_conv3x3_s2_matches_torch(hip, Nimg, H, W, Cin, Cout, act):
     xd = dev(x.permute(0, 2, 3, 1).contiguous())
     wd = dev(_s2_w(w.float())).to(torch.bfloat16)
     out = torch.full((Nimg, Ho, Wo, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
-    hip.conv3x3_s2(xd, wd, dev(scale), dev(shift), out, Nimg, H, W, Cin, Cout, act)
+    hip.conv3x3_s2(xd, wd, None, dev(shift), out, Nimg, H, W, Cin, Cout, act)
     torch.cuda.synchronize()
     assert not torch.isnan(out.float()).any()
     assert rel(out.float().permute(0, 3, 1, 2), want) < 6e-3           # bf16 output rounding (2^-9 relative) on exact-input sums
