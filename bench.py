@@ -319,6 +319,8 @@ def kname(k):
         return "wino2_c64_kernel<%s>" % ("true" if k[1] else "false")
     if k[0] == "s2":
         return "conv3x3_s2_kernel<%d>" % k[1]
+    if k[0] == "s1x":
+        return "conv3x3_s1x_kernel<%d>" % k[1]
     if k[0] == "ring":
         tf = ("true" if k[1] else "false", k[2], k[3], "true" if k[4] else "false")
         if len(k) > 7 and k[7] == 8:             # one wave per SIMD, streamed weights (128-channel tile)
@@ -356,10 +358,10 @@ def roofline_of(prof, steps):
         return None, {}
     dom = max(by, key=lambda k: by[k][1])
     fl, t, n, nb = by[dom]
-    bf16 = dom[0] in ("bf16", "s2") or (dom[0] == "ring" and dom[1])
+    bf16 = dom[0] in ("bf16", "s2", "s1x") or (dom[0] == "ring" and dom[1])
     peak_tf = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
     t_mfma, t_hbm = fl / (peak_tf * 1e12), nb / (PEAK_HBM_GBPS * 1e9)
-    tile, am = (65, 2) if dom[0] in ("ring", "s2") else ((dom[1], dom[2]) if bf16 else (dom[0], dom[1]))
+    tile, am = (65, 2) if dom[0] in ("ring", "s2", "s1x") else ((dom[1], dom[2]) if bf16 else (dom[0], dom[1]))
     desc = "%s tile, %s%s" % (TILE.get(tile, tile), AM.get(am, am), ", bf16" if bf16 else "")
     if dom[0] == "wino_c64":
         desc = "fused Winograd F(2x2,3x3) of the fp32 64 -> 64 stage (executed FLOPs)"

@@ -58,18 +58,14 @@ int cadre_fail(const char* msg);
 #ifndef S2_ABL
 #define S2_ABL 0
 #endif
-// L2 warming of the plane windows — built, measured, OFF (S2_TOUCH=1 builds it for A/B runs).  A window can be requested only
-// once its ring buffer is free — one or two k-tiles before its first reader for the windows behind the short phases — and a
-// first-touch line comes from HBM: the ablation of the first build put 17-33 % of a launch on the window DMA.  The idea: group 1
-// TOUCHES a window's lines three k-tiles before it requests them (4-byte LDS-DMA loads, one lane per 64-byte sector, into a
-// junk area).  Measured (profiles/r05_s2_l2_touch_ab.txt, same box, interleaved): 614 / 499 / 456 us with the touches against
-// 515 / 423 / 403 without — the three touch instructions per odd k-tile carry ~15 VALU each (a floor-division by Wo per lane),
-// and vector-ALU work inside a staging slot is starved by the other group's MFMAs (the slot then lasts as long
-// as their MFMA slot); even with NO window DMA the touches alone cost 158 us.  Whatever they save in HBM latency is far less.
-#ifndef S2_TOUCH
-#define S2_TOUCH 0
-#endif
-#define S2_NTOUCH (S2_TOUCH ? 3 : 0)       // touch instructions per window (4 pieces = 64 sectors each)
+// L2 warming of the plane windows — built, measured, REMOVED (git history: "L2-warming touches").  A window can be requested
+// only once its ring buffer is free — one or two k-tiles before its first reader for the windows behind the short phases —
+// and a first-touch line comes from HBM: the ablation of the first build put 17-33 % of a launch on the window DMA.  The idea:
+// group 1 TOUCHES a window's lines three k-tiles before it requests them (4-byte LDS-DMA loads, one lane per 64-byte sector,
+// into a junk area).  Measured (profiles/r05_s2_l2_touch_ab.txt, same box, interleaved): 614 / 499 / 456 us with the touches
+// against 515 / 423 / 403 without — the three touch instructions per odd k-tile carry ~15 VALU each (a floor-division by Wo per
+// lane), and vector-ALU work inside a staging slot is starved by the other group's MFMAs; even with NO window
+// DMA the touches alone cost 158 us.  Whatever they save in HBM latency is far less.
 
 struct s2_args {
   const void* x;          // [F][H][W][Cin] bf16, H = 2 Ho, W = 2 Wo
@@ -102,7 +98,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(s2_args a) {
   char* bst = smem + 3 * S2_WIN_B;
   char* dump = bst + 2 * S2_STG_B;
   float* sc_lds = reinterpret_cast<float*>(dump + 1024);
-  char* junk = dump + 1024 + a.ntiles * S2_NTILE * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 256;      // this wave's target of its touch loads
 
   const int i_begin = blockIdx.x * a.ipw, i_end = min(a.items, i_begin + a.ipw);
   const int nitems = i_end - i_begin;
@@ -126,45 +121,33 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(s2_args a) {
   const int sw_lane = (((lane & 7) ^ (lane >> 4) ^ (4 * (pb & 1)))) << 4;
   bool abl_pro = true;
   // (the compiler hoists the plane-position arithmetic of a chunk's 40 pieces out of the k-tile loop: ~40 live registers, two
-  //  VALU per request left in the staging slots.  The touches' offsets are computed in their slot from opaque copies of the lane
-  //  index: hoisted too they pushed the kernel into scratch, and spill traffic would break the hand-counted vmcnt)
-  auto send_win = [&](int mt_n, int c_n, auto ph_c, int bufsel, int n, bool live, int lrow, int swl) {
+  //  VALU per request left in the staging slots — computed IN the slots the same arithmetic, ~15 VALU per piece, made them the
+  //  longest part of the kernel)
+  // (An odd-row plane's pixel is the even-row plane's pixel of the same column parity ONE INPUT ROW UP: row r of window (1,1) /
+  //  (1,0) = row r of window (0,1) / (0,0) minus W pixels.  The two families share the division: 25 hoisted offsets per chunk
+  //  instead of 40 — the difference between fitting 256 registers and spilling — and one subtraction left in the staging slot.)
+  auto send_win = [&](int mt_n, int c_n, auto ph_c, int bufsel, int n, bool live) {
     constexpr int ph = decltype(ph_c)::value;              // 0: plane (1,1), 1: (0,1), 2: (1,0), 3: (0,0)
-    constexpr int pr = (ph == 0 || ph == 2) ? 1 : 0, pc = (ph == 0 || ph == 1) ? 1 : 0;
-    const int start = ph == 0 ? -(Wo + 1) : (ph == 1 ? -1 : (ph == 2 ? -Wo : 0));
+    constexpr int pc = (ph == 0 || ph == 1) ? 1 : 0;       // column parity; the family's even-row window starts at -pc
+    constexpr bool up = (ph == 0 || ph == 2);
+    const int lrow = lane >> 3;
     const int j = 4 * n + pb;
-    const int pp = mt_n * S2_BM + start + 8 * j + lrow;
+    const int pp = mt_n * S2_BM - pc + 8 * j + lrow;       // plane position in the family's EVEN-row plane
     int q = (int)((float)pp * inv_wo);                     // exact after one correction step (|pp| < 2^24)
     const int r = pp - q * Wo;
     q += (r >= Wo) ? 1 : 0;
     q -= (r < 0) ? 1 : 0;
-    const int px = 2 * pp + q * Wi + pr * Wi + pc;
+    const int px = 2 * pp + q * Wi + pc;
     const bool ok = live && j < a.PA;
-    unsigned voff = (unsigned)(px * cin_b + c_n * 128 + swl) | (ok ? 0u : OOB);
+    unsigned common = (unsigned)(px * cin_b + c_n * 128 + sw_lane);
+    if constexpr (up) {
+      asm volatile("" : "+v"(common));                     // (the shared value is hoisted, the row-up subtraction stays here)
+      common -= (unsigned)(Wi * cin_b);
+    }
+    unsigned voff = common | (ok ? 0u : OOB);
     char* dst = ok ? win0 + bufsel * S2_WIN_B + j * 1024 : dump;
     if ((S2_ABL & 4) && !abl_pro) { voff = OOB; dst = dump; }
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)dst, 16, (int)voff, 0, 0, 0);
-  };
-  // touch instruction k of a window (pieces 4 k .. 4 k + 3 of this wave): lane -> (piece 4 k + (lane >> 4), row (lane >> 1) & 7,
-  // 64-byte sector lane & 1)
-  auto touch_win = [&](int mt_n, int c_n, auto ph_c, bool live, int lk) {
-    constexpr int ph = decltype(ph_c)::value;
-    constexpr int pr = (ph == 0 || ph == 2) ? 1 : 0, pc = (ph == 0 || ph == 1) ? 1 : 0;
-    const int start = ph == 0 ? -(Wo + 1) : (ph == 1 ? -1 : (ph == 2 ? -Wo : 0));
-#pragma unroll
-    for (int k = 0; k < S2_NTOUCH; ++k) {
-      const int n = 4 * k + (lk >> 4);
-      const int j = 4 * n + pb;
-      const int pp = mt_n * S2_BM + start + 8 * j + ((lk >> 1) & 7);
-      int q = (int)((float)pp * inv_wo);
-      const int r = pp - __mul24(q, Wo);                   // (full-rate 24-bit multiplies: |pp| < 2^23, q < 2^19)
-      q += (r >= Wo) ? 1 : 0;
-      q -= (r < 0) ? 1 : 0;
-      const int px_nc = __mul24(pp, 2 * a.NC) + __mul24(q, Wi * a.NC) + (pr * Wi + pc) * a.NC;      // pixel index x chunks per pixel
-      const bool ok = live && n < NPW && j < a.PA;
-      const unsigned voff = (unsigned)((px_nc << 7) + c_n * 128 + 64 * (lk & 1)) | (ok ? 0u : OOB);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)junk, 4, (int)voff, 0, 0, 0);
-    }
   };
   // ---- weight DMA (group 0): stage piece pc4 = 4 pb + k (k = 0 .. 3): rows 8 pc4 .. + 7
   int b_lane[4];
@@ -277,9 +260,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(s2_args a) {
   // k-tile 0; everything landed and published
   if (grp == 1) {
 #pragma unroll
-    for (int n = 0; n < NPW; ++n) send_win(mt, 0, std::integral_constant<int, 0>{}, 0, n, true, lane >> 3, sw_lane);
+    for (int n = 0; n < NPW; ++n) send_win(mt, 0, std::integral_constant<int, 0>{}, 0, n, true);
 #pragma unroll
-    for (int n = 0; n < NH; ++n) send_win(mt, 0, std::integral_constant<int, 1>{}, 1, n, true, lane >> 3, sw_lane);
+    for (int n = 0; n < NH; ++n) send_win(mt, 0, std::integral_constant<int, 1>{}, 1, n, true);
   } else {
     send_wts(nt, 0, 0, 0, true);
   }
@@ -290,172 +273,176 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(s2_args a) {
   if (grp == 1) __builtin_amdgcn_s_barrier();              // group 1 runs one slot behind
   abl_pro = false;
 
-  int b0 = 0, b1 = 1, b2 = 2;                              // window buffers of the current chunk's planes (1,1) / (0,1) / (1,0); (0,0) re-uses b0
-  int kpar = 0;                                            // weight stage of the current chunk's k-tile 0 (9 k-tiles per chunk: flips)
-  int mt_p = 0, nt_p = 0;
-  bool have_prev = false;
+  // ---- main loop.  The ping-pong GROUP is a compile-time parameter of the whole item loop (two instances, one per group):
+  // with the group's DMA duty and the end-of-item cases as run-time conditions every staging slot carried two or three scalar
+  // branches — on the stride-1 ping-pong kernel taking them out of the k-loop was worth 5-10 %.  What stays: the
+  // loops and, per chunk, one branch at its first k-tile (first of the item?) and one at its last (last of the item?).
+  using std::integral_constant;
+  auto run = [&](auto grp_c) {
+    constexpr int GRP = decltype(grp_c)::value;
+    int b0 = 0, b1 = 1, b2 = 2;                            // window buffers of the current chunk's planes (1,1) / (0,1) / (1,0); (0,0) re-uses b0
+    int kpar = 0;                                          // weight stage of the current chunk's k-tile 0 (9 k-tiles per chunk: flips)
+    int mt_p = 0, nt_p = 0;
+    bool have_prev = false;
+    for (int li = 0; li < nitems; ++li) {
+      int mt1 = mt, nt1 = nt + 1;
+      if (nt1 == a.ntiles) { nt1 = 0; ++mt1; }
+      const bool more = li + 1 < nitems;
+      // halo masks in k-tile order: bit t set = the tap's pixel exists (kh = 0 needs ho > 0, kw = 0 needs wo > 0)
+      unsigned mask[2];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        const unsigned top = ph_[rb] > 0 ? 1u : 0u, left = pw_[rb] > 0 ? 1u : 0u;
+        mask[rb] = (top & left) | (top << 1) | (left << 2) | (1u << 3) | (left << 4) | (1u << 5) | (top << 6) | (1u << 7) | (1u << 8);
+      }
+      // ---- head of the item's first staging slot: group 0 requests the weights of k-tile 1 FIRST (its stores then stand
+      // behind them in the queue: the wait at the end of M(0) need not drain them), then the previous item's epilogue, both
+      // groups side by side (group 1 is still in its M slot of the previous item's last k-tile: it takes that slot's closing
+      // barrier only now)
+      __builtin_amdgcn_s_setprio(2);
+      if constexpr (GRP == 0) send_wts(nt, 0, 1, kpar ^ 1, true);
+      if (have_prev) {
+        epilogue(mt_p, nt_p);
+        if constexpr (GRP == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+      }
+      acc_init(nt);                                        // the sums start at the folded-BN shift
 
-  for (int li = 0; li < nitems; ++li) {
-    int mt1 = mt, nt1 = nt + 1;
-    if (nt1 == a.ntiles) { nt1 = 0; ++mt1; }
-    const bool more = li + 1 < nitems;
-    // halo masks in k-tile order: bit t set = the tap's pixel exists (kh = 0 needs ho > 0, kw = 0 needs wo > 0)
-    unsigned mask[2];
+      for (int c = 0; c < a.NC; ++c) {
+        const bool last_c = c + 1 == a.NC;
+        const int mt_n = last_c ? mt1 : mt, nt_n = last_c ? nt1 : nt, c_n = last_c ? 0 : c + 1;
+        const bool live_n = !last_c || more;
+        const unsigned wb0 = (unsigned)(b0 * S2_WIN_B), wb1 = (unsigned)(b1 * S2_WIN_B), wb2 = (unsigned)(b2 * S2_WIN_B);
+        const unsigned st_even = (unsigned)((bst - smem) + kpar * S2_STG_B), st_odd = (unsigned)((bst - smem) + (kpar ^ 1) * S2_STG_B);
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
-      const unsigned top = ph_[rb] > 0 ? 1u : 0u, left = pw_[rb] > 0 ? 1u : 0u;
-      mask[rb] = (top & left) | (top << 1) | (left << 2) | (1u << 3) | (left << 4) | (1u << 5) | (top << 6) | (1u << 7) | (1u << 8);
-    }
-    // ---- head of the item's first staging slot: group 0 requests the weights of k-tile 1 FIRST (its stores then stand
-    // behind them in the queue: the wait at the end of M(0) need not drain them), then the previous item's epilogue, both
-    // groups side by side (group 1 is still in its M slot of the previous item's last k-tile: it takes that slot's closing
-    // barrier only now)
-    __builtin_amdgcn_s_setprio(2);
-    if (grp == 0) send_wts(nt, 0, 1, kpar ^ 1, true);
-    if (have_prev) {
-      epilogue(mt_p, nt_p);
-      if (grp == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
-    }
-    acc_init(nt);                                          // the sums start at the folded-BN shift
-
-    for (int c = 0; c < a.NC; ++c) {
-      const bool last_c = c + 1 == a.NC;
-      const int mt_n = last_c ? mt1 : mt, nt_n = last_c ? nt1 : nt, c_n = last_c ? 0 : c + 1;
-      const bool live_n = !last_c || more;
-      const unsigned wb0 = (unsigned)(b0 * S2_WIN_B), wb1 = (unsigned)(b1 * S2_WIN_B), wb2 = (unsigned)(b2 * S2_WIN_B);
-      const unsigned st_even = (unsigned)((bst - smem) + kpar * S2_STG_B), st_odd = (unsigned)((bst - smem) + (kpar ^ 1) * S2_STG_B);
+        for (int t = 0; t < 9; ++t) {
+          // ================= R slot: fragment reads of k-tile t, DMA issue (at raised priority: between the other group's MFMAs)
+          __builtin_amdgcn_s_setprio(2);
+          // window buffer and row offset of k-tile t (static)
+          const unsigned wbase = t < 4 ? wb0 : (t < 6 ? wb1 : (t < 8 ? wb2 : wb0));
+          const int ro = (t == 1 || t == 5) ? 1 : ((t == 2 || t == 7) ? Wo : (t == 3 ? Wo + 1 : 0));
+          const unsigned sbase = (t & 1) ? st_odd : st_even;
+          f32x4 afr[2][4], bfr[2][4];
+          {
+            unsigned arow_sw[2];
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        // ================= R slot: fragment reads of k-tile t, DMA issue (at raised priority: between the other group's MFMAs)
-        if (t > 0 || c > 0) __builtin_amdgcn_s_setprio(2);
-        constexpr int dummy = 0; (void)dummy;
-        // window buffer and row offset of k-tile t (static)
-        const unsigned wbase = t < 4 ? wb0 : (t < 6 ? wb1 : (t < 8 ? wb2 : wb0));
-        const int ro = (t == 1 || t == 5) ? 1 : ((t == 2 || t == 7) ? Wo : (t == 3 ? Wo + 1 : 0));
-        const unsigned sbase = (t & 1) ? st_odd : st_even;
-        f32x4 afr[2][4], bfr[2][4];
-        {
-          unsigned arow_sw[2];
+            for (int rb = 0; rb < 2; ++rb) {
+              const int idx = 64 * wm + 32 * rb + l31 + ro;
+              const unsigned row = ((mask[rb] >> t) & 1u) ? wbase + (unsigned)(idx << 7) : zrow_off;
+              arow_sw[rb] = row ^ (unsigned)(swz(idx) << 4) ^ lh4;
+            }
+            const unsigned bsw = sbase + bbase;              // (stages start on 16 KB boundaries)
 #pragma unroll
-          for (int rb = 0; rb < 2; ++rb) {
-            const int idx = 64 * wm + 32 * rb + l31 + ro;
-            const unsigned row = ((mask[rb] >> t) & 1u) ? wbase + (unsigned)(idx << 7) : zrow_off;
-            arow_sw[rb] = row ^ (unsigned)(swz(idx) << 4) ^ lh4;
+            for (int s = 0; s < 4; ++s) {
+              bfr[0][s] = *reinterpret_cast<const f32x4*>(smem + (bsw ^ (unsigned)(s << 5)));
+#pragma unroll
+              for (int rb = 0; rb < 2; ++rb) afr[rb][s] = *reinterpret_cast<const f32x4*>(smem + (arow_sw[rb] ^ (unsigned)(s << 5)));
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) bfr[1][s] = *reinterpret_cast<const f32x4*>(smem + (bsw ^ (unsigned)(s << 5)) + 32 * 128);
           }
-          const unsigned bsw = sbase + bbase;                // (stages start on 16 KB boundaries)
+          if constexpr ((S2_ABL & 2) != 0) {
 #pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            bfr[0][s] = *reinterpret_cast<const f32x4*>(smem + (bsw ^ (unsigned)(s << 5)));
+            for (int s = 0; s < 4; ++s) {
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb) afr[rb][s] = *reinterpret_cast<const f32x4*>(smem + (arow_sw[rb] ^ (unsigned)(s << 5)));
-          }
+              for (int rb = 0; rb < 2; ++rb) afr[rb][s] = f32x4{(float)(lane * 3 + s), 1.5f + rb, -0.75f * lane, 0.3f};
 #pragma unroll
-          for (int s = 0; s < 4; ++s) bfr[1][s] = *reinterpret_cast<const f32x4*>(smem + (bsw ^ (unsigned)(s << 5)) + 32 * 128);
-        }
-        if constexpr ((S2_ABL & 2) != 0) {
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb) afr[rb][s] = f32x4{(float)(lane * 3 + s), 1.5f + rb, -0.75f * lane, 0.3f};
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) bfr[cb][s] = f32x4{0.01f * lane, -2.5f + cb, 0.125f * s, 1.f};
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);                 // (the reads go out first: their latency runs under the issue below)
-        if (grp == 0) {
-          // weights of k-tile t + 1 into the stage k-tile t - 1 was read from (its last readers, group 1, finished a slot ago)
-          if (t < 8) { if (t > 0 || c > 0) send_wts(nt, c, t + 1, ((t + 1) & 1) ^ kpar, true); }      // (t == 0 of the item's first chunk: sent in the head)
-          else send_wts(nt_n, c_n, 0, kpar ^ 1, live_n);   // next chunk's k-tile 0: the stage parity flips with the chunk
-        } else {
-          int lk = lane;
-          int mt_s = mt, mt_ns = mt_n, c_s = c, c_ns = c_n;
-          asm volatile("" : "+v"(lk), "+s"(mt_s), "+s"(mt_ns), "+s"(c_s), "+s"(c_ns));      // (the touches' offsets are computed here, not hoisted)
-          // window pieces, static schedule (the buffer a window goes into was read last two phases ago):
-          //   t0: (0,1) of this chunk, second half | t1, t2: (1,0) of this chunk | t4, t5: (0,0) of this chunk (re-uses b0)
-          //   t6, t7: (1,1) of the NEXT chunk -> b1 | t8: (0,1) of the next chunk, first half -> b2
-          if (t == 0) {
-#pragma unroll
-            for (int n = NH; n < NPW; ++n) send_win(mt, c, std::integral_constant<int, 1>{}, b1, n, true, lane >> 3, sw_lane);
-          } else if (t == 1) {
-#pragma unroll
-            for (int n = 0; n < NH; ++n) send_win(mt, c, std::integral_constant<int, 2>{}, b2, n, true, lane >> 3, sw_lane);
-          } else if (t == 2) {
-#pragma unroll
-            for (int n = NH; n < NPW; ++n) send_win(mt, c, std::integral_constant<int, 2>{}, b2, n, true, lane >> 3, sw_lane);
-          } else if (t == 4) {
-#pragma unroll
-            for (int n = 0; n < NH; ++n) send_win(mt, c, std::integral_constant<int, 3>{}, b0, n, true, lane >> 3, sw_lane);
-          } else if (t == 5) {
-#pragma unroll
-            for (int n = NH; n < NPW; ++n) send_win(mt, c, std::integral_constant<int, 3>{}, b0, n, true, lane >> 3, sw_lane);
-          } else if (t == 6) {
-#pragma unroll
-            for (int n = 0; n < NH; ++n) send_win(mt_n, c_n, std::integral_constant<int, 0>{}, b1, n, live_n, lane >> 3, sw_lane);
-          } else if (t == 7) {
-#pragma unroll
-            for (int n = NH; n < NPW; ++n) send_win(mt_n, c_n, std::integral_constant<int, 0>{}, b1, n, live_n, lane >> 3, sw_lane);
-          } else if (t == 8) {
-#pragma unroll
-            for (int n = 0; n < NH; ++n) send_win(mt_n, c_n, std::integral_constant<int, 1>{}, b2, n, live_n, lane >> 3, sw_lane);
-          }
-          // touches, three k-tiles ahead of the requests (behind this slot's pieces in the queue): t1: (0,0) of this chunk,
-          // t3: (1,1) of the next chunk, t5: (0,1) of the next chunk, t7: (1,0) of the next chunk (requested at its t1, t2)
-          if constexpr (S2_TOUCH != 0) {
-            if (t == 1) touch_win(mt_s, c_s, std::integral_constant<int, 3>{}, true, lk);
-            if (t == 3) touch_win(mt_ns, c_ns, std::integral_constant<int, 0>{}, live_n, lk);
-            if (t == 5) touch_win(mt_ns, c_ns, std::integral_constant<int, 1>{}, live_n, lk);
-            if (t == 7) touch_win(mt_ns, c_ns, std::integral_constant<int, 2>{}, live_n, lk);
-          }
-          // a window is confirmed (in-order completion: everything but the operations issued after its last piece) in the
-          // slot before group 0 first reads it: (0,1) at t3, (1,0) at t5, (0,0) at t7, the next chunk's (1,1) at t8
-          constexpr int NQ = S2_NTOUCH;
-          if (t == 3) s2_wait_vm<NPW + 2 * NQ>();          // younger: t1 (pieces, touches) + t2 + t3 (touches)
-          if (t == 5) s2_wait_vm<NPW + 2 * NQ>();          // younger: t3 (touches) + t4 + t5 (pieces, touches)
-          if (t == 7) s2_wait_vm<NPW + 2 * NQ>();          // younger: t5 (touches) + t6 + t7 (pieces, touches)
-          if (t == 8) s2_wait_vm<NH + NQ>();               // younger: t7 (touches) + t8
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        // ================= M slot
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            if constexpr ((S2_ABL & 1) != 0) {
-#pragma unroll
-              for (int rb = 0; rb < 2; ++rb) asm volatile("" :: "v"(bfr[cb][s]), "v"(afr[rb][s]));
-            } else {
-#pragma unroll
-              for (int rb = 0; rb < 2; ++rb)
-                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bfr[cb][s]), __builtin_bit_cast(bf16x8, afr[rb][s]),
-                                                                      acc[rb][cb], 0, 0, 0);
+              for (int cb = 0; cb < 2; ++cb) bfr[cb][s] = f32x4{0.01f * lane, -2.5f + cb, 0.125f * s, 1.f};
             }
           }
-        __builtin_amdgcn_sched_barrier(0);
-        if (grp == 0) {
-          // the weights of k-tile t + 1 (issued in R(t)) have landed; after the item's first k-tile the previous item's
-          // stores (issued behind them) may stay in flight
-          if (t == 0 && c == 0 && have_prev && !(S2_ABL & 16)) s2_wait_vm<NST>();
-          else s2_wait_vm<0>();
+          __builtin_amdgcn_sched_barrier(0);               // (the reads go out first: their latency runs under the issue below)
+          if constexpr (GRP == 0) {
+            // weights of k-tile t + 1 into the stage k-tile t - 1 was read from (its last readers, group 1, finished a slot ago)
+            if (t == 0) { if (c > 0) send_wts(nt, c, 1, kpar ^ 1, true); }      // (the item's first chunk: sent in the head)
+            else if (t < 8) send_wts(nt, c, t + 1, ((t + 1) & 1) ^ kpar, true);
+            else send_wts(nt_n, c_n, 0, kpar ^ 1, live_n); // next chunk's k-tile 0: the stage parity flips with the chunk
+          } else {
+            // window pieces, static schedule (the buffer a window goes into was read last two phases ago):
+            //   t0: (0,1) of this chunk, second half | t1, t2: (1,0) of this chunk | t4, t5: (0,0) of this chunk (re-uses b0)
+            //   t6, t7: (1,1) of the NEXT chunk -> b1 | t8: (0,1) of the next chunk, first half -> b2
+            if (t == 0) {
+#pragma unroll
+              for (int n = NH; n < NPW; ++n) send_win(mt, c, integral_constant<int, 1>{}, b1, n, true);
+            } else if (t == 1) {
+#pragma unroll
+              for (int n = 0; n < NH; ++n) send_win(mt, c, integral_constant<int, 2>{}, b2, n, true);
+            } else if (t == 2) {
+#pragma unroll
+              for (int n = NH; n < NPW; ++n) send_win(mt, c, integral_constant<int, 2>{}, b2, n, true);
+            } else if (t == 4) {
+#pragma unroll
+              for (int n = 0; n < NH; ++n) send_win(mt, c, integral_constant<int, 3>{}, b0, n, true);
+            } else if (t == 5) {
+#pragma unroll
+              for (int n = NH; n < NPW; ++n) send_win(mt, c, integral_constant<int, 3>{}, b0, n, true);
+            } else if (t == 6) {
+#pragma unroll
+              for (int n = 0; n < NH; ++n) send_win(mt_n, c_n, integral_constant<int, 0>{}, b1, n, live_n);
+            } else if (t == 7) {
+#pragma unroll
+              for (int n = NH; n < NPW; ++n) send_win(mt_n, c_n, integral_constant<int, 0>{}, b1, n, live_n);
+            } else if (t == 8) {
+#pragma unroll
+              for (int n = 0; n < NH; ++n) send_win(mt_n, c_n, integral_constant<int, 1>{}, b2, n, live_n);
+            }
+            // a window is confirmed (in-order completion: everything but the pieces issued after its last one) in the slot
+            // before group 0 first reads it: (0,1) at t3, (1,0) at t5, (0,0) at t7, the next chunk's (1,1) at t8
+            if (t == 3) s2_wait_vm<NPW>();                 // younger: t1 + t2
+            if (t == 5) s2_wait_vm<NPW>();                 // younger: t4 + t5
+            if (t == 7) s2_wait_vm<NPW>();                 // younger: t6 + t7
+            if (t == 8) s2_wait_vm<NH>();                  // younger: t8
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
+          // ================= M slot
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              if constexpr ((S2_ABL & 1) != 0) {
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) asm volatile("" :: "v"(bfr[cb][s]), "v"(afr[rb][s]));
+              } else {
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+                  acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bfr[cb][s]), __builtin_bit_cast(bf16x8, afr[rb][s]),
+                                                                        acc[rb][cb], 0, 0, 0);
+              }
+            }
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (GRP == 0) {
+            // the weights of k-tile t + 1 (issued in R(t)) have landed; after the item's first k-tile the previous item's
+            // stores (issued behind them) may stay in flight
+            if (t == 0) {
+              if (c == 0 && have_prev && !(S2_ABL & 16)) s2_wait_vm<NST>();
+              else s2_wait_vm<0>();
+            } else {
+              s2_wait_vm<0>();
+            }
+            __builtin_amdgcn_s_barrier();
+          } else {
+            if (t == 8) { if (!last_c) __builtin_amdgcn_s_barrier(); }      // (group 1, end of an item: the closing barrier comes after its epilogue)
+            else __builtin_amdgcn_s_barrier();
+          }
+          asm volatile("" ::: "memory");
         }
-        if (!(t == 8 && last_c && grp == 1)) __builtin_amdgcn_s_barrier();      // (group 1, end of an item: after its epilogue)
-        asm volatile("" ::: "memory");
+        // next chunk: planes (1,1) / (0,1) / (1,0) in b1 / b2 / b0
+        { const int t0 = b0; b0 = b1; b1 = b2; b2 = t0; }
+        kpar ^= 1;
       }
-      // next chunk: planes (1,1) / (0,1) / (1,0) in b1 / b2 / b0
-      { const int t0 = b0; b0 = b1; b1 = b2; b2 = t0; }
-      kpar ^= 1;
+      mt_p = mt; nt_p = nt; have_prev = true;
+      if (mt1 != mt) advance_mtile();
+      mt = mt1; nt = nt1;
     }
-    mt_p = mt; nt_p = nt; have_prev = true;
-    if (mt1 != mt) advance_mtile();
-    mt = mt1; nt = nt1;
-  }
-  // ---- tail: the last item's epilogue (group 0 one slot before group 1)
-  __builtin_amdgcn_s_setprio(0);
-  epilogue(mt_p, nt_p);
-  __builtin_amdgcn_s_barrier();
+    // ---- tail: the last item's epilogue (group 0 one slot before group 1)
+    __builtin_amdgcn_s_setprio(0);
+    epilogue(mt_p, nt_p);
+    __builtin_amdgcn_s_barrier();
+  };
+  if (grp == 0) run(integral_constant<int, 0>{});
+  else run(integral_constant<int, 1>{});
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -468,7 +455,7 @@ static int s2_capable(int F, int H, int W, int Cin, int N) {
   if (Min * Cin * 2 >= lim || (long long)N * Cin * 9 * 2 >= lim || M * N * 2 >= lim) return 0;
   if (M >= (1 << 23)) return 0;                            // the plane-position division runs in fp32
   const int ntiles = (N + S2_NTILE - 1) / S2_NTILE;
-  if ((size_t)3 * S2_WIN_B + 2 * S2_STG_B + 1024 + (size_t)ntiles * S2_NTILE * 4 + 2048 > 160 * 1024) return 0;
+  if ((size_t)3 * S2_WIN_B + 2 * S2_STG_B + 1024 + (size_t)ntiles * S2_NTILE * 4 > 160 * 1024) return 0;
   return 1;
 }
 
@@ -498,7 +485,7 @@ extern "C" int cadre_conv3x3_s2(const void* x, const void* w, const float* scale
   a.ipw = (a.items + wgs - 1) / wgs;
   const int grid = (a.items + a.ipw - 1) / a.ipw;
   a.PA = (S2_BM + a.Wo + 1 + 7) / 8;
-  const size_t lds = (size_t)3 * S2_WIN_B + 2 * S2_STG_B + 1024 + (size_t)a.ntiles * S2_NTILE * 4 + 2048;      // (+ 8 x 256 B of touch targets)
+  const size_t lds = (size_t)3 * S2_WIN_B + 2 * S2_STG_B + 1024 + (size_t)a.ntiles * S2_NTILE * 4;
   hipStream_t st = (hipStream_t)stream;
   if (a.PA <= 36) {
     (void)hipFuncSetAttribute((const void*)conv3x3_s2_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -94,6 +94,21 @@ def _s2_w(w):
     return taps.reshape(o, 9, i // 64, 64).permute(0, 2, 1, 3).contiguous()
 
 
+def _s1x_w(w2, wd):
+    """conv2 weights OIHW [O][C1][3][3] + shortcut weights [O][Cd][1][1] (both with their folded-BN scale already multiplied in)
+    -> [O][9 C1/64 + Cd/64][64] in the k-tile order of cadre_conv3x3_s1x: per 64-channel chunk c of C1 the nine taps kh*3 + kw,
+    then (c < Cd/64) chunk c of the shortcut."""
+    o, c1 = w2.shape[0], w2.shape[1]
+    cd = wd.shape[1]
+    assert c1 % 64 == 0 and cd % 64 == 0 and cd <= c1 and wd.shape[0] == o
+    rows = []
+    for c in range(c1 // 64):
+        rows.append(w2[:, 64 * c:64 * c + 64].permute(0, 2, 3, 1).reshape(o, 9, 64))
+        if c < cd // 64:
+            rows.append(wd[:, 64 * c:64 * c + 64, 0, 0].reshape(o, 1, 64))
+    return torch.cat(rows, dim=1).contiguous()
+
+
 def _winograd_min_c():
     """Stride-1 3x3 convs of the fp32 model with at least this many input channels (and >= 128 output channels) run as
     Winograd F(3x3, 3x3) / F(2x2, 3x3): 128 = layer2, layer3, layer4, head — at 64 channels (layer1) the transform-domain
@@ -255,6 +270,8 @@ class DANetEncoderHIP:
             self.Wp = max(W + 6, (Wo - 1) * 2 + 8)
             self.Wp += self.Wp & 1
         self.blocks = []
+        self.s1x = {}                                   # block index -> (fused conv2 + shortcut weights, summed shifts)
+        self.use_s1x = os.environ.get("CADRE_S1X_CONV", "1") != "0"
         for li in range(1, 5):
             for bi in range(2):
                 pre = "backbone.layer%d.%d" % (li, bi)
@@ -265,6 +282,12 @@ class DANetEncoderHIP:
                 if (pre + ".downsample.0.weight") in sd:
                     down = _Conv(sd[pre + ".downsample.0.weight"], *_fold_bn(sd, pre + ".downsample.1"), 1, stride, 0, 0, dev, wd)
                 self.blocks.append((c1, c2, down))
+                if down is not None and self.bf16 and c2.cin % 64 == 0 and down.cin % 64 == 0 and down.cin <= c2.cin:
+                    # bf16 model: the block's shortcut (1x1 / s2 conv + BN) rides as extra k-tiles of conv2 (csrc/conv3x3_s1x.hip):
+                    # both folded-BN scales go into the weight rows (fp32 product, one rounding to bf16), the shifts add up
+                    w2 = sd[pre + ".conv2.weight"].float() * c2.scale.detach().cpu().float().view(-1, 1, 1, 1)
+                    wdn = sd[pre + ".downsample.0.weight"].float() * down.scale.detach().cpu().float().view(-1, 1, 1, 1)
+                    self.s1x[len(self.blocks) - 1] = (_s1x_w(w2, wdn).to(dev).to(wd), (c2.shift + down.shift).contiguous())
         # ---- DANet head (danet.py:21-41)
         hd = "da_head."
         self.conv5a = _Conv(sd[hd + "conv5a.0.weight"], *_fold_bn(sd, hd + "conv5a.1"), 3, 1, 1, 1, dev, wd)
@@ -476,6 +499,15 @@ class DANetEncoderHIP:
             taps["pool"] = p
         for i, (c1, c2, down) in enumerate(self.blocks):                      # resnet.py:40-55
             t, H2, W2 = self._conv(c1, cur, F, H, W, "b%d_t" % i)
+            if (i in self.s1x and self.use_s1x and H == 2 * H2 and W == 2 * W2 and t.dtype == torch.bfloat16
+                    and bool(L.cadre_conv3x3_s1x_supported(F, H2, W2, c2.cin, down.cin, c2.cout))):
+                # down-sampling block of the bf16 model: relu(bn2(conv2(t)) + bn_d(conv_d(cur))) as ONE accumulation — the
+                # shortcut's 1 / 2 / 4 k-tiles ride behind conv2's, no shortcut tensor is written or read back
+                w_f, sh_f = self.s1x[i]
+                out = self._buf("b%d_o" % i, (F, H2, W2, c2.cout), torch.bfloat16)
+                hip.conv3x3_s1x(t, cur, w_f, sh_f, out, F, H2, W2, c2.cin, down.cin, c2.cout, 1)
+                cur, H, W = out, H2, W2
+                continue
             idt = cur
             if down is not None:
                 idt, _, _ = self._conv(down, cur, F, H, W, "b%d_d" % i)

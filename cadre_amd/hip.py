@@ -43,6 +43,8 @@ SYMBOLS = {
     "cadre_conv3x3_ring_ntile": [i32, i32, i32, i32, i32, i32],
     "cadre_conv3x3_s2": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "cadre_conv3x3_s2_supported": [i32, i32, i32, i32, i32],
+    "cadre_conv3x3_s1x": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "cadre_conv3x3_s1x_supported": [i32, i32, i32, i32, i32, i32],
     "cadre_maxpool3x3s2_bf16": [vp, vp, i32, i32, i32, i32, vp],
     "cadre_pam_bf16out": [vp, vp, f32, vp, i32, i32, vp],
     "cadre_cam_bf16out": [vp, f32, vp, i32, i32, vp],
@@ -264,6 +266,25 @@ def conv3x3_s2(x, w_s2, scale, shift, out, F, H, W, Cin, N, act):
     nbytes = F * H * W * Cin * 2 + N * 9 * Cin * 2 + M * N * 2
     npw = 9 if (256 + W // 2 + 1 + 7) // 8 <= 36 else 10
     PROFILE.append((("s2", npw), 2.0 * M * N * 9 * Cin, e0, e1, (M, N, 9 * Cin, 1, 1, 0), nbytes))
+
+
+def conv3x3_s1x(x, x2, w_s1x, shift, out, F, H, W, C1, Cd, N, act):
+    """cadre_conv3x3_s1x (3x3 / s1 conv + the block's 1x1 / s2 shortcut as extra k-tiles, one accumulation); profiling key
+    ("s1x", nps): conv3x3_s1x_kernel<nps>, nps = stride-1 window pieces per wave (9 / 10 / 11 by map width)."""
+    fn = lib().cadre_conv3x3_s1x
+    args = (ptr(x), ptr(x2), ptr(w_s1x), ptr(shift), ptr(out), F, H, W, C1, Cd, N, act, stream())
+    if PROFILE is None or torch.cuda.is_current_stream_capturing():
+        check(fn(*args), "cadre_conv3x3_s1x")
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(fn(*args), "cadre_conv3x3_s1x")
+    e1.record()
+    M = F * H * W
+    nbytes = (M * C1 + M * Cd + N * (9 * C1 + Cd) + M * N) * 2          # (the shortcut reads one pixel in four of x2)
+    pa = ((256 + 2 * W + 2 + 7) // 8 * 8) // 8
+    nps = 9 if pa <= 36 else (10 if pa <= 40 else 11)
+    PROFILE.append((("s1x", nps), 2.0 * M * N * (9 * C1 + Cd), e0, e1, (M, N, 9 * C1 + Cd, 1, 1, 0), nbytes))
 
 
 def conv3x3_ring(x, w_ring, scale, shift, resid, out, F, H, W, Cin, N, act):

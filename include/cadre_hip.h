@@ -113,6 +113,14 @@ int cadre_conv3x3_ring_ntile(int32_t F, int32_t H, int32_t W, int32_t Cin, int32
 int cadre_conv3x3_s2(const void* x, const void* w, const float* scale, const float* shift, void* out, int32_t F, int32_t H,
                      int32_t W, int32_t Cin, int32_t N, int32_t act, void* stream);
 int cadre_conv3x3_s2_supported(int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N);
+/* Second conv of a down-sampling BasicBlock with the block's shortcut folded in (resnet.py:40-55 with downsample = resnet.py:152-158),
+ * bf16 model: out = act( conv3x3_s1_p1(x; W2) + conv1x1_s2(x2; Wd) + shift[n] ) as bf16 [F*H*W][N], one fp32 accumulation —
+ * x [F][H][W][C1], x2 [F][2H][2W][Cd] (the shortcut reads pixel (2h, 2w)), both folded-BN scales already in the weight rows,
+ * shift = shift2 + shift_d.  w [N][9*C1/64 + Cd/64][64]: per 64-channel chunk c of C1 the nine taps kh*3+kw of W2, then (c < Cd/64)
+ * chunk c of Wd (cadre_amd/encoder.py _s1x_w).  Needs Cd <= C1.  conv3x3_s1x.hip; _supported: host logic, no launch. */
+int cadre_conv3x3_s1x(const void* x, const void* x2, const void* w, const float* shift, void* out, int32_t F, int32_t H, int32_t W,
+                      int32_t C1, int32_t Cd, int32_t N, int32_t act, void* stream);
+int cadre_conv3x3_s1x_supported(int32_t F, int32_t H, int32_t W, int32_t C1, int32_t Cd, int32_t N);
 /* Sustained matrix-pipe rate of this device (peaks.hip; SURVEY.md 8d asks for the measured peak next to the datasheet
  * one): workgroups x 4 waves, each iters x 8 register-operand MFMAs on independent accumulators (fp32:
  * v_mfma_f32_32x32x2_f32 = 4096 FLOP, bf16: v_mfma_f32_32x32x16_bf16 = 32768 FLOP).  The caller times the launch. */

@@ -1506,3 +1506,57 @@ def test_conv3x3_s2_full_size_repeatable_under_load(hip):
             ref = F.conv2d(x[sl].float().cpu().permute(0, 3, 1, 2), w.float().cpu(), None, 2, 1).permute(0, 2, 3, 1) + sh.cpu()
             ref = torch.relu(ref)
             assert float((outs[0][sl].float().cpu() - ref).abs().max() / ref.abs().max()) < 6e-3, (H, Cin)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# conv2 of a down-sampling block with the shortcut as K-extension (csrc/conv3x3_s1x.hip, round 5)
+@pytest.mark.parametrize("Nimg,H,W,C1,Cd,Cout", [(3, 9, 9, 128, 64, 128), (2, 18, 18, 256, 128, 256), (5, 4, 6, 64, 64, 64),
+                                                 (1, 1, 2, 128, 64, 32), (7, 5, 3, 256, 128, 160), (2, 36, 36, 128, 64, 128),
+                                                 (3, 9, 9, 512, 256, 512), (4, 7, 46, 128, 128, 96)])
+def test_conv3x3_s1x_matches_torch(hip, Nimg, H, W, C1, Cd, Cout):
+    """cadre_conv3x3_s1x vs torch-CPU fp32: relu(conv2d(t, W2, pad 1) + conv2d(x, Wd, stride 2) + shift) on bf16-rounded operands
+    (resnet.py:40-55 with the downsample of resnet.py:152-158; both BN scales folded into the weights): 1-8 chunks with 1-4
+    shortcut k-tiles (incl. one behind EVERY chunk, Cd == C1), maps narrower than a DMA piece and as wide as the kernel takes,
+    M tiles that straddle rows and frames, partial N tiles."""
+    from cadre_amd.encoder import _s1x_w
+    g = torch.Generator().manual_seed(Nimg * 1000 + H * 10 + C1 + Cout)
+    t = _bf(torch.randn(Nimg, C1, H, W, generator=g))
+    x = _bf(torch.randn(Nimg, Cd, 2 * H, 2 * W, generator=g))
+    w2 = _bf(torch.randn(Cout, C1, 3, 3, generator=g) / (C1 * 9) ** 0.5)
+    wd = _bf(torch.randn(Cout, Cd, 1, 1, generator=g) / Cd ** 0.5)
+    shift = torch.randn(Cout, generator=g)
+    want = F.relu(F.conv2d(t.float(), w2.float(), None, 1, 1) + F.conv2d(x.float(), wd.float(), None, 2, 0) + shift.view(1, -1, 1, 1))
+    assert hip.lib().cadre_conv3x3_s1x_supported(Nimg, H, W, C1, Cd, Cout) == 1
+    td = dev(t.permute(0, 2, 3, 1).contiguous()); xd = dev(x.permute(0, 2, 3, 1).contiguous())
+    wf = dev(_s1x_w(w2.float(), wd.float())).to(torch.bfloat16)
+    out = torch.full((Nimg, H, W, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+    hip.conv3x3_s1x(td, xd, wf, dev(shift), out, Nimg, H, W, C1, Cd, Cout, 1)
+    torch.cuda.synchronize()
+    assert not torch.isnan(out.float()).any()
+    assert rel(out.float().permute(0, 3, 1, 2), want) < 6e-3
+
+
+def test_conv3x3_s1x_full_size_repeatable_under_load(hip):
+    """The three trunk shapes at many frames: 10 launches agree bit for bit (hand-counted vmcnt + raw barriers), first and last
+    frames agree with torch-CPU fp32."""
+    from cadre_amd.encoder import _s1x_w
+    for F_, H, C1, Cd in ((160, 36, 128, 64), (256, 18, 256, 128), (512, 9, 512, 256)):
+        g = torch.Generator(device="cuda").manual_seed(H + C1)
+        t = torch.randn(F_, H, H, C1, device="cuda", generator=g).to(torch.bfloat16)
+        x = torch.randn(F_, 2 * H, 2 * H, Cd, device="cuda", generator=g).to(torch.bfloat16)
+        w2 = (torch.randn(C1, C1, 3, 3, device="cuda", generator=g) / np.sqrt(9 * C1)).to(torch.bfloat16)
+        wd = (torch.randn(C1, Cd, 1, 1, device="cuda", generator=g) / np.sqrt(Cd)).to(torch.bfloat16)
+        sh = torch.randn(C1, device="cuda", generator=g)
+        wf = _s1x_w(w2.float().cpu(), wd.float().cpu()).to(torch.bfloat16).cuda()
+        outs = []
+        for rep in range(10):
+            out = torch.empty(F_, H, H, C1, device="cuda", dtype=torch.bfloat16)
+            hip.conv3x3_s1x(t, x, wf, sh, out, F_, H, H, C1, Cd, C1, 1)
+            outs.append(out)
+        torch.cuda.synchronize()
+        assert all(torch.equal(outs[0], o) for o in outs[1:]), (H, C1)
+        for sl in (slice(0, 2), slice(F_ - 2, F_)):
+            ref = (F.conv2d(t[sl].float().cpu().permute(0, 3, 1, 2), w2.float().cpu(), None, 1, 1)
+                   + F.conv2d(x[sl].float().cpu().permute(0, 3, 1, 2), wd.float().cpu(), None, 2, 0)).permute(0, 2, 3, 1) + sh.cpu()
+            ref = torch.relu(ref)
+            assert float((outs[0][sl].float().cpu() - ref).abs().max() / ref.abs().max()) < 6e-3, (H, C1)

@@ -14,11 +14,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ABLS = [0, 100, 4, 104, 16, 12, 30]
+ABLS = [0, 4, 8, 16, 12, 30]
 NAMES = {0: "full kernel", 1: "no MFMA", 2: "no fragment reads", 4: "no window DMA", 8: "no weight DMA", 16: "no epilogue",
          12: "no DMA at all", 14: "MFMA + epilogue only (no reads, no DMA)", 30: "schedule + MFMA only", 31: "empty schedule (barriers + waits)",
-         100: "full kernel, no L2 touches (S2_TOUCH=0)", 104: "no window DMA, no touches"}
-# codes >= 100: the ablation code - 100 built with -DS2_TOUCH=0
+         }
 
 
 def so_path(abl):
@@ -29,7 +28,7 @@ def build(extra):
     os.makedirs(os.path.join(ROOT, "tools", "_trace"), exist_ok=True)
     srcs = [os.path.join(ROOT, "cadre_amd", "csrc", f) for f in ("conv3x3_s2.hip", "cadre_kernels.hip")]
     procs = [subprocess.Popen(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-                               "-DS2_ABL=%d" % (abl % 100)] + (["-DS2_TOUCH=0"] if abl >= 100 else []) + extra + ["-o", so_path(abl)] + srcs,
+                               "-DS2_ABL=%d" % abl] + extra + ["-o", so_path(abl)] + srcs,
                               stderr=subprocess.DEVNULL) for abl in ABLS]
     for p in procs:
         assert p.wait() == 0
