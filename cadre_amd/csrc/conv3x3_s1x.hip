@@ -50,10 +50,21 @@ template <int N>
 __device__ __forceinline__ void sx_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // NPS: stride-1 window pieces per wave of group 1 (4 * NPS >= PA): 9, 10 or 11
-template <int NPS>
+// NSTG: weight stages.  2: k-tile t + 1 requested in R(t), confirmed at the end of M(t) (one slot and a half of lead).  3 (where
+//       LDS allows): k-tile t + 2 requested in R(t), k-tile t + 1 confirmed at the end of R(t) — three slots of lead, and group
+//       0's MFMA slot ends without a wait, as in conv3x3_ring_pp_kernel.
+template <int NPS, int NSTG>
 __global__ __launch_bounds__(512, 2) void conv3x3_s1x_kernel(s1x_args a) {
   constexpr int NST = 8;                                   // epilogue stores per wave
   constexpr unsigned OOB = 0x80000000u;
+  // SYM (three weight stages, opt-in): every wave issues weights AND window pieces, as in conv3x3_ring_pp_kernel.  With two stages
+  // the duties are split by group (group 1's weight pieces would land a slot too late).  At equal work (a plain stride-1 conv, no
+  // shortcut) the split form runs 6-8 % behind conv3x3_ring_pp_kernel and the symmetric form 10-15 %: that kernel's staging slot is
+  // leaner — 9 k-tiles per chunk on 3 stages make every stage offset an immediate and every DMA target a scalar constant, here the
+  // 9- or 10-k-tile chunks on 2 stages leave both to run-time arithmetic (4 + 2 VALU per slot).
+  constexpr bool SYM = NSTG == 3;
+  constexpr int NBW = SYM ? 2 : 4;                         // weight pieces per issuing wave and k-tile
+  constexpr int NS8 = (4 * NPS + 7) / 8;                   // SYM: stride-1 window pieces per wave (8 waves)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -64,7 +75,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s1x_kernel(s1x_args a) {
   char* win0 = smem;                                       // two stride-1 windows, the shortcut window, two weight stages, zero row / dump, shifts
   char* xwin = smem + 2 * win_bytes;
   char* bst = xwin + SX_XWIN_B;
-  char* dump = bst + 2 * SX_STG_B;
+  char* dump = bst + NSTG * SX_STG_B;
   float* sh_lds = reinterpret_cast<float*>(dump + 1024);
 
   const int i_begin = blockIdx.x * a.ipw, i_end = min(a.items, i_begin + a.ipw);
@@ -86,7 +97,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s1x_kernel(s1x_args a) {
   const int sw_lane = (((lane & 7) ^ (lane >> 4) ^ (4 * (pb & 1)))) << 4;
   const int s_lane = (lane >> 3) * cin_b + sw_lane;        // stride-1 window: linear in the position
   auto send_s = [&](int mt_n, int c_n, int bufsel, int n, bool live) {
-    const int j = 4 * n + pb;
+    const int j = SYM ? 8 * n + wave : 4 * n + pb;
     const bool ok = live && j < a.PA;
     const unsigned voff = (unsigned)((mt_n * SX_BM - W - 1 + 8 * j) * cin_b + c_n * 128 + s_lane) | (ok ? 0u : OOB);
     char* dst = ok ? win0 + bufsel * win_bytes + j * 1024 : dump;
@@ -95,11 +106,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s1x_kernel(s1x_args a) {
   // shortcut window: row r of M tile mt holds position p = mt * 256 + r = (q, w) with q = floor(p / W) (rows counted across
   // frames), i.e. pixel (2 q) * (2 W) + 2 w = 2 p + 2 q W of x2.  The per-lane pixel offsets of the wave's 8 pieces are computed
   // once per M tile (xoff), not in the staging slots (vector-ALU work there is starved by the other group's MFMAs).
-  int xoff[8];
+  constexpr int NXP = SYM ? 4 : 8;                         // shortcut-window pieces per issuing wave
+  int xoff[NXP];
   auto plan_x = [&](int mt_x) {
 #pragma unroll
-    for (int n = 0; n < 8; ++n) {
-      const int p = mt_x * SX_BM + 8 * (4 * n + pb) + (lane >> 3);
+    for (int n = 0; n < NXP; ++n) {
+      const int p = mt_x * SX_BM + 8 * (SYM ? 8 * n + wave : 4 * n + pb) + (lane >> 3);
       int q = (int)((float)p * inv_w);                     // exact after one correction step (p < 2^23)
       const int r = p - q * W;
       q += (r >= W) ? 1 : 0;
@@ -109,21 +121,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s1x_kernel(s1x_args a) {
   };
   auto send_x = [&](int c_x, int n, bool live) {
     const unsigned voff = (unsigned)(xoff[n] + c_x * 128) | (live ? 0u : OOB);
-    char* dst = live ? xwin + (4 * n + pb) * 1024 : dump;
+    char* dst = live ? xwin + (SYM ? 8 * n + wave : 4 * n + pb) * 1024 : dump;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX2, (__attribute__((address_space(3))) void*)dst, 16, (int)voff, 0, 0, 0);
   };
   // ---- weight DMA (group 0): stage piece 4 pb + k (k = 0 .. 3)
-  int b_lane[4];
+  int b_lane[NBW];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int r = (4 * pb + k) * 8 + (lane >> 3);
+  for (int k = 0; k < NBW; ++k) {
+    const int r = ((SYM ? 2 * wave : 4 * pb) + k) * 8 + (lane >> 3);
     b_lane[k] = r * a.KT * 128 + (((lane & 7) ^ swz(r)) << 4);
   }
   auto send_wts = [&](int nt_b, int kt, int stg, bool live) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < NBW; ++k) {
       const unsigned voff = (unsigned)(nt_b * (SX_NTILE * a.KT * 128) + kt * 128 + b_lane[k]) | (live ? 0u : OOB);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(bst + stg * SX_STG_B + (4 * pb + k) * 1024),
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(bst + stg * SX_STG_B + ((SYM ? 2 * wave : 4 * pb) + k) * 1024),
                                                16, (int)voff, 0, 0, 0);
     }
   };
@@ -204,7 +216,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s1x_kernel(s1x_args a) {
 
   // ---- prologue: group 1 brings the first stride-1 window, group 0 the weights of k-tile 0
   plan_x(mt);
-  if (grp == 1) {
+  if constexpr (SYM) {
+#pragma unroll
+    for (int n = 0; n < NS8; ++n) send_s(mt, 0, 0, n, true);
+    send_wts(nt, 0, 0, true);
+    send_wts(nt, 1, 1, true);
+  } else if (grp == 1) {
 #pragma unroll
     for (int n = 0; n < NPS; ++n) send_s(mt, 0, 0, n, true);
   } else {
@@ -225,7 +242,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s1x_kernel(s1x_args a) {
   auto run = [&](auto grp_c) {
     constexpr int GRP = decltype(grp_c)::value;
     int sbuf = 0;                                          // window buffer of the current stride-1 phase
-    int kpar = 0;                                          // weight stage of the current k-tile (toggles every k-tile, across items)
+    int kpar = 0;                                          // weight stage of the current k-tile (advances every k-tile, across items)
+    auto stg_next = [&](int st) -> int { return NSTG == 2 ? (st ^ 1) : (st == 2 ? 0 : st + 1); };
     int mt_p = 0, nt_p = 0;
     bool have_prev = false;
     for (int li = 0; li < nitems; ++li) {
@@ -247,7 +265,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s1x_kernel(s1x_args a) {
       // head of the item's first staging slot: group 0's weights of k-tile 1 first (its stores then stand behind them in the
       // queue), the previous item's epilogue — group 1, still in the M slot of that item's last k-tile, takes its closing barrier now
       __builtin_amdgcn_s_setprio(2);
-      if constexpr (GRP == 0) send_wts(nt, 1, kpar ^ 1, true);
+      if constexpr (GRP == 0 && NSTG == 2) send_wts(nt, 1, kpar ^ 1, true);
       if (have_prev) {
         epilogue(mt_p, nt_p);
         if constexpr (GRP == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
@@ -295,7 +313,38 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s1x_kernel(s1x_args a) {
             for (int s = 0; s < 4; ++s) bfr[1][s] = *reinterpret_cast<const f32x4*>(smem + (bsw ^ (unsigned)(s << 5)) + 32 * 128);
           }
           __builtin_amdgcn_sched_barrier(0);
-          if constexpr (GRP == 0) {
+          if constexpr (SYM) {
+            // every wave: its two pieces of k-tile kt + 2 of the weight stream (past the item's end: k-tile 0 / 1 of the next
+            // item) into the stage k-tile kt - 1 was read from, then its window pieces — the next stride-1 window two pieces per
+            // k-tile at taps 1 .. 3, this chunk's shortcut window two per k-tile at taps 4, 5 (conv3x3_ring_pp_kernel's scheme).
+            // Then k-tile kt + 1 — requested a slot pair ago, FIRST in its slot — is confirmed: all but the window pieces of the
+            // previous slot and this slot's operations (and, in the item's first slot, the previous item's stores) has completed.
+            const bool wrap = kt + 2 >= a.KT;
+            send_wts(wrap ? nt1 : nt, wrap ? kt + 2 - a.KT : kt + 2, stg_next(stg_next(kpar)), wrap ? more : true);
+            auto w_of = [](int kind, int t) constexpr -> int {       // window pieces a wave issues in the slot of (kind, t)
+              if (kind != 0) return 0;
+              if (t == 1 || t == 2) return 2;
+              if (t == 3) return NS8 - 4;
+              if (t == 4 || t == 5) return HAS_E ? 2 : 0;
+              return 0;
+            };
+            if constexpr (KIND == 0 && T >= 1 && T <= 3) {
+              if constexpr (2 * (T - 1) < NS8) send_s(mt_n, c_n, sbuf ^ 1, 2 * (T - 1), live_n);
+              if constexpr (2 * (T - 1) + 1 < NS8) send_s(mt_n, c_n, sbuf ^ 1, 2 * (T - 1) + 1, live_n);
+            }
+            if constexpr (KIND == 0 && HAS_E && (T == 4 || T == 5)) {
+              send_x(c, 2 * (T - 4), true);
+              send_x(c, 2 * (T - 4) + 1, true);
+            }
+            constexpr int W_PREV = KIND == 1 ? w_of(0, 8) : (T == 0 ? 0 : w_of(0, T - 1));
+            constexpr int ALLOW = W_PREV + NBW + w_of(KIND, T);
+            if constexpr (FIRST) {
+              if (item_first && have_prev) sx_wait_vm<ALLOW + NST>();
+              else sx_wait_vm<ALLOW>();
+            } else {
+              sx_wait_vm<ALLOW>();
+            }
+          } else if constexpr (GRP == 0) {
             // weights of the next k-tile of the stream into the stage the previous k-tile was read from; after the item's last
             // k-tile: k-tile 0 of the next item.  (The item's first k-tile: k-tile 1 went out in the head.)
             if constexpr (FIRST) {
@@ -339,13 +388,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s1x_kernel(s1x_args a) {
                                                                       acc[rb][cb], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (GRP == 0) {
-            // the weights requested in this k-tile's R slot have landed (after the item's first k-tile the previous item's stores,
-            // issued behind k-tile 1's weights, may stay in flight)
-            if constexpr (FIRST) {
-              if (item_first && have_prev) sx_wait_vm<NST>();
-              else sx_wait_vm<0>();
-            } else {
-              sx_wait_vm<0>();
+            if constexpr (NSTG == 2) {
+              // the weights requested in this k-tile's R slot have landed (after the item's first k-tile the previous item's
+              // stores, issued behind k-tile 1's weights, may stay in flight)
+              if constexpr (FIRST) {
+                if (item_first && have_prev) sx_wait_vm<NST>();
+                else sx_wait_vm<0>();
+              } else {
+                sx_wait_vm<0>();
+              }
             }
             __builtin_amdgcn_s_barrier();
           } else {
@@ -356,7 +407,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s1x_kernel(s1x_args a) {
             }
           }
           asm volatile("" ::: "memory");
-          kpar ^= 1;
+          kpar = stg_next(kpar);
           ++kt;
         };
         step(integral_constant<int, 0>{}, integral_constant<int, 0>{}, c == 0, false);
@@ -389,9 +440,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s1x_kernel(s1x_args a) {
 // ---------------------------------------------------------------------------------------------------------------
 static int s1x_wpx(int W) { return (SX_BM + 2 * W + 2 + 7) & ~7; }
 
+// Weight stages.  Default 2 (DMA duties split by group).  CADRE_S1X_STAGES=3: three stages with every wave issuing weights and
+// window pieces (conv3x3_ring_pp_kernel's scheme) where they fit beside the windows — built for A/B runs and measured SLOWER
+// here (same box, 2048 frames, conv2 + shortcut: 0.735 / 0.745 vs 0.717 / 0.710 ms on layer3.0 / layer4.0; as a plain conv 0.693 /
+// 0.712 vs 0.658 / 0.642: profiles/r05_s1x_three_stages_symmetric_issue.txt, r05_s1x_two_stages_split_issue.txt).
+static int s1x_stages(int W, int N) {
+  static const int want = [] { const char* e = getenv("CADRE_S1X_STAGES"); return e ? atoi(e) : 2; }();
+  const int ntiles = (N + SX_NTILE - 1) / SX_NTILE;
+  const size_t fixed = (size_t)2 * ((SX_BM + 2 * W + 2 + 7) & ~7) * 128 + SX_XWIN_B + 1024 + (size_t)ntiles * SX_NTILE * 4;
+  return (want == 3 && fixed + 3 * SX_STG_B <= 160 * 1024) ? 3 : 2;
+}
+
 static int s1x_capable(int F, int H, int W, int C1, int Cd, int N) {
   if (F < 1 || H < 1 || W < 2 || W > 46) return 0;          // 4 * 11 pieces of 8 pixels >= 256 + 2 W + 2
-  if (C1 % 64 != 0 || Cd % 64 != 0 || C1 < 64 || Cd < 64 || N % 32 != 0) return 0;
+  if (C1 % 64 != 0 || Cd % 64 != 0 || C1 < 64 || Cd < 0 || N % 32 != 0) return 0;      // (Cd == 0: no shortcut, a plain 3x3 / s1 conv)
   if (Cd / 64 > C1 / 64) return 0;                          // a shortcut k-tile rides behind each of the first NCd chunks
   const long long M = (long long)F * H * W, lim = 1ll << 31;
   if (M * C1 * 2 >= lim || 4 * M * Cd * 2 >= lim || (long long)N * (9 * C1 + Cd) * 2 >= lim || M * N * 2 >= lim) return 0;
@@ -409,7 +471,8 @@ extern "C" int cadre_conv3x3_s1x_supported(int32_t F, int32_t H, int32_t W, int3
 
 extern "C" int cadre_conv3x3_s1x(const void* x, const void* x2, const void* w, const float* shift, void* out, int32_t F, int32_t H,
                                  int32_t W, int32_t C1, int32_t Cd, int32_t N, int32_t act, void* stream) {
-  if (!x || !x2 || !w || !out) return cadre_fail("cadre_conv3x3_s1x: null operand");
+  if (!x || (!x2 && Cd > 0) || !w || !out) return cadre_fail("cadre_conv3x3_s1x: null operand");
+  if (!x2) x2 = x;
   if (!s1x_capable(F, H, W, C1, Cd, N))
     return cadre_fail("cadre_conv3x3_s1x: unsupported geometry (W in 2..46; C1, Cd multiples of 64 with Cd <= C1; N % 32 == 0; every tensor < 2 GiB: chunk the batch)");
   if ((act & 15) > 1 || (act & 16)) return cadre_fail("cadre_conv3x3_s1x: act 0 (none) or 1 (ReLU)");
@@ -425,16 +488,19 @@ extern "C" int cadre_conv3x3_s1x(const void* x, const void* x2, const void* w, c
   a.ipw = (a.items + wgs - 1) / wgs;
   const int grid = (a.items + a.ipw - 1) / a.ipw;
   a.WPX = s1x_wpx(W); a.PA = a.WPX / 8;
-  const size_t lds = (size_t)2 * a.WPX * 128 + SX_XWIN_B + 2 * SX_STG_B + 1024 + (size_t)a.ntiles * SX_NTILE * 4;
+  const int nstg = s1x_stages(W, N);
+  const size_t lds = (size_t)2 * a.WPX * 128 + SX_XWIN_B + nstg * SX_STG_B + 1024 + (size_t)a.ntiles * SX_NTILE * 4;
   hipStream_t st = (hipStream_t)stream;
-#define SX_LAUNCH(NPS_)                                                                                                       \
-  do {                                                                                                                        \
-    (void)hipFuncSetAttribute((const void*)conv3x3_s1x_kernel<NPS_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    hipLaunchKernelGGL((conv3x3_s1x_kernel<NPS_>), dim3(grid), dim3(512), lds, st, a);                                        \
+#define SX_LAUNCH2(NPS_, NSTG_)                                                                                                       \
+  do {                                                                                                                                \
+    (void)hipFuncSetAttribute((const void*)conv3x3_s1x_kernel<NPS_, NSTG_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL((conv3x3_s1x_kernel<NPS_, NSTG_>), dim3(grid), dim3(512), lds, st, a);                                        \
   } while (0)
+#define SX_LAUNCH(NPS_) do { if (nstg == 3) SX_LAUNCH2(NPS_, 3); else SX_LAUNCH2(NPS_, 2); } while (0)
   if (a.PA <= 36) SX_LAUNCH(9);
   else if (a.PA <= 40) SX_LAUNCH(10);
   else SX_LAUNCH(11);
+#undef SX_LAUNCH2
 #undef SX_LAUNCH
   return (int)hipGetLastError();
 }

@@ -100,7 +100,7 @@ def _s1x_w(w2, wd):
     then (c < Cd/64) chunk c of the shortcut."""
     o, c1 = w2.shape[0], w2.shape[1]
     cd = wd.shape[1]
-    assert c1 % 64 == 0 and cd % 64 == 0 and cd <= c1 and wd.shape[0] == o
+    assert c1 % 64 == 0 and cd % 64 == 0 and cd <= c1 and (cd == 0 or wd.shape[0] == o)
     rows = []
     for c in range(c1 // 64):
         rows.append(w2[:, 64 * c:64 * c + 64].permute(0, 2, 3, 1).reshape(o, 9, 64))
@@ -504,9 +504,9 @@ class DANetEncoderHIP:
                 # down-sampling block of the bf16 model: relu(bn2(conv2(t)) + bn_d(conv_d(cur))) as ONE accumulation — the
                 # shortcut's 1 / 2 / 4 k-tiles ride behind conv2's, no shortcut tensor is written or read back
                 w_f, sh_f = self.s1x[i]
-                out = self._buf("b%d_o" % i, (F, H2, W2, c2.cout), torch.bfloat16)
-                hip.conv3x3_s1x(t, cur, w_f, sh_f, out, F, H2, W2, c2.cin, down.cin, c2.cout, 1)
-                cur, H, W = out, H2, W2
+                blk_out = self._buf("b%d_o" % i, (F, H2, W2, c2.cout), torch.bfloat16)
+                hip.conv3x3_s1x(t, cur, w_f, sh_f, blk_out, F, H2, W2, c2.cin, down.cin, c2.cout, 1)
+                cur, H, W = blk_out, H2, W2
                 continue
             idt = cur
             if down is not None:

@@ -1512,7 +1512,8 @@ def test_conv3x3_s2_full_size_repeatable_under_load(hip):
 # conv2 of a down-sampling block with the shortcut as K-extension (csrc/conv3x3_s1x.hip, round 5)
 @pytest.mark.parametrize("Nimg,H,W,C1,Cd,Cout", [(3, 9, 9, 128, 64, 128), (2, 18, 18, 256, 128, 256), (5, 4, 6, 64, 64, 64),
                                                  (1, 1, 2, 128, 64, 32), (7, 5, 3, 256, 128, 160), (2, 36, 36, 128, 64, 128),
-                                                 (3, 9, 9, 512, 256, 512), (4, 7, 46, 128, 128, 96)])
+                                                 (3, 9, 9, 512, 256, 512), (4, 7, 46, 128, 128, 96), (3, 18, 18, 128, 0, 128),
+                                                 (2, 36, 36, 64, 0, 64)])
 def test_conv3x3_s1x_matches_torch(hip, Nimg, H, W, C1, Cd, Cout):
     """cadre_conv3x3_s1x vs torch-CPU fp32: relu(conv2d(t, W2, pad 1) + conv2d(x, Wd, stride 2) + shift) on bf16-rounded operands
     (resnet.py:40-55 with the downsample of resnet.py:152-158; both BN scales folded into the weights): 1-8 chunks with 1-4
@@ -1521,13 +1522,16 @@ def test_conv3x3_s1x_matches_torch(hip, Nimg, H, W, C1, Cd, Cout):
     from cadre_amd.encoder import _s1x_w
     g = torch.Generator().manual_seed(Nimg * 1000 + H * 10 + C1 + Cout)
     t = _bf(torch.randn(Nimg, C1, H, W, generator=g))
-    x = _bf(torch.randn(Nimg, Cd, 2 * H, 2 * W, generator=g))
+    x = _bf(torch.randn(Nimg, max(Cd, 1), 2 * H, 2 * W, generator=g))
     w2 = _bf(torch.randn(Cout, C1, 3, 3, generator=g) / (C1 * 9) ** 0.5)
-    wd = _bf(torch.randn(Cout, Cd, 1, 1, generator=g) / Cd ** 0.5)
+    wd = _bf(torch.randn(Cout, Cd, 1, 1, generator=g) / max(Cd, 1) ** 0.5)
     shift = torch.randn(Cout, generator=g)
-    want = F.relu(F.conv2d(t.float(), w2.float(), None, 1, 1) + F.conv2d(x.float(), wd.float(), None, 2, 0) + shift.view(1, -1, 1, 1))
+    want = F.conv2d(t.float(), w2.float(), None, 1, 1) + shift.view(1, -1, 1, 1)
+    if Cd:                                                    # (Cd == 0: no shortcut — the kernel as a plain 3x3 / s1 conv)
+        want = want + F.conv2d(x.float(), wd.float(), None, 2, 0)
+    want = F.relu(want)
     assert hip.lib().cadre_conv3x3_s1x_supported(Nimg, H, W, C1, Cd, Cout) == 1
-    td = dev(t.permute(0, 2, 3, 1).contiguous()); xd = dev(x.permute(0, 2, 3, 1).contiguous())
+    td = dev(t.permute(0, 2, 3, 1).contiguous()); xd = dev(x.permute(0, 2, 3, 1).contiguous()) if Cd else None
     wf = dev(_s1x_w(w2.float(), wd.float())).to(torch.bfloat16)
     out = torch.full((Nimg, H, W, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
     hip.conv3x3_s1x(td, xd, wf, dev(shift), out, Nimg, H, W, C1, Cd, Cout, 1)

@@ -93,5 +93,37 @@ def main():
               % (name, C1, C1, H, Cd, C1, tf, fl / tf / 1e9, tr, td_, tr + td_, d), flush=True)
 
 
+def plain():
+    """The new kernel's structure against conv3x3_ring_pp_kernel at equal work: cadre_conv3x3_s1x with NO shortcut (Cd = 0) on the
+    stride-1 convs without residual (conv1 of the second blocks)."""
+    F = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+    g = torch.Generator(device="cuda").manual_seed(2)
+    for name, H, C in (("layer2", 36, 128), ("layer3", 18, 256), ("layer4", 9, 512)):
+        t = torch.randn(F, H, H, C, device="cuda", generator=g).to(torch.bfloat16)
+        w = (torch.randn(C, C, 3, 3, device="cuda", generator=g) / np.sqrt(9 * C)).to(torch.bfloat16)
+        sh = torch.randn(C, device="cuda", generator=g)
+        wr = _ring_w(w.float().cpu(), 64).to(torch.bfloat16).cuda()
+        wf = wr.reshape(C, -1, 64).contiguous()
+        o1 = torch.empty(F, H, H, C, device="cuda", dtype=torch.bfloat16); o2 = torch.empty_like(o1)
+        ts = {"s1x": [], "ring": []}
+        fns = {"s1x": lambda: hip.conv3x3_s1x(t, None, wf, sh, o1, F, H, H, C, 0, C, 1),
+               "ring": lambda: hip.conv3x3_ring(t, wr, None, sh, None, o2, F, H, H, C, C, 1)}
+        for rnd in range(6):
+            for k, fn in fns.items():
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                fn(); torch.cuda.synchronize()
+                e0.record()
+                for _ in range(5):
+                    fn()
+                e1.record(); torch.cuda.synchronize()
+                if rnd:
+                    ts[k].append(e0.elapsed_time(e1) / 5)
+        fl = 2.0 * F * H * H * C * 9 * C
+        d = float((o1.float() - o2.float()).abs().max() / o2.float().abs().max())
+        print("%s 3x3/s1 %d->%d @%d no residual: s1x (no shortcut) %.3f ms (%.1f TFLOP/s) | ring_pp %.3f ms (%.1f TFLOP/s)   max diff %.2e"
+              % (name, C, C, H, np.median(ts["s1x"]), fl / np.median(ts["s1x"]) / 1e9, np.median(ts["ring"]), fl / np.median(ts["ring"]) / 1e9, d), flush=True)
+
+
 if __name__ == "__main__":
     main()
+    plain()
