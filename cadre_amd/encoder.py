@@ -541,7 +541,10 @@ class DANetEncoderHIP:
         hid = self._buf("ita_hid", (F, 3072))
         # split-K chosen from K alone: every output element is then summed in the same order for any
         # frame batch, so per-frame results are bit-identical across batch sizes (latent cache, §8f-1)
-        split = int(max(1, min(32, Kin // 2048)))
+        # (K per slice ~ 2592: at 288 x 288 (Kin = 41472) 16 slices — 48 tiles of 256 x 256 x 16 = 768 workgroups = three full rounds
+        #  of the 256 CUs (bf16; fp32: 96 tiles of 128 x 128 x 16 = 1536 = three rounds at two per CU) and a fifth less fp32 slab
+        #  traffic than the 20 slices of rounds 1-4, which left 960 / 1920 workgroups = 3.75 rounds)
+        split = int(max(1, min(32, (Kin + 1296) // 2592)))
         for b, src in enumerate((vis, bc)):
             if split > 1:
                 slabs = self._buf("ita_slab", (split, F, 1536))
