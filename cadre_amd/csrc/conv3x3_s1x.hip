@@ -14,7 +14,7 @@
 //     E_c  (c < NCd) one k-tile from the 256-row window of x's even-row / even-column pixels (2h, 2w), chunk c of x —
 //          the lane computes the NHWC address of its pixel (one floor-division by W per 8-pixel piece, once per M tile).
 // Weights arrive in exactly that k-tile order: [N][9 NC + NCd][64].  The epilogue is conv3x3_s2.hip's: sums start at the
-// shift, ReLU, pairwise conversion to bf16, one v_permlane32_swap per dword pair, 16-byte stores, no LDS.
+// shift, ReLU, pairwise conversion to bf16, a 4 KB LDS slab per wave, stores of eight full 128-byte lines per instruction.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s1x_kernel(s1x_args a) {
     }
   };
 
-  // ---- epilogue (conv3x3_s2.hip): sums start at the shift; ReLU, bf16 pairs, one lane-half exchange per dword pair, 16-byte stores
+  // ---- epilogue (conv3x3_s2.hip): sums start at the shift; ReLU, bf16 pairs, an LDS slab turns them into full-line stores
   f32x16 acc[2][2];
   const float act_floor = (a.act & 15) == 1 ? 0.f : -__builtin_inff();
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -185,33 +185,36 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s1x_kernel(s1x_args a) {
       }
     }
   };
-  auto epilogue = [&](int mt_e, int nt_e) {
-    const int eb = (mt_e * SX_BM + 64 * wm + l31) * a.N + nt_e * SX_NTILE + 64 * wn + 8 * lh;
+  // (stores through a 4 KB slab per wave, as in conv3x3_s2.hip: every store instruction writes eight full 128-byte lines.  `slab`:
+  //  the stride-1 window buffer that is free while the epilogue runs — the last chunk's, read last two slots ago, requested again
+  //  at the new item's first k-tile, after the epilogue)
+  auto epilogue = [&](int mt_e, int nt_e, unsigned slab) {
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    char* sl = smem + slab + wave * 4096;
+    const int prow = lane >> 3, pch = lane & 7;
+    const bool ch_ok = nt_e * SX_NTILE + 64 * wn + 32 * (pch >> 2) < a.N;
+    const int eb = (mt_e * SX_BM + 64 * wm + prow) * a.N + nt_e * SX_NTILE + 64 * wn + 8 * pch;
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-      const bool ch_ok = nt_e * SX_NTILE + 64 * wn + 32 * cb < a.N;
+    for (int rb = 0; rb < 2; ++rb) {
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
-        unsigned d[8];
+      for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const bf16x2 pk = {(__bf16)fmaxf(acc[rb][cb][2 * j], act_floor), (__bf16)fmaxf(acc[rb][cb][2 * j + 1], act_floor)};
-          d[j] = __builtin_bit_cast(unsigned, pk);
+        for (int g = 0; g < 4; ++g) {
+          const bf16x2 p0 = {(__bf16)fmaxf(acc[rb][cb][4 * g], act_floor), (__bf16)fmaxf(acc[rb][cb][4 * g + 1], act_floor)};
+          const bf16x2 p1 = {(__bf16)fmaxf(acc[rb][cb][4 * g + 2], act_floor), (__bf16)fmaxf(acc[rb][cb][4 * g + 3], act_floor)};
+          *reinterpret_cast<u32x2_t*>(sl + l31 * 128 + (((4 * cb + g) ^ (l31 & 7)) << 4) + 8 * lh) =
+              u32x2_t{__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)};
         }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          unsigned fx[2], fy[2];
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            fx[e] = d[4 * h + e]; fy[e] = d[4 * h + 2 + e];
-            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(fx[e]), "+v"(fy[e]));
-          }
-          const int eo = eb + 32 * rb * a.N + 32 * cb + 16 * h;
-          const int bo = (int)((unsigned)(eo * 2) | (ch_ok ? 0u : OOB));
-          __builtin_amdgcn_raw_buffer_store_b128(u32x4{fx[0], fx[1], fy[0], fy[1]}, rsC, bo, 0, 0);
-        }
+      for (int i = 0; i < 4; ++i) {
+        const int pos = 8 * i + prow;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(sl + pos * 128 + ((pch ^ (pos & 7)) << 4));
+        const int eo = eb + (32 * rb + 8 * i) * a.N;
+        const int bo = (int)((unsigned)(eo * 2) | (ch_ok ? 0u : OOB));
+        __builtin_amdgcn_raw_buffer_store_b128(v, rsC, bo, 0, 0);
       }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
 
   // ---- prologue: group 1 brings the first stride-1 window, group 0 the weights of k-tile 0
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s1x_kernel(s1x_args a) {
       __builtin_amdgcn_s_setprio(2);
       if constexpr (GRP == 0 && NSTG == 2) send_wts(nt, 1, kpar ^ 1, true);
       if (have_prev) {
-        epilogue(mt_p, nt_p);
+        epilogue(mt_p, nt_p, (unsigned)((sbuf ^ 1) * win_bytes));
         if constexpr (GRP == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
       }
       acc_init(nt);
@@ -430,7 +433,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s1x_kernel(s1x_args a) {
     }
     // tail: the last item's epilogue (group 0 one slot before group 1)
     __builtin_amdgcn_s_setprio(0);
-    epilogue(mt_p, nt_p);
+    epilogue(mt_p, nt_p, (unsigned)((sbuf ^ 1) * win_bytes));
     __builtin_amdgcn_s_barrier();
   };
   if (grp == 0) run(integral_constant<int, 0>{});

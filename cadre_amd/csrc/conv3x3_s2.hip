@@ -86,7 +86,7 @@ __device__ __forceinline__ void s2_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)
 template <int NPW>
 __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(s2_args a) {
   constexpr int NH = (NPW + 1) / 2;                         // a window's pieces go out in two k-tiles: NH, then NPW - NH
-  constexpr int NST = 8;                                   // epilogue stores per wave: 4 blocks of 32 x 32 x two 16-byte halves
+  constexpr int NST = 8;                                   // epilogue stores per wave: two 32-position x 64-channel blocks x four 1 KB stores
   constexpr unsigned OOB = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -197,11 +197,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(s2_args a) {
     }
   };
 
-  // ---- epilogue of one item, no LDS slab and no BN arithmetic: the folded-BN scale is in the weights (the caller folds it:
-  // scale == NULL is part of the contract), the shift is the accumulators' initial value.  Accumulator tile (rb, cb): lane
-  // (l31, lh), register r holds position 32 rb + l31, channel 32 cb + 8 (r >> 2) + 4 lh + (r & 3).  ReLU, pairwise conversion
-  // to bf16 (dword j = channels 8 (j >> 1) + 4 lh + 2 (j & 1) + {0, 1}), then ONE v_permlane32_swap per dword pair leaves lane
-  // (l31, lh) with channels 32 cb + 16 h + 8 lh .. + 7 (h = 0, 1): one 16-byte store per (tile, h), 16 swaps per item.
+  // ---- epilogue of one item, no BN arithmetic: the folded-BN scale is in the weights (the caller folds it: scale == NULL is
+  // part of the contract), the shift is the accumulators' initial value.  Accumulator tile (rb, cb): lane (l31, lh), register r
+  // holds position 32 rb + l31, channel 32 cb + 8 (r >> 2) + 4 lh + (r & 3).  ReLU and pairwise conversion to bf16 in registers.
   f32x16 acc[2][2];
   const float act_floor = (a.act & 15) == 1 ? 0.f : -__builtin_inff();
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -217,7 +215,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(s2_args a) {
       }
     }
   };
-  auto epilogue = [&](int mt_e, int nt_e) {
+  // Stores.  The lane-half exchange leaves a lane with 16 bytes of a position: a store instruction then writes 32 rows x 32 bytes,
+  // four instructions per 128-byte line — measured against (wrong) fully coalesced stores that pattern costs 6-8 % of a launch
+  // (profiles/r05_s2_store_coalescing_ablation.txt).  So the bf16 pairs of a 32-position x 64-channel block go through a 4 KB
+  // slab of LDS instead (rows of 128 bytes, 16-byte chunks XOR-swizzled by the row) and come back as (position lane >> 3,
+  // chunk lane & 7): every store instruction writes EIGHT FULL 128-byte lines, four instructions per block instead of eight
+  // pieces.  The slabs live in the window buffer that is free while the epilogue runs (`slab`: the (1,0) buffer of the chunk that
+  // begins — read last two slots ago, requested again at its k-tile 1).
+  auto epilogue = [&](int mt_e, int nt_e, unsigned slab) {
     if constexpr ((S2_ABL & 16) != 0) {
 #pragma unroll
       for (int rb = 0; rb < 2; ++rb)
@@ -226,33 +231,33 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(s2_args a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) { const float t = acc[rb][cb][r]; asm volatile("" :: "v"(t)); }
     } else {
-      const int eb = (mt_e * S2_BM + 64 * wm + l31) * a.N + nt_e * S2_NTILE + 64 * wn + 8 * lh;
+      typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+      char* sl = smem + slab + wave * 4096;
+      const int prow = lane >> 3, pch = lane & 7;           // read-back: position 8 i + prow, 16-byte chunk pch (channels 8 pch .. + 7)
+      const bool ch_ok = nt_e * S2_NTILE + 64 * wn + 32 * (pch >> 2) < a.N;     // (N % 32 == 0)
+      const int eb = (mt_e * S2_BM + 64 * wm + prow) * a.N + nt_e * S2_NTILE + 64 * wn + 8 * pch;
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
-        const bool ch_ok = nt_e * S2_NTILE + 64 * wn + 32 * cb < a.N;          // (N % 32 == 0)
+      for (int rb = 0; rb < 2; ++rb) {
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-          unsigned d[8];
+        for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const bf16x2 pk = {(__bf16)fmaxf(acc[rb][cb][2 * j], act_floor), (__bf16)fmaxf(acc[rb][cb][2 * j + 1], act_floor)};
-            d[j] = __builtin_bit_cast(unsigned, pk);
+          for (int g = 0; g < 4; ++g) {
+            // registers 4 g .. 4 g + 3 of tile (rb, cb): channels 32 cb + 8 g + 4 lh .. + 3 of position l31 -> 8 bytes of chunk 4 cb + g
+            const bf16x2 p0 = {(__bf16)fmaxf(acc[rb][cb][4 * g], act_floor), (__bf16)fmaxf(acc[rb][cb][4 * g + 1], act_floor)};
+            const bf16x2 p1 = {(__bf16)fmaxf(acc[rb][cb][4 * g + 2], act_floor), (__bf16)fmaxf(acc[rb][cb][4 * g + 3], act_floor)};
+            *reinterpret_cast<u32x2_t*>(sl + l31 * 128 + (((4 * cb + g) ^ (l31 & 7)) << 4) + 8 * lh) =
+                u32x2_t{__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)};
           }
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            unsigned fx[2], fy[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-              // v_permlane32_swap x, y: x <- [x.lo, y.lo], y <- [x.hi, y.hi] (inline asm: see conv3x3_ring.hip on the builtin)
-              fx[e] = d[4 * h + e]; fy[e] = d[4 * h + 2 + e];
-              asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(fx[e]), "+v"(fy[e]));
-            }
-            const int eo = eb + 32 * rb * a.N + 32 * cb + 16 * h;
-            const int bo = (int)((unsigned)(eo * 2) | (ch_ok ? 0u : OOB));      // (a position past M lies past num_records)
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{fx[0], fx[1], fy[0], fy[1]}, rsC, bo, 0, 0);
-          }
+        for (int i = 0; i < 4; ++i) {
+          const int pos = 8 * i + prow;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(sl + pos * 128 + ((pch ^ (pos & 7)) << 4));
+          const int eo = eb + (32 * rb + 8 * i) * a.N;
+          const int bo = (int)((unsigned)(eo * 2) | (ch_ok ? 0u : OOB));        // (a position past M lies past num_records)
+          __builtin_amdgcn_raw_buffer_store_b128(v, rsC, bo, 0, 0);
         }
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (slab reads done before this buffer's next window may land)
     }
   };
 
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(s2_args a) {
       __builtin_amdgcn_s_setprio(2);
       if constexpr (GRP == 0) send_wts(nt, 0, 1, kpar ^ 1, true);
       if (have_prev) {
-        epilogue(mt_p, nt_p);
+        epilogue(mt_p, nt_p, (unsigned)(b2 * S2_WIN_B));
         if constexpr (GRP == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
       }
       acc_init(nt);                                        // the sums start at the folded-BN shift
@@ -438,7 +443,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(s2_args a) {
     }
     // ---- tail: the last item's epilogue (group 0 one slot before group 1)
     __builtin_amdgcn_s_setprio(0);
-    epilogue(mt_p, nt_p);
+    epilogue(mt_p, nt_p, (unsigned)(b2 * S2_WIN_B));
     __builtin_amdgcn_s_barrier();
   };
   if (grp == 0) run(integral_constant<int, 0>{});

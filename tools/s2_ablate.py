@@ -14,10 +14,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ABLS = [0, 4, 8, 16, 12, 30]
+ABLS = [0, 16, 32]
 NAMES = {0: "full kernel", 1: "no MFMA", 2: "no fragment reads", 4: "no window DMA", 8: "no weight DMA", 16: "no epilogue",
          12: "no DMA at all", 14: "MFMA + epilogue only (no reads, no DMA)", 30: "schedule + MFMA only", 31: "empty schedule (barriers + waits)",
-         }
+         32: "stores fully coalesced (wrong places)"}
 
 
 def so_path(abl):
