@@ -49,8 +49,8 @@ int cadre_fail(const char* msg);
 
 #define S2_BM 256                  // output positions per item
 #define S2_NTILE 128               // output channels per item
-#define S2_PA_MAX 37               // 8-pixel pieces per window buffer: 296 pixels >= 256 + Wo + 1 (Wo <= 39)
-#define S2_WIN_B (S2_PA_MAX * 1024)
+// a window buffer holds 4 * NPW pieces of 8 pixels (NPW = 9: 288 pixels >= 256 + Wo + 1 for Wo <= 31; NPW = 10: 320 pixels, Wo <= 39):
+// every piece of a window is then requested unconditionally — no per-piece "inside the window?" select in the staging slots
 #define S2_STG_B (S2_NTILE * 128)
 
 // -DS2_ABL=<bits>: timing ablations (results wrong by construction, never in the product build): 1 no MFMAs, 2 no fragment
@@ -76,7 +76,6 @@ struct s2_args {
   int Ho, Wo, W, Cin, N, NC;
   int act;                // 0 none, 1 ReLU
   int mtiles, ntiles, items, ipw;
-  int PA;                 // live 8-pixel pieces of a window: ceil((256 + Wo + 1) / 8) <= S2_PA_MAX
 };
 
 template <int N>
@@ -86,6 +85,7 @@ __device__ __forceinline__ void s2_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)
 template <int NPW>
 __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(s2_args a) {
   constexpr int NH = (NPW + 1) / 2;                         // a window's pieces go out in two k-tiles: NH, then NPW - NH
+  constexpr int S2_WIN_B = 4 * NPW * 1024;                  // bytes of one window buffer
   constexpr int NST = 8;                                   // epilogue stores per wave: two 32-position x 64-channel blocks x four 1 KB stores
   constexpr unsigned OOB = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(s2_args a) {
   const int wm = wave >> 1, wn = wave & 1;                 // 64-position block, 64-channel half
   const int grp = wave >> 2, pb = wave & 3;                // ping-pong group (waves w, w + 4 share a SIMD); DMA piece lane of the wave
   char* win0 = smem;                                       // three window buffers, two weight stages, the zero row / dump, folded BN
-  char* bst = smem + 3 * S2_WIN_B;
+  char* bst = smem + 3 * (4 * NPW * 1024);
   char* dump = bst + 2 * S2_STG_B;
   float* sc_lds = reinterpret_cast<float*>(dump + 1024);
 
@@ -104,7 +104,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(s2_args a) {
   if (nitems <= 0) return;
   const int cin_b = a.Cin * 2;
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.Min * cin_b, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsX0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, 0, 0x00020000);      // zero records: every request reads zeros
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.N * a.NC * 9 * 128, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, a.M * a.N * 2, 0x00020000);
   for (int i = tid; i < 256; i += 512) reinterpret_cast<unsigned*>(dump)[i] = 0u;       // ZERO ROW (halo taps) and dummy DMA target
   for (int i = tid; i < a.ntiles * S2_NTILE; i += 512) sc_lds[i] = (a.shift && i < a.N) ? a.shift[i] : 0.f;      // folded-BN shift of every channel
@@ -126,7 +128,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(s2_args a) {
   // (An odd-row plane's pixel is the even-row plane's pixel of the same column parity ONE INPUT ROW UP: row r of window (1,1) /
   //  (1,0) = row r of window (0,1) / (0,0) minus W pixels.  The two families share the division: 25 hoisted offsets per chunk
   //  instead of 40 — the difference between fitting 256 registers and spilling — and one subtraction left in the staging slot.)
-  auto send_win = [&](int mt_n, int c_n, auto ph_c, int bufsel, int n, bool live) {
+  // (a window of the chunk AFTER the workgroup's last one is requested through a descriptor with zero records — zeros land in a
+  //  buffer nobody reads — instead of a per-piece "live?" select of offset and target)
+  auto send_win = [&](const __amdgpu_buffer_rsrc_t rs, int mt_n, int c_n, auto ph_c, int bufsel, int n) {
     constexpr int ph = decltype(ph_c)::value;              // 0: plane (1,1), 1: (0,1), 2: (1,0), 3: (0,0)
     constexpr int pc = (ph == 0 || ph == 1) ? 1 : 0;       // column parity; the family's even-row window starts at -pc
     constexpr bool up = (ph == 0 || ph == 2);
@@ -138,16 +142,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(s2_args a) {
     q += (r >= Wo) ? 1 : 0;
     q -= (r < 0) ? 1 : 0;
     const int px = 2 * pp + q * Wi + pc;
-    const bool ok = live && j < a.PA;
-    unsigned common = (unsigned)(px * cin_b + c_n * 128 + sw_lane);
+    unsigned voff = (unsigned)(px * cin_b + c_n * 128 + sw_lane);
     if constexpr (up) {
-      asm volatile("" : "+v"(common));                     // (the shared value is hoisted, the row-up subtraction stays here)
-      common -= (unsigned)(Wi * cin_b);
+      asm volatile("" : "+v"(voff));                       // (the shared value is hoisted, the row-up subtraction stays here)
+      voff -= (unsigned)(Wi * cin_b);
     }
-    unsigned voff = common | (ok ? 0u : OOB);
-    char* dst = ok ? win0 + bufsel * S2_WIN_B + j * 1024 : dump;
+    char* dst = win0 + bufsel * S2_WIN_B + j * 1024;
     if ((S2_ABL & 4) && !abl_pro) { voff = OOB; dst = dump; }
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (__attribute__((address_space(3))) void*)dst, 16, (int)voff, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, (int)voff, 0, 0, 0);
   };
   // ---- weight DMA (group 0): stage piece pc4 = 4 pb + k (k = 0 .. 3): rows 8 pc4 .. + 7
   int b_lane[4];
@@ -156,13 +158,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(s2_args a) {
     const int r = (4 * pb + k) * 8 + (lane >> 3);
     b_lane[k] = r * a.NC * 9 * 128 + (((lane & 7) ^ swz(r)) << 4);
   }
-  auto send_wts = [&](int nt_b, int c, int tap, int stg, bool live) {
+  auto send_wts = [&](const __amdgpu_buffer_rsrc_t rs, int nt_b, int c, int tap, int stg) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      unsigned voff = (unsigned)(nt_b * (S2_NTILE * a.NC * 9 * 128) + (c * 9 + tap) * 128 + b_lane[k]) | (live ? 0u : OOB);
+      unsigned voff = (unsigned)(nt_b * (S2_NTILE * a.NC * 9 * 128) + (c * 9 + tap) * 128 + b_lane[k]);
       char* dst = bst + stg * S2_STG_B + (4 * pb + k) * 1024;
       if ((S2_ABL & 8) && !abl_pro) { voff = OOB; dst = dump; }
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)dst, 16, (int)voff, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, (int)voff, 0, 0, 0);
     }
   };
   // ---- lane constants of the fragment reads.  k-step s of this lane half reads the logical 16-byte chunk 2 s + lh = (s << 1) | lh;
@@ -265,11 +267,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(s2_args a) {
   // k-tile 0; everything landed and published
   if (grp == 1) {
 #pragma unroll
-    for (int n = 0; n < NPW; ++n) send_win(mt, 0, std::integral_constant<int, 0>{}, 0, n, true);
+    for (int n = 0; n < NPW; ++n) send_win(rsX, mt, 0, std::integral_constant<int, 0>{}, 0, n);
 #pragma unroll
-    for (int n = 0; n < NH; ++n) send_win(mt, 0, std::integral_constant<int, 1>{}, 1, n, true);
+    for (int n = 0; n < NH; ++n) send_win(rsX, mt, 0, std::integral_constant<int, 1>{}, 1, n);
   } else {
-    send_wts(nt, 0, 0, 0, true);
+    send_wts(rsW, nt, 0, 0, 0);
   }
   s2_wait_vm<0>();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(s2_args a) {
       // groups side by side (group 1 is still in its M slot of the previous item's last k-tile: it takes that slot's closing
       // barrier only now)
       __builtin_amdgcn_s_setprio(2);
-      if constexpr (GRP == 0) send_wts(nt, 0, 1, kpar ^ 1, true);
+      if constexpr (GRP == 0) send_wts(rsW, nt, 0, 1, kpar ^ 1);
       if (have_prev) {
         epilogue(mt_p, nt_p, (unsigned)(b2 * S2_WIN_B));
         if constexpr (GRP == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
@@ -316,6 +318,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(s2_args a) {
         const bool last_c = c + 1 == a.NC;
         const int mt_n = last_c ? mt1 : mt, nt_n = last_c ? nt1 : nt, c_n = last_c ? 0 : c + 1;
         const bool live_n = !last_c || more;
+        const __amdgpu_buffer_rsrc_t rsXn = live_n ? rsX : rsX0, rsWn = live_n ? rsW : rsW0;      // (past the workgroup's last chunk: zero records)
         const unsigned wb0 = (unsigned)(b0 * S2_WIN_B), wb1 = (unsigned)(b1 * S2_WIN_B), wb2 = (unsigned)(b2 * S2_WIN_B);
         const unsigned st_even = (unsigned)((bst - smem) + kpar * S2_STG_B), st_odd = (unsigned)((bst - smem) + (kpar ^ 1) * S2_STG_B);
 #pragma unroll
@@ -357,37 +360,37 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_kernel(s2_args a) {
           __builtin_amdgcn_sched_barrier(0);               // (the reads go out first: their latency runs under the issue below)
           if constexpr (GRP == 0) {
             // weights of k-tile t + 1 into the stage k-tile t - 1 was read from (its last readers, group 1, finished a slot ago)
-            if (t == 0) { if (c > 0) send_wts(nt, c, 1, kpar ^ 1, true); }      // (the item's first chunk: sent in the head)
-            else if (t < 8) send_wts(nt, c, t + 1, ((t + 1) & 1) ^ kpar, true);
-            else send_wts(nt_n, c_n, 0, kpar ^ 1, live_n); // next chunk's k-tile 0: the stage parity flips with the chunk
+            if (t == 0) { if (c > 0) send_wts(rsW, nt, c, 1, kpar ^ 1); }      // (the item's first chunk: sent in the head)
+            else if (t < 8) send_wts(rsW, nt, c, t + 1, ((t + 1) & 1) ^ kpar);
+            else send_wts(rsWn, nt_n, c_n, 0, kpar ^ 1);   // next chunk's k-tile 0: the stage parity flips with the chunk
           } else {
             // window pieces, static schedule (the buffer a window goes into was read last two phases ago):
             //   t0: (0,1) of this chunk, second half | t1, t2: (1,0) of this chunk | t4, t5: (0,0) of this chunk (re-uses b0)
             //   t6, t7: (1,1) of the NEXT chunk -> b1 | t8: (0,1) of the next chunk, first half -> b2
             if (t == 0) {
 #pragma unroll
-              for (int n = NH; n < NPW; ++n) send_win(mt, c, integral_constant<int, 1>{}, b1, n, true);
+              for (int n = NH; n < NPW; ++n) send_win(rsX, mt, c, integral_constant<int, 1>{}, b1, n);
             } else if (t == 1) {
 #pragma unroll
-              for (int n = 0; n < NH; ++n) send_win(mt, c, integral_constant<int, 2>{}, b2, n, true);
+              for (int n = 0; n < NH; ++n) send_win(rsX, mt, c, integral_constant<int, 2>{}, b2, n);
             } else if (t == 2) {
 #pragma unroll
-              for (int n = NH; n < NPW; ++n) send_win(mt, c, integral_constant<int, 2>{}, b2, n, true);
+              for (int n = NH; n < NPW; ++n) send_win(rsX, mt, c, integral_constant<int, 2>{}, b2, n);
             } else if (t == 4) {
 #pragma unroll
-              for (int n = 0; n < NH; ++n) send_win(mt, c, integral_constant<int, 3>{}, b0, n, true);
+              for (int n = 0; n < NH; ++n) send_win(rsX, mt, c, integral_constant<int, 3>{}, b0, n);
             } else if (t == 5) {
 #pragma unroll
-              for (int n = NH; n < NPW; ++n) send_win(mt, c, integral_constant<int, 3>{}, b0, n, true);
+              for (int n = NH; n < NPW; ++n) send_win(rsX, mt, c, integral_constant<int, 3>{}, b0, n);
             } else if (t == 6) {
 #pragma unroll
-              for (int n = 0; n < NH; ++n) send_win(mt_n, c_n, integral_constant<int, 0>{}, b1, n, live_n);
+              for (int n = 0; n < NH; ++n) send_win(rsXn, mt_n, c_n, integral_constant<int, 0>{}, b1, n);
             } else if (t == 7) {
 #pragma unroll
-              for (int n = NH; n < NPW; ++n) send_win(mt_n, c_n, integral_constant<int, 0>{}, b1, n, live_n);
+              for (int n = NH; n < NPW; ++n) send_win(rsXn, mt_n, c_n, integral_constant<int, 0>{}, b1, n);
             } else if (t == 8) {
 #pragma unroll
-              for (int n = 0; n < NH; ++n) send_win(mt_n, c_n, integral_constant<int, 1>{}, b2, n, live_n);
+              for (int n = 0; n < NH; ++n) send_win(rsXn, mt_n, c_n, integral_constant<int, 1>{}, b2, n);
             }
             // a window is confirmed (in-order completion: everything but the pieces issued after its last one) in the slot
             // before group 0 first reads it: (0,1) at t3, (1,0) at t5, (0,0) at t7, the next chunk's (1,1) at t8
@@ -460,7 +463,8 @@ static int s2_capable(int F, int H, int W, int Cin, int N) {
   if (Min * Cin * 2 >= lim || (long long)N * Cin * 9 * 2 >= lim || M * N * 2 >= lim) return 0;
   if (M >= (1 << 23)) return 0;                            // the plane-position division runs in fp32
   const int ntiles = (N + S2_NTILE - 1) / S2_NTILE;
-  if ((size_t)3 * S2_WIN_B + 2 * S2_STG_B + 1024 + (size_t)ntiles * S2_NTILE * 4 > 160 * 1024) return 0;
+  const int npw = (S2_BM + Wo + 1 + 7) / 8 <= 36 ? 9 : 10;
+  if ((size_t)3 * 4 * npw * 1024 + 2 * S2_STG_B + 1024 + (size_t)ntiles * S2_NTILE * 4 > 160 * 1024) return 0;
   return 1;
 }
 
@@ -489,10 +493,10 @@ extern "C" int cadre_conv3x3_s2(const void* x, const void* w, const float* scale
   const int wgs = a.items < 256 ? a.items : 256;           // persistent workgroups: one per CU
   a.ipw = (a.items + wgs - 1) / wgs;
   const int grid = (a.items + a.ipw - 1) / a.ipw;
-  a.PA = (S2_BM + a.Wo + 1 + 7) / 8;
-  const size_t lds = (size_t)3 * S2_WIN_B + 2 * S2_STG_B + 1024 + (size_t)a.ntiles * S2_NTILE * 4;
+  const int npw = (S2_BM + a.Wo + 1 + 7) / 8 <= 36 ? 9 : 10;
+  const size_t lds = (size_t)3 * 4 * npw * 1024 + 2 * S2_STG_B + 1024 + (size_t)a.ntiles * S2_NTILE * 4;
   hipStream_t st = (hipStream_t)stream;
-  if (a.PA <= 36) {
+  if (npw == 9) {
     (void)hipFuncSetAttribute((const void*)conv3x3_s2_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL((conv3x3_s2_kernel<9>), dim3(grid), dim3(512), lds, st, a);
   } else {

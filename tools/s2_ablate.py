@@ -14,7 +14,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ABLS = [0, 16, 32]
+ABLS = [0, 16]
 NAMES = {0: "full kernel", 1: "no MFMA", 2: "no fragment reads", 4: "no window DMA", 8: "no weight DMA", 16: "no epilogue",
          12: "no DMA at all", 14: "MFMA + epilogue only (no reads, no DMA)", 30: "schedule + MFMA only", 31: "empty schedule (barriers + waits)",
          32: "stores fully coalesced (wrong places)"}
