@@ -320,7 +320,7 @@ def kname(k):
     if k[0] == "s2":
         return "conv3x3_s2_kernel<%d>" % k[1]
     if k[0] == "s1x":
-        return "conv3x3_s1x_kernel<%d>" % k[1]
+        return "conv3x3_s1x_kernel<%d, %d>" % (k[1], k[2])
     if k[0] == "ring":
         tf = ("true" if k[1] else "false", k[2], k[3], "true" if k[4] else "false")
         if len(k) > 7 and k[7] == 8:             # one wave per SIMD, streamed weights (128-channel tile)

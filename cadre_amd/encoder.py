@@ -94,6 +94,15 @@ def _s2_w(w):
     return taps.reshape(o, 9, i // 64, 64).permute(0, 2, 1, 3).contiguous()
 
 
+def _w128_w(w):
+    """3x3 / s1 weights [O][I][3][3] (fp32, BN scale folded) in the FRAGMENT order of cadre_conv3x3_w128 (include/cadre_hip.h):
+    [O/128][I/64][9 taps][4 k-steps][4 blocks][lane half lh][32 lanes l31][8] with channel 128 g + 32 cb + l31, input channel
+    64 c + 16 s + 8 lh + e."""
+    O, I = w.shape[0], w.shape[1]
+    t = w.reshape(O // 128, 4, 32, I // 64, 4, 2, 8, 9)                       # g cb l31 c s lh e tap
+    return t.permute(0, 3, 7, 4, 1, 5, 2, 6).contiguous().reshape(-1)          # g c tap s cb lh l31 e
+
+
 def _s1x_w(w2, wd):
     """conv2 weights OIHW [O][C1][3][3] + shortcut weights [O][Cd][1][1] (both with their folded-BN scale already multiplied in)
     -> [O][9 C1/64 + Cd/64][64] in the k-tile order of cadre_conv3x3_s1x: per 64-channel chunk c of C1 the nine taps kh*3 + kw,

@@ -102,6 +102,8 @@ AB_SYMBOLS = {
     "cadre_colsum2": [vp, i64, i64, vp, vp, i64, i32, i32, i32, vp, i32, vp],
     "cadre_conv3x3_c64_bf16": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "cadre_lstm_seq_fwd": [vp, i64, vp, i64, vp, i32, i64, vp, vp, vp, i32, i64, i32, i32, i32, i32, vp, vp, vp],
+    "cadre_conv3x3_w128": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "cadre_conv3x3_w128_supported": [i32, i32, i32, i32, i32],
 }
 
 
@@ -270,7 +272,8 @@ def conv3x3_s2(x, w_s2, scale, shift, out, F, H, W, Cin, N, act):
 
 def conv3x3_s1x(x, x2, w_s1x, shift, out, F, H, W, C1, Cd, N, act):
     """cadre_conv3x3_s1x (3x3 / s1 conv + the block's 1x1 / s2 shortcut as extra k-tiles, one accumulation); profiling key
-    ("s1x", nps): conv3x3_s1x_kernel<nps>, nps = stride-1 window pieces per wave (9 / 10 / 11 by map width)."""
+    ("s1x", nps, nstg): conv3x3_s1x_kernel<nps, nstg>, nps = stride-1 window pieces per wave (9 / 10 / 11 by map width), nstg =
+    weight stages (2; CADRE_S1X_STAGES=3 selects the symmetric-issue form)."""
     fn = lib().cadre_conv3x3_s1x
     args = (ptr(x), ptr(x2), ptr(w_s1x), ptr(shift), ptr(out), F, H, W, C1, Cd, N, act, stream())
     if PROFILE is None or torch.cuda.is_current_stream_capturing():
@@ -284,7 +287,37 @@ def conv3x3_s1x(x, x2, w_s1x, shift, out, F, H, W, C1, Cd, N, act):
     nbytes = (M * C1 + M * Cd + N * (9 * C1 + Cd) + M * N) * 2          # (the shortcut reads one pixel in four of x2)
     pa = ((256 + 2 * W + 2 + 7) // 8 * 8) // 8
     nps = 9 if pa <= 36 else (10 if pa <= 40 else 11)
-    PROFILE.append((("s1x", nps), 2.0 * M * N * (9 * C1 + Cd), e0, e1, (M, N, 9 * C1 + Cd, 1, 1, 0), nbytes))
+    nstg = 3 if os.environ.get("CADRE_S1X_STAGES", "2") == "3" else 2
+    PROFILE.append((("s1x", nps, nstg), 2.0 * M * N * (9 * C1 + Cd), e0, e1, (M, N, 9 * C1 + Cd, 1, 1, 0), nbytes))
+
+
+def w128_shape(W, N):
+    """(MW, NPW) template arguments cadre_conv3x3_w128 picks (conv3x3_w128.hip w128_pick) — the profiling key / kernel name."""
+    mw = 2 if N % 256 == 0 else 4
+    need = (128 * mw + 2 * W + 2 + 31) // 32
+    if mw == 2:
+        return mw, (9 if need <= 9 else (10 if need <= 10 else 11))
+    return mw, (17 if need <= 17 else 19)
+
+
+def conv3x3_w128(x, w_frag, shift, resid, out, F, H, W, Cin, N, act):
+    """cadre_conv3x3_w128 (3x3 / s1 window conv, 128 x 128 wave tile, weights streamed to registers); profiling key
+    ("w128", mw, npw, residual): conv3x3_w128_kernel<mw, npw, residual>.  A/B build only."""
+    if not has_ab_kernels():
+        raise CadreHipError("cadre_conv3x3_w128 exists only in the A/B build (CADRE_BUILD_AB=1 python -m cadre_amd.build)")
+    fn = lib().cadre_conv3x3_w128
+    args = (ptr(x), ptr(w_frag), None, ptr(shift), ptr(resid), ptr(out), F, H, W, Cin, N, act, stream())
+    if PROFILE is None or torch.cuda.is_current_stream_capturing():
+        check(fn(*args), "cadre_conv3x3_w128")
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(fn(*args), "cadre_conv3x3_w128")
+    e1.record()
+    M = F * H * W
+    nbytes = (M * Cin + N * 9 * Cin + M * N * (2 if resid is not None else 1)) * 2
+    mw, npw = w128_shape(W, N)
+    PROFILE.append((("w128", mw, npw, resid is not None), 2.0 * M * N * 9 * Cin, e0, e1, (M, N, 9 * Cin, 1, 1, 0), nbytes))
 
 
 def conv3x3_ring(x, w_ring, scale, shift, resid, out, F, H, W, Cin, N, act):

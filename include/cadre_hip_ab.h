@@ -6,6 +6,7 @@
  *   gemm_f32_skinny.hip                         cadre_gemm_t.tile 11 (fp32): register-direct skinny GEMM
  *   gemm_stream_f32.hip                         cadre_gemm_t.tile 13 (fp32): short-K dense NT product, several M-tiles per workgroup
  *   conv3x3_c64_bf16.hip                        cadre_conv3x3_c64_bf16 below
+ *   conv3x3_w128.hip                            cadre_conv3x3_w128 below: 128 x 128 wave tile, weights streamed to registers (round 5)
  *   ppo_update.hip (under CADRE_AB_KERNELS)     cadre_lstm_seq_fwd below: the persistent forward LSTM (208 vs 110 us)
  *   conv3x3_ring.hip (under CADRE_AB_KERNELS)   the 16x16x32-MFMA instantiations of the window conv (CADRE_RING_M16=1)
  *   cadre_kernels.hip (under CADRE_AB_KERNELS)  the unfused LSTM cell passes and the two-output column sum of the
@@ -24,6 +25,16 @@ extern "C" {
 int cadre_conv3x3_c64_bf16(const void* x, const void* w, const float* scale, const float* shift,
                            const void* resid, void* out, int32_t F, int32_t H, int32_t W, int32_t relu,
                            void* stream);
+/* 3x3 / stride 1 / pad 1 convolution on dense bf16 NHWC with a 128-position x 128-channel WAVE tile (resnet.py:26-55 conv1 / conv2 of
+ * layer2 .. layer4, danet.py:21-41 head convs), bf16 model: y = act(conv(x; w) + shift[n] + resid) as bf16 [F*H*W][N]; x [F][H][W][Cin],
+ * Cin % 64 == 0, Cin >= 128, N % 128 == 0; scale must be NULL (folded into the weight rows by the caller); resid bf16 [F*H*W][N] or
+ * NULL (added before the activation); act 0 / 1 (ReLU).  w in FRAGMENT order [N/128][Cin/64][9 taps kh*3+kw][4 k-steps][4 blocks of
+ * 32 channels][64 lanes][8]: lane (l31, lh) of block cb of k-step s holds channel 128 g + 32 cb + l31, input channels
+ * 64 c + 16 s + 8 lh .. + 7 (cadre_amd/encoder.py _w128_w) — the weights go from memory straight to the matrix cores' operand
+ * registers, only the pixel window is staged in LDS (ab/conv3x3_w128.hip; a tie with the ping-pong kernel: profiles/r05_w128_wave_tile_vs_ping_pong.txt).  _supported: host logic, no launch. */
+int cadre_conv3x3_w128(const void* x, const void* w, const float* scale, const float* shift, const void* resid, void* out, int32_t F,
+                       int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t act, void* stream);
+int cadre_conv3x3_w128_supported(int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N);
 /* ---------------------------------------------------------------- LSTM cell pointwise
  * nn.LSTMCell gate math (models.py:130-152).  gates [B][ldg] pre-activations (i,f,g,o blocks
  * of Hd), batched over `batch` nets with strides; c_prev of net z is read at

@@ -1564,3 +1564,68 @@ def test_conv3x3_s1x_full_size_repeatable_under_load(hip):
                    + F.conv2d(x[sl].float().cpu().permute(0, 3, 1, 2), wd.float().cpu(), None, 2, 0)).permute(0, 2, 3, 1) + sh.cpu()
             ref = torch.relu(ref)
             assert float((outs[0][sl].float().cpu() - ref).abs().max() / ref.abs().max()) < 6e-3, (H, C1)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 3x3 / s1 window conv with a 128 x 128 wave tile, weights streamed to registers (csrc/ab/conv3x3_w128.hip, round 5; A/B build:
+# a tie with the ping-pong kernel, profiles/r05_w128_wave_tile_vs_ping_pong.txt)
+@pytest.mark.parametrize("Nimg,H,W,Cin,Cout,res,act", [(3, 9, 9, 128, 256, False, 1), (2, 18, 18, 256, 256, True, 1),
+                                                       (5, 4, 6, 128, 128, True, 1), (1, 1, 2, 128, 128, False, 0),
+                                                       (2, 36, 36, 128, 128, True, 1), (3, 9, 9, 512, 512, True, 1),
+                                                       (4, 7, 46, 192, 256, False, 1), (2, 5, 47, 128, 384, True, 0),
+                                                       (9, 9, 9, 512, 128, False, 1), (40, 18, 18, 128, 256, True, 1),
+                                                       (2, 36, 36, 64, 128, True, 1)])
+@needs_ab
+def test_conv3x3_w128_matches_torch(hip, Nimg, H, W, Cin, Cout, res, act):
+    """cadre_conv3x3_w128 vs torch-CPU fp32: act(conv2d(x, w, pad 1) + shift (+ residual)) on bf16-rounded operands
+    (resnet.py:26-55, BN scale folded into the weights): both tile shapes (N % 256 == 0: 256 x 256, else 512 x 128), 2-8 chunks,
+    maps narrower than a DMA piece and as wide as the kernel takes, M tiles that straddle rows and frames, several items per
+    workgroup (the last case: more items than CUs would need many frames; 40 frames give every persistent workgroup one item and
+    the residual prefetch its full pattern)."""
+    from cadre_amd.encoder import _w128_w
+    g = torch.Generator().manual_seed(Nimg * 1000 + H * 10 + Cin + Cout)
+    x = _bf(torch.randn(Nimg, Cin, H, W, generator=g))
+    w = _bf(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
+    r = _bf(torch.randn(Nimg, Cout, H, W, generator=g))
+    shift = torch.randn(Cout, generator=g)
+    want = F.conv2d(x.float(), w.float(), None, 1, 1) + shift.view(1, -1, 1, 1)
+    if res:
+        want = want + r.float()
+    if act:
+        want = F.relu(want)
+    assert hip.lib().cadre_conv3x3_w128_supported(Nimg, H, W, Cin, Cout) == 1
+    xd = dev(x.permute(0, 2, 3, 1).contiguous())
+    rd = dev(r.permute(0, 2, 3, 1).contiguous()) if res else None
+    wf = dev(_w128_w(w.float())).to(torch.bfloat16)
+    out = torch.full((Nimg, H, W, Cout), float("nan"), device="cuda", dtype=torch.bfloat16)
+    hip.conv3x3_w128(xd, wf, dev(shift), rd, out, Nimg, H, W, Cin, Cout, act)
+    torch.cuda.synchronize()
+    assert not torch.isnan(out.float()).any()
+    assert rel(out.float().permute(0, 3, 1, 2), want) < 6e-3
+
+
+@needs_ab
+def test_conv3x3_w128_full_size_repeatable_under_load(hip):
+    """The trunk shapes at many frames (several persistent items per workgroup): 10 launches agree bit for bit (counted vmcnt,
+    one raw barrier per chunk: a race shows up as run-to-run differences), first and last frames agree with torch-CPU fp32."""
+    from cadre_amd.encoder import _w128_w
+    for F_, H, C, res in ((160, 36, 128, True), (256, 18, 256, True), (512, 9, 512, False)):
+        g = torch.Generator(device="cuda").manual_seed(H + C)
+        x = torch.randn(F_, H, H, C, device="cuda", generator=g).to(torch.bfloat16)
+        r = torch.randn(F_, H, H, C, device="cuda", generator=g).to(torch.bfloat16)
+        w = (torch.randn(C, C, 3, 3, device="cuda", generator=g) / np.sqrt(9 * C)).to(torch.bfloat16)
+        sh = torch.randn(C, device="cuda", generator=g)
+        wf = _w128_w(w.float().cpu()).to(torch.bfloat16).cuda()
+        outs = []
+        for rep in range(10):
+            out = torch.empty(F_, H, H, C, device="cuda", dtype=torch.bfloat16)
+            hip.conv3x3_w128(x, wf, sh, r if res else None, out, F_, H, H, C, C, 1)
+            outs.append(out)
+        torch.cuda.synchronize()
+        assert all(torch.equal(outs[0], o) for o in outs[1:]), (H, C)
+        for sl in (slice(0, 2), slice(F_ - 2, F_)):
+            ref = F.conv2d(x[sl].float().cpu().permute(0, 3, 1, 2), w.float().cpu(), None, 1, 1).permute(0, 2, 3, 1) + sh.cpu()
+            if res:
+                ref = ref + r[sl].float().cpu()
+            ref = torch.relu(ref)
+            assert float((outs[0][sl].float().cpu() - ref).abs().max() / ref.abs().max()) < 6e-3, (H, C)

@@ -121,7 +121,7 @@ def test_c3_bf16_goldens_inside_2048_frame_joint_chunk(golden):
     # round 5: the three stride-2 3x3 convs on the plane-window kernel, the three conv2 + shortcut pairs on the K-extension kernel;
     # no implicit-GEMM conv is left on the tile kernel (the 1x1 / s2 shortcut launches are gone)
     assert [k for k, *_ in prof if k[0] == "s2"] == [("s2", 10), ("s2", 9), ("s2", 9)], [k for k, *_ in prof if k[0] in ("s2", "s1x")]
-    assert [k for k, *_ in prof if k[0] == "s1x"] == [("s1x", 11), ("s1x", 10), ("s1x", 9)]
+    assert [k for k, *_ in prof if k[0] == "s1x"] == [("s1x", 11, 2), ("s1x", 10, 2), ("s1x", 9, 2)]
     conv3 = [(k, shp) for k, _f, _a, _b, shp, _nb in prof if k[0] == "bf16" and k[2] == 2]
     assert len(conv3) == 0, conv3
     got = torch.stack([lat[0, :512], lat[F - 1, :512]])
