@@ -286,12 +286,12 @@ def test_arena_pickle_drops_process_local_state():
 
 
 def test_bench_kernel_names_are_keys_of_the_hbm_traffic_file():
-    """Every kernel name the committed round-4 bench line prints (roofline.kernel, per_kernel of the headline, the C3 section and
+    """Every kernel name the committed round-5 bench line prints (roofline.kernel, per_kernel of the headline, the C3 section and
     the direct-conv section) is a key of profiles/hbm_traffic.json — the rocprofv3 PMC passes of the same command — so that
     `roofline.traffic` is never null because of a naming drift between bench.kname() and the profiler."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    line = open(os.path.join(root, "profiles", "r04_bench_c2_c3.json")).read().strip().splitlines()[-1]
+    line = open(os.path.join(root, "profiles", "r05_bench_c2_c3.json")).read().strip().splitlines()[-1]
     bench = json.loads(line)
     traffic = json.load(open(os.path.join(root, "profiles", "hbm_traffic.json")))
     names = set()
