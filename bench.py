@@ -308,7 +308,8 @@ TPL_BF16 = {1: (2, 2, 2, 2, 2), 2: (2, 1, 2, 2, 2), 3: (1, 1, 2, 2, 2), 4: (4, 2
 TILE = {1: "128x128", 2: "128x64", 3: "64x64", 4: "256x128", 5: "128x256", 6: "256x64", 7: "256x256 (8 waves)",
         8: "128x128 (8 waves)", 9: "32x128", 10: "128x64 (8 waves)", 11: "256x64 (8 waves)",
         12: "64x64, 8 M-tiles per workgroup", 64: "128 positions x 64, weights resident in LDS, pixel ring",
-        65: "128/256 positions x 64/128, pixel window resident in LDS"}
+        65: "128/256 positions x 64/128, pixel window resident in LDS",
+        66: "256x256 on four waves (128x128 each), B streamed to registers in fragment order"}
 AM = {0: "dense A[M][K]", 1: "dense A[K][M]", 2: "NHWC implicit-GEMM conv", 3: "Cin=4 stem conv",
       4: "Cin=4 stem conv on the zero-padded image"}
 
@@ -317,6 +318,8 @@ def kname(k):
     """Exact kernel symbol as rocprofv3 prints it, from a hip.PROFILE key."""
     if k[0] == "wino_c64":
         return "wino2_c64_kernel<%s>" % ("true" if k[1] else "false")
+    if k[0] == "gw128":
+        return "gemm_bf16_w128_kernel"
     if k[0] == "s2":
         return "conv3x3_s2_kernel<%d>" % k[1]
     if k[0] == "s1x":
@@ -358,10 +361,10 @@ def roofline_of(prof, steps):
         return None, {}
     dom = max(by, key=lambda k: by[k][1])
     fl, t, n, nb = by[dom]
-    bf16 = dom[0] in ("bf16", "s2", "s1x") or (dom[0] == "ring" and dom[1])
+    bf16 = dom[0] in ("bf16", "s2", "s1x", "gw128") or (dom[0] == "ring" and dom[1])
     peak_tf = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
     t_mfma, t_hbm = fl / (peak_tf * 1e12), nb / (PEAK_HBM_GBPS * 1e9)
-    tile, am = (65, 2) if dom[0] in ("ring", "s2", "s1x") else ((dom[1], dom[2]) if bf16 else (dom[0], dom[1]))
+    tile, am = (65, 2) if dom[0] in ("ring", "s2", "s1x") else ((66, 0) if dom[0] == "gw128" else ((dom[1], dom[2]) if bf16 else (dom[0], dom[1])))
     desc = "%s tile, %s%s" % (TILE.get(tile, tile), AM.get(am, am), ", bf16" if bf16 else "")
     if dom[0] == "wino_c64":
         desc = "fused Winograd F(2x2,3x3) of the fp32 64 -> 64 stage (executed FLOPs)"

@@ -11,13 +11,14 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 INCLUDE = os.path.join(os.path.dirname(CSRC), "..", "include")
-SOURCES = ["gemm_f32.hip", "gemm_bf16.hip", "stem_pool.hip", "conv3x3_ring.hip", "conv3x3_s2.hip", "conv3x3_s1x.hip", "ppo_update.hip", "peaks.hip", "winograd.hip", "winograd_c64.hip",
+SOURCES = ["gemm_f32.hip", "gemm_bf16.hip", "gemm_bf16_w128.hip", "stem_pool.hip", "conv3x3_ring.hip", "conv3x3_s2.hip", "conv3x3_s1x.hip", "ppo_update.hip", "peaks.hip", "winograd.hip", "winograd_c64.hip",
            "cadre_kernels.hip"]
 AB_SOURCES = ["ab/gemm_f32_skinny.hip", "ab/gemm_stream_f32.hip", "ab/conv_stream_f32.hip", "ab/conv_stream_bf16.hip", "ab/conv3x3_c64_bf16.hip", "ab/conv3x3_w128.hip"]
 # per-file flags: the fused Winograd kernel is written in issue order; the machine scheduler's reordering costs it 40 spills.  Its
 # step loop (8 steps x 128 inline-asm MFMAs + the epilogue's pinned accumulator reads) is past the default size limit of
 # "#pragma unroll": not unrolled, the register sets indexed by step parity would live in scratch
 EXTRA_FLAGS = {"winograd_c64.hip": ["-mllvm", "-enable-misched=0", "-mllvm", "-pragma-unroll-threshold=262144"],
+               "gemm_bf16_w128.hip": ["-mllvm", "-enable-misched=0", "-mllvm", "-pragma-unroll-threshold=262144"],
                "ab/conv3x3_w128.hip": ["-mllvm", "-enable-misched=0", "-mllvm", "-pragma-unroll-threshold=262144"]}
 LIB = os.path.join(CSRC, "libcadre_hip.so")
 LIB_AB = os.path.join(CSRC, "libcadre_hip_ab.so")

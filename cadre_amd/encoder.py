@@ -103,6 +103,14 @@ def _w128_w(w):
     return t.permute(0, 3, 7, 4, 1, 5, 2, 6).contiguous().reshape(-1)          # g c tap s cb lh l31 e
 
 
+def _w128_dense_b(w):
+    """Dense weights [N][K] (fp32) in the FRAGMENT order of cadre_gemm_bf16_w128 (include/cadre_hip.h): [N/128][K/16][4 blocks][lane
+    half lh][32 lanes l31][8] with row 128 g + 32 cb + l31, column 16 q + 8 lh + e."""
+    N, K = w.shape
+    t = w.reshape(N // 128, 4, 32, K // 16, 2, 8)                              # g cb l31 q lh e
+    return t.permute(0, 3, 1, 4, 2, 5).contiguous().reshape(-1)                # g q cb lh l31 e
+
+
 def _s1x_w(w2, wd):
     """conv2 weights OIHW [O][C1][3][3] + shortcut weights [O][Cd][1][1] (both with their folded-BN scale already multiplied in)
     -> [O][9 C1/64 + Cd/64][64] in the k-tile order of cadre_conv3x3_s1x: per 64-channel chunk c of C1 the nine taps kh*3 + kw,
@@ -312,7 +320,7 @@ class DANetEncoderHIP:
         self.bc_conv = _Conv(sd["bc_conv.weight"], None, sd["bc_conv.bias"], 1, 1, 0, 0, dev, wd)
         # ---- inter-task attention MLPs (intertask_att.py:39-80); order q,k,v per branch
         Np = self.Np
-        self.ita_w1, self.ita_b1 = [], []
+        self.ita_w1, self.ita_b1, self.ita_w1f = [], [], []
         w2, b2 = [], []
         for br in ("visual", "bc"):
             ws, bs = [], []
@@ -324,6 +332,8 @@ class DANetEncoderHIP:
                 w2.append(sd[pre + ".3.weight"])
                 b2.append(sd[pre + ".3.bias"])
             self.ita_w1.append(torch.cat(ws).contiguous().to(dev).to(wd))  # [1536][Np*512]
+            # the same matrix in fragment order for cadre_gemm_bf16_w128 (bf16 model, large frame batches)
+            self.ita_w1f.append(_w128_dense_b(torch.cat(ws).float()).to(dev).to(wd) if wd == torch.bfloat16 else None)
             self.ita_b1.append(torch.cat(bs).contiguous().to(dev))
         self.ita_w2 = torch.stack(w2).contiguous().to(dev)                # [6][256][512]
         self.ita_b2 = torch.stack(b2).contiguous().to(dev)                # [6][256]
@@ -557,8 +567,12 @@ class DANetEncoderHIP:
         for b, src in enumerate((vis, bc)):
             if split > 1:
                 slabs = self._buf("ita_slab", (split, F, 1536))
-                hip.gemm(src, self.ita_w1[b], slabs, F, 1536, Kin, Kin, Kin, 1536, split_k=split,
-                         tile=3 if F <= 64 else 0, bf16=self.bf16)
+                if self.bf16 and F > 64 and self.ita_w1f[b] is not None and L.cadre_gemm_bf16_w128_supported(F, 1536, Kin, Kin, 1536, split):
+                    # 256 x 256 tiles, weights streamed in fragment order: the same slices and k order, bit-identical partial sums
+                    hip.gemm_bf16_w128(src, self.ita_w1f[b], slabs, F, 1536, Kin, Kin, 1536, split)
+                else:
+                    hip.gemm(src, self.ita_w1[b], slabs, F, 1536, Kin, Kin, Kin, 1536, split_k=split,
+                             tile=3 if F <= 64 else 0, bf16=self.bf16)
                 hip.check(L.cadre_splitk_reduce(hip.ptr(slabs), split, F * 1536, 1536, hid.data_ptr() + 4 * 1536 * b,
                                                 3072, F, 1536, None, hip.ptr(self.ita_b1[b]), 2, 0.01, None, 0, st),
                           "cadre_splitk_reduce")

@@ -45,6 +45,8 @@ SYMBOLS = {
     "cadre_conv3x3_s2_supported": [i32, i32, i32, i32, i32],
     "cadre_conv3x3_s1x": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "cadre_conv3x3_s1x_supported": [i32, i32, i32, i32, i32, i32],
+    "cadre_gemm_bf16_w128": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "cadre_gemm_bf16_w128_supported": [i32, i32, i32, i32, i32, i32],
     "cadre_maxpool3x3s2_bf16": [vp, vp, i32, i32, i32, i32, vp],
     "cadre_pam_bf16out": [vp, vp, f32, vp, i32, i32, vp],
     "cadre_cam_bf16out": [vp, f32, vp, i32, i32, vp],
@@ -107,7 +109,7 @@ AB_SYMBOLS = {
 }
 
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class CadreHipError(RuntimeError):
@@ -289,6 +291,22 @@ def conv3x3_s1x(x, x2, w_s1x, shift, out, F, H, W, C1, Cd, N, act):
     nps = 9 if pa <= 36 else (10 if pa <= 40 else 11)
     nstg = 3 if os.environ.get("CADRE_S1X_STAGES", "2") == "3" else 2
     PROFILE.append((("s1x", nps, nstg), 2.0 * M * N * (9 * C1 + Cd), e0, e1, (M, N, 9 * C1 + Cd, 1, 1, 0), nbytes))
+
+
+def gemm_bf16_w128(A, B_frag, slabs, M, N, K, lda, ldc, split_k):
+    """cadre_gemm_bf16_w128 (dense bf16 split-K product, 128 x 128 wave tile, B streamed to registers in fragment order); profiling
+    key ("gw128",): gemm_bf16_w128_kernel."""
+    fn = lib().cadre_gemm_bf16_w128
+    args = (ptr(A), ptr(B_frag), ptr(slabs), M, N, K, lda, ldc, split_k, stream())
+    if PROFILE is None or torch.cuda.is_current_stream_capturing():
+        check(fn(*args), "cadre_gemm_bf16_w128")
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(fn(*args), "cadre_gemm_bf16_w128")
+    e1.record()
+    nbytes = (M * K + N * K) * 2 + M * N * 4 * split_k
+    PROFILE.append((("gw128",), 2.0 * M * N * K, e0, e1, (M, N, K, 1, split_k, 0), nbytes))
 
 
 def w128_shape(W, N):

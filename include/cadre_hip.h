@@ -15,7 +15,7 @@
 extern "C" {
 #endif
 
-#define CADRE_ABI_VERSION 12
+#define CADRE_ABI_VERSION 13
 int cadre_abi_version(void);
 /* human-readable last argument error of the calling thread ("" if none) */
 const char* cadre_last_error(void);
@@ -121,6 +121,16 @@ int cadre_conv3x3_s2_supported(int32_t F, int32_t H, int32_t W, int32_t Cin, int
 int cadre_conv3x3_s1x(const void* x, const void* x2, const void* w, const float* shift, void* out, int32_t F, int32_t H, int32_t W,
                       int32_t C1, int32_t Cd, int32_t N, int32_t act, void* stream);
 int cadre_conv3x3_s1x_supported(int32_t F, int32_t H, int32_t W, int32_t C1, int32_t Cd, int32_t N);
+/* Dense bf16 NT product with split-K into raw fp32 partial sums (the inter-task attention's first layers, intertask_att.py:39-80, bf16
+ * model): slab[s][M][ldc] = A[M][k in slice s] . B[N][k in slice s]^T, slice s = 64-element k-tiles [s * per, (s + 1) * per), per =
+ * ceil(K / 64 / split_k) — the slices, the k order and therefore every partial sum of cadre_gemm_bf16 with split_k (reduce with
+ * cadre_splitk_reduce).  A [M][lda] bf16; B in FRAGMENT order [N/128][K/16][4 blocks of 32 columns][64 lanes][8]: lane (l31, lh) of
+ * block cb of 16-element k-step q holds B[128 g + 32 cb + l31][16 q + 8 lh .. + 7] (cadre_amd/encoder.py _w128_dense_b) — it goes from
+ * memory straight to the matrix cores' operand registers, only A is staged in LDS (gemm_bf16_w128.hip).  N % 256 == 0, K % 64 == 0.
+ * _supported: host logic, no launch. */
+int cadre_gemm_bf16_w128(const void* A, const void* B, float* C, int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldc,
+                         int32_t split_k, void* stream);
+int cadre_gemm_bf16_w128_supported(int32_t M, int32_t N, int32_t K, int32_t lda, int32_t ldc, int32_t split_k);
 /* Sustained matrix-pipe rate of this device (peaks.hip; SURVEY.md 8d asks for the measured peak next to the datasheet
  * one): workgroups x 4 waves, each iters x 8 register-operand MFMAs on independent accumulators (fp32:
  * v_mfma_f32_32x32x2_f32 = 4096 FLOP, bf16: v_mfma_f32_32x32x16_bf16 = 32768 FLOP).  The caller times the launch. */

@@ -906,6 +906,56 @@ def test_gemm_bf16_dense(hip, M, N, K, tile):
     assert rel(out16.float(), want) < 5e-3              # one bf16 rounding of the result
 
 
+@pytest.mark.parametrize("M,N,K,split", [(300, 256, 4608, 2), (2048, 1536, 8192, 4), (77, 256, 128, 1), (513, 512, 4608, 3),
+                                         (256, 768, 320, 4), (1000, 1536, 41472, 16)])
+def test_gemm_bf16_w128_partial_sums_equal_the_tile_kernels(hip, M, N, K, split):
+    """cadre_gemm_bf16_w128 (gemm_bf16_w128.hip, round 5: 256 x 256 tiles, one wave per SIMD, B streamed to registers in fragment
+    order — the inter-task first layers, intertask_att.py:39-80) writes the SAME raw split-K partial sums, bit for bit, as
+    cadre_gemm_bf16 with split_k (same slices, same k order): the encoder's results must not depend on which kernel a frame batch
+    selects.  Their sum agrees with torch-CPU fp32.  Shapes: M tiles with a tail, one and several N tiles, slices of an odd and an
+    even number of 64-element k-tiles, a slice of ONE k-tile and an EMPTY slice (K = 320, split 4: 2 + 2 + 1 + 0), the 288 x 288
+    model's K = 41472 in 16 slices (41 k-tiles each, the last 33)."""
+    from cadre_amd.encoder import _w128_dense_b
+    g = torch.Generator().manual_seed(M + N + K)
+    A, B = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g) * 0.1)
+    assert hip.lib().cadre_gemm_bf16_w128_supported(M, N, K, K, N, split) == 1
+    Ad, Bd = dev(A), dev(B)
+    Bf = dev(_w128_dense_b(B.float())).to(torch.bfloat16)
+    got = torch.full((split, M, N), float("nan"), device="cuda")
+    hip.gemm_bf16_w128(Ad, Bf, got, M, N, K, K, N, split)
+    ref = torch.full((split, M, N), float("nan"), device="cuda")
+    if split > 1:
+        hip.gemm(Ad, Bd, ref, M, N, K, K, K, N, split_k=split, bf16=True)
+    else:
+        hip.gemm(Ad, Bd, ref[0], M, N, K, K, K, N, bf16=True)
+    torch.cuda.synchronize()
+    assert not torch.isnan(got).any()
+    assert torch.equal(got, ref)
+    rows = slice(0, min(M, 96))
+    want = A[rows].float() @ B.float().t()
+    assert rel(got.sum(0)[rows], want) < 2e-5
+
+
+def test_gemm_bf16_w128_repeatable_under_load(hip):
+    """The inter-task shape of the 288 x 288 model at 2048 frames: 10 launches agree bit for bit (counted vmcnt + one raw barrier
+    per k-tile of 64: a race shows up as run-to-run differences)."""
+    from cadre_amd.encoder import _w128_dense_b
+    M, N, K, split = 2048, 1536, 41472, 16
+    g = torch.Generator(device="cuda").manual_seed(7)
+    A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    B = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    Bf = _w128_dense_b(B.float().cpu()).to(torch.bfloat16).cuda()
+    outs = []
+    for rep in range(10):
+        o = torch.empty(split, M, N, device="cuda")
+        hip.gemm_bf16_w128(A, Bf, o, M, N, K, K, N, split)
+        outs.append(o.sum(0))
+    torch.cuda.synchronize()
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    want = A[:32].float().cpu() @ B.float().cpu().t()
+    assert rel(outs[0][:32], want) < 2e-5
+
+
 @pytest.mark.parametrize("Cin,Cout,H,W,k,s,p,tile", [(64, 64, 18, 22, 3, 1, 1, 0), (64, 128, 18, 22, 3, 2, 1, 0),
                                                       (64, 128, 17, 21, 1, 2, 0, 0), (512, 128, 9, 9, 3, 1, 1, 0),
                                                       (256, 256, 18, 18, 3, 1, 1, 7), (128, 512, 9, 9, 1, 1, 0, 7),
