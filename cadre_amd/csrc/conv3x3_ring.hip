@@ -1640,7 +1640,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64s_kernel(ring_args a) {
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
       const int idx = bi + 32 * rb + toff;
-      const unsigned row = ((mk[rb] >> tap) & 1u) ? (unsigned)(win_off + (idx << 7)) : zrow_off;
+      unsigned row = ((mk[rb] >> tap) & 1u) ? (unsigned)(win_off + (idx << 7)) : zrow_off;
+      if constexpr ((RING_ABL & 128) != 0) row = (unsigned)(win_off + (idx << 7));      // (padded-layout emulation: no halo masks)
       const unsigned rsw = row ^ (unsigned)(swz(idx) << 4) ^ lhb;
 #pragma unroll
       for (int s = 0; s < 4; ++s) out[rb][s] = lds0 + (rsw ^ (unsigned)(s << 5));
@@ -1757,7 +1758,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64s_kernel(ring_args a) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
       }
-      if (tap == 4) {                                        // the next item's positions and halo masks: vector work under this tap's MFMAs
+      if (tap == 4 && (RING_ABL & 128) == 0) {               // the next item's positions and halo masks: vector work under this tap's MFMAs
         advance_item();
         masks_of(mt + 1, mkn);
       }

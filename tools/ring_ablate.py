@@ -16,7 +16,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ABLS = [0, 1, 2, 4, 8, 16, 32, 64, 3, 12, 48, 15, 63, 127, 46, 44, 36, 34, 126]
-NAMES = {0: "full kernel", 1: "no MFMA", 2: "no fragment reads", 4: "no window DMA", 8: "no weight DMA", 16: "no stores",
+NAMES = {128: "no halo masks, no position arithmetic (padded-layout emulation)", 160: "no halo masks, no epilogue", 0: "full kernel", 1: "no MFMA", 2: "no fragment reads", 4: "no window DMA", 8: "no weight DMA", 16: "no stores",
          32: "no epilogue", 64: "no residual loads", 3: "no MFMA, no reads", 12: "no DMA at all", 48: "no epilogue, no stores",
          46: "schedule + MFMA only (no reads, DMA, epilogue)", 44: "MFMA + reads only (no DMA, no epilogue)",
          36: "no window DMA, no epilogue", 34: "no reads, no epilogue", 126: "schedule + MFMA only, residual loads off too",
