@@ -11,13 +11,15 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 INCLUDE = os.path.join(os.path.dirname(CSRC), "..", "include")
-SOURCES = ["gemm_f32.hip", "gemm_bf16.hip", "gemm_bf16_w128.hip", "stem_pool.hip", "conv3x3_ring.hip", "conv3x3_s2.hip", "conv3x3_s1x.hip", "ppo_update.hip", "peaks.hip", "winograd.hip", "winograd_c64.hip",
+SOURCES = ["gemm_f32.hip", "gemm_bf16.hip", "gemm_bf16_w128.hip", "stem_pool.hip", "conv3x3_ring.hip", "conv3x3_s2.hip", "conv3x3_s1x.hip", "ppo_update.hip", "peaks.hip", "winograd.hip", "winograd_c64.hip", "winograd_fused.hip",
            "cadre_kernels.hip"]
 AB_SOURCES = ["ab/gemm_f32_skinny.hip", "ab/gemm_stream_f32.hip", "ab/conv_stream_f32.hip", "ab/conv_stream_bf16.hip", "ab/conv3x3_c64_bf16.hip", "ab/conv3x3_w128.hip"]
 # per-file flags: the fused Winograd kernel is written in issue order; the machine scheduler's reordering costs it 40 spills.  Its
 # step loop (8 steps x 128 inline-asm MFMAs + the epilogue's pinned accumulator reads) is past the default size limit of
 # "#pragma unroll": not unrolled, the register sets indexed by step parity would live in scratch
 EXTRA_FLAGS = {"winograd_c64.hip": ["-mllvm", "-enable-misched=0", "-mllvm", "-pragma-unroll-threshold=262144"],
+               # (written in issue order too: the scheduler sinks the fragment reads of the next slot down to their MFMAs)
+               "winograd_fused.hip": ["-mllvm", "-enable-misched=0", "-mllvm", "-pragma-unroll-threshold=262144"],
                "gemm_bf16_w128.hip": ["-mllvm", "-enable-misched=0", "-mllvm", "-pragma-unroll-threshold=262144"],
                "ab/conv3x3_w128.hip": ["-mllvm", "-enable-misched=0", "-mllvm", "-pragma-unroll-threshold=262144"]}
 LIB = os.path.join(CSRC, "libcadre_hip.so")
@@ -31,7 +33,7 @@ def _ab():
 def _plan(ab):
     srcs = SOURCES + (AB_SOURCES if ab else [])
     odir = os.path.join(CSRC, "build", "ab" if ab else "default")
-    hdrs = [os.path.join(INCLUDE, "cadre_hip.h")] + ([os.path.join(INCLUDE, "cadre_hip_ab.h")] if ab else [])
+    hdrs = [os.path.join(INCLUDE, "cadre_hip.h"), os.path.join(CSRC, "winograd_mats.h")] + ([os.path.join(INCLUDE, "cadre_hip_ab.h")] if ab else [])
     return srcs, odir, hdrs, (LIB_AB if ab else LIB)
 
 

@@ -14,63 +14,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/cadre_hip.h"
+#include "winograd_mats.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 int cadre_fail(const char* msg);
 
-// Transform matrices (Cook-Toom; F(2x2): points 0, 1, -1, infinity; F(3x3): 0, 3/4, -3/4, 2, infinity).  F(2x2, 3x3): 4x4 input tiles, 16 planes, 2.25x fewer
-// multiplies than direct; F(3x3, 3x3): 5x5 tiles, 25 planes, 3.24x fewer and only 2.78x (not 4x) the input in transform-domain
-// traffic — the form the encoder picks when it tiles the map at least as well (9x9 and 18x18 maps: exactly).
-template <int M> struct wino_mat;
-template <> struct wino_mat<2> {
-  static constexpr int N = 4;
-  static constexpr float BT[4][4] = {{1, 0, -1, 0}, {0, 1, 1, 0}, {0, -1, 1, 0}, {0, 1, 0, -1}};
-  static constexpr float AT[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
-};
-template <> struct wino_mat<3> {
-  static constexpr int N = 5;
-  // points 0, 3/4, -3/4, 2, infinity: 30 % less rounding error than 0, 1, -1, 2 (rms 2.2e-7 against 3.2e-7 of the tensor's max
-  // at K = 512; the direct conv: 1.6e-7) — every coefficient is a dyadic rational, exact in fp32
-  static constexpr float BT[5][5] = {{1.125f, -0.5625f, -2.f, 1.f, 0.f}, {0.f, -1.5f, -1.25f, 1.f, 0.f}, {0.f, 1.5f, -2.75f, 1.f, 0.f},
-                                     {0.f, -0.5625f, 0.f, 1.f, 0.f}, {0.f, 1.125f, -0.5625f, -2.f, 1.f}};
-  static constexpr float AT[3][5] = {{1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 0.75f, -0.75f, 2.f, 0.f}, {0.f, 0.5625f, 0.5625f, 4.f, 1.f}};
-};
-template <> struct wino_mat<4> {
-  static constexpr int N = 6;
-  // F(4x4, 3x3): 6x6 tiles, 36 planes, 4x fewer multiplies than direct and 2.25x (F(3x3): 2.78x) the input in transform-domain
-  // traffic.  Points 0, 3/4, -3/4, 3/2, -3/2, infinity — searched like the F(3x3) set (float32 emulation: rms error 1.6x the
-  // F(3x3) set's, against 4.2x for the textbook 0, +-1, +-2); rows of B^T scaled by powers of two, every coefficient dyadic
-  static constexpr float BT[6][6] = {{1.265625f, 0.f, -2.8125f, 0.f, 1.f, 0.f},      {0.f, 1.6875f, 2.25f, -0.75f, -1.f, 0.f},
-                                     {0.f, -1.6875f, 2.25f, 0.75f, -1.f, 0.f},       {0.f, -0.84375f, -0.5625f, 1.5f, 1.f, 0.f},
-                                     {0.f, 0.84375f, -0.5625f, -1.5f, 1.f, 0.f},     {0.f, 1.265625f, 0.f, -2.8125f, 0.f, 1.f}};
-  static constexpr float AT[4][6] = {{1.f, 1.f, 1.f, 1.f, 1.f, 0.f},                 {0.f, 0.75f, -0.75f, 1.5f, -1.5f, 0.f},
-                                     {0.f, 0.5625f, 0.5625f, 2.25f, 2.25f, 0.f},     {0.f, 0.421875f, -0.421875f, 3.375f, -3.375f, 1.f}};
-};
-constexpr float wino_mat<2>::BT[4][4];
-constexpr float wino_mat<2>::AT[2][4];
-constexpr float wino_mat<3>::BT[5][5];
-constexpr float wino_mat<3>::AT[3][5];
-constexpr float wino_mat<4>::BT[6][6];
-constexpr float wino_mat<4>::AT[4][6];
-
-// sum_k c[k] * v[k] over the non-zero constants (unrolled at compile time; +-1 become adds)
-template <int N>
-__device__ __forceinline__ f32x4 wino_dot(const float (&c)[N], const f32x4* v, int stride) {
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  bool first = true;
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    if (c[k] == 0.f) continue;
-    const f32x4 x = v[k * stride];
-    if (first) { acc = c[k] == 1.f ? x : (c[k] == -1.f ? -x : x * c[k]); first = false; }
-    else if (c[k] == 1.f) acc += x;
-    else if (c[k] == -1.f) acc -= x;
-    else acc += x * c[k];
-  }
-  return acc;
-}
-
+// Transform matrices and the constant-folded dot product: winograd_mats.h (shared with winograd_fused.hip)
 template <int M>
 __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ x, float* __restrict__ V, int F, int H, int W, int C,
                                                        int TH, int TW, long long total) {
@@ -99,7 +49,7 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
       d[i] = v;
     }
 #pragma unroll
-    for (int i = 0; i < N; ++i) t[i * N + j] = wino_dot<N>(wino_mat<M>::BT[i], d, 1);
+    for (int i = 0; i < N; ++i) t[i * N + j] = wino_dot<N, f32x4>(wino_mat<M>::BT[i], d, 1);
   }
   const long long T = (long long)F * TH * TW;
   float* vp = V + tile * C + 4 * c4;
@@ -108,7 +58,7 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
   for (int i = 0; i < N; ++i)                        // (B^T d) B
 #pragma unroll
     for (int j = 0; j < N; ++j)
-      *reinterpret_cast<f32x4*>(vp + (i * N + j) * plane) = wino_dot<N>(wino_mat<M>::BT[j], t + i * N, 1);
+      *reinterpret_cast<f32x4*>(vp + (i * N + j) * plane) = wino_dot<N, f32x4>(wino_mat<M>::BT[j], t + i * N, 1);
 }
 
 // act: 0 none, 1 ReLU; bit 4: the residual is added AFTER the activation (same codes as cadre_gemm_t.act)
@@ -136,7 +86,7 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
 #pragma unroll
     for (int i = 0; i < N; ++i) m[i] = *reinterpret_cast<const f32x4*>(mp + (i * N + j) * plane);
 #pragma unroll
-    for (int i = 0; i < M; ++i) s[i * N + j] = wino_dot<N>(wino_mat<M>::AT[i], m, 1);
+    for (int i = 0; i < M; ++i) s[i * N + j] = wino_dot<N, f32x4>(wino_mat<M>::AT[i], m, 1);
   }
   const f32x4 sc = scale ? *reinterpret_cast<const f32x4*>(scale + 4 * n4) : f32x4{1.f, 1.f, 1.f, 1.f};
   const f32x4 sh = shift ? *reinterpret_cast<const f32x4*>(shift + 4 * n4) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -148,7 +98,7 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
       const int r = M * ty + i, q = M * tx + j;
       if (r < H && q < W) {
         const long long e = (((long long)f * H + r) * W + q) * Nc + 4 * n4;
-        f32x4 y = wino_dot<N>(wino_mat<M>::AT[j], s + i * N, 1) * sc + sh;       // (A^T m) A
+        f32x4 y = wino_dot<N, f32x4>(wino_mat<M>::AT[j], s + i * N, 1) * sc + sh;       // (A^T m) A
         f32x4 rv = {0.f, 0.f, 0.f, 0.f};
         if (resid) rv = *reinterpret_cast<const f32x4*>(resid + e);
         if (!post) y += rv;

@@ -153,6 +153,17 @@ def _winograd_u(w, m=2):
     return u.reshape((m + 2) ** 2, w.shape[0], w.shape[1]).float().contiguous()
 
 
+def _winograd_u_frag(w, m):
+    """OIHW 3x3 weights -> U = (G g G^T)[xi][O][I] in the fragment order of cadre_winograd_gemm_out (csrc/winograd_fused.hip):
+    [O/32][I/16][(m+2)^2][2 nb][4 kk][16 couts][4 e] with output channel 32 nt + 16 nb + co and input channel 16 c + 4 kk + e — the
+    2 KB block (nt, c, xi) is what the two channel-block waves read as one ds_read_b128 per lane (lane = 16 kk + co)."""
+    u = _winograd_u(w, m)                                            # [P][O][I]
+    P, O, I = u.shape
+    assert O % 32 == 0 and I % 16 == 0
+    t = u.reshape(P, O // 32, 2, 16, I // 16, 4, 4)                  # p nt nb co c kk e
+    return t.permute(1, 4, 0, 2, 5, 3, 6).contiguous().reshape(-1)   # nt c p nb kk co e
+
+
 def _winograd_u_c64(w, cin_pairs=True):
     """OIHW 64 x 64 x 3 x 3 -> the fused kernel's layout [8 chunks of 8 cin][16 planes][64 positions][8 cin]
     (csrc/winograd_c64.hip); position 16 b + n of the cout axis holds output channel 4 n + b: column n of the kernel's MFMA
@@ -193,6 +204,11 @@ class _Conv:
         if m not in self.w_wino:
             self.w_wino[m] = _winograd_u(self._w_oihw, m).to(dev)
         return self.w_wino[m]
+
+    def wino_u_frag(self, m, dev):
+        if ("frag", m) not in self.w_wino:
+            self.w_wino[("frag", m)] = _winograd_u_frag(self._w_oihw, m).to(dev)
+        return self.w_wino[("frag", m)]
 
     def __init__(self, w, scale, shift, k, stride, pad, act, dev, wdtype=torch.float32):
         self.w = _khwc(w).to(dev).to(wdtype)
@@ -418,10 +434,16 @@ class DANetEncoderHIP:
         elif c.w_wino is not None and x.dtype == torch.float32 and odt == torch.float32 and (act & 15) <= 1:
             # Winograd F(2x2, 3x3): input transform -> one batched GEMM over the 16 transform planes -> inverse transform + BN + residual + ReLU
             m = _winograd_m(H, W)
+            L = hip.lib()
+            if L.cadre_winograd_fused_supported(F, H, W, c.cin, c.cout, m):
+                # round 6: the plane products and the inverse transform in one kernel (csrc/winograd_fused.hip): V goes out in
+                # MFMA-fragment order, the (m+2)^2 product planes never reach HBM
+                V = self._flat("wino_v", int(L.cadre_winograd_frag_elems(F, H, W, c.cin, m)))
+                hip.winograd_fused(x, V, c.wino_u_frag(m, self.device), c.scale, c.shift, resid, out, F, H, W, c.cin, c.cout, act, m)
+                return out, Ho, Wo
             P, T = (m + 2) ** 2, F * -(-H // m) * -(-W // m)
             V = self._flat("wino_v", P * T * c.cin).view(P, T, c.cin)
             Mx = self._flat("wino_m", P * T * c.cout).view(P, T, c.cout)
-            L = hip.lib()
             hip.check(L.cadre_winograd_in(hip.ptr(x), hip.ptr(V), F, H, W, c.cin, m, hip.stream()), "cadre_winograd_in")
             hip.gemm(V, c.wino_u(m, self.device), Mx, T, c.cout, c.cin, c.cin, c.cin, c.cout, batch=P,
                      a_z=(1, P, T * c.cin), b_z=(1, P, c.cout * c.cin), c_z=(1, P, T * c.cout))

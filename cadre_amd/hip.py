@@ -61,6 +61,11 @@ SYMBOLS = {
     "cadre_winograd_c64": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "cadre_winograd_in": [vp, vp, i32, i32, i32, i32, i32, vp],
     "cadre_winograd_out": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
+    "cadre_winograd_fused_supported": [i32, i32, i32, i32, i32, i32],
+    "cadre_winograd_fused_capable": [i32, i32, i32, i32, i32, i32],
+    "cadre_winograd_frag_elems": [i32, i32, i32, i32, i32],
+    "cadre_winograd_in_frag": [vp, vp, i32, i32, i32, i32, i32, vp],
+    "cadre_winograd_gemm_out": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "cadre_pam": [vp, vp, f32, vp, i32, i32, vp],
     "cadre_cam": [vp, f32, vp, i32, i32, vp],
     "cadre_intertask_att": [vp, vp, i64, i32, f32, vp],
@@ -109,7 +114,7 @@ AB_SYMBOLS = {
 }
 
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class CadreHipError(RuntimeError):
@@ -133,7 +138,7 @@ def lib():
         for name, args in SYMBOLS.items():
             fn = getattr(L, name)
             fn.argtypes = args
-            fn.restype = C.c_char_p if name == "cadre_last_error" else C.c_int
+            fn.restype = C.c_char_p if name == "cadre_last_error" else (C.c_int64 if name == "cadre_winograd_frag_elems" else C.c_int)
         if L.cadre_abi_version() != ABI_VERSION:
             raise CadreHipError("libcadre_hip.so ABI version mismatch (library %d, binding %d): rebuild with "
                                 "`python -m cadre_amd.build`" % (L.cadre_abi_version(), ABI_VERSION))
@@ -252,6 +257,26 @@ def winograd_c64(x, u, scale, shift, resid, out, F, H, W, act):
     T = F * ((H + 1) // 2) * ((W + 1) // 2)
     nbytes = F * H * W * 64 * 4 * (3 if resid is not None else 2) + 16 * 64 * 64 * 4
     PROFILE.append((("wino_c64", resid is not None), 2.0 * 16 * T * 64 * 64, e0, e1, (T, 64, 64 * 16, 1, 1, 0), nbytes))
+
+
+def winograd_fused(x, V, u_frag, scale, shift, resid, out, F, H, W, Cin, N, act, m):
+    """cadre_winograd_in_frag + cadre_winograd_gemm_out (Winograd F(m x m, 3x3): the plane products and the inverse transform in one
+    kernel, csrc/winograd_fused.hip).  Profiling key ("wgo", m) on the product kernel: wino_gemm_out_kernel<m>; FLOPs = the EXECUTED
+    ones ((m+2)^2 planes x tiles x Cin x N), bytes = V read once + the output written (+ the residual read) + U."""
+    L = lib()
+    check(L.cadre_winograd_in_frag(ptr(x), ptr(V), F, H, W, Cin, m, stream()), "cadre_winograd_in_frag")
+    fn = L.cadre_winograd_gemm_out
+    args = (ptr(V), ptr(u_frag), ptr(scale), ptr(shift), ptr(resid), ptr(out), F, H, W, Cin, N, act, m, stream())
+    if PROFILE is None or torch.cuda.is_current_stream_capturing():
+        check(fn(*args), "cadre_winograd_gemm_out")
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(fn(*args), "cadre_winograd_gemm_out")
+    e1.record()
+    P, T = (m + 2) ** 2, F * -(-H // m) * -(-W // m)
+    nbytes = (P * T * Cin + P * N * Cin + F * H * W * N * (2 if resid is not None else 1)) * 4
+    PROFILE.append((("wgo", m), 2.0 * P * T * Cin * N, e0, e1, (T, N, Cin * P, 1, 1, 0), nbytes))
 
 
 def conv3x3_s2(x, w_s2, scale, shift, out, F, H, W, Cin, N, act):

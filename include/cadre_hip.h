@@ -15,7 +15,7 @@
 extern "C" {
 #endif
 
-#define CADRE_ABI_VERSION 13
+#define CADRE_ABI_VERSION 14
 int cadre_abi_version(void);
 /* human-readable last argument error of the calling thread ("" if none) */
 const char* cadre_last_error(void);
@@ -206,6 +206,21 @@ int cadre_winograd_c64(const float* x, const float* U, const float* scale, const
 int cadre_winograd_in(const float* x, float* V, int32_t F, int32_t H, int32_t W, int32_t C, int32_t m, void* stream);
 int cadre_winograd_out(const float* Mx, const float* scale, const float* shift, const float* resid, float* out,
                        int32_t F, int32_t H, int32_t W, int32_t N, int32_t act, int32_t m, void* stream);
+/* Winograd F(m x m, 3x3), m = 2, 3 or 4, fp32, with the plane products and the inverse transform in ONE kernel (csrc/winograd_fused.hip;
+ * the stride-1 / pad-1 3x3 convs of resnet.py:26-55 and danet.py:21-41 with >= 128 channels): the (m+2)^2 product planes M never
+ * reach HBM.  cadre_winograd_in_frag writes V = B^T d B in MFMA-fragment order [(m+2)^2][C/16][Tpad/16][4 kk][16 tiles][4]
+ * (channel 16 c + 4 kk + e of tile 16 tb + t at float ((((xi * C/16 + c) * Tpad/16 + tb) * 4 + kk) * 16 + t) * 4 + e; Tpad = T rounded up
+ * to 64; cadre_winograd_frag_elems floats); cadre_winograd_gemm_out multiplies every plane by U — (G g G^T)[xi][cout][cin] packed
+ * [N/32][C/16][(m+2)^2][2 nb][4 kk][16 couts][4] (cadre_amd/encoder.py _winograd_u_frag) — and stores
+ * out = act(A^T M A * scale + shift (+ resid)), act as in cadre_winograd_out.  The kernels take m 2..4, C % 32 == 0, N % 32 == 0, every
+ * tensor below 2 GiB; cadre_winograd_fused_capable says so; cadre_winograd_fused_supported is the encoder's dispatch question — capability AND policy (default: m == 4, where
+ * the fused form measured faster; CADRE_WINOGRAD_FUSED=2: every geometry the kernels take, 0: never). */
+int cadre_winograd_fused_supported(int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t m);
+int cadre_winograd_fused_capable(int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t m);
+int64_t cadre_winograd_frag_elems(int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t m);
+int cadre_winograd_in_frag(const float* x, float* V, int32_t F, int32_t H, int32_t W, int32_t C, int32_t m, void* stream);
+int cadre_winograd_gemm_out(const float* V, const float* U, const float* scale, const float* shift, const float* resid, float* out,
+                            int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t act, int32_t m, void* stream);
 /* The fused front converts bytes arithmetically (fma(x, r_hi, x * r_lo), r_hi + r_lo = 1/255 split in two floats) instead of through the
  * table: counts, into *mismatches (device int32), the i in 0..255 for which that differs from lut255[i]; must be 0. */
 int cadre_div255_selfcheck(const float* lut255, int32_t* mismatches, void* stream);

@@ -1334,6 +1334,91 @@ def test_winograd_conv3x3_matches_torch(hip, F, H, W, Cin, N, use_resid, act, m)
     assert torch.equal(gb[2:2 + F], got) or F + 2 > big
 
 
+def _wino_fused_run(hip, xd, u, scd, shd, rd, Fb, H, W, Cin, N, act, m):
+    L = hip.lib()
+    assert L.cadre_winograd_fused_capable(Fb, H, W, Cin, N, m) == 1
+    V = torch.full((int(L.cadre_winograd_frag_elems(Fb, H, W, Cin, m)),), float("nan"), device="cuda")
+    out = torch.full((Fb, H, W, N), 7.0, device="cuda")
+    hip.winograd_fused(xd, V, u, scd, shd, rd, out, Fb, H, W, Cin, N, act, m)
+    return out
+
+
+@pytest.mark.parametrize("F,H,W,Cin,N,use_resid,act", [(3, 9, 9, 64, 128, True, 1), (2, 18, 18, 32, 64, False, 1), (2, 7, 10, 32, 32, True, 17),
+                                                     (1, 1, 1, 32, 32, False, 0), (5, 6, 5, 96, 160, True, 0), (9, 36, 36, 128, 128, True, 1)])
+@pytest.mark.parametrize("m", [2, 3, 4])
+def test_winograd_fused_matches_torch(hip, F, H, W, Cin, N, use_resid, act, m):
+    """cadre_winograd_in_frag -> cadre_winograd_gemm_out (all (m+2)^2 plane products and the inverse transform in one kernel,
+    csrc/winograd_fused.hip) vs torch conv2d fp32 on the reference layer's formulation (resnet.py:26-55: conv3x3 / s1 / p1 + folded
+    BN + residual + ReLU): maps the tiles do not divide, a 1x1 map, tile counts that are no multiple of 64 (V is padded with NaN
+    here: a padding tile must never reach a stored output), several items per tile block; the same frames inside a larger batch
+    give the same bits (the latent cache rests on it)."""
+    from cadre_amd.encoder import _winograd_u_frag
+    g = torch.Generator().manual_seed(F * 100 + H + m)
+    x = torch.randn(F, H, W, Cin, generator=g)
+    w = torch.randn(N, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5
+    sc, sh = 0.5 + torch.rand(N, generator=g), torch.randn(N, generator=g)
+    res = torch.randn(F, H, W, N, generator=g) if use_resid else None
+    want = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1) * sc + sh
+    if res is not None and not (act & 16):
+        want = want + res
+    if (act & 15) == 1:
+        want = torch.relu(want)
+    if res is not None and (act & 16):
+        want = want + res
+    u, scd, shd = dev(_winograd_u_frag(w, m)), dev(sc), dev(sh)
+    got = _wino_fused_run(hip, dev(x), u, scd, shd, None if res is None else dev(res), F, H, W, Cin, N, act, m)
+    assert torch.isfinite(got).all()
+    assert rel(got.cpu(), want) < 2e-5, float((got.cpu() - want).abs().max())
+    big = F + 5
+    xb = torch.randn(big, H, W, Cin, generator=g)
+    rb = torch.randn(big, H, W, N, generator=g) if use_resid else None
+    xb[2:2 + F] = x
+    if rb is not None:
+        rb[2:2 + F] = res
+    gb = _wino_fused_run(hip, dev(xb), u, scd, shd, None if rb is None else dev(rb), big, H, W, Cin, N, act, m)
+    assert torch.equal(gb[2:2 + F], got)
+
+
+@pytest.mark.parametrize("m,H,Cin,N,F", [(4, 36, 128, 128, 80), (3, 18, 256, 256, 150), (3, 9, 512, 128, 500)])
+def test_winograd_fused_persistent_items_and_repeatable_under_load(hip, m, H, Cin, N, F):
+    """More items than workgroups (every workgroup walks several (tile block, channel block) items: requests run on across item
+    boundaries, the epilogue's stores and residual loads share the queue with them) on the encoder's own layer shapes, against
+    torch-CPU fp32 on sampled frames; ten launches with every CU loaded give the same bits (hand-counted vmcnt + raw barriers)."""
+    from cadre_amd.encoder import _winograd_u_frag
+    g = torch.Generator().manual_seed(m * 1000 + H)
+    x = torch.randn(F, H, H, Cin, generator=g)
+    w = torch.randn(N, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5
+    sc, sh = 0.5 + torch.rand(N, generator=g), torch.randn(N, generator=g)
+    res = torch.randn(F, H, H, N, generator=g)
+    T = F * (-(-H // m)) ** 2
+    assert -(-T // 64) * (N // 32) > 256
+    u, scd, shd, xd, rd = dev(_winograd_u_frag(w, m)), dev(sc), dev(sh), dev(x), dev(res)
+    outs = [_wino_fused_run(hip, xd, u, scd, shd, rd, F, H, H, Cin, N, 1, m) for _ in range(10)]
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    for sl in (slice(0, 2), slice(F // 2, F // 2 + 2), slice(F - 2, F)):
+        ref = torch.nn.functional.conv2d(x[sl].permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1) * sc + sh + res[sl]
+        ref = torch.relu(ref)
+        assert float((outs[0][sl].cpu() - ref).abs().max() / ref.abs().max()) < 2e-5
+
+
+def test_winograd_fused_rejects_bad_arguments(hip):
+    L = hip.lib()
+    assert L.cadre_winograd_fused_capable(4, 36, 36, 128, 128, 4) == 1
+    assert L.cadre_winograd_fused_capable(4, 36, 36, 100, 128, 4) == 0      # Cin % 32
+    assert L.cadre_winograd_fused_capable(4, 36, 36, 128, 48, 4) == 0       # N % 32
+    assert L.cadre_winograd_fused_capable(4, 36, 36, 128, 128, 5) == 0
+    assert L.cadre_winograd_fused_capable(4096, 36, 36, 128, 128, 4) == 0    # V past 2 GiB
+    assert L.cadre_winograd_fused_supported(4, 36, 36, 100, 128, 4) == 0    # (policy never says yes where the kernels cannot)
+    x = torch.zeros(1, 4, 4, 32, device="cuda")
+    V = torch.zeros(int(L.cadre_winograd_frag_elems(1, 4, 4, 32, 2)), device="cuda")
+    with pytest.raises(hip.CadreHipError):
+        hip.check(L.cadre_winograd_gemm_out(hip.ptr(V), hip.ptr(x), None, None, None, hip.ptr(x), 1, 4, 4, 32, 48, 0, 2, hip.stream()), "bad N")
+    with pytest.raises(hip.CadreHipError):
+        hip.check(L.cadre_winograd_in_frag(hip.ptr(x), None, 1, 4, 4, 32, 2, hip.stream()), "null V")
+
+
 @pytest.mark.parametrize("H,W,F", [(84, 84, 3), (144, 256, 2), (288, 288, 2)])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_fused_stem_pool(hip, H, W, F, dtype):

@@ -57,7 +57,7 @@ def test_c2_encoder_goldens_inside_1024_frame_chunk(golden):
         torch.cuda.synchronize()
     finally:
         hip.PROFILE = None
-    code = lambda k: {"ring": 65, "wino_c64": 66}.get(k[0], k[0])
+    code = lambda k: {"ring": 65, "wino_c64": 66, "wgo": 67}.get(k[0], k[0])
     tiles = {code(k) for k, *_ in prof}
     launched = {(code(k), shape[0], shape[1]) for k, _f, _a, _b, shape, _nb in prof}
     # the timed run's kernels: fused front (stem_pool.hip, no GEMM launch for the stem), the four stage-1 convs as the fused
@@ -65,6 +65,8 @@ def test_c2_encoder_goldens_inside_1024_frame_chunk(golden):
     # Winograd convs' batched GEMMs
     assert enc.fused_stem and 8 in tiles, sorted(tiles)
     assert sum(1 for k, *_ in prof if k[0] == "wino_c64") == 4 and (66, F * 36 * 36, 64) in launched, sorted(launched)[:8]
+    # layer2's three stride-1 convs: F(4x4) with the plane products and the inverse transform in one kernel (winograd_fused.hip)
+    assert sum(1 for k, *_ in prof if k[0] == "wgo") == 3 and (67, F * 81, 128) in launched, sorted(launched)[:8]
     got = torch.stack([lat[0], lat[F - 1]])
     e = rel(got.cpu().numpy(), g["latent"])
     print("288x288 goldens inside a 1024-frame chunk: latent rel-max-err %.2e, tiles %s" % (e, sorted(tiles)))

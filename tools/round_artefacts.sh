@@ -6,7 +6,7 @@
 # into profiles/ (tracked) afterwards.  No step names = all steps.
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-TAG=${1:-r05}; shift
+TAG=${1:-r06}; shift
 STEPS="${*:-tests bench prof peaks layers}"
 O=gpurun_out/${TAG}_artefacts; mkdir -p $O
 has() { [[ " $STEPS " == *" $1 "* ]]; }
@@ -19,9 +19,13 @@ if has bench; then
 fi
 if has prof; then
   bash tools/prof_bench.sh > $O/prof_bench.log 2>&1; echo "prof rc=$?"
-  cp gpurun_out/prof_bench/summary.txt $O/rocprof_summary.txt; cp gpurun_out/prof_bench/traffic.json $O/hbm_traffic.json
-  f=$(find gpurun_out/prof_bench/trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats.csv
-  cp gpurun_out/prof_bench/trace.json $O/bench_under_rocprof.json
+  for S in headline c3; do
+    cp gpurun_out/prof_bench/summary_$S.txt $O/rocprof_summary_$S.txt; cp gpurun_out/prof_bench/kernel_stats_$S.csv $O/kernel_stats_$S.csv
+    cp gpurun_out/prof_bench/bench_under_rocprof_$S.json $O/bench_under_rocprof_$S.json
+  done
+  cp gpurun_out/prof_bench/traffic.json $O/hbm_traffic.json
+  cp gpurun_out/prof_bench/update_step_census_headline.txt $O/update_step_census_C2.txt
+  cp gpurun_out/prof_bench/update_step_census_c3.txt $O/update_step_census_C3.txt
 fi
 if has peaks; then
   timeout 300 python tools/peaks_bench.py > $O/peaks.txt 2>&1; tail -3 $O/peaks.txt

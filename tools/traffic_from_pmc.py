@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Turn the FETCH_SIZE / WRITE_SIZE passes of tools/prof_bench.sh into per-launch HBM traffic of
-the GEMM kernels (gfx950 correction: FETCH_SIZE counts half the bytes of wide coalesced reads —
+"""Turn the FETCH_SIZE / WRITE_SIZE passes of ONE bench section (tools/prof_bench.sh: `bench.py --section ...`) into per-launch
+HBM traffic of its kernels: {"rounds": learner rounds of the profiled command, "kernels": {name: {..., "launches"}}} (gfx950 correction: FETCH_SIZE counts half the bytes of wide coalesced reads —
 MI355X_MICROARCH.md §HBM — so reads are doubled; both counters are in KiB)."""
 import csv
 import glob
@@ -10,6 +10,7 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else None
 out = {}
 for name, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
     for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
@@ -25,4 +26,4 @@ for name, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
             out[k]["launches"] = cnt[k]
 for k, d in out.items():
     d["hbm_bytes_per_launch"] = d.get("FETCH_SIZE_bytes_per_launch", 0.0) + d.get("WRITE_SIZE_bytes_per_launch", 0.0)
-json.dump(out, sys.stdout, indent=1, sort_keys=True)
+json.dump({"rounds": rounds, "kernels": out}, sys.stdout, indent=1, sort_keys=True)
