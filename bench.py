@@ -596,6 +596,13 @@ def run_config(name, args, rank, local_rank, world, use_dist, steps, warmup, epi
         out["allreduce_ms_per_step"] = round(e0.elapsed_time(e1) / reps, 4)
         out["allreduce_bytes"] = int(g.numel() * 4)
         out["exchanges_in_timed_region"] = n_ex          # one per optimiser step: 8 per round
+        # replicated optimiser: every rank must hold the same parameter bits after the timed rounds.  Checksum = the parameters'
+        # bit patterns summed as int64, gathered from every rank (the first multi-GPU box checks C4 without a builder turn)
+        cs = agent.arena.params.view(torch.int32).to(torch.int64).sum().reshape(1)
+        allcs = [torch.zeros_like(cs) for _ in range(world)]
+        dist.all_gather(allcs, cs)
+        out["param_checksum_by_rank"] = [int(c.item()) for c in allcs]
+        out["params_identical_across_ranks"] = len(set(out["param_checksum_by_rank"])) == 1
     del workers, shared, agent
     torch.cuda.empty_cache()
     return out, cfg, enc_state, ppo_state

@@ -86,9 +86,15 @@ class PPOArena:
         self.step = 0
         # clip segments in reference model order is irrelevant for the math; one segment per model
         offs = [g * self.size_L for g in range(self.Z)] + [self.P0 + g * self.size_P for g in range(self.Z)] + [self.total]
-        self.seg_off = self._alloc_shared(lambda: torch.tensor(offs, dtype=torch.int64).to(self.device))
-        self.norms2 = self._alloc_shared(lambda: torch.zeros(2 * self.Z + 2, dtype=torch.float64, device=self.device))
-        self.step_dev = self._alloc_shared(lambda: torch.zeros(1, dtype=torch.int32, device=self.device))   # Adam step count (graph replay)
+        # the three small device tensors of the optimiser step share ONE pooled block (with a never-split pool each tensor is its
+        # own hipMalloc: ADVICE r5): [segment offsets (int64) | per-model square norms (float64) | Adam step count (int32)]
+        n_off = len(offs)
+        n_nrm = 2 * self.Z + 2
+        self._small = self._alloc_shared(lambda: torch.zeros(n_off + n_nrm + 1, dtype=torch.int64, device=self.device))
+        self.seg_off = self._small[:n_off]
+        self.seg_off.copy_(torch.tensor(offs, dtype=torch.int64))
+        self.norms2 = self._small[n_off:n_off + n_nrm].view(torch.float64)
+        self.step_dev = self._small[n_off + n_nrm:].view(torch.int32)[:1]                 # Adam step count (graph replay)
 
     # ------------------------------------------------------------------ naming
     def net_index(self, head, command):
@@ -183,5 +189,7 @@ class PPOArena:
             raise RuntimeError("this arena's Adam state is sharded over the data-parallel ranks (elements [%d, %d)); "
                                "the replicated optimiser step cannot follow sharded ones" % self._shard)
         if self.exp_avg is None:
-            self.exp_avg = torch.zeros_like(self.params)
-            self.exp_avg_sq = torch.zeros_like(self.params)
+            # (the moments are pickled with the arena once they exist — main.py:57-70 hands the optimiser's owner to the chief —,
+            #  so they come from the private pool like everything else that travels: ADVICE r5)
+            self.exp_avg = self._alloc_shared(lambda: torch.zeros_like(self.params))
+            self.exp_avg_sq = self._alloc_shared(lambda: torch.zeros_like(self.params))

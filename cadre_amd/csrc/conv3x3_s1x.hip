@@ -454,6 +454,10 @@ static int s1x_stages(int W, int N) {
   return (want == 3 && fixed + 3 * SX_STG_B <= 160 * 1024) ? 3 : 2;
 }
 
+// weight stages cadre_conv3x3_s1x runs with at this map width and channel count (the profiling key / kernel name of the launch:
+// conv3x3_s1x_kernel<nps, stages>; a request for 3 falls back to 2 where three stages do not fit beside the windows)
+extern "C" int cadre_conv3x3_s1x_stages(int32_t W, int32_t N) { return s1x_stages(W, N); }
+
 static int s1x_capable(int F, int H, int W, int C1, int Cd, int N) {
   if (F < 1 || H < 1 || W < 2 || W > 46) return 0;          // 4 * 11 pieces of 8 pixels >= 256 + 2 W + 2
   if (C1 % 64 != 0 || Cd % 64 != 0 || C1 < 64 || Cd < 0 || N % 32 != 0) return 0;      // (Cd == 0: no shortcut, a plain 3x3 / s1 conv)

@@ -348,8 +348,9 @@ class DANetEncoderHIP:
                 w2.append(sd[pre + ".3.weight"])
                 b2.append(sd[pre + ".3.bias"])
             self.ita_w1.append(torch.cat(ws).contiguous().to(dev).to(wd))  # [1536][Np*512]
-            # the same matrix in fragment order for cadre_gemm_bf16_w128 (bf16 model, large frame batches)
-            self.ita_w1f.append(_w128_dense_b(torch.cat(ws).float()).to(dev).to(wd) if wd == torch.bfloat16 else None)
+            # (the same matrix in fragment order for cadre_gemm_bf16_w128 — bf16 model, frame batches > 64 — is built on the first
+            #  such call: _ita_frag; 127 MB per branch at 288 x 288 that an act()-only agent never needs: ADVICE r5)
+            self.ita_w1f.append(None)
             self.ita_b1.append(torch.cat(bs).contiguous().to(dev))
         self.ita_w2 = torch.stack(w2).contiguous().to(dev)                # [6][256][512]
         self.ita_b2 = torch.stack(b2).contiguous().to(dev)                # [6][256]
@@ -368,6 +369,13 @@ class DANetEncoderHIP:
         self._pass_frames = 0
         self.ws_generation = 0
         self.n_weights = sum(t.numel() for t in self._all_weight_tensors())
+
+    def _ita_frag(self, b):
+        """Inter-task first-layer matrix of branch b in the fragment order of cadre_gemm_bf16_w128, built on first use (on the device,
+        from the bf16 matrix: a permutation, the same bits)."""
+        if self.ita_w1f[b] is None:
+            self.ita_w1f[b] = _w128_dense_b(self.ita_w1[b]).contiguous()
+        return self.ita_w1f[b]
 
     def _all_weight_tensors(self):
         convs = [self.stem, self.conv5a, self.conv5c, self.conv51, self.conv52, self.conv8, self.visual_conv, self.bc_conv]
@@ -589,9 +597,9 @@ class DANetEncoderHIP:
         for b, src in enumerate((vis, bc)):
             if split > 1:
                 slabs = self._buf("ita_slab", (split, F, 1536))
-                if self.bf16 and F > 64 and self.ita_w1f[b] is not None and L.cadre_gemm_bf16_w128_supported(F, 1536, Kin, Kin, 1536, split):
+                if self.bf16 and F > 64 and L.cadre_gemm_bf16_w128_supported(F, 1536, Kin, Kin, 1536, split):
                     # 256 x 256 tiles, weights streamed in fragment order: the same slices and k order, bit-identical partial sums
-                    hip.gemm_bf16_w128(src, self.ita_w1f[b], slabs, F, 1536, Kin, Kin, 1536, split)
+                    hip.gemm_bf16_w128(src, self._ita_frag(b), slabs, F, 1536, Kin, Kin, 1536, split)
                 else:
                     hip.gemm(src, self.ita_w1[b], slabs, F, 1536, Kin, Kin, Kin, 1536, split_k=split,
                              tile=3 if F <= 64 else 0, bf16=self.bf16)

@@ -45,6 +45,7 @@ SYMBOLS = {
     "cadre_conv3x3_s2_supported": [i32, i32, i32, i32, i32],
     "cadre_conv3x3_s1x": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "cadre_conv3x3_s1x_supported": [i32, i32, i32, i32, i32, i32],
+    "cadre_conv3x3_s1x_stages": [i32, i32],
     "cadre_gemm_bf16_w128": [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "cadre_gemm_bf16_w128_supported": [i32, i32, i32, i32, i32, i32],
     "cadre_maxpool3x3s2_bf16": [vp, vp, i32, i32, i32, i32, vp],
@@ -314,7 +315,7 @@ def conv3x3_s1x(x, x2, w_s1x, shift, out, F, H, W, C1, Cd, N, act):
     nbytes = (M * C1 + M * Cd + N * (9 * C1 + Cd) + M * N) * 2          # (the shortcut reads one pixel in four of x2)
     pa = ((256 + 2 * W + 2 + 7) // 8 * 8) // 8
     nps = 9 if pa <= 36 else (10 if pa <= 40 else 11)
-    nstg = 3 if os.environ.get("CADRE_S1X_STAGES", "2") == "3" else 2
+    nstg = int(lib().cadre_conv3x3_s1x_stages(W, N))       # (what the library launches: a request for 3 stages falls back to 2 where they do not fit)
     PROFILE.append((("s1x", nps, nstg), 2.0 * M * N * (9 * C1 + Cd), e0, e1, (M, N, 9 * C1 + Cd, 1, 1, 0), nbytes))
 
 

@@ -121,6 +121,9 @@ int cadre_conv3x3_s2_supported(int32_t F, int32_t H, int32_t W, int32_t Cin, int
 int cadre_conv3x3_s1x(const void* x, const void* x2, const void* w, const float* shift, void* out, int32_t F, int32_t H, int32_t W,
                       int32_t C1, int32_t Cd, int32_t N, int32_t act, void* stream);
 int cadre_conv3x3_s1x_supported(int32_t F, int32_t H, int32_t W, int32_t C1, int32_t Cd, int32_t N);
+/* weight stages of the launch at this map width / channel count (2, or 3 under CADRE_S1X_STAGES=3 where they fit): the second
+ * template argument of conv3x3_s1x_kernel<nps, stages> */
+int cadre_conv3x3_s1x_stages(int32_t W, int32_t N);
 /* Dense bf16 NT product with split-K into raw fp32 partial sums (the inter-task attention's first layers, intertask_att.py:39-80, bf16
  * model): slab[s][M][ldc] = A[M][k in slice s] . B[N][k in slice s]^T, slice s = 64-element k-tiles [s * per, (s + 1) * per), per =
  * ceil(K / 64 / split_k) — the slices, the k order and therefore every partial sum of cadre_gemm_bf16 with split_k (reduce with

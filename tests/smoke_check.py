@@ -1,5 +1,5 @@
-"""smoke(): one small hot-path invocation on cuda:0 checked against the oracle.
-This is the only module under cadre_amd/ allowed to import oracle/ (test infrastructure)."""
+"""smoke(): one small hot-path invocation on cuda:0 checked against the oracle — test infrastructure, called by
+__graft_entry__.smoke() (moved out of the product package in round 6: nothing under cadre_amd/ imports oracle/)."""
 import numpy as np
 import torch
 

@@ -44,6 +44,7 @@ def test_bench_main_at_world_two_on_one_gpu(mode):
     assert ("3 buckets" in d["grad_exchange"]) == (mode == "buckets")
     assert "cpu_baseline" not in d and "measured_peaks" not in d           # rank 0 at N = 1 only
     assert all(abs(x) < 1e3 for x in d["last_losses"])
+    assert d["params_identical_across_ranks"] is True and len(d["param_checksum_by_rank"]) == 2
 
 
 def test_default_headline_is_the_same_config_at_every_world_size():
@@ -65,3 +66,33 @@ def test_default_headline_is_the_same_config_at_every_world_size():
         assert 0.0 < d[k]["update_share_of_round"] < 1.0
     ur = d["update_roofline"]
     assert ur["bound"] in ("hbm", "mfma") and abs(ur["frac"] - max(ur["hbm_frac"], ur["mfma_frac"])) < 1e-9
+
+
+def _device_count():
+    import torch
+    return torch.cuda.device_count()          # (counting devices does not initialise the GPU on this image)
+
+
+@pytest.mark.skipif(_device_count() < 2, reason="needs two GPUs: real RCCL over xGMI (BASELINE C4); one-GPU boxes run the gloo form above")
+def test_bench_two_gpus_over_rccl():
+    """BASELINE C4's exchange on real RCCL as soon as a box has two GPUs: `python bench.py --gpus 2` — fresh
+    children of a parent that never touches the GPU, backend nccl, one GPU per rank — in the three exchange forms.  Asserts the
+    communicator's size, ONE exchange per optimiser step, bit-identical parameter arenas on both ranks, and that the sharded and
+    the three-bucket forms end on the same parameter bits as the plain all-reduce (a + b is one rounding whichever collective
+    adds).  Reference: ppo_agent/models.py:231-239 (gradient hand-off), chief.py:13-21, main.py:57-70."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                            "CADRE_BENCH_BACKEND", "CADRE_BENCH_ONE_DEVICE")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sums = {}
+    for mode, extra in (("allreduce", []), ("sharded", ["--grad-exchange", "sharded"]), ("buckets", ["--grad-buckets"])):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "C1",
+                            "--no-c3", "--no-cpu-baseline", "--no-peaks"] + extra, env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-4000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, p.stdout[-2000:]
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["backend"] == "nccl (RCCL)" and "one_device" not in d
+        assert d["exchanges_in_timed_region"] == 16 and d["allreduce_bytes"] == 4 * 19998848 and d["allreduce_ms_per_step"] > 0
+        assert d["params_identical_across_ranks"] is True, d["param_checksum_by_rank"]
+        sums[mode] = d["param_checksum_by_rank"][0]
+    assert sums["sharded"] == sums["allreduce"] and sums["buckets"] == sums["allreduce"], sums

@@ -143,8 +143,8 @@ def test_act_matches_reference(golden):
         assert rel(feat.cpu().numpy(), g["feats"][i]) < 2e-4
         assert [int(a[0]), int(a[1])] == list(g["actions"][i]), (i, g["margins"][2 * i:2 * i + 2])   # bit-exact
         assert a[0].dim() == 0 and a[0].dtype == torch.int64 and tuple(lp[0].shape) == (1, 1)
-        assert rel([lp[0].item(), lp[1].item()], g["log_probs"][i]) < 1e-3
-        assert rel([v[0].item(), v[1].item()], g["values"][i]) < 1e-3
+        assert rel([lp[0].item(), lp[1].item()], g["log_probs"][i]) < 1e-4      # (one bar for act-time heads: the C2 contract's)
+        assert rel([v[0].item(), v[1].item()], g["values"][i]) < 1e-4
         ctl = agent.convert_action(a)
         assert len(ctl) == 3
 
@@ -153,7 +153,7 @@ def test_act_matches_reference_at_288(golden):
     """F-act at the size bench.py times (288 x 288: Winograd F(4x4) / F(3x3) / the fused layer-1 kernel are the fp32 defaults
     exactly here): agent.py:97-141 of the imported reference (tests/golden/act_288.npz, make_golden.py `act_288`) —
     features within 2e-4, action indices BIT-EXACT (smallest top-2 margin of p/q in the fixture: 1.1e-2, recorded in
-    `margins`), log-probs and values within 1e-3."""
+    `margins`), log-probs and values within 1e-4 (the bar of the C2 contract test)."""
     g = golden("act_288")
     agent = make_agent(288, 288)
     steps = synth.synth_rollout(len(g["actions"]), 288, 288, seed=int(g["rollout_seed"]))
@@ -166,8 +166,8 @@ def test_act_matches_reference_at_288(golden):
         worst = max(worst, e)
         assert e < 2e-4, (i, e)
         assert [int(a[0]), int(a[1])] == list(g["actions"][i]), (i, g["margins"][2 * i:2 * i + 2])   # bit-exact
-        assert rel([lp[0].item(), lp[1].item()], g["log_probs"][i]) < 1e-3
-        assert rel([v[0].item(), v[1].item()], g["values"][i]) < 1e-3
+        assert rel([lp[0].item(), lp[1].item()], g["log_probs"][i]) < 1e-4
+        assert rel([v[0].item(), v[1].item()], g["values"][i]) < 1e-4
     print("act at 288x288: worst feature error %.2e, min margin of the fixture %.2e" % (worst, float(g["margins"].min())))
 
 

@@ -28,7 +28,7 @@ C3_FEAT_TOL = 1.5e-2      # max |feat_bf16 - feat_fp32| / max |feat_fp32|   (mea
 C3_LOSS_TOL = 2e-2        # each of the three update_policy losses, relative, vs oracle-on-fp32 (measured 3e-3)
 C3_VALUE_TOL = 2e-2       # critic values / log-probs of act(): abs error relative to max(1, |ref|) (measured 3e-3)
 C3_MARGIN = 0.25          # action indices must agree wherever the fp32 top-2 gap of log(p/q) exceeds this
-C3_GRAD_NORM_TOL = 5e-2   # |grad| of update_policy on bf16 features vs on fp32 features (measured 0.4-2.8 %)
+C3_GRAD_NORM_TOL = 5e-2   # ceiling on |grad| (bf16 features) vs |grad| (fp32 features); the operative bound is 4 sigma of the measured noise spread (sigma ~ 1.3 %)
 
 
 def test_c2_encoder_goldens_inside_1024_frame_chunk(golden):
@@ -280,10 +280,42 @@ def test_c3_bf16_contract_end_to_end():
     gn = float(agent.arena.grads.double().norm())
     print("C3 contract: losses rel err %.2e (got %s want %s), |grad| %.4f vs %.4f" % (e_loss, got_l, want_l, gn, gn_ref))
     assert e_loss < C3_LOSS_TOL
-    # the NORM of the 19 M-element gradient of a 12-window minibatch is more sensitive to the bf16 features than the losses are
-    # (measured 0.4-0.9 % off in round 4, 2.8 % in round 5 with the same feature error, 7.9e-3 -> 8.5e-3, and losses 100x closer):
-    # a sanity bound on the backward pass, not part of the C3 contract
-    assert abs(gn - gn_ref) / gn_ref < C3_GRAD_NORM_TOL
+    # ---- the backward pass, model by model (VERDICT r5 item 4 / ADVICE r5: one global norm with a loosened bound could hide a
+    # numeric change in a kernel).  Root cause of the 0.4-0.9 % -> 2.8 % jump of round 5, measured with
+    # tools/dbg/c3_gradnorm_bisect.py (profiles/r06_c3_gradnorm_bisect.txt): NOT the update kernels — fed the oracle's fp32
+    # features the device's gradients equal the oracle's to 1e-7, fed the device's bf16 features the ORACLE reproduces the
+    # device's norm to the digit — but the statistic: 65 % of |grad| of this 12-window minibatch is ONE net (throttle_lstm_0) and
+    # it moves 1.3 % (1 sigma) under unbiased feature noise of the bf16 encoder's rms (2e-3 of max); every kernel selection is
+    # another draw (-2.85 / -3.07 / -2.76 / -0.91 / +1.67 % for s2+s1x / s2 / s1x / neither / tile kernels only, bias / rms of the
+    # feature error -0.05).  So: (1) per model, device vs oracle ON THE SAME bf16 features at 2e-5 — any change in an update kernel
+    # shows here; (2) the bf16-vs-fp32 deviation against the spread unbiased noise of the same rms gives the oracle (8 draws).
+    per_dev = {name: float(torch.sqrt(sum((q.grad.double() ** 2).sum() for q in mod.parameters()))) for name, mod in agent.model_dict.items()}
+    p3 = ppo_ref.to_torch_params(st0, requires_grad=True)
+    s_b = samples(fb, lambda x: x.contiguous())
+    ppo_ref.update_policy(p3, s_b[0], s_b[1])
+    worst_m = 0.0
+    for m, d in p3.items():
+        ref_m = float(torch.sqrt(sum((q.grad.double() ** 2).sum() for q in d.values())))
+        worst_m = max(worst_m, abs(per_dev[m] - ref_m) / ref_m)
+    dfe = (fb - fr)[..., :512]
+    rms = float(dfe.pow(2).mean().sqrt())
+    gen = torch.Generator().manual_seed(5)
+    devs = []
+    for _ in range(8):
+        fn = fr.clone()
+        fn[..., :512] += rms * torch.randn(fr[..., :512].shape, generator=gen)
+        pn = ppo_ref.to_torch_params(st0, requires_grad=True)
+        sn = samples(fn, lambda x: x.contiguous())
+        ppo_ref.update_policy(pn, sn[0], sn[1])
+        devs.append(float(torch.sqrt(sum((q.grad.double() ** 2).sum() for d in pn.values() for q in d.values()))) / gn_ref - 1.0)
+    sigma = float(np.sqrt(np.mean(np.square(devs))))
+    dev_bf16 = abs(gn - gn_ref) / gn_ref
+    print("C3 contract: per-model |grad| device vs oracle on the same bf16 features: worst %.2e; bf16-vs-fp32 |grad| %.2f %% = %.1f sigma of "
+          "unbiased feature noise (sigma %.2f %%, feature bias / rms %.3f)" % (worst_m, 100 * dev_bf16, dev_bf16 / sigma, 100 * sigma,
+                                                                           float(dfe.mean()) / rms))
+    assert worst_m < 2e-5
+    assert abs(float(dfe.mean())) / rms < 0.2           # the encoder's error is noise, not an offset
+    assert dev_bf16 < 4.0 * sigma and dev_bf16 < C3_GRAD_NORM_TOL
 
 
 # ---------------------------------------------------------------------------------------------------------------
