@@ -1514,57 +1514,74 @@ struct whh_pack_t {
   int64_t p_str;
 };
 
+// Round 6: ONE WAVE PER 16 x 16 TILE of a W_hh, the copies written as whole KiB.  (Round 4's form gave a thread a 4 x 4 block and
+// stored its rows / columns straight into the copies: 64 distinct 64-byte segments per wave instruction — bit-identical, one
+// launch and 110 MB less per step, and not faster.)  Lane (r = lane >> 2, cq = lane & 3) steps row 16 mt + r, columns
+// 16 jt + 4 cq .. + 3 — 16 rows x 64 contiguous bytes per instruction for p, g, m, v —, leaves the new parameters in a 16 x 16 LDS
+// tile of the wave (row pitch 20 floats), and then, as lane (q = lane >> 4, c = lane & 15),
+//   forward copy:  reads row c, columns 4 q .. + 3 (one ds_read_b128)   -> [slice][gate][k-block jt][lane][4]: for a gate-aligned tile
+//                  one contiguous KiB; D = 530 is 2 mod 16, so gate g's tiles start 2 g rows into a slice: two runs per store;
+//   backward copy: reads column c of rows 4 q .. 4 q + 3 (four ds_read_b32) -> [slice jt][quarter][k-block][lane][4]: the row tiles of
+//                  the backward layout are the absolute 16-row groups this kernel walks: ONE contiguous KiB per tile.
+// Rows past 4 D and hidden units past D are never written: the copies are allocated zeroed and nothing else touches those
+// elements (cadre_pack_lstm_weights writes the same zeros).
 __global__ __launch_bounds__(256) void adam_whh_pack_kernel(float* p, const float* g, float* m, float* v, const double* norms2,
                                                             int n_models, float max_norm, float w1, float beta2, float w2, float eps,
                                                             whh_pack_t k) {
+  __shared__ __attribute__((aligned(16))) float tile_s[4][16 * 20];
   const int z = blockIdx.y;
-  const int cb = k.ldw / 4, rbk = k.H4 / 4;                 // 4 x 4 blocks per row / per column of blocks
-  const int id = blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= cb * rbk) return;
-  const int n = (id / cb) * 4, kk = (id % cb) * 4;          // consecutive lanes: consecutive column blocks of one row block
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int CT = k.ldw / 16, RT = (k.H4 + 15) / 16;
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile >= RT * CT) return;
+  const int mt = tile / CT, jt = tile - mt * CT;           // consecutive waves: consecutive column tiles of one row tile
   const float total = (float)sqrt(norms2[z]);
   const float coef = fminf(max_norm / (total + 1e-6f), 1.f);
   const float step_size = (float)norms2[n_models], bc2_sqrt = (float)norms2[n_models + 1];
   const int64_t base = (int64_t)z * k.lstm_str + k.o_whh;
-  float4 np[4];
+  float* ts = tile_s[wave];
+  {
+    const int r = lane >> 2, cq = lane & 3;
+    const int row = 16 * mt + r;
+    float4 pp = {0.f, 0.f, 0.f, 0.f};
+    if (row < k.H4) {
+      const int64_t e = base + (int64_t)row * k.ldw + 16 * jt + 4 * cq;
+      pp = *reinterpret_cast<float4*>(p + e);
+      float4 gg = *reinterpret_cast<const float4*>(g + e), mm = *reinterpret_cast<float4*>(m + e), vv = *reinterpret_cast<float4*>(v + e);
+      float* pe = &pp.x; float* ge = &gg.x; float* me = &mm.x; float* ve = &vv.x;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int64_t e = base + (int64_t)(n + i) * k.ldw + kk;
-    float4 pp = *reinterpret_cast<float4*>(p + e), gg = *reinterpret_cast<const float4*>(g + e);
-    float4 mm = *reinterpret_cast<float4*>(m + e), vv = *reinterpret_cast<float4*>(v + e);
-    float* pe = &pp.x; float* ge = &gg.x; float* me = &mm.x; float* ve = &vv.x;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {                           // (the arithmetic of adam_dev_kernel, same order)
-      const float gi = ge[c] * coef;
-      me[c] = me[c] + w1 * (gi - me[c]);
-      ve[c] = ve[c] * beta2 + w2 * (gi * gi);
-      pe[c] = pe[c] - step_size * (me[c] / (sqrtf(ve[c]) / bc2_sqrt + eps));
+      for (int c = 0; c < 4; ++c) {                         // (the arithmetic of adam_dev_kernel, same order)
+        const float gi = ge[c] * coef;
+        me[c] = me[c] + w1 * (gi - me[c]);
+        ve[c] = ve[c] * beta2 + w2 * (gi * gi);
+        pe[c] = pe[c] - step_size * (me[c] / (sqrtf(ve[c]) / bc2_sqrt + eps));
+      }
+      *reinterpret_cast<float4*>(p + e) = pp;
+      *reinterpret_cast<float4*>(m + e) = mm;
+      *reinterpret_cast<float4*>(v + e) = vv;
     }
-    *reinterpret_cast<float4*>(p + e) = pp;
-    *reinterpret_cast<float4*>(m + e) = mm;
-    *reinterpret_cast<float4*>(v + e) = vv;
-    np[i] = pp;
+    *reinterpret_cast<float4*>(ts + r * 20 + 4 * cq) = pp;
   }
-  const int NB = k.ldw / 16;
-  // forward copy: row r = gate * D + u -> [slice u / 16][gate][k-block kk / 16][lane (q = (kk % 16) / 4, c = u % 16)][4]
-  float* fz = k.fwd + (int64_t)z * k.p_str;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = n + i, gate = r / k.D, u = r - gate * k.D;
-    const int64_t blk = (int64_t)((u >> 4) * 4 + gate) * NB + (kk >> 4);
-    *reinterpret_cast<float4*>(fz + (blk * 64 + ((kk & 15) >> 2) * 16 + (u & 15)) * 4) = np[i];
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  const int q = lane >> 4, c = lane & 15;
+  const int NB = CT;
+  {  // forward copy: row 16 mt + c = gate * D + u
+    const int row = 16 * mt + c;
+    if (row < k.H4) {
+      const int gate = row / k.D, u = row - gate * k.D;
+      const float4 val = *reinterpret_cast<const float4*>(ts + c * 20 + 4 * q);
+      const int64_t blk = (int64_t)((u >> 4) * 4 + gate) * NB + jt;
+      *reinterpret_cast<float4*>(k.fwd + (int64_t)z * k.p_str + (blk * 64 + q * 16 + (u & 15)) * 4) = val;
+    }
   }
-  // backward copy: column u = kk + c (a hidden unit; columns past D hold zeros in W and are not part of the copy), rows
-  // n .. n+3 = 16 (NB w + j) + 4 q + i -> [slice u / 16][quarter w][k-block j][lane (q, c = u % 16)][4]
-  float* bz = k.bwd + (int64_t)z * k.p_str;
-  const int nb16 = n >> 4, w = nb16 / NB, j = nb16 - w * NB, q = (n & 15) >> 2;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int u = kk + c;
+  {  // backward copy: hidden unit u = 16 jt + c, rows 16 mt + 4 q .. + 3 (zeros past 4 D: the tile's padding rows hold zeros)
+    const int u = 16 * jt + c;
     if (u < k.D) {
-      const float* a0 = &np[0].x; const float* a1 = &np[1].x; const float* a2 = &np[2].x; const float* a3 = &np[3].x;
-      const int64_t blk = (int64_t)((u >> 4) * 4 + w) * NB + j;
-      *reinterpret_cast<float4*>(bz + (blk * 64 + q * 16 + (u & 15)) * 4) = float4{a0[c], a1[c], a2[c], a3[c]};
+      const float4 val = {ts[(4 * q) * 20 + c], ts[(4 * q + 1) * 20 + c], ts[(4 * q + 2) * 20 + c], ts[(4 * q + 3) * 20 + c]};
+      const int w = mt / NB, j = mt - w * NB;
+      const int64_t blk = (int64_t)(jt * 4 + w) * NB + j;
+      *reinterpret_cast<float4*>(k.bwd + (int64_t)z * k.p_str + (blk * 64 + lane) * 4) = val;
     }
   }
 }
@@ -1621,7 +1638,7 @@ extern "C" int cadre_clip_adam_pack_graph(float* params, const float* grads, flo
   hipLaunchKernelGGL(adam_dev_skip_kernel, dim3(256, n_models), dim3(256), 0, ST(stream), params, grads, exp_avg, exp_avg_sq, seg_off,
                      norms2, n_models, (float)max_norm, w1, b2, w2, (float)eps, n_lstm, o_whh, (int64_t)H4 * ldw);
   whh_pack_t k{n_lstm, lstm_str, o_whh, H4, ldw, D, fwd, bwd, p_str};
-  const int blocks = ((H4 / 4) * (ldw / 4) + 255) / 256;
+  const int blocks = (((H4 + 15) / 16) * (ldw / 16) + 3) / 4;                                 // four 16 x 16 tiles (one per wave) per workgroup
   hipLaunchKernelGGL(adam_whh_pack_kernel, dim3(blocks, n_lstm), dim3(256), 0, ST(stream), params, grads, exp_avg, exp_avg_sq,
                      norms2, n_models, (float)max_norm, w1, b2, w2, (float)eps, k);
   return (int)hipGetLastError();
