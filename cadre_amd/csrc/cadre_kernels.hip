@@ -1528,61 +1528,81 @@ struct whh_pack_t {
 __global__ __launch_bounds__(256) void adam_whh_pack_kernel(float* p, const float* g, float* m, float* v, const double* norms2,
                                                             int n_models, float max_norm, float w1, float beta2, float w2, float eps,
                                                             whh_pack_t k) {
-  __shared__ __attribute__((aligned(16))) float tile_s[4][16 * 20];
+  constexpr int TW = 2;                                    // tiles per wave and pass: 8 x 16-byte loads in flight per lane
+  __shared__ __attribute__((aligned(16))) float tile_s[4][TW][16 * 20];
   const int z = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int CT = k.ldw / 16, RT = (k.H4 + 15) / 16;
-  const int tile = blockIdx.x * 4 + wave;
-  if (tile >= RT * CT) return;
-  const int mt = tile / CT, jt = tile - mt * CT;           // consecutive waves: consecutive column tiles of one row tile
+  const int CT = k.ldw / 16, RT = (k.H4 + 15) / 16, NB = CT;
+  const int ntile = RT * CT;
   const float total = (float)sqrt(norms2[z]);
   const float coef = fminf(max_norm / (total + 1e-6f), 1.f);
   const float step_size = (float)norms2[n_models], bc2_sqrt = (float)norms2[n_models + 1];
   const int64_t base = (int64_t)z * k.lstm_str + k.o_whh;
-  float* ts = tile_s[wave];
-  {
-    const int r = lane >> 2, cq = lane & 3;
-    const int row = 16 * mt + r;
-    float4 pp = {0.f, 0.f, 0.f, 0.f};
-    if (row < k.H4) {
-      const int64_t e = base + (int64_t)row * k.ldw + 16 * jt + 4 * cq;
-      pp = *reinterpret_cast<float4*>(p + e);
-      float4 gg = *reinterpret_cast<const float4*>(g + e), mm = *reinterpret_cast<float4*>(m + e), vv = *reinterpret_cast<float4*>(v + e);
-      float* pe = &pp.x; float* ge = &gg.x; float* me = &mm.x; float* ve = &vv.x;
+  const int r = lane >> 2, cq = lane & 3, q = lane >> 4, c = lane & 15;
+  for (int t0 = (blockIdx.x * 4 + wave) * TW; t0 < ntile; t0 += gridDim.x * 4 * TW) {
+    float4 pp[TW], gg[TW], mm[TW], vv[TW];
+    int64_t e[TW];
+    bool ok[TW];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {                         // (the arithmetic of adam_dev_kernel, same order)
-        const float gi = ge[c] * coef;
-        me[c] = me[c] + w1 * (gi - me[c]);
-        ve[c] = ve[c] * beta2 + w2 * (gi * gi);
-        pe[c] = pe[c] - step_size * (me[c] / (sqrtf(ve[c]) / bc2_sqrt + eps));
+    for (int i = 0; i < TW; ++i) {                          // consecutive tiles: consecutive column tiles of one row tile
+      const int tile = t0 + i, mt = tile / CT, jt = tile - mt * CT;
+      const int row = 16 * mt + r;
+      ok[i] = tile < ntile && row < k.H4;
+      e[i] = base + (int64_t)row * k.ldw + 16 * jt + 4 * cq;
+      pp[i] = gg[i] = mm[i] = vv[i] = float4{0.f, 0.f, 0.f, 0.f};
+      if (ok[i]) {
+        pp[i] = *reinterpret_cast<float4*>(p + e[i]);
+        gg[i] = *reinterpret_cast<const float4*>(g + e[i]);
+        mm[i] = *reinterpret_cast<float4*>(m + e[i]);
+        vv[i] = *reinterpret_cast<float4*>(v + e[i]);
       }
-      *reinterpret_cast<float4*>(p + e) = pp;
-      *reinterpret_cast<float4*>(m + e) = mm;
-      *reinterpret_cast<float4*>(v + e) = vv;
     }
-    *reinterpret_cast<float4*>(ts + r * 20 + 4 * cq) = pp;
-  }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  const int q = lane >> 4, c = lane & 15;
-  const int NB = CT;
-  {  // forward copy: row 16 mt + c = gate * D + u
-    const int row = 16 * mt + c;
-    if (row < k.H4) {
-      const int gate = row / k.D, u = row - gate * k.D;
-      const float4 val = *reinterpret_cast<const float4*>(ts + c * 20 + 4 * q);
-      const int64_t blk = (int64_t)((u >> 4) * 4 + gate) * NB + jt;
-      *reinterpret_cast<float4*>(k.fwd + (int64_t)z * k.p_str + (blk * 64 + q * 16 + (u & 15)) * 4) = val;
+#pragma unroll
+    for (int i = 0; i < TW; ++i) {
+      float* pe = &pp[i].x; float* ge = &gg[i].x; float* me = &mm[i].x; float* ve = &vv[i].x;
+      if (ok[i]) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {                    // (the arithmetic of adam_dev_kernel, same order)
+          const float gi = ge[cc] * coef;
+          me[cc] = me[cc] + w1 * (gi - me[cc]);
+          ve[cc] = ve[cc] * beta2 + w2 * (gi * gi);
+          pe[cc] = pe[cc] - step_size * (me[cc] / (sqrtf(ve[cc]) / bc2_sqrt + eps));
+        }
+        *reinterpret_cast<float4*>(p + e[i]) = pp[i];
+        *reinterpret_cast<float4*>(m + e[i]) = mm[i];
+        *reinterpret_cast<float4*>(v + e[i]) = vv[i];
+      }
+      *reinterpret_cast<float4*>(tile_s[wave][i] + r * 20 + 4 * cq) = pp[i];
     }
-  }
-  {  // backward copy: hidden unit u = 16 jt + c, rows 16 mt + 4 q .. + 3 (zeros past 4 D: the tile's padding rows hold zeros)
-    const int u = 16 * jt + c;
-    if (u < k.D) {
-      const float4 val = {ts[(4 * q) * 20 + c], ts[(4 * q + 1) * 20 + c], ts[(4 * q + 2) * 20 + c], ts[(4 * q + 3) * 20 + c]};
-      const int w = mt / NB, j = mt - w * NB;
-      const int64_t blk = (int64_t)(jt * 4 + w) * NB + j;
-      *reinterpret_cast<float4*>(k.bwd + (int64_t)z * k.p_str + (blk * 64 + lane) * 4) = val;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < TW; ++i) {
+      const int tile = t0 + i, mt = tile / CT, jt = tile - mt * CT;
+      const float* ts = tile_s[wave][i];
+      if (tile < ntile) {
+        {  // forward copy: row 16 mt + c = gate * D + u
+          const int row = 16 * mt + c;
+          if (row < k.H4) {
+            const int gate = row / k.D, u = row - gate * k.D;
+            const float4 val = *reinterpret_cast<const float4*>(ts + c * 20 + 4 * q);
+            const int64_t blk = (int64_t)((u >> 4) * 4 + gate) * NB + jt;
+            *reinterpret_cast<float4*>(k.fwd + (int64_t)z * k.p_str + (blk * 64 + q * 16 + (u & 15)) * 4) = val;
+          }
+        }
+        {  // backward copy: hidden unit u = 16 jt + c, rows 16 mt + 4 q .. + 3 (zeros past 4 D: the tile's padding rows hold zeros)
+          const int u = 16 * jt + c;
+          if (u < k.D) {
+            const float4 val = {ts[(4 * q) * 20 + c], ts[(4 * q + 1) * 20 + c], ts[(4 * q + 2) * 20 + c], ts[(4 * q + 3) * 20 + c]};
+            const int w = mt / NB, j = mt - w * NB;
+            const int64_t blk = (int64_t)(jt * 4 + w) * NB + j;
+            *reinterpret_cast<float4*>(k.bwd + (int64_t)z * k.p_str + (blk * 64 + lane) * 4) = val;
+          }
+        }
+      }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -1638,7 +1658,7 @@ extern "C" int cadre_clip_adam_pack_graph(float* params, const float* grads, flo
   hipLaunchKernelGGL(adam_dev_skip_kernel, dim3(256, n_models), dim3(256), 0, ST(stream), params, grads, exp_avg, exp_avg_sq, seg_off,
                      norms2, n_models, (float)max_norm, w1, b2, w2, (float)eps, n_lstm, o_whh, (int64_t)H4 * ldw);
   whh_pack_t k{n_lstm, lstm_str, o_whh, H4, ldw, D, fwd, bwd, p_str};
-  const int blocks = (((H4 + 15) / 16) * (ldw / 16) + 3) / 4;                                 // four 16 x 16 tiles (one per wave) per workgroup
+  const int blocks = (((H4 + 15) / 16) * (ldw / 16) + 7) / 8;                                 // per pass: two 16 x 16 tiles per wave, four waves per workgroup
   hipLaunchKernelGGL(adam_whh_pack_kernel, dim3(blocks, n_lstm), dim3(256), 0, ST(stream), params, grads, exp_avg, exp_avg_sq,
                      norms2, n_models, (float)max_norm, w1, b2, w2, (float)eps, k);
   return (int)hipGetLastError();

@@ -141,7 +141,10 @@ _WINO_G = {2: [[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.
                [0.0, 0.0, 1.0]],
            # F(4x4): points 0, 3/4, -3/4, 3/2, -3/2, infinity; rows scaled against the powers of two taken out of B^T (winograd.hip)
            4: [[64.0 / 81, 0.0, 0.0], [128.0 / 243, 128.0 / 324, 128.0 / 432], [128.0 / 243, -128.0 / 324, 128.0 / 432],
-               [32.0 / 243, 32.0 / 162, 32.0 / 108], [32.0 / 243, -32.0 / 162, 32.0 / 108], [0.0, 0.0, 1.0]]}
+               [32.0 / 243, 32.0 / 162, 32.0 / 108], [32.0 / 243, -32.0 / 162, 32.0 / 108], [0.0, 0.0, 1.0]],
+           # F(6x6): points 0, +-1/2, +-1, +-2, infinity (tools/dbg/wino_points.py prints G for the B^T / A^T of csrc/winograd_mats.h)
+           6: [[-2.0, 0.0, 0.0], [64.0 / 45, 32.0 / 45, 16.0 / 45], [64.0 / 45, -32.0 / 45, 16.0 / 45], [-4.0 / 9, -4.0 / 9, -4.0 / 9],
+               [-4.0 / 9, 4.0 / 9, -4.0 / 9], [1.0 / 90, 1.0 / 45, 2.0 / 45], [1.0 / 90, -1.0 / 45, 2.0 / 45], [0.0, 0.0, 2.0]]}
 
 
 def _winograd_u(w, m=2):
@@ -182,18 +185,27 @@ def _winograd_u_c64(w, cin_pairs=True):
 
 def _winograd_m(H, W):
     """Output tile edge of the Winograd form for an H x W map: the one with fewer transform-domain multiplies,
-    (m+2)^2 * ceil(H/m) * ceil(W/m) (F(3x3) tiles the 9x9 and 18x18 maps of the 288x288 model exactly; F(4x4) is taken only
-    where 4x4 tiles cover the map exactly and it is the cheapest: the 36x36 maps).  CADRE_WINOGRAD_M forces 2, 3 or 4."""
+    (m+2)^2 * ceil(H/m) * ceil(W/m) (F(3x3) tiles the 9x9 maps of the 288x288 model exactly; F(4x4) is taken only where 4x4 tiles
+    cover the map exactly and it is the cheapest of m <= 4: the 36x36 maps, where the fused kernel of csrc/winograd_fused.hip runs;
+    F(6x6) — round 6: 64 planes, 5.06x fewer multiplies, rounding error 4-5x the F(4x4) set's — where 6x6 tiles cover the map
+    exactly, it is cheaper still, and the map's larger edge lies in [CADRE_WINOGRAD_M6_MIN, CADRE_WINOGRAD_M6_MAX] (default 18 .. 18:
+    the 18x18 maps of layer3 at 288x288 — the small maps of the 84x84 test model keep F(3x3), whose error the 16-step data-parallel
+    parameter test was tuned on; the 36x36 maps keep the fused F(4x4) kernel).
+    CADRE_WINOGRAD_M forces 2, 3, 4 or 6; CADRE_WINOGRAD_M4=0 / CADRE_WINOGRAD_M6=0: never."""
     e = os.environ.get("CADRE_WINOGRAD_M", "")
-    if e in ("2", "3", "4"):
+    if e in ("2", "3", "4", "6"):
         return int(e)
     cost = {m: (m + 2) ** 2 * -(-H // m) * -(-W // m) for m in (2, 3)}
     best = 3 if cost[3] <= cost[2] else 2
+    bc = cost[best]
     # F(4x4) only where 4 x 4 tiles cover the map EXACTLY (36 x 36: layer2 of the 288 x 288 model) and beat the others: its
     # rounding error is 1.6x the F(3x3) set's (CADRE_WINOGRAD_M4=0: never)
     if (os.environ.get("CADRE_WINOGRAD_M4", "1") != "0" and H % 4 == 0 and W % 4 == 0
-            and 36 * (H // 4) * (W // 4) < cost[best]):
-        return 4
+            and 36 * (H // 4) * (W // 4) < bc):
+        best, bc = 4, 36 * (H // 4) * (W // 4)
+    if (os.environ.get("CADRE_WINOGRAD_M6", "1") != "0" and H % 6 == 0 and W % 6 == 0 and 64 * (H // 6) * (W // 6) < bc
+            and int(os.environ.get("CADRE_WINOGRAD_M6_MIN", "18")) <= max(H, W) <= int(os.environ.get("CADRE_WINOGRAD_M6_MAX", "18"))):
+        best = 6
     return best
 
 

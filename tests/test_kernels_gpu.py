@@ -1291,7 +1291,7 @@ def test_winograd_c64_fused_repeatable_under_load(hip, use_resid):
 
 @pytest.mark.parametrize("F,H,W,Cin,N,use_resid,act", [(3, 9, 9, 64, 128, True, 1), (2, 18, 18, 32, 64, False, 1), (2, 7, 10, 16, 32, True, 17),
                                                      (1, 1, 1, 8, 8, False, 0), (5, 6, 5, 12, 20, True, 0)])
-@pytest.mark.parametrize("m", [2, 3, 4])
+@pytest.mark.parametrize("m", [2, 3, 4, 6])
 def test_winograd_conv3x3_matches_torch(hip, F, H, W, Cin, N, use_resid, act, m):
     """cadre_winograd_in -> batched cadre_gemm_f32 over the (m+2)^2 transform planes -> cadre_winograd_out, F(2x2,3x3) and
     F(3x3,3x3), vs torch conv2d fp32 on the reference layer's formulation (resnet.py:26-55: conv3x3 / s1 / p1 + folded BN +
@@ -1323,7 +1323,8 @@ def test_winograd_conv3x3_matches_torch(hip, F, H, W, Cin, N, use_resid, act, m)
         return out
     u, scd, shd = dev(_winograd_u(w, m)), dev(sc), dev(sh)
     got = run(dev(x), None if res is None else dev(res), F)
-    assert rel(got.cpu(), want) < 2e-5, float((got.cpu() - want).abs().max())
+    # (F(6x6): 4-5x the rounding error of F(4x4) — tools/dbg/wino_points.py; its own bar)
+    assert rel(got.cpu(), want) < (1e-4 if m == 6 else 2e-5), float((got.cpu() - want).abs().max())
     big = 7
     xb = torch.randn(big, H, W, Cin, generator=g)
     rb = torch.randn(big, H, W, N, generator=g) if use_resid else None
