@@ -861,6 +861,87 @@ extern "C" int cadre_gather_minibatch_multi(const void* src_table, int32_t n_src
   return (int)hipGetLastError();
 }
 
+// Gather + stable counting sort by command + placement in ONE launch (round 6; until then three: gather into staging rows,
+// sort_rows_kernel, permute_minibatch_kernel — 20 us and two launch boundaries of a 580 us minibatch step).  Every workgroup
+// (row b of source zi, window step s) re-derives the destination of ITS row from the commands of all Bt rows of its head — Bt
+// is 64 .. 256, the commands come out of L2 — and copies the row straight to its sorted place: rank = rows with a smaller command
+// + earlier rows with the same command (the order sort_rows_kernel produces: every reduction downstream keeps its order).
+// Workgroup (0, S, head's first source) also writes the head's run table seg[2 * (head * C + c)] = (first row, rows) and pos.
+__global__ __launch_bounds__(128) void gather_sorted_multi_kernel(const gather_src_t* src, int64_t ldo, int S, int64_t ldh,
+                                                                  const int64_t* idx, int Bw, int D, int Hd, int Bt, int C, float* X,
+                                                                  int64_t x_hs, int64_t ldx, float* h0, float* c0, int64_t h_hs,
+                                                                  int64_t ldho, int64_t* actions_o, int32_t* commands_o,
+                                                                  float* old_values_o, float* returns_o, float* old_logp_o,
+                                                                  float* adv_o, int32_t* pos, int32_t* seg) {
+  extern __shared__ int32_t gs_cmd[];                      // [Bt] commands of this head, then 2 counters
+  const int b = blockIdx.x, s = blockIdx.y, zi = blockIdx.z;
+  const int wi = zi >> 1, hd = zi & 1;
+  for (int r = threadIdx.x; r < Bt; r += blockDim.x) {
+    const int w2 = r / Bw, b2 = r - w2 * Bw;
+    const int z2 = 2 * w2 + hd;
+    gs_cmd[r] = src[z2].command[idx[(int64_t)z2 * Bw + b2]];
+  }
+  int32_t* cnt = gs_cmd + Bt;
+  if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int ob = wi * Bw + b;
+  const int cme = gs_cmd[ob];
+  int below = 0, before = 0;
+  for (int r = threadIdx.x; r < Bt; r += blockDim.x) {
+    const int c = gs_cmd[r];
+    below += c < cme;
+    before += (c == cme) & (r < ob);
+  }
+  atomicAdd(&cnt[0], below);                               // (integer sums: any order gives the same value)
+  atomicAdd(&cnt[1], before);
+  __syncthreads();
+  const int d = cnt[0] + cnt[1];
+  const gather_src_t g = src[zi];
+  const int64_t t = idx[(int64_t)zi * Bw + b];
+  if (s < S) {
+    const float* sp = g.obs + (t * S + s) * ldo;
+    float* dst = X + hd * x_hs + ((int64_t)s * Bt + d) * ldx;
+    for (int k = threadIdx.x; k < ldx; k += blockDim.x) dst[k] = k < D ? sp[k] : 0.f;
+    return;
+  }
+  const float* hs = g.hn + t * ldh;
+  const float* cs = g.cn + t * ldh;
+  for (int k = threadIdx.x; k < ldho; k += blockDim.x) {
+    h0[hd * h_hs + (int64_t)d * ldho + k] = k < Hd ? hs[k] : 0.f;
+    c0[hd * h_hs + (int64_t)d * ldho + k] = k < Hd ? cs[k] : 0.f;
+  }
+  if (threadIdx.x == 0) {
+    const int64_t o = (int64_t)hd * Bt + d;
+    actions_o[o] = g.action[t];
+    commands_o[o] = cme;
+    old_values_o[o] = g.value_preds[t];
+    returns_o[o] = g.returns[t];
+    old_logp_o[o] = g.logp[t];
+    adv_o[o] = g.adv[t];
+    pos[hd * Bt + ob] = d;
+  }
+  if (b == 0 && wi == 0 && (int)threadIdx.x < C) {         // the head's run table
+    int off = 0, n = 0;
+    for (int r = 0; r < Bt; ++r) { off += gs_cmd[r] < (int)threadIdx.x; n += gs_cmd[r] == (int)threadIdx.x; }
+    seg[2 * (hd * C + threadIdx.x)] = off;
+    seg[2 * (hd * C + threadIdx.x) + 1] = n;
+  }
+}
+extern "C" int cadre_gather_sorted_multi(const void* src_table, int32_t n_src, int64_t ldo, int32_t S, int64_t ldh,
+                                         const int64_t* idx, int32_t Bw, int32_t D, int32_t Hd, int32_t Bt, int32_t C, float* X,
+                                         int64_t x_head_stride, int64_t ldx, float* h0, float* c0, int64_t h_head_stride,
+                                         int64_t ldho, int64_t* actions_o, int32_t* commands_o, float* old_values_o,
+                                         float* returns_o, float* old_logp_o, float* adv_o, int32_t* pos, int32_t* seg, void* stream) {
+  FAIL_IF(!src_table || !idx || !X || !h0 || !c0 || !actions_o || !commands_o || !old_values_o || !returns_o || !old_logp_o ||
+              !adv_o || !pos || !seg || n_src < 2 || (n_src & 1) || S < 1 || Bw < 1 || D < 1 || Hd < 1 || (n_src / 2) * Bw != Bt ||
+              Bt > 8192 || C < 1 || C > 16 || ldx < D || ldho < Hd,
+          "cadre_gather_sorted_multi: bad argument (every row of the minibatch comes from the table: (n_src / 2) * Bw == Bt)");
+  hipLaunchKernelGGL(gather_sorted_multi_kernel, dim3(Bw, S + 1, n_src), dim3(128), (Bt + 2) * sizeof(int32_t), ST(stream),
+                     (const gather_src_t*)src_table, ldo, S, ldh, idx, Bw, D, Hd, Bt, C, X, x_head_stride, ldx, h0, c0, h_head_stride,
+                     ldho, actions_o, commands_o, old_values_o, returns_o, old_logp_o, adv_o, pos, seg);
+  return (int)hipGetLastError();
+}
+
 #ifdef CADRE_AB_KERNELS      // A/B build only (include/cadre_hip_ab.h): the update's cell math now lives in ppo_update.hip
 // ============================================================================ LSTM cell pointwise
 // Rows sorted by command (row_seg != NULL: net z owns rows [row_seg[2z], +row_seg[2z+1]) of its B): only the rows of

@@ -58,22 +58,32 @@ int cadre_fail(const char* msg);
 
 // ---------------------------------------------------------------------------------------------------------------
 // input transform into fragment order
+// A wave owns 8 tiles x 32 channels: per patch pixel its 64 lanes read 8 x 128 contiguous bytes (whole cache lines), per plane
+// they write, for each of the 8 (16-channel chunk, kk) rows of the fragment layout, 8 tiles x 16 B = 128 contiguous bytes.
+// (First build: 16 tiles x 16 channels per wave — one contiguous KiB per plane store, but 16 half lines per load: 0.49 ms on
+// layer2 against 0.40 for the row-major transform of winograd.hip.)  WIF_LANES: 0 lane = 8 q + t (a lane quad = four tiles of
+// one channel quad: contiguous in the store), 1 lane = 8 t + q (a lane quad = four channel quads of one tile: contiguous in the load).
+#ifndef WIF_LANES
+#define WIF_LANES 0
+#endif
 template <int M>
 __global__ __launch_bounds__(256) void wino_in_frag_kernel(const float* __restrict__ x, float* __restrict__ V, int F, int H, int W, int C,
                                                             int TH, int TW, int T, int TB16, int KC16) {
   constexpr int N = wino_mat<M>::N;
-  const int lane = threadIdx.x & 63;
-  const int c16 = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (c16 >= KC16) return;
-  const int kk = lane >> 4, t16 = lane & 15;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c32 = blockIdx.y * 2 + (wave >> 1);
+  if (c32 * 2 >= KC16) return;
+  const int t8 = WIF_LANES ? lane >> 3 : lane & 7, q8 = WIF_LANES ? lane & 7 : lane >> 3;
   const int tbg = blockIdx.x;
+  const int t16 = (wave & 1) * 8 + t8;
   const int tile = tbg * 16 + t16;
+  const int c16 = 2 * c32 + (q8 >> 2), kk = q8 & 3;
   const bool live = tile < T;
   const int tx = tile % TW;
   const int t2 = tile / TW;
   const int ty = t2 % TH, f = t2 / TH;
   const int r0 = M * ty - 1, q0 = M * tx - 1;
-  const int ch = 16 * c16 + 4 * kk;
+  const int ch = 32 * c32 + 4 * q8;
   // B^T d one patch COLUMN at a time (winograd.hip wino_in_kernel: same sums in the same order)
   f32x4 t[N * N];
 #pragma unroll
@@ -91,7 +101,7 @@ __global__ __launch_bounds__(256) void wino_in_frag_kernel(const float* __restri
     for (int i = 0; i < N; ++i) t[i * N + j] = wino_dot<N, f32x4>(wino_mat<M>::BT[i], d, 1);
   }
   const long long plane = (long long)KC16 * TB16 * 256;          // floats per plane
-  float* vp = V + ((long long)c16 * TB16 + tbg) * 256 + lane * 4;
+  float* vp = V + ((long long)c16 * TB16 + tbg) * 256 + (kk * 16 + t16) * 4;
 #pragma unroll
   for (int i = 0; i < N; ++i)                                    // (B^T d) B
 #pragma unroll
@@ -498,7 +508,7 @@ extern "C" int cadre_winograd_in_frag(const float* x, float* V, int32_t F, int32
   if (((uintptr_t)x & 15) || ((uintptr_t)V & 15)) return cadre_fail("cadre_winograd_in_frag: operands must be 16-byte aligned");
   const int TH = (H + m - 1) / m, TW = (W + m - 1) / m, T = F * TH * TW;
   const int TB16 = (T + 63) / 64 * 4, KC16 = C / 16;
-  const dim3 grid((unsigned)TB16, (unsigned)((KC16 + 3) / 4));
+  const dim3 grid((unsigned)TB16, (unsigned)((KC16 + 3) / 4));      // a workgroup: 16 tiles x 64 channels
   hipStream_t st = (hipStream_t)stream;
   if (m == 2) hipLaunchKernelGGL(wino_in_frag_kernel<2>, grid, dim3(256), 0, st, x, V, F, H, W, C, TH, TW, T, TB16, KC16);
   else if (m == 3) hipLaunchKernelGGL(wino_in_frag_kernel<3>, grid, dim3(256), 0, st, x, V, F, H, W, C, TH, TW, T, TB16, KC16);

@@ -77,6 +77,8 @@ SYMBOLS = {
                                vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp],
     "cadre_gather_minibatch_multi": [vp, i32, i64, i32, i64, vp, i32, i32, i32, i32, vp, i64, i64, vp, vp, i64, i64,
                                      vp, vp, vp, vp, vp, vp, vp],
+    "cadre_gather_sorted_multi": [vp, i32, i64, i32, i64, vp, i32, i32, i32, i32, i32, vp, i64, i64, vp, vp, i64, i64,
+                                  vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "cadre_pack_lstm_weights": [vp, i64, i32, i32, i32, vp, vp, i64, vp],
     "cadre_lstm_step_fwd": [vp, i64, vp, i64, vp, i32, i64, vp, vp, vp, vp, vp, i32, i64, i32, i32, i32, vp, i32, vp],
     "cadre_lstm_step_bwd": [vp, i64, vp, vp, i64, vp, vp, i32, i64, vp, vp, i64, vp, vp, i32, i64, i32, i32, i32, vp, i32, vp, i32, vp],

@@ -2,6 +2,8 @@
 method contracts (act / get_value / update_policy / update_model / convert_action / avg_action /
 save_snapshot / load_snapshot), every tensor op on HIP kernels via cadre_amd.encoder and
 cadre_amd.learner."""
+import os
+
 import numpy as np
 import torch
 
@@ -385,6 +387,16 @@ class CadreAgent(object):
         stage[1].copy_(stage[0], non_blocking=True)
         stage[2] = torch.cuda.Event()
         stage[2].record()
+        if srt and os.environ.get("CADRE_GATHER_SORTED", "1") != "0":
+            # rows sorted by command: gather, stable counting sort and placement in ONE launch (round 6; CADRE_GATHER_SORTED=0:
+            # gather into staging rows, then cadre_sort_rows_by_command + cadre_permute_minibatch)
+            hip.check(L.cadre_gather_sorted_multi(
+                hip.ptr(table), 2 * nW, s0._ldo, s0.seq_length, s0._ldh, hip.ptr(stage[1]), Bw, a.D, a.D, B, a.C,
+                hip.ptr(w["X"]), w["X"].stride(0), a.DP, hip.ptr(w["h0"]), hip.ptr(w["c0"]), w["h0"].stride(0), a.DP,
+                hip.ptr(w["actions"]), hip.ptr(w["commands"]), hip.ptr(w["old_values"]),
+                hip.ptr(w["returns"]), hip.ptr(w["old_logp"]), hip.ptr(w["adv"]), hip.ptr(w["pos"]), hip.ptr(w["seg"]), st),
+                "cadre_gather_sorted_multi")
+            return self._finish_update(w, B, nW, srt, sync, mlp_grads_ready, placed=True)
         hip.check(L.cadre_gather_minibatch_multi(
             hip.ptr(table), 2 * nW, s0._ldo, s0.seq_length, s0._ldh, hip.ptr(stage[1]), Bw, a.D, a.D, B,
             hip.ptr(w[Xk]), w[Xk].stride(0), a.DP, hip.ptr(w[hk]), hip.ptr(w[ck]), w[hk].stride(0), a.DP,
@@ -393,10 +405,11 @@ class CadreAgent(object):
             "cadre_gather_minibatch_multi")
         return self._finish_update(w, B, nW, srt, sync, mlp_grads_ready)
 
-    def _finish_update(self, w, B, nW, srt, sync, mlp_grads_ready=None):
-        """Row sort by command (sorted mode), the fused update and the loss hand-back."""
+    def _finish_update(self, w, B, nW, srt, sync, mlp_grads_ready=None, placed=False):
+        """Row sort by command (sorted mode; placed: the gather already put every row at its sorted position), the fused update
+        and the loss hand-back."""
         L, st, a = hip.lib(), hip.stream(), self.arena
-        if srt:
+        if srt and not placed:
             hip.check(L.cadre_sort_rows_by_command(hip.ptr(w["commands_u"]), B, a.C, hip.ptr(w["pos"]), hip.ptr(w["seg"]),
                                                    st), "cadre_sort_rows_by_command")
             hip.check(L.cadre_permute_minibatch(                   # both heads in one launch

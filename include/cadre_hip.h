@@ -286,6 +286,15 @@ int cadre_gather_minibatch_multi(const void* src_table, int32_t n_src, int64_t l
                                  int64_t x_head_stride, int64_t ldx, float* h0, float* c0, int64_t h_head_stride,
                                  int64_t ldho, int64_t* actions_o, int32_t* commands_o, float* old_values_o,
                                  float* returns_o, float* old_logp_o, float* adv_o, void* stream);
+/* The same gather with the stable counting sort by command and the placement of cadre_sort_rows_by_command +
+ * cadre_permute_minibatch in the SAME launch: row (worker, b) of head hd lands at its sorted position in the [2][...] workspace
+ * arrays, pos[hd * Bt + row] gets that position and seg[2 * (hd * C + c)] = (first row, rows) of command c (agent.py:166-237's
+ * per-command nets each read one run of rows).  Needs (n_src / 2) * Bw == Bt. */
+int cadre_gather_sorted_multi(const void* src_table, int32_t n_src, int64_t ldo, int32_t S, int64_t ldh,
+                              const int64_t* idx, int32_t Bw, int32_t D, int32_t Hd, int32_t Bt, int32_t C, float* X,
+                              int64_t x_head_stride, int64_t ldx, float* h0, float* c0, int64_t h_head_stride,
+                              int64_t ldho, int64_t* actions_o, int32_t* commands_o, float* old_values_o,
+                              float* returns_o, float* old_logp_o, float* adv_o, int32_t* pos, int32_t* seg, void* stream);
 
 /* Recurrent weights W [4*D][ldw = 544] of `Z` nets (net z at + z * w_str) -> MFMA FRAGMENT ORDER for the fused LSTM
  * steps, both directions (ppo_update.hip): `fwd` for cadre_lstm_step_fwd, `bwd` (the transpose: the backward reduces

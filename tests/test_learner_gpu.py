@@ -508,6 +508,49 @@ def test_row_sorted_update_equals_unsorted(Bw, nW):
         assert int(a_p.learner.workspace(Bw * nW)["sync"][-1]) == 0      # no bounded spin ran out
 
 
+@pytest.mark.parametrize("Bw,nW", [(64, 1), (64, 4), (40, 2)])
+def test_one_launch_gather_sort_equals_three_launches(Bw, nW, monkeypatch):
+    """cadre_gather_sorted_multi (round 6: gather + stable counting sort by command + placement in one launch) against the
+    three-launch form it replaces (cadre_gather_minibatch_multi -> cadre_sort_rows_by_command -> cadre_permute_minibatch,
+    CADRE_GATHER_SORTED=0): every workspace tensor of the minibatch, the run table, the positions, the losses and the whole
+    gradient arena bit for bit, over several minibatches (agent.py:166-237: the per-command nets each read one run of rows)."""
+    from ppo_agent.storage import RolloutStorage
+    a_1, a_3 = make_agent(84, 84), make_agent(84, 84)
+    assert a_1.learner.sorted_rows(Bw * nW)
+    T = 2 * Bw
+    stor = []
+    for w in range(nW):
+        data = fill_storages(T, 1700 + w)
+        pair = []
+        for hd in ("steer", "throttle"):
+            s = RolloutStorage(T, 2, 530, 8, 530, True, 0.99, 0.95)
+            for k, v in data[hd].items():
+                getattr(s, k).copy_(torch.from_numpy(v))
+            if w == 0 and hd == "throttle":
+                s.command[: T // 2] = 3                      # an unbalanced command mix (one command may own no row at all)
+            s.to("cuda:0")
+            s.compute_returns(torch.tensor([0.05 * (w + 1)]))
+            pair.append(s)
+        stor.append(pair)
+    g = torch.Generator().manual_seed(3)
+    keys = ("X", "h0", "c0", "actions", "commands", "old_values", "returns", "old_logp", "adv", "seg", "pos")
+    for it in range(3):
+        idx = [torch.randperm(T, generator=g)[:Bw] for _ in range(2 * nW)]
+        batches = [(stor[w][0], idx[2 * w], stor[w][0].advantages, stor[w][1], idx[2 * w + 1], stor[w][1].advantages)
+                   for w in range(nW)]
+        monkeypatch.setenv("CADRE_GATHER_SORTED", "1")
+        l1 = a_1.update_policy_from_storages(batches)
+        monkeypatch.setenv("CADRE_GATHER_SORTED", "0")
+        l3 = a_3.update_policy_from_storages(batches)
+        w1, w3 = a_1.learner.workspace(Bw * nW), a_3.learner.workspace(Bw * nW)
+        for k in keys:
+            assert torch.equal(w1[k], w3[k]), (it, k)
+        assert torch.equal(torch.as_tensor(l1).cpu(), torch.as_tensor(l3).cpu()), it
+        assert torch.equal(a_1.arena.grads, a_3.arena.grads), it
+    seg = a_1.learner.workspace(Bw * nW)["seg"].cpu().view(2, -1, 2)
+    assert int(seg[0, :, 1].sum()) == Bw * nW and int(seg[1, :, 1].sum()) == Bw * nW
+
+
 def test_optimiser_step_that_writes_the_weight_copies_is_bit_identical():
     """CADRE_ADAM_PACK=1 (opt-in): clip_adam() writes the fragment-order W_hh copies itself and the next update carries
     no packing launch.  Several update -> optimiser-step rounds, plus a parameter write from outside in between (which

@@ -75,7 +75,7 @@ def main():
     F = args.frames
     for shp in args.shapes.split(";"):
         H, Cin, N = (int(v) for v in shp.split(","))
-        m = _winograd_m(H, H)
+        m = 4 if H % 4 == 0 else 3                         # (the tile edges the fused kernels are built for: F(4x4) on 36 x 36, F(3x3) on 18 x 18 / 9 x 9)
         P, T = (m + 2) ** 2, F * (-(-H // m)) ** 2
         x = torch.randn(F, H, H, Cin, device="cuda")
         uf = _winograd_u_frag(torch.randn(N, Cin, 3, 3) * 0.05, m).cuda()
@@ -100,6 +100,18 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 t[k].append(e0.elapsed_time(e1) / 3)
+        # the input transform into fragment order of every build (same process, interleaved)
+        tin = {k: [] for k in libs}
+        for _ in range(args.rounds):
+            for k, L in libs.items():
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    assert L.cadre_winograd_in_frag(x.data_ptr(), Vf.data_ptr(), F, H, H, Cin, m, None) == 0
+                e1.record()
+                torch.cuda.synchronize()
+                tin[k].append(e0.elapsed_time(e1) / 3)
+        print("   cadre_winograd_in_frag: " + "  ".join("%s %.3f ms" % (NAMES.get(k, str(k)), np.median(tin[k])) for k in libs))
         fl = 2.0 * P * T * Cin * N
         print("fp32 Winograd F(%dx%d) gemm_out F=%d %dx%d %d->%d  (%.0f GFLOP executed, MFMA floor %.3f ms)" % (m, m, F, H, H, Cin, N, fl / 1e9, fl / 157.3e9))
         base = np.median(t[ABLS[0]])
