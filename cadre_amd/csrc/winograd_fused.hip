@@ -349,19 +349,8 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_out_kernel(wgo_args a) {
     for (int p = 0; p < P; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
 
-  // ---- start phases.  Every workgroup has the same work per item, so left alone all 256 reach their epilogues TOGETHER: the chip
-  // asks HBM for 67 MB of residual lines and stores at once, waits for them with idle matrix pipes, then goes back to streaming V at a
-  // quarter of the HBM rate (measured: the epilogue cost 28 % of the launch, 17 us per item for 2 us of instructions).  A start
-  // delay of (a hash of the workgroup id) / 64 of an item spreads the epilogues over the item time; workgroups with one item more
-  // than the others take a quarter of it — their extra item ends the launch.
-#ifndef WGO_NO_DEPHASE
-  {
-    const int max_items = (a.items + G - 1) / G;
-    const int slots = (((bid * 37) & 63) * KC16 * NG) >> (nitems < max_items ? 6 : 8);      // delay in slot times
-    for (int i = 0; i < slots; ++i) __builtin_amdgcn_s_sleep(16);                             // ~1024 cycles: one slot of 4 PG MFMAs per wave pair
-  }
-#endif
-
+  // (Measured and not kept: start delays of (a hash of the workgroup id) / 64 of an item, so that the 256 workgroups do not reach
+  //  their epilogues — 67 MB of residual lines and stores chip-wide — together: 1.381 vs 1.377 ms on layer2, no effect.)
   // ---- prologue: slots 0 .. D - 1 of the first item requested, landed, published; fragments of slot 0 in register set 0
   int mt = bid / a.ntiles, nt = bid - mt * a.ntiles;
   {

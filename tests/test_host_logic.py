@@ -286,23 +286,34 @@ def test_arena_pickle_drops_process_local_state():
 
 
 def test_bench_kernel_names_are_keys_of_the_hbm_traffic_file():
-    """Every kernel name the committed round-5 bench line prints (roofline.kernel, per_kernel of the headline, the C3 section and
-    the direct-conv section) is a key of profiles/hbm_traffic.json — the rocprofv3 PMC passes of the same command — so that
-    `roofline.traffic` is never null because of a naming drift between bench.kname() and the profiler."""
+    """profiles/ reproduces the line.  `bench.py --section headline|c3` is the command tools/prof_bench.sh
+    profiles, ONE section per command; profiles/hbm_traffic.json holds, per section, the rocprofv3 FETCH_SIZE / WRITE_SIZE averages
+    and dispatch counts of every kernel of that command.  For both sections: every kernel name the profiled line prints
+    (roofline.kernel and per_kernel) is a key of the section's table — no `traffic: null` through a naming drift between
+    bench.kname() and the profiler — and the launch populations MATCH: launches per round from the HIP events of the timed region
+    == dispatches / rounds of the profiled command.  The committed full line (profiles/r06_bench_c2_c3.json) carries a traffic
+    figure for the dominant kernel of the headline and of the c3 section, at least the algorithmic bytes."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    line = open(os.path.join(root, "profiles", "r05_bench_c2_c3.json")).read().strip().splitlines()[-1]
-    bench = json.loads(line)
     traffic = json.load(open(os.path.join(root, "profiles", "hbm_traffic.json")))
-    names = set()
-    for sect in (bench, bench.get("c3"), bench.get("c2_direct_conv")):
-        assert sect and sect.get("roofline"), "the committed line carries the headline, c3 and c2_direct_conv sections"
+    for sec in ("headline", "c3"):
+        line = open(os.path.join(root, "profiles", "r06_bench_under_rocprof_%s.json" % sec)).read().strip().splitlines()[-1]
+        b = json.loads(line)
+        assert b.get("section") == sec and "c3" not in b and "cpu_baseline" not in b and "c2_latent_cache" not in b
+        t = traffic[sec]
+        assert t["rounds"] == b["steps"] + b["warmup"] + 3
+        r = b["roofline"]
+        names = {r["kernel"]} | set(r["per_kernel"])
+        assert len(names) >= 5
+        missing = sorted(n for n in names if n not in t["kernels"])
+        assert not missing, (sec, missing)
+        for n in names:
+            e = t["kernels"][n]
+            assert e["hbm_bytes_per_launch"] > 0 and e["launches"] > 0
+            if n in r["per_kernel"]:
+                assert e["launches"] == r["per_kernel"][n]["launches_per_step"] * t["rounds"], (sec, n, e["launches"])
+    full = json.loads(open(os.path.join(root, "profiles", "r06_bench_c2_c3.json")).read().strip().splitlines()[-1])
+    for sect in (full, full["c3"]):
         r = sect["roofline"]
-        names.add(r["kernel"])
-        names |= set(r["per_kernel"])
-        assert r["traffic"] is not None and r["traffic"] > 0
-    assert len(names) >= 10
-    missing = sorted(n for n in names if n not in traffic)
-    assert not missing, missing
-    for n in names:
-        assert traffic[n]["hbm_bytes_per_launch"] > 0 and traffic[n]["launches"] > 0
+        assert r["traffic"] is not None and r["traffic_launches_per_round"] == r["launches_per_round"]
+        assert r["traffic"] >= 0.95 * r["bytes_per_launch"], (r["kernel"], r["traffic"], r["bytes_per_launch"])

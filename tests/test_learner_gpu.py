@@ -508,7 +508,7 @@ def test_row_sorted_update_equals_unsorted(Bw, nW):
         assert int(a_p.learner.workspace(Bw * nW)["sync"][-1]) == 0      # no bounded spin ran out
 
 
-@pytest.mark.parametrize("Bw,nW", [(64, 1), (64, 4), (40, 2)])
+@pytest.mark.parametrize("Bw,nW", [(64, 1), (64, 4), (48, 2)])
 def test_one_launch_gather_sort_equals_three_launches(Bw, nW, monkeypatch):
     """cadre_gather_sorted_multi (round 6: gather + stable counting sort by command + placement in one launch) against the
     three-launch form it replaces (cadre_gather_minibatch_multi -> cadre_sort_rows_by_command -> cadre_permute_minibatch,
