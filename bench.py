@@ -544,9 +544,10 @@ def run_config(name, args, rank, local_rank, world, use_dist, steps, warmup, epi
                                   "fp32" if enc_dtype == "f32" else "bf16 encoder / fp32 losses"),
                    "workers_per_gpu": nW, "num_steps": T, "obs": [H, W], "minibatch_per_gpu": nW * T // MINI_BATCH_NUM,
                    "parallelism": "dp%d" % world, "frames_per_round_per_gpu": frames,
-                   "conv_algorithm": ("Winograd in fp32 on %d stride-1 3x3 convs: F(4x4,3x3) on the 36x36 maps (layer2), F(3x3,3x3) on the 18x18 / 9x9 maps "
-                                      "(layer3, layer4, head) — exact tilings —, the fused F(2x2,3x3) kernel on the 64-channel stage "
-                                      "(layer1); direct convolution elsewhere; CADRE_WINOGRAD=0 = direct everywhere (c2_direct_conv)" % n_wino) if n_wino else "direct"},
+                   "conv_algorithm": ("Winograd in fp32 on %d stride-1 3x3 convs: F(4x4,3x3) on the 36x36 maps (layer2: plane products and inverse "
+                                      "transform in one kernel), F(6x6,3x3) on the 18x18 maps (layer3), F(3x3,3x3) on the 9x9 maps (layer4, head) — exact "
+                                      "tilings —, the fused F(2x2,3x3) kernel on the 64-channel stage (layer1); direct convolution elsewhere; "
+                                      "CADRE_WINOGRAD=0 = direct everywhere (c2_direct_conv)" % n_wino) if n_wino else "direct"},
         "t_encode_ms": round(t_enc * 1e3, 3), "t_update_ms": round(t_upd * 1e3, 3),
         "encoder_frames_per_sec": round(frames / t_enc, 1),
         "encoder_tflops": round(frames * flops_frame / t_enc / 1e12, 2),
