@@ -150,8 +150,12 @@ __device__ __forceinline__ void wgo_inverse(const float (&m)[wino_mat<M>::N * wi
     for (int j = 0; j < M; ++j) y[i * M + j] = wino_dot<N, float>(wino_mat<M>::AT[j], &s[i * N], 1);
 }
 
-template <int MT>
-__global__ __launch_bounds__(512, 2) void wino_gemm_out_kernel(wgo_args a) {
+// NTB: 16-tile blocks per workgroup (waves = 2 NTB: NTB tile blocks x the two channel blocks).  4: the learner's shape (items of
+// 64 tiles x 32 channels); 1: few tiles — an 8-frame act() pass has 648 tiles on a 36 x 36 map: 44 items of 64 tiles leave 212 CUs
+// idle, 164 items of 16 tiles (two 128-thread workgroups per CU) do not.  Every (tile, channel) is summed in the same order by
+// either shape: the choice may depend on the batch size without touching batch invariance.
+template <int MT, int NTB>
+__global__ __launch_bounds__(128 * NTB, (NTB == 4 ? 2 : 1)) void wino_gemm_out_kernel(wgo_args a) {
   constexpr int NN = wino_mat<MT>::N, P = NN * NN;
   constexpr int PG = (P == 25) ? 5 : 4;                 // planes per slot
   constexpr int NG = P / PG;                            // slots per 16-channel chunk
@@ -163,16 +167,17 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_out_kernel(wgo_args a) {
 #endif
   constexpr int CU = (MT == 2) ? 1 : 2;                 // chunks per unrolled block: NG * CU is even and a multiple of R
   static_assert((NG * CU) % R == 0 && (NG * CU) % 2 == 0, "slot buffer and register set must be static per unrolled step");
-  constexpr int SLOT_B = 6 * PG * 1024;                 // V: PG x 4 tile blocks x 1 KB, U: PG x 2 channel blocks x 1 KB
-  constexpr int U_OFF = 4 * PG * 1024;
-  constexpr int NI_V = (4 * PG + 7) / 8, NI_U = (2 * PG + 7) / 8, NI = NI_V + NI_U;       // DMA instructions per wave and slot
+  constexpr int NW = 2 * NTB;                           // waves
+  constexpr int SLOT_B = (NTB + 2) * PG * 1024;         // V: PG x NTB tile blocks x 1 KB, U: PG x 2 channel blocks x 1 KB
+  constexpr int U_OFF = NTB * PG * 1024;
+  constexpr int NI_V = (NTB * PG + NW - 1) / NW, NI_U = (2 * PG + NW - 1) / NW, NI = NI_V + NI_U;       // DMA instructions per wave and slot
   constexpr int WAITN = NI * (D - 2);                   // younger requests when slot q + 1 must have landed (slots q + 2 .. q + D - 1)
   static_assert(WAITN < 64, "vmcnt is a 6-bit field");
   constexpr unsigned OOB = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tb = wave & 3, nb = wave >> 2;              // (waves w and w + 4 share a SIMD: the same tile block, the two channel blocks)
+  const int tb = wave % NTB, nb = wave / NTB;           // (NTB = 4: waves w and w + 4 share a SIMD — the same tile block, the two channel blocks)
   const unsigned dump_off = (unsigned)(R * SLOT_B);
 
   // ---- items of this workgroup.  Workgroups are dealt round-robin over the 8 XCDs: give each XCD a contiguous run of item ids
@@ -191,20 +196,20 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_out_kernel(wgo_args a) {
   const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)a.V, 0, (int)a.v_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc((void*)a.U, 0, (int)a.u_bytes, 0x00020000);
 
-  // ---- DMA duties of this wave.  V instruction i: block jv = wave + 8 i of the slot's 4 PG (plane pp = jv >> 2, tile block jv & 3);
-  // U instruction i: KB ju = wave + 8 i of the slot's 2 PG contiguous KB.  Surplus instructions (jv >= 4 PG / ju >= 2 PG: F(3x3)
+  // ---- DMA duties of this wave.  V instruction i: block jv = wave + NW i of the slot's NTB PG (plane pp = jv / NTB, tile block jv % NTB);
+  // U instruction i: KB ju = wave + NW i of the slot's 2 PG contiguous KB.  Surplus instructions (jv >= NTB PG / ju >= 2 PG: F(3x3)
   // only) request out of range and land their zeros in the dump KB — every wave issues NI per slot, one vmcnt count fits all.
   unsigned vlane[NI_V], vdst[NI_V], ulane[NI_U], udst[NI_U];
 #pragma unroll
   for (int i = 0; i < NI_V; ++i) {
-    const int jv = wave + 8 * i;
-    const bool real = jv < 4 * PG;
-    vlane[i] = real ? (unsigned)(((jv >> 2) * KC16 * TB16 + (jv & 3)) * 1024 + lane * 16) : OOB;
+    const int jv = wave + NW * i;
+    const bool real = jv < NTB * PG;
+    vlane[i] = real ? (unsigned)(((jv / NTB) * KC16 * TB16 + (jv % NTB)) * 1024 + lane * 16) : OOB;
     vdst[i] = real ? (unsigned)(jv * 1024) : dump_off;
   }
 #pragma unroll
   for (int i = 0; i < NI_U; ++i) {
-    const int ju = wave + 8 * i;
+    const int ju = wave + NW * i;
     const bool real = ju < 2 * PG;
     ulane[i] = real ? (unsigned)(ju * 1024 + lane * 16) : OOB;
     udst[i] = real ? (unsigned)(U_OFF + ju * 1024) : dump_off;
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_out_kernel(wgo_args a) {
   auto send = [&](int buf, int mt_x, int nt_x, int c_x, int g, bool live) {
     if ((WGO_ABL & 4) && !abl_pro) live = false;
     const unsigned dead = live ? 0u : OOB;
-    const unsigned sV = (unsigned)(((PG * g * KC16 + c_x) * TB16 + mt_x * 4) * 1024) | dead;
+    const unsigned sV = (unsigned)(((PG * g * KC16 + c_x) * TB16 + mt_x * NTB) * 1024) | dead;
     const unsigned sU = (unsigned)(((nt_x * KC16 + c_x) * P + PG * g) * 2048) | dead;
 #pragma unroll
     for (int i = 0; i < NI_V; ++i) {
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_out_kernel(wgo_args a) {
       fa[set][pp] = f32x4{(float)lane, 1.5f, -0.25f * pp, 0.3f};
       fb[set][pp] = f32x4{0.01f * lane, -2.5f, 0.125f * pp, 1.f};
     } else {
-      constexpr unsigned ta = (unsigned)(buf * SLOT_B + pp * 4096), tbo = (unsigned)(buf * SLOT_B + U_OFF + pp * 2048);
+      constexpr unsigned ta = (unsigned)(buf * SLOT_B + pp * NTB * 1024), tbo = (unsigned)(buf * SLOT_B + U_OFF + pp * 2048);
       asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[set][pp]) : "v"(a_base[ta >> 16]), "n"(ta & 0xffffu));
       asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[set][pp]) : "v"(b_base[tbo >> 16]), "n"(tbo & 0xffffu));
     }
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_out_kernel(wgo_args a) {
       typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
       constexpr int NPX = MT * MT, HALF = (NPX + 1) / 2;
       // the tile this lane stores: (f, ty, tx) by a float reciprocal + one correction step (t < 2^23)
-      const int t = mt_e * 64 + tb * 16 + 4 * (lane >> 4) + (lane & 3);
+      const int t = mt_e * (16 * NTB) + tb * 16 + 4 * (lane >> 4) + (lane & 3);
       int q1 = (int)((float)t * inv_tw);
       int tx = t - q1 * a.TW;
       q1 += (tx >= a.TW) ? 1 : 0; q1 -= (tx < 0) ? 1 : 0;
@@ -505,13 +510,14 @@ extern "C" int cadre_winograd_in_frag(const float* x, float* V, int32_t F, int32
   return (int)hipGetLastError();
 }
 
-template <int MT>
+template <int MT, int NTB>
 static int wgo_launch(const wgo_args& a, hipStream_t st) {
   constexpr int NN = wino_mat<MT>::N, P = NN * NN, PG = (P == 25) ? 5 : 4, R = (MT == 4) ? 6 : (MT == 3 ? 5 : 4);
-  const size_t lds = (size_t)R * 6 * PG * 1024 + 1024;
-  (void)hipFuncSetAttribute((const void*)wino_gemm_out_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  const int wgs = a.items < 256 ? a.items : 256;           // persistent workgroups: one per CU
-  hipLaunchKernelGGL((wino_gemm_out_kernel<MT>), dim3(wgs), dim3(512), lds, st, a);
+  const size_t lds = (size_t)R * (NTB + 2) * PG * 1024 + 1024;
+  (void)hipFuncSetAttribute((const void*)wino_gemm_out_kernel<MT, NTB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const int slots = NTB == 4 ? 256 : 512;                  // persistent workgroups: one per CU (two of the 128-thread shape)
+  const int wgs = a.items < slots ? a.items : slots;
+  hipLaunchKernelGGL((wino_gemm_out_kernel<MT, NTB>), dim3(wgs), dim3(128 * NTB), lds, st, a);
   return (int)hipGetLastError();
 }
 
@@ -528,15 +534,25 @@ extern "C" int cadre_winograd_gemm_out(const float* V, const float* U, const flo
   a.V = V; a.U = U; a.scale = scale; a.shift = shift; a.resid = resid; a.out = out;
   a.F = F; a.H = H; a.W = W; a.N = N; a.act = act;
   a.TH = (H + m - 1) / m; a.TW = (W + m - 1) / m; a.T = F * a.TH * a.TW;
-  const int mtiles = (a.T + 63) / 64;
-  a.TB16 = mtiles * 4; a.KC16 = Cin / 16;
-  a.ntiles = N / 32; a.items = mtiles * a.ntiles;
+  const int mtiles64 = (a.T + 63) / 64;
+  a.TB16 = mtiles64 * 4; a.KC16 = Cin / 16;               // (the V layout pads the tiles to 64 whatever the item shape)
+  a.ntiles = N / 32;
+  // items of 64 tiles where they fill the chip, of 16 tiles (128-thread workgroups, two per CU) where they would not — the same
+  // bits either way (CADRE_WINOGRAD_FUSED_NTB=1|4 forces a shape)
+  static const int ntb_env = [] { const char* e = getenv("CADRE_WINOGRAD_FUSED_NTB"); return e ? atoi(e) : 0; }();
+  const bool small = ntb_env ? ntb_env == 1 : mtiles64 * a.ntiles < 256;
+  a.items = (small ? (a.T + 15) / 16 : mtiles64) * a.ntiles;
   const long long P = (m + 2) * (m + 2);
-  a.v_bytes = (unsigned)(P * Cin * (long long)mtiles * 64 * 4);
+  a.v_bytes = (unsigned)(P * Cin * (long long)mtiles64 * 64 * 4);
   a.u_bytes = (unsigned)(P * Cin * (long long)N * 4);
   a.o_bytes = (unsigned)((long long)F * H * W * N * 4);
   hipStream_t st = (hipStream_t)stream;
-  if (m == 2) return wgo_launch<2>(a, st);
-  if (m == 3) return wgo_launch<3>(a, st);
-  return wgo_launch<4>(a, st);
+  if (small) {
+    if (m == 2) return wgo_launch<2, 1>(a, st);
+    if (m == 3) return wgo_launch<3, 1>(a, st);
+    return wgo_launch<4, 1>(a, st);
+  }
+  if (m == 2) return wgo_launch<2, 4>(a, st);
+  if (m == 3) return wgo_launch<3, 4>(a, st);
+  return wgo_launch<4, 4>(a, st);
 }

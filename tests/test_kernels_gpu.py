@@ -1398,6 +1398,10 @@ def test_winograd_fused_persistent_items_and_repeatable_under_load(hip, m, H, Ci
     torch.cuda.synchronize()
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
+    # the same two frames alone: few tiles -> the 16-tile / 128-thread item shape (NTB = 1) instead of 64 tiles / 512 threads;
+    # every (tile, channel) is summed in the same order by either shape: the bits must not depend on the batch
+    alone = _wino_fused_run(hip, xd[F - 2:].contiguous(), u, scd, shd, rd[F - 2:].contiguous(), 2, H, H, Cin, N, 1, m)
+    assert torch.equal(alone, outs[0][F - 2:])
     for sl in (slice(0, 2), slice(F // 2, F // 2 + 2), slice(F - 2, F)):
         ref = torch.nn.functional.conv2d(x[sl].permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1) * sc + sh + res[sl]
         ref = torch.relu(ref)
