@@ -43,7 +43,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 int cadre_fail(const char* msg);
 
 // -DWGO_ABL=<bits>: timing ablations (results wrong by construction, never in the product build): 1 no MFMAs, 2 no fragment
-// reads, 4 no DMA after the prologue, 8 no epilogue, 16 no stores (the epilogue's arithmetic and residual loads stay)
+// reads, 4 no DMA after the prologue, 8 no epilogue, 16 no stores (the epilogue's arithmetic and residual loads stay), 32 no inverse
+// transform / transposes, 64 no drain in front of the epilogue
 #ifndef WGO_ABL
 #define WGO_ABL 0
 #endif
@@ -234,6 +235,21 @@ __global__ __launch_bounds__(128 * NTB, (NTB == 4 ? 2 : 1)) void wino_gemm_out_k
     }
   };
 
+  // one DMA instruction of a slot (i < NI_V: V instruction i, else U instruction i - NI_V): issued BETWEEN the MFMAs of a step, one
+  // at a time (-DWGO_BURST: all NI right behind the barrier — 24 requests at once keep every wave of the CU in the texture
+  // addresser's queue with its MFMAs behind them in program order, the lesson of winograd_c64.hip: 1.211 vs 1.158 ms on layer2,
+  // 1.301 / 1.145 vs 1.175 / 1.046 ms on the F(3x3) shapes)
+  auto send_one = [&](auto i_c, int buf, unsigned sV, unsigned sU) {
+    constexpr int i = decltype(i_c)::value;
+    if constexpr (i < NI_V) {
+      const unsigned dst = vdst[i] == dump_off ? dump_off : (unsigned)(buf * SLOT_B) + vdst[i];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (__attribute__((address_space(3))) void*)(smem + dst), 16, (int)(vlane[i] + sV), 0, 0, WGO_VAUX);
+    } else {
+      const unsigned dst = udst[i - NI_V] == dump_off ? dump_off : (unsigned)(buf * SLOT_B) + udst[i - NI_V];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (__attribute__((address_space(3))) void*)(smem + dst), 16, (int)(ulane[i - NI_V] + sU), 0, 0, WGO_UAUX);
+    }
+  };
+
   // ---- fragments: lane l reads bytes 16 l of its 1 KB block.  The reads are inline asm with the waits placed by hand: ONE
   // s_waitcnt lgkmcnt(0) per step, behind the barrier (the reads went out a whole step earlier) — hipcc's own counted waits sit in
   // front of each MFMA and count only ITS loads; with LDS-DMA requests of the same wave in flight they made every step wait for the
@@ -315,7 +331,10 @@ __global__ __launch_bounds__(128 * NTB, (NTB == 4 ? 2 : 1)) void wino_gemm_out_k
       // inverse transform on register QUADS (the four tiles of a lane at once): A^T m column by column — the six planes of a column
       // die as its four sums are formed — then (A^T m) A row by row, and the folded BN of this lane's channel
       f32x4 y[NPX];
-      {
+      if constexpr ((WGO_ABL & 32) != 0) {
+#pragma unroll
+        for (int e = 0; e < NPX; ++e) y[e] = acc[e] * bn_sc + bn_sh;
+      } else {
         f32x4 s4[MT * NN];
 #pragma unroll
         for (int j = 0; j < NN; ++j)
@@ -340,6 +359,7 @@ __global__ __launch_bounds__(128 * NTB, (NTB == 4 ? 2 : 1)) void wino_gemm_out_k
         const float u0 = xch(n0, std::integral_constant<int, 0x4E>{}), u1 = xch(n1, std::integral_constant<int, 0x4E>{});
         const float u2 = xch(n2, std::integral_constant<int, 0x4E>{}), u3 = xch(n3, std::integral_constant<int, 0x4E>{});
         f32x4 v = {hi ? u2 : n0, hi ? u3 : n1, hi ? n2 : u0, hi ? n3 : u1};
+        if constexpr ((WGO_ABL & 32) != 0) v = y[e];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           float w = v[c] + (post ? 0.f : rr[e][c]);
@@ -374,6 +394,9 @@ __global__ __launch_bounds__(128 * NTB, (NTB == 4 ? 2 : 1)) void wino_gemm_out_k
   //  reads between the second and third k-step of the slot's MFMAs, MI355X_MICROARCH.md "two waves per SIMD" item 9.  F(3x3):
   //  1.169 / 1.154 ms against 1.152 / 1.128 in lockstep on layer3 / layer4; F(4x4): the second code path cost 193 spilled registers.
   //  The LATE role stays a compile-time parameter of the item loop for that measurement: -DWGO_STAGGER.)
+  unsigned sV_cur = 0, sU_cur = 0;
+  int tgt_cur = 0;
+  (void)sV_cur; (void)sU_cur; (void)tgt_cur;
   auto run = [&](auto late_c) {
     constexpr bool LATE = decltype(late_c)::value;
     for (int li = 0; li < nitems; ++li) {
@@ -417,6 +440,13 @@ __global__ __launch_bounds__(128 * NTB, (NTB == 4 ? 2 : 1)) void wino_gemm_out_k
                   asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[PG * g + pp]) : "v"(fa[s & 1][pp][e]), "v"(fb[s & 1][pp][e]));
                 }
                 if constexpr (e == ER && ahead) read_frag(integral_constant<int, (s + 1) & 1>{}, integral_constant<int, nxt>{}, pp_c);
+#ifndef WGO_BURST
+                {   // DMA instruction i behind MFMA number PG + 1 + i * stride of the step (behind the fragment reads of k-step 0)
+                  constexpr int idx = e * PG + pp, STR = (3 * PG - 1) / NI > 0 ? (3 * PG - 1) / NI : 1;
+                  if constexpr (!LATE && idx >= PG && (idx - PG) % STR == 0 && (idx - PG) / STR < NI)
+                    send_one(integral_constant<int, (idx - PG) / STR>{}, tgt_cur, sV_cur, sU_cur);
+                }
+#endif
               });
             });
           };
@@ -429,12 +459,21 @@ __global__ __launch_bounds__(128 * NTB, (NTB == 4 ? 2 : 1)) void wino_gemm_out_k
           __builtin_amdgcn_s_barrier();
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           // requests of slot q + D: (chunk, group) = (c0 + cu, g) + D slots, possibly in the next item
+          constexpr int gd = (g + D) % NG;
+          const int cd = c0 + cu + (g + D) / NG;
+          const bool wrap = cd >= KC16;
+#ifndef WGO_BURST
           {
-            constexpr int gd = (g + D) % NG;
-            const int cd = c0 + cu + (g + D) / NG;
-            const bool wrap = cd >= KC16;
-            send(tgt, wrap ? mt_n : mt, wrap ? nt_n : nt, wrap ? cd - KC16 : cd, gd, !wrap || more);
+            const bool live = (!wrap || more) && !((WGO_ABL & 4) != 0);
+            const unsigned dead = live ? 0u : OOB;
+            const int mt_x = wrap ? mt_n : mt, nt_x = wrap ? nt_n : nt, c_x = wrap ? cd - KC16 : cd;
+            sV_cur = (unsigned)(((PG * gd * KC16 + c_x) * TB16 + mt_x * NTB) * 1024) | dead;
+            sU_cur = (unsigned)(((nt_x * KC16 + c_x) * P + PG * gd) * 2048) | dead;
+            tgt_cur = tgt;
           }
+#else
+          send(tgt, wrap ? mt_n : mt, wrap ? nt_n : nt, wrap ? cd - KC16 : cd, gd, !wrap || more);
+#endif
           if constexpr (LATE) mfmas(integral_constant<int, 2>{}, integral_constant<int, 4>{}, integral_constant<int, 2>{});
           else mfmas(integral_constant<int, 0>{}, integral_constant<int, 4>{}, integral_constant<int, 0>{});
         });
@@ -446,6 +485,7 @@ __global__ __launch_bounds__(128 * NTB, (NTB == 4 ? 2 : 1)) void wino_gemm_out_k
         for (int c0 = CU; c0 + CU < KC16; c0 += CU) block(integral_constant<bool, false>{}, integral_constant<bool, false>{}, c0);
         block(integral_constant<bool, false>{}, integral_constant<bool, true>{}, KC16 - CU);
       }
+      if constexpr ((WGO_ABL & 64) == 0)
       wgo_wait_vm<0>();                                  // (the next item's first D slots: requested up to a step ago; the epilogue's
                                                          //  own loads and stores count from zero, and nothing waits for the stores
                                                          //  before step D - 1 of the next item)

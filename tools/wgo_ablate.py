@@ -14,8 +14,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ABLS = [0, 8, 16, 1, 2, 4, 9, 6, 14, 11, 15]
-NAMES = {16: "no stores", 0: "full kernel", 1: "no MFMA", 2: "no fragment reads", 4: "no DMA", 8: "no epilogue", 9: "no MFMA, no epilogue",
+ABLS = [0, 8, 16, 32, 48, 64, 1, 2, 4, 9, 6, 14, 11, 15]
+NAMES = {32: "epilogue without inverse transform / transposes", 48: "epilogue: residual loads + waits only", 64: "no drain before the epilogue", 16: "no stores", 0: "full kernel", 1: "no MFMA", 2: "no fragment reads", 4: "no DMA", 8: "no epilogue", 9: "no MFMA, no epilogue",
          6: "no reads, no DMA", 14: "schedule + MFMA only", 11: "schedule + DMA only", 15: "empty schedule (barriers + waits)"}
 
 
