@@ -319,7 +319,7 @@ def kname(k):
     if k[0] == "wino_c64":
         return "wino2_c64_kernel<%s>" % ("true" if k[1] else "false")
     if k[0] == "wgo":
-        return "wino_gemm_out_kernel<%d>" % k[1]
+        return "wino_gemm_out_kernel<%d, %d>" % (k[1], k[2])
     if k[0] == "gw128":
         return "gemm_bf16_w128_kernel"
     if k[0] == "s2":

@@ -550,6 +550,14 @@ extern "C" int cadre_winograd_in_frag(const float* x, float* V, int32_t F, int32
   return (int)hipGetLastError();
 }
 
+// 16-tile blocks per workgroup cadre_winograd_gemm_out runs with for T tiles and N output channels (the second template argument of
+// wino_gemm_out_kernel<m, NTB>: the profiling key / kernel name of the launch): 4 where items of 64 tiles fill the chip, else 1
+extern "C" int cadre_winograd_fused_ntb(int32_t T, int32_t N) {
+  static const int ntb_env = [] { const char* e = getenv("CADRE_WINOGRAD_FUSED_NTB"); return e ? atoi(e) : 0; }();
+  if (ntb_env == 1 || ntb_env == 4) return ntb_env;
+  return ((T + 63) / 64) * (N / 32) < 256 ? 1 : 4;
+}
+
 template <int MT, int NTB>
 static int wgo_launch(const wgo_args& a, hipStream_t st) {
   constexpr int NN = wino_mat<MT>::N, P = NN * NN, PG = (P == 25) ? 5 : 4, R = (MT == 4) ? 6 : (MT == 3 ? 5 : 4);
@@ -579,8 +587,7 @@ extern "C" int cadre_winograd_gemm_out(const float* V, const float* U, const flo
   a.ntiles = N / 32;
   // items of 64 tiles where they fill the chip, of 16 tiles (128-thread workgroups, two per CU) where they would not — the same
   // bits either way (CADRE_WINOGRAD_FUSED_NTB=1|4 forces a shape)
-  static const int ntb_env = [] { const char* e = getenv("CADRE_WINOGRAD_FUSED_NTB"); return e ? atoi(e) : 0; }();
-  const bool small = ntb_env ? ntb_env == 1 : mtiles64 * a.ntiles < 256;
+  const bool small = cadre_winograd_fused_ntb(a.T, N) == 1;
   a.items = (small ? (a.T + 15) / 16 : mtiles64) * a.ntiles;
   const long long P = (m + 2) * (m + 2);
   a.v_bytes = (unsigned)(P * Cin * (long long)mtiles64 * 64 * 4);

@@ -64,6 +64,7 @@ SYMBOLS = {
     "cadre_winograd_out": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp],
     "cadre_winograd_fused_supported": [i32, i32, i32, i32, i32, i32],
     "cadre_winograd_fused_capable": [i32, i32, i32, i32, i32, i32],
+    "cadre_winograd_fused_ntb": [i32, i32],
     "cadre_winograd_frag_elems": [i32, i32, i32, i32, i32],
     "cadre_winograd_in_frag": [vp, vp, i32, i32, i32, i32, i32, vp],
     "cadre_winograd_gemm_out": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
@@ -264,7 +265,7 @@ def winograd_c64(x, u, scale, shift, resid, out, F, H, W, act):
 
 def winograd_fused(x, V, u_frag, scale, shift, resid, out, F, H, W, Cin, N, act, m):
     """cadre_winograd_in_frag + cadre_winograd_gemm_out (Winograd F(m x m, 3x3): the plane products and the inverse transform in one
-    kernel, csrc/winograd_fused.hip).  Profiling key ("wgo", m) on the product kernel: wino_gemm_out_kernel<m>; FLOPs = the EXECUTED
+    kernel, csrc/winograd_fused.hip).  Profiling key ("wgo", m, ntb) on the product kernel: wino_gemm_out_kernel<m, ntb>; FLOPs = the EXECUTED
     ones ((m+2)^2 planes x tiles x Cin x N), bytes = V read once + the output written (+ the residual read) + U."""
     L = lib()
     check(L.cadre_winograd_in_frag(ptr(x), ptr(V), F, H, W, Cin, m, stream()), "cadre_winograd_in_frag")
@@ -279,7 +280,7 @@ def winograd_fused(x, V, u_frag, scale, shift, resid, out, F, H, W, Cin, N, act,
     e1.record()
     P, T = (m + 2) ** 2, F * -(-H // m) * -(-W // m)
     nbytes = (P * T * Cin + P * N * Cin + F * H * W * N * (2 if resid is not None else 1)) * 4
-    PROFILE.append((("wgo", m), 2.0 * P * T * Cin * N, e0, e1, (T, N, Cin * P, 1, 1, 0), nbytes))
+    PROFILE.append((("wgo", m, int(L.cadre_winograd_fused_ntb(T, N))), 2.0 * P * T * Cin * N, e0, e1, (T, N, Cin * P, 1, 1, 0), nbytes))
 
 
 def conv3x3_s2(x, w_s2, scale, shift, out, F, H, W, Cin, N, act):

@@ -220,6 +220,9 @@ int cadre_winograd_out(const float* Mx, const float* scale, const float* shift, 
  * the fused form measured faster; CADRE_WINOGRAD_FUSED=2: every geometry the kernels take, 0: never). */
 int cadre_winograd_fused_supported(int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t m);
 int cadre_winograd_fused_capable(int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t N, int32_t m);
+/* tile blocks per workgroup of the cadre_winograd_gemm_out launch for T tiles x N channels: 4 (items of 64 tiles) or 1 (few tiles: items
+ * of 16 tiles on 128-thread workgroups) — the same bits either way; wino_gemm_out_kernel<m, NTB> */
+int cadre_winograd_fused_ntb(int32_t T, int32_t N);
 int64_t cadre_winograd_frag_elems(int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t m);
 int cadre_winograd_in_frag(const float* x, float* V, int32_t F, int32_t H, int32_t W, int32_t C, int32_t m, void* stream);
 int cadre_winograd_gemm_out(const float* V, const float* U, const float* scale, const float* shift, const float* resid, float* out,
