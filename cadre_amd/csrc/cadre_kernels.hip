@@ -354,9 +354,10 @@ extern "C" int cadre_maxpool3x3s2(const float* x, float* y, int32_t F, int32_t H
 // arithmetic as a scalar k-ascending loop): energy = q k^T (da_att.py:43, 96x96 padded, K = 16) as 3x3 tiles,
 // out = attention v (da_att.py:47, 96x128, K = 96) as 3x4 tiles; the row softmax in between is a wave-shuffle
 // reduction over LDS.  Rows / columns >= Np are zero padding (their energies are -inf before the softmax).
-#define PAM_MAXNP 96
+#define PAM_MAXNP 128
 typedef float pam_f32x16 __attribute__((ext_vector_type(16)));
-// R = Np rounded up to 32 (1, 2 or 3 row blocks): the staged rows, the LDS footprint (25 / 58 / 97 KB) and the tile
+// R = Np rounded up to 32 (1 .. 4 row blocks; 128 positions = 149 KB is what one CU's LDS holds): the staged rows, the LDS
+// footprint (25 / 58 / 97 / 149 KB) and the tile
 // counts follow the map — the reference's native 5 x 8 map (Np = 40) runs 4 + 8 tiles instead of 9 + 12 and two
 // workgroups per CU.  The padding contributes exact zeros at the END of every fma chain, so the results do not depend
 // on R (same bits as the fixed 96-row form).
@@ -475,7 +476,7 @@ extern "C" int cadre_pam_bf16out(const float* x, const float* qkv, float gamma, 
 }
 static int pam_launch(const float* x, const float* qkv, float gamma, void* y, int32_t F, int32_t Np, int out_bf16,
                       void* stream) {
-  FAIL_IF(!x || !qkv || !y || F < 1 || Np < 1 || Np > PAM_MAXNP, "cadre_pam: bad argument (Np<=96)");
+  FAIL_IF(!x || !qkv || !y || F < 1 || Np < 1 || Np > PAM_MAXNP, "cadre_pam: bad argument (Np<=128)");
   const size_t R = (size_t)((Np + 31) / 32) * 32;
   const size_t shm = sizeof(float) * (R * 34 + R * 128 + R * (R + 1));
   static bool attr_set = false;
@@ -593,7 +594,7 @@ extern "C" int cadre_cam_bf16out(const float* x, float gamma, void* y, int32_t F
   return cam_launch(x, gamma, y, F, Np, 1, stream);
 }
 static int cam_launch(const float* x, float gamma, void* y, int32_t F, int32_t Np, int out_bf16, void* stream) {
-  FAIL_IF(!x || !y || F < 1 || Np < 1 || Np > PAM_MAXNP, "cadre_cam: bad argument (Np<=96)");
+  FAIL_IF(!x || !y || F < 1 || Np < 1 || Np > PAM_MAXNP, "cadre_cam: bad argument (Np<=128)");
   const size_t shm = sizeof(float) * ((size_t)((Np + 31) / 32) * 32 * CAM_XP + 128 * CAM_EP);
   static bool attr_set = false;
   if (!attr_set) {

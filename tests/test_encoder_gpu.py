@@ -39,6 +39,35 @@ def test_encoder_vs_reference_golden(golden, tag):
     assert e[0] < TOL and e[1] < TOL and e[2] < TOL
 
 
+@pytest.mark.parametrize("H,W", [(320, 352), (352, 352)])
+def test_encoder_above_96_positions_vs_oracle(H, W):
+    """Layer-4 maps of 10 x 11 = 110 and 11 x 11 = 121 positions (the PAM / CAM kernels hold a frame's attention matrix in one CU's
+    LDS up to 128; the reference itself only builds 5 x 8, intertask_att.py:17-18): the whole fp32 encoder against the oracle's
+    restatement (pinned by the goldens above at three sizes) at the same bar, through convs at sizes no other test visits
+    (88 / 44 / 22 / 11-pixel maps), and per-frame bits independent of the batch."""
+    from oracle import encoder_ref
+    from cadre_amd.encoder import DANetEncoderHIP
+    fh, fw = synth.feat_hw(H, W)
+    assert 96 < fh * fw <= 128
+    sd = synth.encoder_state(fh, fw, 11)
+    enc = DANetEncoderHIP(sd, H, W, "cuda:0")
+    r = np.random.RandomState(H + W)
+    n = 2
+    rgb = r.randint(0, 256, (n, H, W, 3)).astype(np.uint8)
+    route = ((r.rand(n, W, H) < 0.15) * 255).astype(np.uint8)
+    x, _ = encoder_ref.pre_process(rgb, route.copy())
+    want, wt = encoder_ref.latent(torch.from_numpy(x), sd, return_taps=True)
+    taps = {}
+    rgb_d, route_d = torch.from_numpy(rgb).cuda(), torch.from_numpy(route).cuda()
+    lat = enc.latent(rgb_d, route_d, taps=taps).clone()
+    e = (rel(taps["layer4"].permute(0, 3, 1, 2).cpu().numpy(), wt["layer4"].numpy()),
+         rel(taps["da"].permute(0, 3, 1, 2).cpu().numpy(), wt["da"].numpy()), rel(lat.cpu().numpy(), want.numpy()))
+    print("encoder %dx%d rel-max-err layer4 %.2e da_head %.2e latent %.2e" % ((H, W) + e))
+    assert e[0] < TOL and e[1] < TOL and e[2] < TOL
+    rgb_b, route_b = torch.cat([rgb_d[:1], rgb_d, rgb_d[-1:]]), torch.cat([route_d[:1], route_d, route_d[-1:]])
+    assert torch.equal(enc.latent(rgb_b, route_b)[1:1 + n], lat)
+
+
 @pytest.mark.parametrize("tag", ["native", "288"])
 @pytest.mark.parametrize("algo", ["winograd", "direct"])
 def test_encoder_conv_algorithms_vs_reference_golden(golden, tag, algo, monkeypatch):
