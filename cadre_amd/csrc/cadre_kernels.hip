@@ -1237,8 +1237,8 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const float* logits, int6
                                                        const float* values, int64_t ldv, int64_t v_ns,
                                                        const int64_t* actions, const int32_t* commands,
                                                        const float* old_values, const float* returns,
-                                                       const float* old_logp, const float* adv, int B, int n_steer,
-                                                       int n_throttle, float clip, float value_coeff,
+                                                       const float* old_logp, const float* adv, int B, int C,
+                                                       int n_steer, int n_throttle, float clip, float value_coeff,
                                                        float clip_coeff, float ent_coeff, float inv_b,
                                                        float* losses, float* dlogits, float* dvalues, float* scratch,
                                                        const int32_t* poison) {
@@ -1252,16 +1252,16 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(const float* logits, int6
     if (b >= B) break;
     const int row = hd * B + b;                    // per-head sample arrays are [2][B]
     const int c = commands[row];
-    const bool own_ok = c >= 0 && c <= 3;
+    const bool own_ok = c >= 0 && c < C;
     // the masked-out command nets (agent.py:178-182 multiply by 0) get exact zeros: whole rows of ldl columns
-    for (int cc = 0; cc < 4; ++cc) {
+    for (int cc = 0; cc < C; ++cc) {
       if (own_ok && cc == c) continue;
-      if (lane < ldl) dlogits[(int64_t)(hd * 4 + cc) * l_ns + (int64_t)b * ldl + lane] = 0.f;
-      if (lane == 0) dvalues[(int64_t)(hd * 4 + cc) * v_ns + (int64_t)b * ldv] = 0.f;
+      if (lane < ldl) dlogits[(int64_t)(hd * C + cc) * l_ns + (int64_t)b * ldl + lane] = 0.f;
+      if (lane == 0) dvalues[(int64_t)(hd * C + cc) * v_ns + (int64_t)b * ldv] = 0.f;
     }
     if (!own_ok) continue;
     const int a = (int)actions[row];
-    const int net = hd * 4 + c;
+    const int net = hd * C + c;
     const bool on = lane < K;
     const float x = on ? logits[(int64_t)net * l_ns + (int64_t)b * ldl + lane] : -INFINITY;
     const float mx = wave_max(x);
@@ -1345,19 +1345,19 @@ __global__ void zero_f32_kernel(float* p, int n) {
 
 extern "C" int cadre_ppo_loss(const float* logits, int64_t ldl, int64_t l_ns, const float* values, int64_t ldv,
                               int64_t v_ns, const int64_t* actions, const int32_t* commands, const float* old_values, const float* returns,
-                              const float* old_logp, const float* adv, int32_t B, int32_t n_out_steer,
+                              const float* old_logp, const float* adv, int32_t B, int32_t C, int32_t n_out_steer,
                               int32_t n_out_throttle, float clip, float value_coeff, float clip_coeff,
                               float ent_coeff, float inv_b, float* losses, float* dlogits, float* dvalues,
                               float* scratch, const int32_t* poison, void* stream) {
   FAIL_IF(!logits || !values || !actions || !commands || !old_values || !returns || !old_logp || !adv || !losses ||
-              !dlogits || !dvalues || !scratch || B < 1 || n_out_steer < 1 || n_out_steer > MAX_NOUT || n_out_throttle < 1 ||
+              !dlogits || !dvalues || !scratch || B < 1 || C < 1 || n_out_steer < 1 || n_out_steer > MAX_NOUT || n_out_throttle < 1 ||
               n_out_throttle > MAX_NOUT || ldl < n_out_steer || ldl < n_out_throttle || ldl > 64,
           "cadre_ppo_loss: bad argument");
   // scratch[0] (arrival counter) must be zero on entry: zero-initialised by the caller once, reset by the kernel's last
   // arriver after every launch
   hipLaunchKernelGGL(ppo_loss_kernel, dim3((B + 15) / 16, 2), dim3(256), 0, ST(stream), logits, ldl, l_ns, values, ldv, v_ns,
                      actions, commands,
-                     old_values, returns, old_logp, adv, B, n_out_steer, n_out_throttle, clip, value_coeff,
+                     old_values, returns, old_logp, adv, B, C, n_out_steer, n_out_throttle, clip, value_coeff,
                      clip_coeff, ent_coeff, inv_b, losses, dlogits, dvalues, scratch, poison);
   return (int)hipGetLastError();
 }

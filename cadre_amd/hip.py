@@ -95,7 +95,7 @@ SYMBOLS = {
     "cadre_mfma_shape": [i32, i32, i32, vp, vp],
     "cadre_sort_rows_by_command": [vp, i32, i32, vp, vp, vp],
     "cadre_permute_minibatch": [vp, i32, i32, vp, vp, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, i64, vp],
-    "cadre_ppo_loss": [vp, i64, i64, vp, i64, i64, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, f32, vp, vp, vp, vp, vp, vp],
+    "cadre_ppo_loss": [vp, i64, i64, vp, i64, i64, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, f32, f32, f32, vp, vp, vp, vp, vp, vp],
     "cadre_sample": [vp, i64, vp, i64, i32, i32, vp, vp, vp],
     "cadre_categorical_eval": [vp, i64, vp, i32, i32, vp, vp, vp],
     "cadre_categorical_dist": [vp, i64, i32, i32, vp, vp, vp, vp],
@@ -118,7 +118,7 @@ AB_SYMBOLS = {
 }
 
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 class CadreHipError(RuntimeError):

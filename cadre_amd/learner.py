@@ -292,7 +292,7 @@ class PPOLearnerHIP:
             self._forward(w, B, (0, 1, Z), C, seg=seg, fused_mlp=True)
             hip.check(L.cadre_ppo_loss(hip.ptr(O3), NP, 2 * B * NP, hip.ptr(O3[1]), NP, 2 * B * NP,
                                        hip.ptr(w["actions"]), hip.ptr(w["commands"]), hip.ptr(w["old_values"]),
-                                       hip.ptr(w["returns"]), hip.ptr(w["old_logp"]), hip.ptr(w["adv"]), B,
+                                       hip.ptr(w["returns"]), hip.ptr(w["old_logp"]), hip.ptr(w["adv"]), B, C,
                                        a.n_out[0], a.n_out[1], self.clip, self.vc, self.cc, self.ec, inv_b,
                                        hip.ptr(w["losses"]), hip.ptr(dO3), hip.ptr(dO3[1]), hip.ptr(w["loss_scratch"]),
                                        hip.ptr(w["sync"][Z * S:]), st), "cadre_ppo_loss")

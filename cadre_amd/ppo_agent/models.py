@@ -217,9 +217,9 @@ def create_model(model_cfg, load_vae=False):
     if not _cfg(model_cfg, "use_lstm", True):
         raise hip.CadreHipError("use_lstm=False is not on the accelerated path (reference default is True)")
     command_num = _cfg(model_cfg, "command_num")
-    if command_num != 4:
-        raise hip.CadreHipError("command_num=%r: the HIP loss / row-sort kernels are built for the reference's 4 "
-                                "navigation commands (agent_config.py: command_num=4)" % (command_num,))
+    if not (isinstance(command_num, int) and 1 <= command_num <= 16):
+        raise hip.CadreHipError("command_num=%r: 1 .. 16 navigation commands (the row sort keeps one counter per command in a "
+                                "wave; agent_config.py ships command_num=4)" % (command_num,))
     n_out = _cfg(model_cfg, "num_output")
     arena = PPOArena(device, obs_dim, {"steer": n_out["steer"], "throttle": n_out["throttle"]}, command_num)
     model_dict = {}

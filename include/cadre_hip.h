@@ -15,7 +15,7 @@
 extern "C" {
 #endif
 
-#define CADRE_ABI_VERSION 14
+#define CADRE_ABI_VERSION 15
 int cadre_abi_version(void);
 /* human-readable last argument error of the calling thread ("" if none) */
 const char* cadre_last_error(void);
@@ -381,7 +381,7 @@ int cadre_permute_minibatch(const int32_t* pos, int32_t B, int32_t S, const floa
 /* ---------------------------------------------------------------- policy head + PPO loss
  * Replaces Model.evaluate_actions (models.py:199-208), Categorical_1d (distributions.py:
  * 66-105) and the loss of CadreAgent.update_policy (agent.py:166-229) forward AND backward.
- * Per head hd in {0:steer,1:throttle}, command net c in 0..3 (net = hd*4+c):
+ * Per head hd in {0:steer,1:throttle}, command net c in 0..C-1 (net = hd*C+c; C = command_num, the reference ships 4):
  *   logits: net n row b at logits + n*l_ns + b*ldl (first n_out[hd] columns valid),
  *   values: net n row b at values + n*v_ns + b*ldv.  Sample arrays are [2 heads][B].
  * Outputs: losses[3] = (value_loss*value_coeff, action_loss*clip_coeff, ent*ent_coeff),
@@ -394,7 +394,7 @@ int cadre_permute_minibatch(const int32_t* pos, int32_t B, int32_t S, const floa
  * nonzero (the status word of the A/B build's cadre_lstm_seq_fwd) the three losses come out NaN. */
 int cadre_ppo_loss(const float* logits, int64_t ldl, int64_t l_ns, const float* values, int64_t ldv,
                    int64_t v_ns, const int64_t* actions, const int32_t* commands, const float* old_values, const float* returns,
-                   const float* old_logp, const float* adv, int32_t B, int32_t n_out_steer,
+                   const float* old_logp, const float* adv, int32_t B, int32_t C, int32_t n_out_steer,
                    int32_t n_out_throttle, float clip, float value_coeff, float clip_coeff,
                    float ent_coeff, float inv_b, float* losses, float* dlogits, float* dvalues,
                    float* scratch, const int32_t* poison, void* stream);

@@ -31,7 +31,8 @@ def oracle_learner_replay(g, max_steps=None, data=None):
     """train.py:76-110 on the oracle.  `data`: storage contents {head: {field: array}} to replay instead of the seeded
     ones of `fill_storages` (the end-to-end contract tests fill them from the oracle's own act path)."""
     T, mbn, epochs = int(g["T"]), int(g["mbn"]), int(g["epochs"])
-    st0 = synth.ppo_state(int(g["ppo_seed"]))
+    C = int(g["command_num"]) if "command_num" in g else 4            # (agent_config.py ships 4; agent.py:170-182 loops over any count)
+    st0 = synth.ppo_state(int(g["ppo_seed"]), command_num=C)
     names = [str(n) for n in g["names"]]
     if data is None:
         data = fill_storages(T, int(g["data_seed"]))
@@ -62,7 +63,7 @@ def oracle_learner_replay(g, max_steps=None, data=None):
                 break
             step += 1
             l3 = ppo_ref.update_policy(params, ppo_ref.gather_minibatch(stor["steer"], a, adv["steer"]),
-                                       ppo_ref.gather_minibatch(stor["throttle"], b, adv["throttle"]))
+                                       ppo_ref.gather_minibatch(stor["throttle"], b, adv["throttle"]), command_num=C)
             out["losses"].append(l3)
             out["grad_norms"].append([float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params[n].values())))
                                       for n in names])

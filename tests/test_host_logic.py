@@ -20,7 +20,7 @@ def test_cabi_exports_every_declared_symbol():
     L = ctypes.CDLL(hip.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert hip.lib().cadre_abi_version() == hip.ABI_VERSION == 14
+    assert hip.lib().cadre_abi_version() == hip.ABI_VERSION == 15
     # the default library exports only entry points the product dispatches: the superseded kernels live in the A/B build
     if os.path.basename(hip.LIB_PATH) == "libcadre_hip.so":
         assert not hip.has_ab_kernels()

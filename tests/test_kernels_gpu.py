@@ -773,7 +773,7 @@ def test_ppo_loss_fwd_bwd(hip, B, scale):
     d_ = [dev(t) for t in (logits, values, actions, cmds, old_v, rets, old_lp, adv)]
     hip.check(hip.lib().cadre_ppo_loss(d_[0].data_ptr(), ldl, B * ldl, d_[1].data_ptr(), 1, B, d_[2].data_ptr(),
                                        d_[3].data_ptr(), d_[4].data_ptr(), d_[5].data_ptr(),
-                                       d_[6].data_ptr(), d_[7].data_ptr(), B, nS, nT, clip, vc, cc, ec,
+                                       d_[6].data_ptr(), d_[7].data_ptr(), B, 4, nS, nT, clip, vc, cc, ec,
                                        1.0 / B, losses.data_ptr(), dl.data_ptr(), dv.data_ptr(), scratch.data_ptr(),
                                        None, hip.stream()), "loss")
     want = torch.tensor([float(tot_v * vc), float(tot_a * cc), float(tot_e * ec)])
@@ -783,14 +783,14 @@ def test_ppo_loss_fwd_bwd(hip, B, scale):
     for _ in range(5):
         hip.check(hip.lib().cadre_ppo_loss(d_[0].data_ptr(), ldl, B * ldl, d_[1].data_ptr(), 1, B, d_[2].data_ptr(),
                                            d_[3].data_ptr(), d_[4].data_ptr(), d_[5].data_ptr(),
-                                           d_[6].data_ptr(), d_[7].data_ptr(), B, nS, nT, clip, vc, cc, ec,
+                                           d_[6].data_ptr(), d_[7].data_ptr(), B, 4, nS, nT, clip, vc, cc, ec,
                                            1.0 / B, losses.data_ptr(), dl.data_ptr(), dv.data_ptr(), scratch.data_ptr(),
                                            None, hip.stream()), "loss")
         assert torch.equal(losses, first)
     poison = torch.ones(1, dtype=torch.int32, device="cuda")                 # a reported forward-pass timeout: NaN losses
     hip.check(hip.lib().cadre_ppo_loss(d_[0].data_ptr(), ldl, B * ldl, d_[1].data_ptr(), 1, B, d_[2].data_ptr(),
                                        d_[3].data_ptr(), d_[4].data_ptr(), d_[5].data_ptr(),
-                                       d_[6].data_ptr(), d_[7].data_ptr(), B, nS, nT, clip, vc, cc, ec,
+                                       d_[6].data_ptr(), d_[7].data_ptr(), B, 4, nS, nT, clip, vc, cc, ec,
                                        1.0 / B, losses.data_ptr(), dl.data_ptr(), dv.data_ptr(), scratch.data_ptr(),
                                        poison.data_ptr(), hip.stream()), "loss")
     assert bool(torch.isnan(losses).all())

@@ -17,17 +17,17 @@ def rel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
-def make_agent(H, W, enc_seed=7, ppo_seed=11):
+def make_agent(H, W, enc_seed=7, ppo_seed=11, command_num=4):
     from ppo_agent.agent import CadreAgent
     fh, fw = synth.feat_hw(H, W)
     cfg = dict(use_lstm=True, vae_device=0, device_num=0, vae_params="CoPM", measurement_dim=18,
-               num_output=dict(steer=33, throttle=3), command_num=4, obs_hw=(H, W), weights_init="none",
+               num_output=dict(steer=33, throttle=3), command_num=command_num, obs_hw=(H, W), weights_init="none",
                vae_state_dict=synth.encoder_state(fh, fw, enc_seed))
     steer = {i: (i - 16) / 16.0 for i in range(33)}
     thr = {0: [0, 0], 1: [0, 1], 2: [0.6, 0]}
     agent = CadreAgent(rank=0, model_cfg=cfg, frame=8, STEER_CONTROL=steer, THROTTLE_CONTROL=thr, ent_coeff=0.01,
                        value_coeff=0.1, clip_coeff=1.0, clip=0.1)
-    agent.arena.load_numpy_state(synth.ppo_state(ppo_seed))
+    agent.arena.load_numpy_state(synth.ppo_state(ppo_seed, command_num=command_num))
     return agent
 
 
@@ -90,13 +90,14 @@ def test_learner_section_replay_vs_reference(golden):
     assert step == len(g["losses"])
 
 
-@pytest.mark.parametrize("B", [24, 64])
-def test_update_policy_matches_oracle_autograd_per_param(B):
+@pytest.mark.parametrize("B,C", [(24, 4), (64, 4), (24, 3), (64, 2), (64, 6), (96, 16)])
+def test_update_policy_matches_oracle_autograd_per_param(B, C):
     """Per-parameter gradient check of the explicit backward against oracle autograd; B=64 is the
-    full C2 minibatch (T=128 / mini_batch_num=2)."""
+    full C2 minibatch (T=128 / mini_batch_num=2).  C = command_num: the reference loops agent.py:170-182 over any count
+    (agent_config.py ships 4); the row-sorted form (B >= 64) and the masked form (B = 24) both with other counts."""
     from oracle import ppo_ref
-    agent = make_agent(84, 84)
-    st0 = synth.ppo_state(11)
+    agent = make_agent(84, 84, command_num=C)
+    st0 = synth.ppo_state(11, command_num=C)
     params = ppo_ref.to_torch_params(st0, requires_grad=True)
     r = np.random.RandomState(5)
     S = 8
@@ -111,10 +112,10 @@ def test_update_policy_matches_oracle_autograd_per_param(B):
                torch.from_numpy(r.standard_normal((B, 1)).astype(np.float32)),
                [torch.from_numpy((0.1 * r.standard_normal((B, 530))).astype(np.float32)),
                 torch.from_numpy((0.1 * r.standard_normal((B, 530))).astype(np.float32))],
-               torch.from_numpy(r.randint(0, 4, (B, 1)).astype(np.int32)))
+               torch.from_numpy(r.randint(0, C, (B, 1)).astype(np.int32)))
         samples.append(tup)
         dsamples.append(tuple(x.cuda() if not isinstance(x, list) else [y.cuda() for y in x] for x in tup))
-    want = ppo_ref.update_policy(params, samples[0], samples[1])
+    want = ppo_ref.update_policy(params, samples[0], samples[1], command_num=C)
     got = agent.update_policy(dsamples[0], dsamples[1])
     assert rel(got, want) < LOSS_TOL
     worst = 0.0
@@ -233,6 +234,55 @@ def test_snapshot_roundtrip(tmp_path):
             assert torch.equal(v, agent.arena.views(before, n)[k])
     with pytest.raises(ImportError):
         agent.load_snapshot(str(tmp_path / "missing.pt"), None)
+
+
+@pytest.mark.parametrize("C", [2, 6])
+def test_act_get_value_and_snapshot_with_other_command_counts(C, tmp_path):
+    """command_num other than the shipped 4 (models.py:201-217 builds that many nets per head, agent.py:113-141 picks by
+    obs['command']): act() against the oracle chain on the same observations and exponential draws — indices bit-exact, log-prob and
+    value at the C2 bar —, get_value of the last window, and the snapshot's key set (agent.py:458-484: no throttle_lstm keys)."""
+    from oracle import encoder_ref, ppo_ref
+    agent = make_agent(84, 84, command_num=C)
+    sd = synth.encoder_state(3, 3, 7)
+    st0 = synth.ppo_state(11, command_num=C)
+    params = ppo_ref.to_torch_params(st0)
+    steps = synth.synth_rollout(2 * C, 84, 84, seed=19)
+    for i, td in enumerate(steps):
+        c = i % C                                                  # every command net once or twice
+        want = encoder_ref.latent_feature(td["rgb"], td["route_fig"], td["measurements"], sd)
+        torch.manual_seed(600 + i)
+        feat, a, lp, v, hid = agent.act(dict(rgb=td["rgb"], route_fig=td["route_fig"].copy(), measurements=td["measurements"], command=c))
+        assert rel(feat.cpu().numpy(), want.numpy()) < 2e-4
+        torch.manual_seed(600 + i)
+        for hd, K, j in (("steer", 33, 0), ("throttle", 3, 1)):
+            with torch.no_grad():
+                x, _ = ppo_ref.lstm_forward(want, (torch.zeros(1, 530), torch.zeros(1, 530)), params["%s_lstm_%d" % (hd, c)])
+                logits = ppo_ref.categorical_logits(x, params["%s_ppo_%d" % (hd, c)])
+                val = ppo_ref.mlp3(x, params["%s_ppo_%d" % (hd, c)], "critic")
+            q = torch.empty(1, K).exponential_(1)
+            a_ref = int(ppo_ref.sample_from_logits(logits, q))
+            assert int(a[j]) == a_ref, (i, hd)
+            assert abs(lp[j].item() - logits[0, a_ref].item()) < 1e-4 * max(1.0, abs(logits[0, a_ref].item()))
+            assert abs(v[j].item() - val.item()) < 1e-4 * max(1.0, abs(val.item()))
+        nv = agent.get_value(False, (feat, c), (feat, c))
+        nd = agent.get_value(False, (feat, torch.tensor(c, device=feat.device)), (feat, torch.tensor(c, device=feat.device)))
+        assert all(torch.equal(x.cpu(), y.cpu()) for x, y in zip(nv, nd))
+        for j, hd in enumerate(("steer", "throttle")):
+            with torch.no_grad():
+                x, _ = ppo_ref.lstm_forward(want, (torch.zeros(1, 530), torch.zeros(1, 530)), params["%s_lstm_%d" % (hd, c)])
+                val = ppo_ref.mlp3(x, params["%s_ppo_%d" % (hd, c)], "critic")
+            assert abs(float(nv[j]) - val.item()) < 1e-4 * max(1.0, abs(val.item()))
+    p = str(tmp_path / "ppo_model_0.pt")
+    agent.save_snapshot(p)
+    saved = torch.load(p, weights_only=False)
+    assert sorted(saved) == sorted(["%s_%d" % (k, c) for c in range(C) for k in ("throttle_ppo", "steer_ppo", "steer_lstm")])
+    before = agent.arena.params.clone()
+    agent.arena.params.mul_(0.5)
+    agent.load_snapshot(p, None)
+    for n in agent.model_dict:
+        if not n.startswith("throttle_lstm"):
+            for k, t in agent.arena.views(agent.arena.params, n).items():
+                assert torch.equal(t, agent.arena.views(before, n)[k])
 
 
 def test_fused_gather_path_equals_tuple_path():
@@ -586,18 +636,26 @@ def test_optimiser_step_that_writes_the_weight_copies_is_bit_identical():
                 a.arena.params.mul_(0.5)
 
 
-def test_full_size_learner_section_vs_oracle():
+@pytest.mark.parametrize("C", [4, 3, 6])
+def test_full_size_learner_section_vs_oracle(C):
     """BASELINE C2 sizes (T=128, mini_batch_num=2 -> minibatch 64, fused-gather + hipGraph path):
-    get_value, GAE, advantage normalisation and one epoch of updates + clip + Adam vs the oracle."""
+    get_value, GAE, advantage normalisation and one epoch of updates + clip + Adam vs the oracle.  C = command_num: the count the
+    reference ships (4) and two others (the reference builds command_num nets per head, models.py:201-217, and loops
+    agent.py:170-182 over them)."""
     from ppo_agent.models import Shared_grad_buffers
     from ppo_agent.storage import RolloutStorage
     from ppo_agent.train import learner_section
     from tests.helpers import oracle_learner_replay
     T, mbn = 128, 2
-    g = dict(T=T, mbn=mbn, epochs=1, ppo_seed=11, data_seed=123, torch_seed=8, names=np.array(sorted(synth.ppo_state(11))))
-    want = oracle_learner_replay(g)
-    agent = make_agent(84, 84)
+    g = dict(T=T, mbn=mbn, epochs=1, ppo_seed=11, data_seed=123, torch_seed=8, command_num=C,
+             names=np.array(sorted(synth.ppo_state(11, command_num=C))))
     data = fill_storages(T, 123)
+    if C != 4:
+        for i, hd in enumerate(("steer", "throttle")):
+            data[hd]["command"] = np.random.RandomState(40 + i).randint(0, C, (T + 1, 1)).astype(np.int32)
+    want = oracle_learner_replay(g, data=data)
+    agent = make_agent(84, 84, command_num=C)
+    assert len(agent.model_dict) == 4 * C
     stor = []
     for hd in ("steer", "throttle"):
         s = RolloutStorage(T, mbn, 530, 8, 530, True, 0.99, 0.95)
