@@ -90,10 +90,55 @@ __global__ __launch_bounds__(256) void mfma_shape_kernel(int iters, float* sink)
   if (s == 12345.678f) sink[0] = s;
 }
 
+// fp32 MFMAs on RANDOM operands (round 6): the constant-operand chain of mfma_peak_kernel holds 2.38 GHz; what the chip holds when every
+// multiplier input toggles is the ceiling the fp32 GEMM / conv kernels are priced against in DESIGN.md.  SHAPE 2: 8 x
+// v_mfma_f32_32x32x2_f32 on 8 accumulators, SHAPE 4: 32 x v_mfma_f32_16x16x4_f32 on 32 accumulators (32768 / 65536 FLOP per wave and
+// iteration); 8 + 8 pseudo-random operand registers per lane.
+template <int SHAPE>
+__global__ __launch_bounds__(256) void mfma_f32_random_kernel(int iters, float* sink) {
+  float a[8], b[8];
+  unsigned h = (threadIdx.x + 1) * 2654435761u ^ (blockIdx.x * 40503u);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    h = h * 1664525u + 1013904223u;
+    a[i] = ((int)(h >> 8 & 0xffffff) - 8388608) * (1.f / 8388608.f);
+    h = h * 1664525u + 1013904223u;
+    b[i] = ((int)(h >> 8 & 0xffffff) - 8388608) * (1.f / 8388608.f);
+  }
+  float s = 0.f;
+  if constexpr (SHAPE == 2) {
+    f32x16 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[(j + 3) & 7], acc[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += acc[j][0];
+  } else {
+    f32x4p acc[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) acc[j] = f32x4p{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int j = 0; j < 32; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j & 7], b[(j + 3 + (j >> 3)) & 7], acc[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) s += acc[j][0];
+  }
+  if (s == 12345.678f) sink[0] = s;
+}
+
 // shape 32: 8 x v_mfma_f32_32x32x16_bf16 per iteration, shape 16: 16 x v_mfma_f32_16x16x32_bf16 (262144 FLOP per wave
 // and iteration either way), random operands.  The caller times the launch.
 extern "C" int cadre_mfma_shape(int32_t shape, int32_t workgroups, int32_t iters, float* sink, void* stream) {
-  if (!sink || workgroups < 1 || iters < 1 || (shape != 16 && shape != 32)) return cadre_fail("cadre_mfma_shape: bad argument");
+  if (!sink || workgroups < 1 || iters < 1 || (shape != 16 && shape != 32 && shape != 2 && shape != 4)) return cadre_fail("cadre_mfma_shape: bad argument");
+  // shapes 2 / 4: the fp32 pipe on random operands (8 x v_mfma_f32_32x32x2_f32 = 32768 FLOP / 32 x v_mfma_f32_16x16x4_f32 = 65536 FLOP per wave and iteration)
+  if (shape == 2) { hipLaunchKernelGGL((mfma_f32_random_kernel<2>), dim3(workgroups), dim3(256), 0, (hipStream_t)stream, iters, sink); return (int)hipGetLastError(); }
+  if (shape == 4) { hipLaunchKernelGGL((mfma_f32_random_kernel<4>), dim3(workgroups), dim3(256), 0, (hipStream_t)stream, iters, sink); return (int)hipGetLastError(); }
   if (shape == 32) hipLaunchKernelGGL((mfma_shape_kernel<32>), dim3(workgroups), dim3(256), 0, (hipStream_t)stream, iters, sink);
   else hipLaunchKernelGGL((mfma_shape_kernel<16>), dim3(workgroups), dim3(256), 0, (hipStream_t)stream, iters, sink);
   return (int)hipGetLastError();

@@ -55,8 +55,18 @@ int cadre_fail(const char* msg);
 #ifndef W2_ASM_MFMA
 #define W2_ASM_MFMA 1
 #endif
+// W2_PIPE = 1: the NEXT step's input transform rides between this step's MFMAs, one packed add behind an MFMA (and the patch requests
+// move a step earlier).  MEASURED AND NOT ADOPTED (round 6, tools/w2_ablate.py, bit-identical): 1.72 / 1.82 ms against 1.66 / 1.74 without /
+// with residual.  The reason is a property of the fp32 matrix instructions (tools/dbg/mfma_shadow.py, profiles/r06_mfma_shadow.txt): a
+// vector-ALU instruction does NOT run in the shadow of a v_mfma_f32_16x16x4_f32 — the first one behind an MFMA costs 13 cycles of the
+// 32, every further one 4 (8 for v_mov_b32), with one wave per SIMD and with two; s_nop and ds_read are free.  fp32 MFMA and fp32 VALU
+// share the multipliers (the datasheet's vector and matrix fp32 rates are the same number).  So the 32 packed adds cost what they cost
+// at the top of the step, plus the 13-cycle switch sixteen times instead of once.
+#ifndef W2_PIPE
+#define W2_PIPE 0
+#endif
 #ifndef W2_ABL
-#define W2_ABL 0      // tools/wino_c64_ablate.py: 1 no MFMA, 2 no patch loads, 4 no weight DMA, 8 no epilogue, 16 no wait + barrier
+#define W2_ABL 0      // tools/w2_ablate.py: 1 no MFMA, 2 no patch loads, 4 no weight DMA, 8 no epilogue, 16 no wait + barrier, 64 no input transform, 128 no fragment reads after a step's first
 #endif
 
 struct w2_args {
@@ -188,9 +198,58 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
   request_u(1, 1);
 #pragma unroll
   for (int k = 0; k < 16; ++k) request_q1(0, dq2[0], k >> 2, k & 3);
+  if constexpr (W2_PIPE != 0) {                    // (the transform of step 2 runs during step 1: double-step 1 is due a step earlier)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) request_q1(1, dq2[1], k >> 2, k & 3);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+
+  // Input transform V = B^T d B of one step's two channels (16 planes, packed pairs).  W2_PIPE: V lives across the steps — the 32 packed
+  // adds of step t+1's transform are issued ONE OR TWO PER PLANE behind the MFMAs of step t (row `i` of the column pass in front of
+  // plane 4i, plane k's value into V[k] once plane k's MFMAs have been issued and the next plane's are in the pipe): with one wave
+  // per SIMD a transform at the top of the step ran with the matrix pipe empty (0.10-0.12 ms of 1.84 per 1024 frames).
+  f32x2 V[16];
+  f32x2 tt[2][4];                  // two rows of the column pass
+  auto dn_of = [&](int cn, int k) -> f32x2 {       // patch pixel k, the two channels of step cn (cn = 8: the next item's step 0)
+    const f32x4& d4 = dq2[((cn & 7) >> 1) & 1][k];
+    return (cn & 1) ? f32x2{d4[2], d4[3]} : f32x2{d4[0], d4[1]};
+  };
+  // (packed adds as asm volatile: they stay exactly where the source puts them — ONE behind an MFMA, in its 32-cycle shadow; left to
+  // hipcc the twelve of a row came out scalar and in one run between two MFMAs: slower than the transform at the top of the step)
+  auto pk_add = [](f32x2 x, f32x2 y) -> f32x2 {
+    f32x2 r;
+    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+  };
+  auto pk_sub = [](f32x2 x, f32x2 y) -> f32x2 {
+    f32x2 r;
+    asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+  };
+  auto tt_one = [&](int cn, int i, int j) {       // element j of row i of tt = B^T d
+    if (i == 0) tt[0][j] = pk_sub(dn_of(cn, 0 + j), dn_of(cn, 8 + j));
+    if (i == 1) tt[1][j] = pk_add(dn_of(cn, 4 + j), dn_of(cn, 8 + j));
+    if (i == 2) tt[0][j] = pk_sub(dn_of(cn, 8 + j), dn_of(cn, 4 + j));
+    if (i == 3) tt[1][j] = pk_sub(dn_of(cn, 4 + j), dn_of(cn, 12 + j));
+  };
+  auto tt_row = [&](int cn, int i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tt_one(cn, i, j);
+  };
+  auto v_of = [&](int k) -> f32x2 {               // V[k] from row k >> 2 of tt
+    const f32x2* t = tt[(k >> 2) & 1];
+    return (k & 3) == 0 ? pk_sub(t[0], t[2]) : (k & 3) == 1 ? pk_add(t[1], t[2]) : (k & 3) == 2 ? pk_sub(t[2], t[1]) : pk_sub(t[1], t[3]);
+  };
+  if constexpr (W2_PIPE != 0) {                   // step 0 of the first item
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      tt_row(0, i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) V[4 * i + j] = v_of(4 * i + j);
+    }
+  }
 
   for (int item_l = 0; item_l < my_items; ++item_l) {
     // (byte offsets of the item's output pixels: formed inside step 6's MFMA block — two integer divisions per tile that would
@@ -212,11 +271,14 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {                 // (unrolled: chunk, LDS buffer c & 1 and "first chunk" are compile-time)
       // ---- input transform of this step's patch: V = B^T d B (per channel), 16 planes x 4 channels
-      f32x2 V[16];
+      if constexpr (W2_PIPE == 0) {
       f32x2 dn[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) dn[k] = f32x2{dq2[(c >> 1) & 1][k][2 * (c & 1)], dq2[(c >> 1) & 1][k][2 * (c & 1) + 1]};
-      {
+      if constexpr ((W2_ABL & 64) != 0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) V[k] = dn[k];
+      } else {
         f32x2 tt[16];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -233,13 +295,17 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
           V[4 * i + 3] = tt[4 * i + 1] - tt[4 * i + 3];
         }
       }
+      }
       // (scheduling fences: hipcc otherwise hoists the NEXT step's transform up to its loads — in front of this step's
       // MFMAs — and waits for memory there, and sinks the B-fragment reads down to their first use)
       __builtin_amdgcn_sched_barrier(0);
       // ---- requests of step t+1: weights chunk into the other buffer (its readers finished at the last barrier), patch
       // (unconditional — past the workgroup's last step the weights land in a buffer nobody reads and the patch offsets
       // are out of bounds: a branch around the loads would put register copies, and with them a wait for memory, right here)
-      if (c == 6) plan_a(item_l + 1);            // (steps t+2, t+3 of chunks 0, 1 belong to the next item)
+      // (W2_PIPE: a double-step's patch is consumed a step earlier — by the transform riding in the step before — so it is requested a
+      // step earlier too: double-step (c + 3) / 2 during ODD step c, into the set whose last reader was step c - 1; steps 5 and 7 ask for
+      // the next item's double-steps 0 and 1)
+      if (c == (W2_PIPE ? 4 : 6)) plan_a(item_l + 1);            // (steps t+2, t+3 of chunks 0, 1 belong to the next item)
       // (epilogue state of the item's last step: byte offsets of tile r's four pixels at channel 4n, residual values.  MFMA
       // block b, column n is output channel 4n + b — the host lays U out that way, cadre_amd/encoder.py _winograd_u_c64 — so a
       // lane ends up with FOUR CONSECUTIVE channels of a pixel: 16-byte stores and residual loads, 16 of each per lane and
@@ -254,9 +320,13 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
       f32x2 bf[2][4];
 #pragma unroll
       for (int b = 0; b < 4; ++b) bf[0][b] = *reinterpret_cast<const f32x2*>(ub + b * 512);
+      if constexpr ((W2_ABL & 128) != 0) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { bf[1][b] = bf[0][b] + f32x2{1.f, 2.f}; asm volatile("" : "+v"(bf[1][b])); }
+      }
 #pragma unroll
       for (int p = 0; p < 16; ++p) {
-        if (p + 1 < 16) {
+        if (p + 1 < 16 && (W2_ABL & 128) == 0) {
 #pragma unroll
           for (int b = 0; b < 4; ++b) bf[(p + 1) & 1][b] = *reinterpret_cast<const f32x2*>(ub + (p + 1) * 2048 + b * 512);
         }
@@ -265,18 +335,28 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
           // waves of the CU in the address queue — not issuing MFMAs — while the texture addresser works through 96 requests
           if (p < 8) request_u1((c + 2) & 7, (c + 2) & 3, p);
           if (c == 6 && (p & 3) == 1) offsets(p >> 2, eo[p >> 2]);
-          if ((c & 1) == 0) request_q1(((c >> 1) + 1) & 3, dq2[((c >> 1) + 1) & 1], p >> 2, p & 3);
+          if (W2_PIPE == 0 && (c & 1) == 0) request_q1(((c >> 1) + 1) & 3, dq2[((c >> 1) + 1) & 1], p >> 2, p & 3);
+          if (W2_PIPE != 0 && (c & 1) == 1 && (c != 7 || (W2_ABL & 8) != 0)) request_q1(((c + 3) >> 1) & 3, dq2[((c + 3) >> 1) & 1], p >> 2, p & 3);      // (step 7: in the epilogue, below)
           if (c == 7 && RES && (W2_ABL & 8) == 0 && (p & 1)) req_res1(p >> 3, (p >> 1) & 3);      // (tiles 0, 1: 8 requests)
         }
+        // step c+1's transform (W2_PIPE): one packed add behind an MFMA — row p/4 of the column pass behind the first four MFMAs of
+        // planes 0, 4, 8, 12; V[p-1] of the next step behind the sixth, once plane p-1's MFMAs are a plane behind (the operand
+        // registers of an issued MFMA are free: it reads them as it starts)
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-          for (int b = 0; b < 4; ++b)
+          for (int b = 0; b < 4; ++b) {
             if constexpr ((W2_ABL & 1) == 0)
               mfma_acc(acc[p][b], V[p][s], bf[p & 1][b][s], c == 0 && s == 0);
             else acc[p][b][s] = ((c == 0 && s == 0) ? 0.f : acc[p][b][s]) + V[p][s] * bf[p & 1][b][s];
+            if constexpr (W2_PIPE != 0) {
+              if ((p & 3) == 0 && s == 0) tt_one(c + 1, p >> 2, b);
+              if (p >= 1 && s == 1 && b == 1) V[p - 1] = v_of(p - 1);
+            }
+          }
         __builtin_amdgcn_sched_barrier(0);          // plane p+1's fragment reads stay in front of plane p's MFMAs
       }
+      if constexpr (W2_PIPE != 0) V[15] = v_of(15);
       __builtin_amdgcn_sched_barrier(0);
       // ---- end of an item: inverse transform (register-local), BN, residual, ReLU, stores
       if (c == 7 && (W2_ABL & 8) != 0) {
@@ -330,6 +410,12 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
             for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], act_floor);      // (no branch: the epilogue stays one basic block per tile)
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rsO, (int)eo[r][px], 0, 0);
           }
+          if constexpr (W2_PIPE != 0) {
+            // the next item's double-step 1 (due at ITS step 1), four pixels beside each tile's stores: the set's registers carry the
+            // residuals of tiles 0, 1 through the MFMA block of this step (requested there, they would be 64 registers too many)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) request_q1(1, dq2[1], r, j);
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -339,6 +425,11 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
         // requests are still in flight
         // even steps: 8 weight pieces + the 16 patch requests of the next double-step stay in flight; odd steps: the weight pieces
         // (+ the epilogue's 16 residual loads and 16 stores at the end of an item)
+        if constexpr (W2_PIPE != 0) {                     // (the patch requests ride in the odd steps: 16 more in flight there, 16 fewer in the even ones)
+          if (c == 7 && (W2_ABL & 8) == 0) { if (RES) asm volatile("s_waitcnt vmcnt(56)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); }
+          else if (c & 1) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else
         if (c == 7 && (W2_ABL & 8) == 0) { if (RES) asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); }
         else if (c & 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");

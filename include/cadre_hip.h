@@ -139,7 +139,8 @@ int cadre_gemm_bf16_w128_supported(int32_t M, int32_t N, int32_t K, int32_t lda,
  * v_mfma_f32_32x32x2_f32 = 4096 FLOP, bf16: v_mfma_f32_32x32x16_bf16 = 32768 FLOP).  The caller times the launch. */
 int cadre_mfma_peak(int32_t bf16, int32_t workgroups, int32_t iters, float* sink, void* stream);
 /* bf16 MFMA shape comparison on pseudo-random register operands (peaks.hip): shape 32 = v_mfma_f32_32x32x16_bf16,
- * shape 16 = v_mfma_f32_16x16x32_bf16; 262144 FLOP per wave and iteration either way; workgroups x 4 waves. */
+ * shape 16 = v_mfma_f32_16x16x32_bf16; 262144 FLOP per wave and iteration either way; workgroups x 4 waves.
+ * shape 2 = v_mfma_f32_32x32x2_f32, shape 4 = v_mfma_f32_16x16x4_f32 on random fp32 operands: 8 x 4096 / 32 x 2048 FLOP per wave and iteration. */
 int cadre_mfma_shape(int32_t shape, int32_t workgroups, int32_t iters, float* sink, void* stream);
 /* HBM stream peaks of this device (peaks.hip): mode 0 reads `bytes` from src with 16-B loads, 8 in flight per lane
  * (nothing stored), mode 1 copies src -> dst.  The caller times the launch (read: bytes / t, copy: 2 * bytes / t). */

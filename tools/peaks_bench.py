@@ -46,6 +46,12 @@ def measure():
         wgs, iters = 512, 20000
         t = timed(lambda: hip.check(L.cadre_mfma_shape(shape, wgs, iters, hip.ptr(sink), hip.stream()), "cadre_mfma_shape"), reps=3)
         out["mfma_bf16_random_%s_TFLOPs" % ("32x32x16" if shape == 32 else "16x16x32")] = round(wgs * 4 * iters * 262144.0 / t / 1e12, 1)
+    # the fp32 pipe on random operands (constants above): what the chip holds when every multiplier input toggles
+    for shape, nm, flop in ((2, "32x32x2", 8 * 4096.0), (4, "16x16x4", 32 * 2048.0)):
+        for wps in (1, 2):
+            wgs, iters = 256 * wps, 20000
+            t = timed(lambda: hip.check(L.cadre_mfma_shape(shape, wgs, iters, hip.ptr(sink), hip.stream()), "cadre_mfma_shape"), reps=3)
+            out["mfma_f32_random_%s_%dwave_TFLOPs" % (nm, wps)] = round(wgs * 4 * iters * flop / t / 1e12, 1)
     return out
 
 
