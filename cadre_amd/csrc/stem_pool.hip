@@ -176,7 +176,16 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(stem_args a) {
   }
   __syncthreads();
 
+  // fp32 (round 6): the A operand is the pixel byte as a float, the /255 of agent.py:46 rides in the folded BN scale — ONE vector
+  // instruction per fragment element (v_cvt_f32_ubyteN) instead of three (convert, multiply, fma of div255()).  A vector instruction is
+  // paid in matrix cycles in fp32 (profiles/r06_mfma_shadow.txt): 12 of them per four 64-cycle MFMAs were a quarter of this kernel.  The
+  // products byte x weight are exact to 1 ulp like before; the one rounding of x / 255 the reference has per input is gone and one of
+  // scale / 255 per channel is new (the goldens move in the eighth digit).  -DSTEM_DIV255_A: the element-wise form.
+#ifdef STEM_DIV255_A
   const float sc = BF16 ? 1.f : a.scale[32 * hN + l31], sh = a.shift[32 * hN + l31];
+#else
+  const float sc = BF16 ? 1.f : a.scale[32 * hN + l31] / 255.f, sh = a.shift[32 * hN + l31];
+#endif
   constexpr int PHN = 4;                             // previous stem row's horizontal maxima, columns k + 4*lh
   float prevH[NT][PHN];
 #pragma unroll
@@ -326,10 +335,61 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(stem_args a) {
             for (int t = 0; t < CH; ++t)
 #pragma unroll
               for (int s = 0; s < 4; ++s) {
+#ifdef STEM_DIV255_A
                 if constexpr ((STEM_ABL & 2) == 0) af[t][s] = div255((float)((px[t] >> (8 * s)) & 255u));
+#else
+                if constexpr ((STEM_ABL & 2) == 0) af[t][s] = (float)((px[t] >> (8 * s)) & 255u);
+#endif
                 else af[t][s] = __builtin_bit_cast(float, px[t] + s);
               }
           };
+#ifndef STEM_UNGROUPED
+          // Vector instructions in ONE run per PAIR of k-steps, behind the pair's first MFMA (round 6): in fp32 the first vector
+          // instruction behind an MFMA costs 13 matrix cycles, every further one of the run 4 (profiles/r06_mfma_shadow.txt) — left to
+          // the scheduler the conversions sat one or two behind each MFMA (four switches per k-step).  The run: the 8 conversions of
+          // k-steps q+2, q+3 (into the other register set), the ring addresses of q+4, q+5 and the side work of the two steps.
+          static_assert(NK >= 2, "two k-steps in the prologue");
+          uint32_t pxn[2][CH];
+          float af[2][2][CH][4];
+          fetch(0, pxn[0]);
+          fetch(1, pxn[1]);
+          conv(pxn[0], af[0][0]);
+          conv(pxn[1], af[0][1]);
+          if (2 < NK) fetch(2, pxn[0]);
+          if (3 < NK) fetch(3, pxn[1]);
+          f32x4 bw = *reinterpret_cast<const f32x4*>(wbase + wlane);
+#pragma unroll
+          for (int q = 0; q < NK; ++q) {
+            const int set = (q >> 1) & 1, h = q & 1;
+            f32x4 bn = bw;
+            if (q + 1 < NK) {
+              if constexpr ((STEM_ABL & 32) == 0) bn = *reinterpret_cast<const f32x4*>(wbase + wlane + (q + 1) * 32);
+              else bn = f32x4{1.f + q, 2.f, 3.f + lane, 4.f};
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            auto mm = [&](int s) {
+#pragma unroll
+              for (int t = 0; t < CH; ++t) {
+                if constexpr ((STEM_ABL & 1) == 0) acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[set][h][t][s], bw[s], (q == 0 && s == 0) ? zero16 : acc[b][t], 0, 0, 0);
+                else acc[b][t][s] = ((q == 0 && s == 0) ? 0.f : acc[b][t][s]) + af[set][h][t][s] * bw[s];
+              }
+            };
+            mm(0);
+            if (h == 0) {
+              __builtin_amdgcn_sched_barrier(0);
+              if (q + 2 < NK) conv(pxn[0], af[set ^ 1][0]);
+              if (q + 3 < NK) conv(pxn[1], af[set ^ 1][1]);
+              if (q + 4 < NK) fetch(q + 4, pxn[0]);
+              if (q + 5 < NK) fetch(q + 5, pxn[1]);
+              side(q);
+              if (q + 1 < NK) side(q + 1);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            mm(1); mm(2); mm(3);
+            __builtin_amdgcn_sched_barrier(0);
+            bw = bn;
+          }
+#else
           uint32_t pxn[CH];
           float af[CH][4];
           fetch(0, pxn);
@@ -357,6 +417,7 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(stem_args a) {
             __builtin_amdgcn_sched_barrier(0);
             bw = bn;
           }
+#endif
         } else {
           unsigned cb[7];                            // the chunk's row bases (keeps every fragment offset inside ds_read2_b64's range)
 #pragma unroll

@@ -65,6 +65,13 @@ int cadre_fail(const char* msg);
 #ifndef W2_PIPE
 #define W2_PIPE 0
 #endif
+// W2_SOFF = 1 (round 6): no vector instruction per patch request inside the MFMA blocks — the 16 patch offsets of a lane (with the
+// out-of-range select) are formed ONCE per item, the double-step's channel offset rides in the load's scalar offset (and the per-pixel
+// masks no longer sit in 32 SGPRs: 75 -> 15 scalars spilled to VGPR lanes).  Bit-identical, 1.66 -> 1.57 / 1.75 -> 1.66 ms without / with
+// residual (tools/w2_ablate.py).  0: the round-4 form (add + select per request).
+#ifndef W2_SOFF
+#define W2_SOFF 1
+#endif
 #ifndef W2_ABL
 #define W2_ABL 0      // tools/w2_ablate.py: 1 no MFMA, 2 no patch loads, 4 no weight DMA, 8 no epilogue, 16 no wait + barrier, 64 no input transform, 128 no fragment reads after a step's first
 #endif
@@ -137,6 +144,7 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
   // ---- per-item lane state of the A side: tile = group * 16 + n, patch origin (2ty-1, 2tx-1), channel slice 4q of a chunk
   int a_base = 0;                 // byte offset of patch pixel (0, 0), channel 4q of double-step 0 (may be negative: masked pixels only)
   unsigned a_rows = 0, a_cols = 0;
+  unsigned a_voff[16];            // (W2_SOFF) byte offset of each patch pixel at double-step 0, or the out-of-range bit
   auto plan_a = [&](int item_l) {      // (branch-free: it runs in front of step 6's MFMA block)
     const int item = item0 + item_l;
     const int tile = (item * 4 + wave) * 16 + n;
@@ -154,6 +162,13 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
     a_rows = live ? rows : 0u;
     a_cols = live ? cols : 0u;
     a_base = ((f * a.H + r0) * a.W + c0) * 256 + 16 * q;
+    if constexpr (W2_SOFF != 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          a_voff[4 * i + j] = ((a_rows >> i) & (a_cols >> j) & 1u) ? (unsigned)(a_base + (i * a.W + j) * 256) : OOB;
+    }
   };
   // patches are requested by DOUBLE-STEP d (16 input channels): a lane asks for the four channels 16d + 4q .. + 3 of each of its
   // 16 patch pixels at once (16 bytes: half the requests — and cache lines touched — per byte of the 8-byte form, measured
@@ -164,6 +179,10 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
     const unsigned okm = (a_rows >> i) & (a_cols >> j) & 1u;
     unsigned off = okm ? (unsigned)(a_base + (i * a.W + j) * 256 + d * 64) : OOB;
     if constexpr ((W2_ABL & 32) != 0) off = (unsigned)(((i * 4 + j) * 256 + d * 64 + 16 * q) + n * 4096);
+    if constexpr (W2_SOFF != 0 && (W2_ABL & 34) == 0) {
+      dq[4 * i + j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)a_voff[4 * i + j], d * 64, 0));
+      return;
+    }
     if constexpr ((W2_ABL & 2) == 0) dq[4 * i + j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)off, 0, 0));
     else dq[4 * i + j] = f32x4{(float)off, (float)d, (float)off, (float)d};
   };
@@ -279,20 +298,22 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) V[k] = dn[k];
       } else {
+        // (32 packed adds, as asm: hipcc split half of them into scalar pairs — 72 vector instructions per step where 32 do, and a
+        // vector instruction is paid in matrix cycles here)
         f32x2 tt[16];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          tt[0 + j] = dn[0 + j] - dn[8 + j];
-          tt[4 + j] = dn[4 + j] + dn[8 + j];
-          tt[8 + j] = dn[8 + j] - dn[4 + j];
-          tt[12 + j] = dn[4 + j] - dn[12 + j];
+          tt[0 + j] = pk_sub(dn[0 + j], dn[8 + j]);
+          tt[4 + j] = pk_add(dn[4 + j], dn[8 + j]);
+          tt[8 + j] = pk_sub(dn[8 + j], dn[4 + j]);
+          tt[12 + j] = pk_sub(dn[4 + j], dn[12 + j]);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          V[4 * i + 0] = tt[4 * i + 0] - tt[4 * i + 2];
-          V[4 * i + 1] = tt[4 * i + 1] + tt[4 * i + 2];
-          V[4 * i + 2] = tt[4 * i + 2] - tt[4 * i + 1];
-          V[4 * i + 3] = tt[4 * i + 1] - tt[4 * i + 3];
+          V[4 * i + 0] = pk_sub(tt[4 * i + 0], tt[4 * i + 2]);
+          V[4 * i + 1] = pk_add(tt[4 * i + 1], tt[4 * i + 2]);
+          V[4 * i + 2] = pk_sub(tt[4 * i + 2], tt[4 * i + 1]);
+          V[4 * i + 3] = pk_sub(tt[4 * i + 1], tt[4 * i + 3]);
         }
       }
       }
@@ -388,12 +409,12 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
             f32x2 s0[4], s1[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              s0[j] = m[0 + j] + m[4 + j] + m[8 + j];
-              s1[j] = m[4 + j] - m[8 + j] - m[12 + j];
+              s0[j] = pk_add(pk_add(m[0 + j], m[4 + j]), m[8 + j]);
+              s1[j] = pk_sub(pk_sub(m[4 + j], m[8 + j]), m[12 + j]);
             }
             f32x2 y[4];
-            y[0] = s0[0] + s0[1] + s0[2]; y[1] = s0[1] - s0[2] - s0[3];
-            y[2] = s1[0] + s1[1] + s1[2]; y[3] = s1[1] - s1[2] - s1[3];
+            y[0] = pk_add(pk_add(s0[0], s0[1]), s0[2]); y[1] = pk_sub(pk_sub(s0[1], s0[2]), s0[3]);
+            y[2] = pk_add(pk_add(s1[0], s1[1]), s1[2]); y[3] = pk_sub(pk_sub(s1[1], s1[2]), s1[3]);
             const f32x2 sc2 = {sc[2 * bp], sc[2 * bp + 1]}, sh2 = {sh[2 * bp], sh[2 * bp + 1]};
 #pragma unroll
             for (int px = 0; px < 4; ++px) {

@@ -196,6 +196,7 @@ __global__ __launch_bounds__(128 * NTB, (NTB == 4 ? 2 : 1)) void wino_gemm_out_k
 
   const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)a.V, 0, (int)a.v_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc((void*)a.U, 0, (int)a.u_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsNull = __builtin_amdgcn_make_buffer_rsrc((void*)a.V, 0, 0, 0x00020000);      // zero records: every request out of range
 
   // ---- DMA duties of this wave.  V instruction i: block jv = wave + NW i of the slot's NTB PG (plane pp = jv / NTB, tile block jv % NTB);
   // U instruction i: KB ju = wave + NW i of the slot's 2 PG contiguous KB.  Surplus instructions (jv >= NTB PG / ju >= 2 PG: F(3x3)
@@ -239,8 +240,13 @@ __global__ __launch_bounds__(128 * NTB, (NTB == 4 ? 2 : 1)) void wino_gemm_out_k
   // at a time (-DWGO_BURST: all NI right behind the barrier — 24 requests at once keep every wave of the CU in the texture
   // addresser's queue with its MFMAs behind them in program order, the lesson of winograd_c64.hip: 1.211 vs 1.158 ms on layer2,
   // 1.301 / 1.145 vs 1.175 / 1.046 ms on the F(3x3) shapes)
+  // (The slot's offset goes in the instruction's SCALAR offset, the lane's in its vector offset — both fixed registers: no vector
+  // instruction per request.  A v_add_u32 behind an MFMA is not free in fp32: it costs 13 matrix cycles, DESIGN.md 3.4 / profiles/
+  // r06_mfma_shadow.txt.  The scalar offset is outside the range check, so a dead slot — past the workgroup's last item — cannot
+  // carry the out-of-range bit there: it swaps in a descriptor of zero records instead, one s_cselect.  -DWGO_VADDR: the round-6 form.)
   auto send_one = [&](auto i_c, int buf, unsigned sV, unsigned sU) {
     constexpr int i = decltype(i_c)::value;
+#ifdef WGO_VADDR
     if constexpr (i < NI_V) {
       const unsigned dst = vdst[i] == dump_off ? dump_off : (unsigned)(buf * SLOT_B) + vdst[i];
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (__attribute__((address_space(3))) void*)(smem + dst), 16, (int)(vlane[i] + sV), 0, 0, WGO_VAUX);
@@ -248,6 +254,28 @@ __global__ __launch_bounds__(128 * NTB, (NTB == 4 ? 2 : 1)) void wino_gemm_out_k
       const unsigned dst = udst[i - NI_V] == dump_off ? dump_off : (unsigned)(buf * SLOT_B) + udst[i - NI_V];
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (__attribute__((address_space(3))) void*)(smem + dst), 16, (int)(ulane[i - NI_V] + sU), 0, 0, WGO_UAUX);
     }
+#else
+    // (a dead slot — past the workgroup's last item — arrives here with scalar offset 0: it re-reads the first KB of V / U into a
+    //  buffer nobody reads; the ablation build without DMA swaps in a descriptor of zero records)
+    // (-DWGO_OPAQUE: LDS addresses and per-slot offsets formed where they are used, behind opaque copies — hoisted out of the item loop
+    //  they are ~60 SGPRs too many and come back through one v_readlane per step.  MEASURED AND NOT ADOPTED: no spills, no readlanes,
+    //  and 1.145 against 1.073 ms on layer2 — the scalar chains in front of each request cost more than the readlane.)
+    if constexpr (i < NI_V) {
+      unsigned vd = vdst[i];
+#ifdef WGO_OPAQUE
+      asm volatile("" : "+s"(vd));
+#endif
+      const unsigned dst = vd == dump_off ? dump_off : (unsigned)(buf * SLOT_B) + vd;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds((WGO_ABL & 4) ? rsNull : rsV, (__attribute__((address_space(3))) void*)(smem + dst), 16, (int)vlane[i], (int)sV, 0, WGO_VAUX);
+    } else {
+      unsigned ud = udst[i - NI_V];
+#ifdef WGO_OPAQUE
+      asm volatile("" : "+s"(ud));
+#endif
+      const unsigned dst = ud == dump_off ? dump_off : (unsigned)(buf * SLOT_B) + ud;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds((WGO_ABL & 4) ? rsNull : rsU, (__attribute__((address_space(3))) void*)(smem + dst), 16, (int)ulane[i - NI_V], (int)sU, 0, WGO_UAUX);
+    }
+#endif
   };
 
   // ---- fragments: lane l reads bytes 16 l of its 1 KB block.  The reads are inline asm with the waits placed by hand: ONE
@@ -288,6 +316,7 @@ __global__ __launch_bounds__(128 * NTB, (NTB == 4 ? 2 : 1)) void wino_gemm_out_k
   const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void*)(a.resid ? a.resid : a.out), 0, a.resid ? (int)a.o_bytes : 0, 0x00020000);
   const float act_floor = (a.act & 15) == 1 ? 0.f : -__builtin_inff();
   const bool post = (a.act & 16) != 0;
+  const float r_pre = post ? 0.f : 1.f, r_post = post ? 1.f : 0.f;
   const float inv_tw = 1.0f / (float)a.TW, inv_th = 1.0f / (float)a.TH;
   auto xch = [](float v, auto ctrl_c) {
     constexpr int ctrl = decltype(ctrl_c)::value;
@@ -360,18 +389,23 @@ __global__ __launch_bounds__(128 * NTB, (NTB == 4 ? 2 : 1)) void wino_gemm_out_k
         const float u2 = xch(n2, std::integral_constant<int, 0x4E>{}), u3 = xch(n3, std::integral_constant<int, 0x4E>{});
         f32x4 v = {hi ? u2 : n0, hi ? u3 : n1, hi ? n2 : u0, hi ? n3 : u1};
         if constexpr ((WGO_ABL & 32) != 0) v = y[e];
+        // (the residual in front of or behind the activation by two uniform multipliers, 1 and 0: x + 1 r and x + 0 r are the sums
+        //  the selects formed — three vector instructions per element where the selects made five; vector instructions are paid
+        //  in the other wave's matrix cycles)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          float w = v[c] + (post ? 0.f : rr[e][c]);
+          float w = __builtin_fmaf(rr[e][c], r_pre, v[c]);
           w = fmaxf(w, act_floor);
-          v[c] = w + (post ? rr[e][c] : 0.f);
+          v[c] = __builtin_fmaf(rr[e][c], r_post, w);
         }
         if constexpr ((WGO_ABL & 16) != 0) { asm volatile("" :: "v"(v)); }
         else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsO, (int)px_off(e), 0, 0);
       }
     }
+#if defined(WGO_STAGGER) || WGO_ABL || !defined(WGO_ZEROC)
 #pragma unroll
     for (int p = 0; p < P; ++p) acc[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
   };
 
   // (Measured and not kept: start delays of (a hash of the workgroup id) / 64 of an item, so that the 256 workgroups do not reach
@@ -437,7 +471,16 @@ __global__ __launch_bounds__(128 * NTB, (NTB == 4 ? 2 : 1)) void wino_gemm_out_k
                   // (inline asm with the accumulator tied: left to the register allocator the builtin's three-address form gets a
                   //  fresh destination block per MFMA — 144 accumulators do not survive that.  Same-register SrcC chains need no
                   //  wait states.)
-                  asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[PG * g + pp]) : "v"(fa[s & 1][pp][e]), "v"(fb[s & 1][pp][e]));
+                  // (-DWGO_ZEROC: an item's first k-step starts its plane from the inline constant 0 instead of 144 cleared registers —
+                  //  measured 1.091 against 1.073 ms on layer2: not adopted)
+#ifdef WGO_ZEROC
+                  if constexpr (FIRST && cu == 0 && e == 0 && !LATE)
+#else
+                  if constexpr (false)
+#endif
+                    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=v"(acc[PG * g + pp]) : "v"(fa[s & 1][pp][e]), "v"(fb[s & 1][pp][e]));
+                  else
+                    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(acc[PG * g + pp]) : "v"(fa[s & 1][pp][e]), "v"(fb[s & 1][pp][e]));
                 }
                 if constexpr (e == ER && ahead) read_frag(integral_constant<int, (s + 1) & 1>{}, integral_constant<int, nxt>{}, pp_c);
 #ifndef WGO_BURST
@@ -465,10 +508,19 @@ __global__ __launch_bounds__(128 * NTB, (NTB == 4 ? 2 : 1)) void wino_gemm_out_k
 #ifndef WGO_BURST
           {
             const bool live = (!wrap || more) && !((WGO_ABL & 4) != 0);
-            const unsigned dead = live ? 0u : OOB;
             const int mt_x = wrap ? mt_n : mt, nt_x = wrap ? nt_n : nt, c_x = wrap ? cd - KC16 : cd;
+#ifdef WGO_VADDR
+            const unsigned dead = live ? 0u : OOB;
             sV_cur = (unsigned)(((PG * gd * KC16 + c_x) * TB16 + mt_x * NTB) * 1024) | dead;
             sU_cur = (unsigned)(((nt_x * KC16 + c_x) * P + PG * gd) * 2048) | dead;
+#else
+            int kc = KC16, tb16 = TB16;
+#ifdef WGO_OPAQUE
+            asm volatile("" : "+s"(kc), "+s"(tb16));
+#endif
+            sV_cur = live ? (unsigned)(((PG * gd * kc + c_x) * tb16 + mt_x * NTB) * 1024) : 0u;
+            sU_cur = live ? (unsigned)(((nt_x * kc + c_x) * P + PG * gd) * 2048) : 0u;
+#endif
             tgt_cur = tgt;
           }
 #else
