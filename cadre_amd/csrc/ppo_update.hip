@@ -609,6 +609,7 @@ __global__ __launch_bounds__(256, TM == 1 ? DW_OCC : 1) void lstm_dw_kernel(dw_a
   // and h / x operands of those rows are masked to zero when they are used (MASK).
   int t_n = 0, b_n = 0, ks_n = 0;
   const bool MASK = ((hi - lo) & 3) != 0;
+  const bool want_bsum = kind == 0 && ng == 0;
   f32x4 aq[PD][TM], yq[PD];
   auto request = [&](int slot) {
     const int row = t_n * p.B + lo + 4 * b_n;             // scalar
@@ -638,7 +639,13 @@ __global__ __launch_bounds__(256, TM == 1 ? DW_OCC : 1) void lstm_dw_kernel(dw_a
       f32x4 yv = yq[s];
       request(s);
       __builtin_amdgcn_sched_barrier(0);
+      // (only the run's LAST 4-row step of a time step can hold foreign rows: the selects — eight vector instructions, paid in matrix
+      //  cycles in fp32 — run there and nowhere else; the column sums only in the waves that store them.  Round 6.)
+#ifdef DW_MASK_ALWAYS
       if (MASK) {
+#else
+      if (MASK && b_c == nb - 1) {
+#endif
         const bool dead = lo + 4 * b_c + q >= hi;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
@@ -651,7 +658,11 @@ __global__ __launch_bounds__(256, TM == 1 ? DW_OCC : 1) void lstm_dw_kernel(dw_a
       b_c = b1 == nb ? 0 : b1;
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) {
+#ifdef DW_MASK_ALWAYS
         bsum[tm] += av[tm];
+#else
+        if (want_bsum) bsum[tm] += av[tm];
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll

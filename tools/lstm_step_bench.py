@@ -83,8 +83,10 @@ def main():
         def tr():
             hip.check(L.cadre_pack_lstm_weights(params.data_ptr() + 4 * H4 * DP, sL, DP, D, Z, packed[0].data_ptr(), packed[1].data_ptr(), NP, st), "t")
         tr()
+        has_seq = hasattr(L, "cadre_lstm_seq_fwd")          # (the persistent recurrence is an A/B-build kernel: CADRE_HIP_LIB=.../libcadre_hip_ab.so)
         print("B=%d: lstm_step_fwd %.1f us, lstm_seq_fwd (8 steps) %.1f us, lstm_step_bwd %.1f us, lstm_dw %.1f us, pack_weights %.1f us, "
-              "seq status %d" % (B, timeit(fwd), timeit(seq, 10), timeit(bwd), timeit(dw, 10), timeit(tr, 10), int(sync[-1])), flush=True)
+              "seq status %d" % (B, timeit(fwd), timeit(seq, 10) if has_seq else float("nan"), timeit(bwd), timeit(dw, 10), timeit(tr, 10),
+                                 int(sync[-1])), flush=True)
 
 
 if __name__ == "__main__":
