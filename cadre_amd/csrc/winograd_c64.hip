@@ -142,6 +142,21 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
   const int thw = a.TH * a.TW;
 
   // ---- per-item lane state of the A side: tile = group * 16 + n, patch origin (2ty-1, 2tx-1), channel slice 4q of a chunk
+  // tile -> (frame, tile row, tile column) by float reciprocals + one correction step each (tile < 2^23: exact in a float; the
+  // quotient estimate is off by at most one): 9 vector instructions per division where the integer division takes 17 — five tile
+  // decodes per item sit inside the MFMA blocks, and vector instructions are paid in matrix cycles (round 6)
+  const float inv_thw = 1.0f / (float)thw, inv_tw = 1.0f / (float)a.TW;
+  auto decode = [&](int t, int& f, int& ty, int& tx) {
+    int qf = (int)((float)t * inv_thw);
+    int rem = t - qf * thw;
+    qf += (rem >= thw) ? 1 : 0; qf -= (rem < 0) ? 1 : 0;
+    rem = t - qf * thw;
+    int qy = (int)((float)rem * inv_tw);
+    int rx = rem - qy * a.TW;
+    qy += (rx >= a.TW) ? 1 : 0; qy -= (rx < 0) ? 1 : 0;
+    rx = rem - qy * a.TW;
+    f = qf; ty = qy; tx = rx;
+  };
   int a_base = 0;                 // byte offset of patch pixel (0, 0), channel 4q of double-step 0 (may be negative: masked pixels only)
   unsigned a_rows = 0, a_cols = 0;
   unsigned a_voff[16];            // (W2_SOFF) byte offset of each patch pixel at double-step 0, or the out-of-range bit
@@ -150,8 +165,8 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
     const int tile = (item * 4 + wave) * 16 + n;
     const bool live = (item_l < my_items) & (tile < a.ntiles);
     const int tl = live ? tile : 0;
-    const int f = tl / thw, rem = tl - f * thw;
-    const int ty = rem / a.TW, tx = rem - ty * a.TW;
+    int f, ty, tx;
+    decode(tl, f, ty, tx);
     const int r0 = 2 * ty - 1, c0 = 2 * tx - 1;
     unsigned rows = 0, cols = 0;
 #pragma unroll
@@ -276,8 +291,8 @@ __global__ __launch_bounds__(256, 1) void wino2_c64_kernel(w2_args a) {
     unsigned eo[4][4];
     auto offsets = [&](int r, unsigned (&o)[4]) {
       const int tile = ((item0 + item_l) * 4 + wave) * 16 + 4 * q + r;
-      const int f = tile / thw, rem = tile - f * thw;
-      const int ty = rem / a.TW, tx = rem - ty * a.TW;
+      int f, ty, tx;
+      decode(tile, f, ty, tx);
       const int y0 = 2 * ty, x0 = 2 * tx;
       const bool tv = tile < a.ntiles;
       const unsigned e00 = (unsigned)((((f * a.H + y0) * a.W + x0) * 64 + 4 * n) * 4);
