@@ -836,6 +836,25 @@ def main():
             "winograd_vs_direct": round(out["value"] / sec["value"], 4),
             "encoder_tflops": sec["encoder_tflops"], "roofline": sec["roofline"], "last_losses": sec["last_losses"],
             "note": "CADRE_WINOGRAD=0: every convolution direct (implicit GEMM / window kernels)"}
+    # The fused front of the fp32 model on the bf16 matrix cores with EXACT products (CADRE_STEM_EXACT_BF16=1: pixel bytes are exact in
+    # bf16, every fp32 weight is the exact sum of three bf16 pieces, sums and epilogue fp32 — stem_pool.hip X3).  Its own
+    # key, never the headline: VERDICT r5 item 6 keeps the dtype-f32 line on v_mfma_f32.
+    if head == "C2" and world == 1 and not args.no_direct_conv and not args.replay and not args.dedup and args.encoder_dtype is None \
+            and os.environ.get("CADRE_STEM_EXACT_BF16", "0") != "1" and os.environ.get("CADRE_FUSED_STEM", "1") != "0":
+        os.environ["CADRE_STEM_EXACT_BF16"] = "1"
+        try:
+            sec, _c, _e, _p = run_config("C2", args, rank, dev_index, world, use_dist, args.steps, 2)
+        finally:
+            os.environ.pop("CADRE_STEM_EXACT_BF16", None)
+        out["c2_stem_bf16x3"] = {
+            "value": sec["value"], "unit": "samples/s", "ms_per_step": sec["ms_per_step"], "steps": sec["steps"],
+            "t_encode_ms": sec["t_encode_ms"], "t_update_ms": sec["t_update_ms"],
+            "vs_headline": round(sec["value"] / out["value"], 4), "last_losses": sec["last_losses"],
+            "dtype": "f32 everywhere except the 7x7 stem conv: u8 pixels (exact in bf16) x fp32 weights split into 3 bf16 pieces whose "
+                     "sum is the fp32 weight exactly, products exact, fp32 accumulate (39 v_mfma_f32_32x32x16_bf16 per tile instead of "
+                     "100 v_mfma_f32_32x32x2_f32); rel-max-err of the front vs torch fp32 4.6e-7 - 6.2e-7 (the v_mfma_f32 front: 5.6e-7 - "
+                     "8.9e-7), tests/test_kernels_gpu.py::test_fused_stem_pool_exact_bf16_pieces",
+            "note": "CADRE_STEM_EXACT_BF16=1; opt-in, not the headline"}
     if rank == 0:
         if not args.no_peaks and world == 1:
             # the datasheet peaks re-measured on this box (stream copy, register-operand MFMA chains): the

@@ -34,6 +34,8 @@ int cadre_fail(const char* msg);
 #define SP_WP32 204       // fp32 weight row pitch in floats ((pitch/4) odd: conflict-free ds_read_b128 over rows)
 #define SP_TAPS16 56      // bf16: 7 kernel rows x 8 taps (kx = 7: zero weights) -> K = 224 (14 k-steps of 16)
 #define SP_WP16 232       // bf16 weight row pitch in bf16 elements (464 B: (pitch_bytes/16) odd)
+#define SP_TAPSX 52       // exact-bf16 form of the fp32 front: 49 taps + 3 zero taps -> K = 208 (13 k-steps of 16), THREE weight pieces
+#define SP_WPX 216        // its weight row pitch in bf16 elements (432 B: (pitch_bytes/16) odd)
 
 struct stem_args {
   const uint32_t* img;    // [F][H][W] packed pixels: R | G<<8 | B<<16 | route<<24 (route byte 0 or 255)
@@ -91,26 +93,35 @@ extern "C" int cadre_div255_selfcheck(const float* lut255, int32_t* mismatches, 
 #define STEM_ABL 0       // tools/stem_ablate.py: 1 no MFMA, 2 no u8 -> float conversion (fp32), 4 no staging, 8 no epilogue, 16 no ring reads, 32 no weight reads, 64 no barrier
 #endif
 
-template <int NT, int CH, bool RAGGED, bool BF16>
+// X3 (round 6, opt-in: cadre_stem_pool mode 2): the fp32 front on the bf16 matrix cores with EXACT products.  The A operand is an 8-bit
+// integer — a pixel byte is exact in bf16 — and an fp32 weight is exactly the sum of three bf16 pieces (8 + 8 + 8 significand bits:
+// p1 = bf16(w), p2 = bf16(w - p1), p3 = w - p1 - p2), so every product byte x piece is exact in fp32 and the sums are fp32: the
+// arithmetic of v_mfma_f32_32x32x2_f32 up to the order of the additions, in 3 x 13 v_mfma_f32_32x32x16_bf16 per tile instead of 100
+// fp32 MFMAs (1248 against 6400 matrix cycles), and the byte -> bf16 conversions ride free beside bf16 MFMAs (profiles/
+// r06_mfma_shadow.txt).  Everything else is the fp32 kernel: packed-u8 ring, fp32 accumulators, BN (with the /255) + ReLU + pool in
+// fp32, fp32 output.  wt: [3 pieces][64][SP_WPX] bf16, k = tap * 4 + channel (tap = ky * 7 + kx; taps 49 .. 51 zero).
+template <int NT, int CH, bool RAGGED, bool BF16, bool X3 = false>
 __global__ __launch_bounds__(512, 2) void stem_pool_kernel(stem_args a) {
   static_assert(NT % CH == 0, "tiles per row pair must split into whole chunks");
+  static_assert(!(BF16 && X3), "X3 is a form of the fp32 front");
   constexpr int NCH = NT / CH;
   constexpr int NLD = (NT + 3) / 4;
-  constexpr int WROW = BF16 ? SP_WP16 / 2 : SP_WP32;
-  constexpr int NK = BF16 ? SP_TAPS16 / 4 : SP_TAPS32 / 2;
+  constexpr int WROW = BF16 ? SP_WP16 / 2 : X3 ? SP_WPX / 2 : SP_WP32;
+  constexpr int WROWS = X3 ? 3 * 64 : 64;          // weight rows in LDS (X3: piece-major)
+  constexpr int NK = BF16 ? SP_TAPS16 / 4 : X3 ? SP_TAPSX / 4 : SP_TAPS32 / 2;
   constexpr int PXD = BF16 ? 2 : 1;
   constexpr int PP = 16 * NT + 4;                   // ring plane pitch in pixels (cadre_stem_pool checks a.PP == PP)
   constexpr int RP = 2 * PP * PXD;                  // ring row pitch in dwords
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* wts = smem;
-  uint32_t* ring0 = reinterpret_cast<uint32_t*>(smem + 64 * WROW);
+  uint32_t* ring0 = reinterpret_cast<uint32_t*>(smem + WROWS * WROW);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // (provably uniform: unit, frame, band live in SGPRs)
   const int l31 = lane & 31, lh = lane >> 5;
   const int pair = wave >> 1, hN = wave & 1;
   {
-    constexpr int CPR = (BF16 ? SP_TAPS16 * 8 : SP_TAPS32 * 16) / 16;
+    constexpr int CPR = (BF16 ? SP_TAPS16 * 8 : X3 ? SP_WPX * 2 : SP_TAPS32 * 16) / 16;
     const char* src = reinterpret_cast<const char*>(a.wt);
-    for (int i = tid; i < 64 * CPR; i += 512) {
+    for (int i = tid; i < WROWS * CPR; i += 512) {
       const int n = i / CPR, c = i - n * CPR;
       *reinterpret_cast<f32x4*>(wts + n * WROW + c * 4) = *reinterpret_cast<const f32x4*>(src + ((size_t)n * CPR + c) * 16);
     }
@@ -208,7 +219,7 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(stem_args a) {
   float carry = 0.f;
   // ring byte offsets of the iteration: fp32 one per k-quad (tap 2q + lane half; the two halves' taps may lie in different
   // kernel rows), bf16 one per kernel row (k-step q = row q>>1, taps 4(q&1) + 2*half + {0,1}: plane = e, pair index + half)
-  unsigned aoff[BF16 ? 7 : NK];
+  unsigned aoff[BF16 ? 7 : X3 ? 2 * NK : NK];      // (X3: two taps per lane and k-step: tap 4 jj + 2 * lane half + e)
 
   // ---- epilogue of tile t of the chunk held in acc[b], in four pieces
   auto epi = [&](int b, int t, int T, int piece, int p, unsigned lane_e) {
@@ -285,6 +296,17 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(stem_args a) {
         if constexpr (BF16) {
 #pragma unroll
           for (int ky = 0; ky < 7; ++ky) aoff[ky] = ro[ky] + (unsigned)(lh * 16);
+        } else if constexpr (X3) {
+#pragma unroll
+          for (int jj = 0; jj < NK; ++jj)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              const int tA = 4 * jj + e, tB = tA + 2;             // lane half 0 / 1 (taps 49 .. 51: zero weights, any mapped LDS address)
+              const int kyA = tA / 7, kxA = tA % 7, kyB = tB / 7, kxB = tB % 7;
+              const unsigned xa = ro[kyA] + (unsigned)(((kxA & 1) * PP + (kxA >> 1)) * 4);
+              const unsigned xb = ro[kyB] + (unsigned)(((kxB & 1) * PP + (kxB >> 1)) * 4);
+              aoff[2 * jj + e] = lh ? xb : xa;
+            }
         } else {
 #pragma unroll
           for (int q = 0; q < NK; ++q) {
@@ -322,7 +344,41 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(stem_args a) {
               if (s >= lo && s < hi && (STEM_ABL & 8) == 0) epi(b ^ 1, s >> 2, (j - 1) * CH + (s >> 2), s & 3, p, lane_e);
           }
         };
-        if constexpr (!BF16) {
+        if constexpr (X3) {
+          auto fetch = [&](int jj, uint32_t (*px)[2], f32x4* bq) {
+#pragma unroll
+            for (int t = 0; t < CH; ++t)
+#pragma unroll
+              for (int e = 0; e < 2; ++e) px[t][e] = *reinterpret_cast<const uint32_t*>(rbase + aoff[2 * jj + e] + j * CHB + t * 64);
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) bq[pc] = *reinterpret_cast<const f32x4*>(wbase + wlane + pc * (64 * WROW * 4) + jj * 32);
+          };
+          uint32_t pxn[CH][2];
+          f32x4 bn[3];
+          fetch(0, pxn, bn);
+#pragma unroll
+          for (int jj = 0; jj < NK; ++jj) {
+            bf16x8 av[CH];
+#pragma unroll
+            for (int t = 0; t < CH; ++t)
+#pragma unroll
+              for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) av[t][4 * e + s2] = (__bf16)(float)((pxn[t][e] >> (8 * s2)) & 255u);
+            bf16x8 bw[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) bw[pc] = __builtin_bit_cast(bf16x8, bn[pc]);
+            if (jj + 1 < NK) fetch(jj + 1, pxn, bn);
+            // (smallest piece first: the sum of a tap's three products is exact either way, the running sum meets the large term last)
+#pragma unroll
+            for (int pc = 2; pc >= 0; --pc)
+#pragma unroll
+              for (int t = 0; t < CH; ++t)
+                acc[b][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[t], bw[pc], (jj == 0 && pc == 2) ? zero16 : acc[b][t], 0, 0, 0);
+            side(jj);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else if constexpr (!BF16) {
           auto fetch = [&](int q, uint32_t* px) {
 #pragma unroll
             for (int t = 0; t < CH; ++t) {
@@ -475,9 +531,14 @@ __global__ __launch_bounds__(512, 2) void stem_pool_kernel(stem_args a) {
 }
 
 template <int NT, int CH32, int CH16, bool RAGGED>
-static int launch_stem(const stem_args& a, bool bf16, size_t lds, hipStream_t st) {
+static int launch_stem(const stem_args& a, int mode, size_t lds, hipStream_t st) {
   const dim3 grid((a.total + 3) / 4), block(512);
-  if (bf16) {
+  const bool bf16 = mode == 1;
+  if (mode == 2) {
+    auto k = stem_pool_kernel<NT, CH32, RAGGED, false, true>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(k, grid, block, lds, st, a);
+  } else if (bf16) {
     auto k = stem_pool_kernel<NT, CH16, RAGGED, true>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(k, grid, block, lds, st, a);
@@ -504,7 +565,8 @@ extern "C" int cadre_stem_pool(const uint32_t* img, const void* wt, const float*
                                void* out, int32_t F, int32_t H, int32_t W, int32_t bf16,
                                int64_t out_frame, int64_t out_row, int32_t out_px, int64_t out_off, void* stream) {
   if (!img || !wt || !shift || !out || F < 1) return cadre_fail("cadre_stem_pool: bad argument");
-  if (bf16 ? scale != nullptr : scale == nullptr)
+  if (bf16 < 0 || bf16 > 2) return cadre_fail("cadre_stem_pool: mode must be 0 (fp32), 1 (bf16) or 2 (fp32 result from three exact bf16 weight pieces)");
+  if (bf16 == 1 ? scale != nullptr : scale == nullptr)
     return cadre_fail("cadre_stem_pool: fp32 takes the folded-BN scale, bf16 takes weights already multiplied by it (scale = NULL)");
   if (!cadre_stem_pool_supported(H, W)) return cadre_fail("cadre_stem_pool: unsupported geometry (see cadre_stem_pool_supported)");
   if (out_px < 64 || ((uintptr_t)img & 15) || ((uintptr_t)wt & 15)) return cadre_fail("cadre_stem_pool: bad output stride / alignment");
@@ -527,15 +589,15 @@ extern "C" int cadre_stem_pool(const uint32_t* img, const void* wt, const float*
   PP = ((PP + 3) / 8) * 8 + 4;                        // == 4 (mod 8): the two stem rows of a tile read disjoint banks
   a.PP = PP;
   a.out_frame = out_frame; a.out_row = out_row; a.out_px = out_px; a.out_off = out_off;
-  const int wrow = bf16 ? SP_WP16 / 2 : SP_WP32;
+  const int wrow = bf16 == 1 ? SP_WP16 / 2 : bf16 == 2 ? 3 * (SP_WPX / 2) : SP_WP32;
   if (PP != 16 * NT + 4) return cadre_fail("cadre_stem_pool: ring plane pitch");       // (always: W <= 32 * NT)
-  const size_t lds = (size_t)64 * wrow * 4 + (size_t)4 * SP_RING * 2 * PP * (bf16 ? 8 : 4);
+  const size_t lds = (size_t)64 * wrow * 4 + (size_t)4 * SP_RING * 2 * PP * (bf16 == 1 ? 8 : 4);
   if (lds > 160 * 1024) return cadre_fail("cadre_stem_pool: frame too wide for the LDS ring");
   hipStream_t st = (hipStream_t)stream;
   const bool ragged = (a.Ws % 16) != 0 || (a.Hs & 1) || a.Wp * 2 != a.Ws;
   // tiles per MFMA chunk (CH): fp32 1 (two accumulator sets + the previous row's maxima: 204 VGPRs), bf16 3 / 2 (B fragment
   // shared by the chunk; 244 VGPRs, no spill at 2 waves per SIMD)
-  if (NT == 9) return ragged ? launch_stem<9, 1, 3, true>(a, bf16 != 0, lds, st) : launch_stem<9, 1, 3, false>(a, bf16 != 0, lds, st);
-  if (NT == 8) return ragged ? launch_stem<8, 1, 2, true>(a, bf16 != 0, lds, st) : launch_stem<8, 1, 2, false>(a, bf16 != 0, lds, st);
-  return launch_stem<3, 1, 3, true>(a, bf16 != 0, lds, st);
+  if (NT == 9) return ragged ? launch_stem<9, 1, 3, true>(a, bf16, lds, st) : launch_stem<9, 1, 3, false>(a, bf16, lds, st);
+  if (NT == 8) return ragged ? launch_stem<8, 1, 2, true>(a, bf16, lds, st) : launch_stem<8, 1, 2, false>(a, bf16, lds, st);
+  return launch_stem<3, 1, 3, true>(a, bf16, lds, st);
 }

@@ -59,6 +59,23 @@ def _stem_taps(w, ntaps, row8=False):
     return out.reshape(o, ntaps * i).contiguous()
 
 
+def _stem_taps_x3(w):
+    """OIHW Cin=4 fp32 stem weights -> [3 pieces][O][216] bf16 for cadre_stem_pool mode 2 (stem_pool.hip X3): k = tap * 4 + channel,
+    tap = ky*7 + kx, zeros past tap 48 (52 taps = 13 k-steps of 16; row pitch 216).  p1 = bf16(w), p2 = bf16(w - p1),
+    p3 = w - p1 - p2: the three pieces sum to the fp32 weight EXACTLY (8 + 8 + 8 significand bits; asserted here)."""
+    o, i, kh, kw = w.shape
+    flat = torch.zeros(o, 216, dtype=torch.float32)
+    flat[:, :kh * kw * i] = w.float().permute(0, 2, 3, 1).reshape(o, kh * kw * i)
+    p1 = flat.to(torch.bfloat16)
+    r1 = flat - p1.float()
+    p2 = r1.to(torch.bfloat16)
+    r2 = r1 - p2.float()
+    p3 = r2.to(torch.bfloat16)
+    if not torch.equal(p1.float() + p2.float() + p3.float(), flat) or not torch.equal(p3.float(), r2):
+        raise hip.CadreHipError("stem weights do not split into three bf16 pieces exactly (subnormal weights?)")
+    return torch.stack([p1, p2, p3]).contiguous()
+
+
 def _stem_rows_bf16(w):
     """OIHW Cin=4 stem weights -> [O][ceil(KH/2)][64] bf16 rows for cadre_gemm_bf16 a_mode 4: k-tile kt
     holds kernel rows 2kt, 2kt+1; within it chunk cc (8 values) = pixels 2(cc&3), 2(cc&3)+1 x 4 channels
@@ -300,12 +317,19 @@ class DANetEncoderHIP:
         self.ring_conv = os.environ.get("CADRE_RING_CONV", "1") != "0"
         # fused front (pack -> LUT -> stem conv + BN + ReLU -> max-pool in one kernel, stem_pool.hip)
         self.fused_stem = bool(hip.lib().cadre_stem_pool_supported(H, W)) and os.environ.get("CADRE_FUSED_STEM", "1") != "0"
+        self.stem_x3 = False
         if self.fused_stem:
             w1 = torch.as_tensor(sd["backbone.conv1.weight"]).float()
             if self.bf16:                            # BN scale folded into the bf16 weights (the kernel starts its sums at the shift)
                 w1 = w1 * self.stem.scale.detach().cpu().float().view(-1, 1, 1, 1)
             wt = _stem_taps(w1, 56 if self.bf16 else 50, row8=self.bf16)
             self.stem_taps = wt.to(dev).to(torch.bfloat16 if self.bf16 else torch.float32)
+            # opt-in (CADRE_STEM_EXACT_BF16=1, fp32 model): the front on the bf16 matrix cores with exact products — three bf16 pieces
+            # of every fp32 weight, pixel bytes exact in bf16, fp32 sums and fp32 epilogue (stem_pool.hip X3).  Reported by bench.py as
+            # its own section; the default and the headline stay on v_mfma_f32.
+            self.stem_x3 = (not self.bf16) and os.environ.get("CADRE_STEM_EXACT_BF16", "0") == "1"
+            if self.stem_x3:
+                self.stem_taps_x3 = _stem_taps_x3(w1).to(dev)
         if self.bf16:
             # bf16 stem on a zero-padded NHWC4 image (3 px halo; row pitch padded so every 8-pixel tap
             # row is in-bounds and 16-B aligned): no halo masks, two kernel rows per 64-deep k-tile
@@ -529,8 +553,10 @@ class DANetEncoderHIP:
             Hs, Ws = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
             Hp, Wp = (Hs + 2 - 3) // 2 + 1, (Ws + 2 - 3) // 2 + 1
             p = self._buf("pool", (F, Hp, Wp, 64), torch.bfloat16 if self.bf16 else torch.float32)
-            hip.check(L.cadre_stem_pool(hip.ptr(x), hip.ptr(self.stem_taps), None if self.bf16 else hip.ptr(self.stem.scale), hip.ptr(self.stem.shift),
-                                        hip.ptr(p), F, H, W, 1 if self.bf16 else 0,
+            x3 = self.stem_x3
+            hip.check(L.cadre_stem_pool(hip.ptr(x), hip.ptr(self.stem_taps_x3 if x3 else self.stem_taps),
+                                        None if self.bf16 else hip.ptr(self.stem.scale), hip.ptr(self.stem.shift),
+                                        hip.ptr(p), F, H, W, 1 if self.bf16 else (2 if x3 else 0),
                                         Hp * Wp * 64, Wp * 64, 64, 0, st), "cadre_stem_pool")
             return self._trunk(p, F, Hp, Wp, out, ldo, taps)
         if self.bf16:

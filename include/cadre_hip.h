@@ -185,7 +185,10 @@ int cadre_pack_obs(const uint8_t* rgb, const uint8_t* route, uint32_t* out, uint
  *     bf16: tap = ky*8 + kx, 56 taps (kx = 7: zeros), ALREADY multiplied by the BN scale and `scale` = NULL
  *     (the kernel starts its sums at the shift).
  * out: pooled map, element (f, p, c, ch) at out_off + f*out_frame + p*out_row + c*out_px + ch (f32, or bf16 when
- * bf16 != 0, which also selects bf16 MFMA).  Geometries: cadre_stem_pool_supported(H, W) (host logic). */
+ * bf16 == 1, which also selects bf16 MFMA).  bf16 == 2: the fp32 front (fp32 `scale`, fp32 out) computed on the bf16 matrix cores
+ * with exact products — wt = [3 pieces][64][216] bf16 with piece1 + piece2 + piece3 == the fp32 weight exactly, k = tap*4 + channel,
+ * tap = ky*7 + kx, zeros past tap 48; pixel bytes are exact in bf16, sums are fp32.  Geometries: cadre_stem_pool_supported(H, W)
+ * (host logic). */
 int cadre_stem_pool(const uint32_t* img, const void* wt, const float* scale, const float* shift,
                     void* out, int32_t F, int32_t H, int32_t W, int32_t bf16,
                     int64_t out_frame, int64_t out_row, int32_t out_px, int64_t out_off, void* stream);

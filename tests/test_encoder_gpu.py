@@ -69,21 +69,23 @@ def test_encoder_above_96_positions_vs_oracle(H, W):
 
 
 @pytest.mark.parametrize("tag", ["native", "288"])
-@pytest.mark.parametrize("algo", ["winograd", "direct"])
+@pytest.mark.parametrize("algo", ["winograd", "direct", "stem_bf16x3"])
 def test_encoder_conv_algorithms_vs_reference_golden(golden, tag, algo, monkeypatch):
     """The fp32 model's >= 128-channel stride-1 3x3 convs (layer2, layer3, layer4, head) run as Winograd F(3x3, 3x3) by default
     and as direct convolution under CADRE_WINOGRAD=0: both against the same goldens at the same tolerance, and the same frames
     in a larger batch give the same bits either way."""
     from cadre_amd.encoder import DANetEncoderHIP
-    monkeypatch.setenv("CADRE_WINOGRAD", "1" if algo == "winograd" else "0")
+    monkeypatch.setenv("CADRE_WINOGRAD", "0" if algo == "direct" else "1")
+    monkeypatch.setenv("CADRE_STEM_EXACT_BF16", "1" if algo == "stem_bf16x3" else "0")     # (the front from three exact bf16 weight pieces: same goldens, same bar)
     g = golden("enc_" + tag)
     H, W, n = int(g["H"]), int(g["W"]), int(g["n"])
     fh, fw = synth.feat_hw(H, W)
     sd = synth.encoder_state(fh, fw, int(g["seed"]))
     enc = DANetEncoderHIP(sd, H, W, "cuda:0")
     nw = sum(c.w_wino is not None for blk in enc.blocks for c in blk[:2]) + sum(c.w_wino is not None for c in (enc.conv5a, enc.conv5c))
-    assert nw == (11 if algo == "winograd" else 0)           # layer2 / layer3 / layer4: three stride-1 convs each; head: conv5a, conv5c
-    assert enc.winograd_convs() == (17 if algo == "winograd" else 0)        # (+ conv51, conv52 and layer1's four fused 64 -> 64 convs)
+    assert nw == (0 if algo == "direct" else 11)             # layer2 / layer3 / layer4: three stride-1 convs each; head: conv5a, conv5c
+    assert enc.winograd_convs() == (0 if algo == "direct" else 17)          # (+ conv51, conv52 and layer1's four fused 64 -> 64 convs)
+    assert enc.stem_x3 == (algo == "stem_bf16x3")
     r = np.random.RandomState(int(g["frame_seed"]))
     rgb = r.randint(0, 256, (n, H, W, 3)).astype(np.uint8)
     route = ((r.rand(n, W, H) < 0.15) * 255).astype(np.uint8)

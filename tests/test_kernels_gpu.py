@@ -1425,6 +1425,56 @@ def test_winograd_fused_rejects_bad_arguments(hip):
 
 
 @pytest.mark.parametrize("H,W,F", [(84, 84, 3), (144, 256, 2), (288, 288, 2)])
+def test_fused_stem_pool_exact_bf16_pieces(hip, H, W, F, monkeypatch):
+    """cadre_stem_pool mode 2 (CADRE_STEM_EXACT_BF16=1): the fp32 front on the bf16 matrix cores — pixel bytes are exact in bf16, every
+    fp32 weight is the exact sum of three bf16 pieces (asserted on the host), products exact, sums fp32.  Against torch-CPU fp32 at the
+    fp32 kernel's bar, against the v_mfma_f32 kernel at accumulation-order distance, band decomposition without a bit of influence."""
+    import torch.nn.functional as Fn
+    from cadre_amd import synth
+    from cadre_amd.encoder import DANetEncoderHIP, _stem_taps_x3
+    sd = synth.encoder_state(*synth.feat_hw(H, W), 7)
+    pcs = _stem_taps_x3(torch.as_tensor(sd["backbone.conv1.weight"]).float())
+    flat = torch.as_tensor(sd["backbone.conv1.weight"]).float().permute(0, 2, 3, 1).reshape(64, -1)
+    assert torch.equal(pcs.float().sum(0)[:, :196], flat) and float(pcs.float().sum(0)[:, 196:].abs().max()) == 0.0
+    r = np.random.RandomState(H + W)
+    rgb = r.randint(0, 256, (F, H, W, 3)).astype(np.uint8)
+    route = ((r.rand(F, W, H) < 0.15) * 255).astype(np.uint8)
+    rgb_d, route_d = torch.from_numpy(rgb).cuda(), torch.from_numpy(route).cuda()
+    pools = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CADRE_STEM_EXACT_BF16", mode)
+        enc = DANetEncoderHIP(sd, H, W, "cuda:0", max_frames=64)
+        assert enc.fused_stem and enc.stem_x3 == (mode == "1")
+        taps = {}
+        enc.forward_nhwc(enc.preprocess(rgb_d, route_d), taps=taps)
+        pools[mode] = taps["pool"].float().cpu().clone()
+        if mode == "1":
+            big = 48
+            rgb_b = torch.from_numpy(r.randint(0, 256, (big, H, W, 3)).astype(np.uint8)).cuda()
+            route_b = torch.from_numpy(((r.rand(big, W, H) < 0.15) * 255).astype(np.uint8)).cuda()
+            rgb_b[5:5 + F], route_b[5:5 + F] = rgb_d, route_d
+            taps2 = {}
+            enc.forward_nhwc(enc.preprocess(rgb_b, route_b), taps=taps2)
+            assert torch.equal(taps2["pool"][5:5 + F].float().cpu(), pools["1"])
+    x = np.zeros((F, 4, H, W), np.float32)
+    x[:, :3] = (rgb.transpose(0, 3, 1, 2) / 255.).astype(np.float32)
+    rt = route.copy()
+    for i in range(F):
+        if rt[i].max() > 0:
+            rt[i] = (1.0 * rt[i] / rt[i].max()).astype(np.uint8)
+    x[:, 3] = rt.transpose(0, 2, 1).astype(np.float32)
+    t = lambda k: torch.as_tensor(sd[k]).float()
+    y = Fn.conv2d(torch.from_numpy(x), t("backbone.conv1.weight"), t("backbone.conv1.bias"), stride=2, padding=3)
+    y = Fn.batch_norm(y, t("backbone.bn1.running_mean"), t("backbone.bn1.running_var"), t("backbone.bn1.weight"),
+                      t("backbone.bn1.bias"), False, 0.0, 1e-5)
+    want = Fn.max_pool2d(torch.relu(y), 3, 2, 1).permute(0, 2, 3, 1)
+    e_ref = float((pools["1"] - want).abs().max() / want.abs().max())
+    e_f32 = float((pools["1"] - pools["0"]).abs().max() / want.abs().max())
+    print("exact-bf16 front %dx%d: rel-max-err vs torch fp32 %.2e, vs the v_mfma_f32 kernel %.2e" % (H, W, e_ref, e_f32))
+    assert e_ref < 2e-5 and e_f32 < 2e-6
+
+
+@pytest.mark.parametrize("H,W,F", [(84, 84, 3), (144, 256, 2), (288, 288, 2)])
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_fused_stem_pool(hip, H, W, F, dtype):
     """cadre_pack_obs + cadre_stem_pool (LUT -> conv 7x7/s2 + BN + ReLU -> max-pool 3x3/s2 in one kernel) vs torch-CPU

@@ -373,7 +373,7 @@ def _c2_oracle_chain():
     return _C2_ORACLE
 
 
-@pytest.mark.parametrize("algo", ["default", "direct"])
+@pytest.mark.parametrize("algo", ["default", "direct", "stem_bf16x3"])
 def test_c2_fp32_contract_end_to_end(algo, monkeypatch):
     from ppo_agent.agent import CadreAgent
     from ppo_agent.models import Shared_grad_buffers
@@ -385,6 +385,8 @@ def test_c2_fp32_contract_end_to_end(algo, monkeypatch):
         monkeypatch.setenv("CADRE_WINOGRAD", "0")
     else:
         monkeypatch.delenv("CADRE_WINOGRAD", raising=False)
+    # (opt-in front: u8 pixels x three exact bf16 pieces of every fp32 weight on the bf16 matrix cores — the whole contract at the same bars)
+    monkeypatch.setenv("CADRE_STEM_EXACT_BF16", "1" if algo == "stem_bf16x3" else "0")
     o = _c2_oracle_chain()
     T, H, W = C2_T, 288, 288
     cfg = dict(use_lstm=True, vae_device=0, device_num=0, vae_params="CoPM", measurement_dim=18,
@@ -393,7 +395,8 @@ def test_c2_fp32_contract_end_to_end(algo, monkeypatch):
     agent = CadreAgent(rank=0, model_cfg=cfg, frame=8, STEER_CONTROL={i: (i - 16) / 16.0 for i in range(33)},
                        THROTTLE_CONTROL={0: [0, 0], 1: [0, 1], 2: [0.6, 0]}, ent_coeff=0.01, value_coeff=0.1,
                        clip_coeff=1.0, clip=0.1)
-    assert (agent.vae_model.winograd_convs() > 0) == (algo == "default")
+    assert (agent.vae_model.winograd_convs() > 0) == (algo != "direct")
+    assert agent.vae_model.stem_x3 == (algo == "stem_bf16x3")
     agent.arena.load_numpy_state(o["st0"])
     stor = [RolloutStorage(T, 2, 530, 8, 530, True, 0.99, 0.95) for _ in range(2)]
     for s in stor:

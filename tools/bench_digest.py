@@ -14,7 +14,7 @@ def sect(tag, d):
 def main(path):
     d = json.loads(open(path).read().strip().splitlines()[-1])
     sect("headline n=%d" % d["n_gpus"], d)
-    for k in ("c3", "c2", "c2_direct_conv", "c2_latent_cache", "c3_latent_cache"):
+    for k in ("c3", "c2", "c2_direct_conv", "c2_stem_bf16x3", "c2_latent_cache", "c3_latent_cache"):
         if k in d:
             sect(k, d[k])
     if d.get("c3", {}).get("encoder_fwd_hbm_frac") is not None:
