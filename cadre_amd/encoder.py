@@ -454,7 +454,7 @@ class DANetEncoderHIP:
         return t[:n]
 
     # ------------------------------------------------------------------ layers
-    def _conv(self, c, x, F, H, W, key, resid=None, act=None, out_f32=False):
+    def _conv(self, c, x, F, H, W, key, resid=None, act=None, out_f32=False, reuse_v=False):
         Ho = (H + 2 * c.pad - c.k) // c.stride + 1
         Wo = (W + 2 * c.pad - c.k) // c.stride + 1
         odt = torch.bfloat16 if (self.bf16 and not out_f32) else torch.float32
@@ -488,7 +488,10 @@ class DANetEncoderHIP:
             P, T = (m + 2) ** 2, F * -(-H // m) * -(-W // m)
             V = self._flat("wino_v", P * T * c.cin).view(P, T, c.cin)
             Mx = self._flat("wino_m", P * T * c.cout).view(P, T, c.cout)
-            hip.check(L.cadre_winograd_in(hip.ptr(x), hip.ptr(V), F, H, W, c.cin, m, hip.stream()), "cadre_winograd_in")
+            # (reuse_v: the caller's previous conv transformed this very input — the head's conv5a / conv5c both read layer4 — and
+            #  nothing has written the transform-domain buffer since: one input transform for the two)
+            if not reuse_v:
+                hip.check(L.cadre_winograd_in(hip.ptr(x), hip.ptr(V), F, H, W, c.cin, m, hip.stream()), "cadre_winograd_in")
             hip.gemm(V, c.wino_u(m, self.device), Mx, T, c.cout, c.cin, c.cin, c.cin, c.cout, batch=P,
                      a_z=(1, P, T * c.cin), b_z=(1, P, c.cout * c.cin), c_z=(1, P, T * c.cout))
             hip.check(L.cadre_winograd_out(hip.ptr(Mx), hip.ptr(c.scale), hip.ptr(c.shift), hip.ptr(resid), hip.ptr(out),
@@ -607,12 +610,18 @@ class DANetEncoderHIP:
         pam_fn = L.cadre_pam_bf16out if self.bf16 else L.cadre_pam      # attention math stays fp32
         cam_fn = L.cadre_cam_bf16out if self.bf16 else L.cadre_cam
         f1, _, _ = self._conv(self.conv5a, l4, F, H, W, "f1", out_f32=True)
+        # conv5c reads layer4 too: run it right behind conv5a, on conv5a's input transform when both took the three-launch Winograd path
+        # with the same tile edge (the same V bits: the results do not change)
+        share_v = (self.conv5a.w_wino is not None and self.conv5c.w_wino is not None and l4.dtype == torch.float32
+                   and self.conv5a.cin == self.conv5c.cin and not L.cadre_winograd_fused_supported(F, H, W, self.conv5a.cin, self.conv5a.cout, _winograd_m(H, W))
+                   and not L.cadre_winograd_fused_supported(F, H, W, self.conv5c.cin, self.conv5c.cout, _winograd_m(H, W))
+                   and os.environ.get("CADRE_HEAD_SHARE_V", "1") != "0")
+        f2, _, _ = self._conv(self.conv5c, l4, F, H, W, "f2", out_f32=True, reuse_v=share_v)
         qkv = self._buf("pam_qkv", (F * Np, 160))
         hip.gemm(f1, self.pam_w, qkv, F * Np, 160, 128, 128, 128, 160, shift=self.pam_b)
         sa = self._buf("sa", (F, H, W, 128), adt)
         hip.check(pam_fn(hip.ptr(f1), hip.ptr(qkv), self.pam_gamma, hip.ptr(sa), F, Np, st), "cadre_pam")
         sa_conv, _, _ = self._conv(self.conv51, sa, F, H, W, "sa_conv")
-        f2, _, _ = self._conv(self.conv5c, l4, F, H, W, "f2", out_f32=True)
         sc = self._buf("sc", (F, H, W, 128), adt)
         hip.check(cam_fn(hip.ptr(f2), self.cam_gamma, hip.ptr(sc), F, Np, st), "cadre_cam")
         # feat_sum = sa_conv + sc_conv (danet.py:57) fused into conv52's epilogue as a residual added
