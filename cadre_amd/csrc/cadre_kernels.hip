@@ -464,6 +464,81 @@ __global__ __launch_bounds__(PAM_THREADS) void pam_kernel(const float* qkv, cons
     }
 }
 
+
+// ---- layer-4 maps above PAM_MAXNP positions (round 6: da_att.py:32-51 is size-free; a 384 x 384 input gives 12 x 12 = 144).  One
+// workgroup per (frame, block of 32 query rows): the block's energies against ALL keys live in LDS (32 x (R + 1) floats, R = Np
+// rounded up to 32: Np <= PAM_BIGNP), keys and values are read from global memory (the frame's qkv rows: L2).  Same arithmetic as the
+// small kernel — MFMA fma chains in ascending k, the same strided softmax sums — at the speed of a generality path.
+#define PAM_BIGNP 1024
+__global__ __launch_bounds__(256) void pam_large_kernel(const float* qkv, const float* x, float gamma, float* y, int Np, int out_bf16) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int QP = 17;
+  const int RB = (Np + 31) >> 5, R = 32 * RB, AP = R + 1;
+  float* q = sm;                    // [32][17]
+  float* att = q + 32 * QP;         // [32][R + 1]
+  const int f = blockIdx.x, n0 = 32 * blockIdx.y, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const float* fq = qkv + (int64_t)f * Np * 160;
+  for (int i = tid; i < 32 * 16; i += 256) {
+    const int r = i >> 4, c = i & 15;
+    q[r * QP + c] = n0 + r < Np ? fq[(int64_t)(n0 + r) * 160 + c] : 0.f;
+  }
+  __syncthreads();
+  for (int mb = wave; mb < RB; mb += 4) {                   // energies of the 32 rows against key block mb
+    const int m = 32 * mb + l31;
+    const float* kr = fq + (int64_t)min(m, Np - 1) * 160 + 16;
+    pam_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const float kv = m < Np ? kr[2 * kk + lh] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(q[l31 * QP + 2 * kk + lh], kv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) att[((r & 3) + 8 * (r >> 2) + 4 * lh) * AP + m] = m < Np ? acc[r] : -INFINITY;
+  }
+  __syncthreads();
+  for (int n = wave; n < 32; n += 4) {                      // row softmax (da_att.py:44); rows past the map become zeros
+    if (n0 + n >= Np) {
+      for (int m = lane; m < R; m += 64) att[n * AP + m] = 0.f;
+      continue;
+    }
+    float mx = -INFINITY;
+    for (int m = lane; m < R; m += 64) mx = fmaxf(mx, att[n * AP + m]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int m = lane; m < R; m += 64) {
+      const float e = expf(att[n * AP + m] - mx);
+      att[n * AP + m] = e;
+      sum += e;
+    }
+    sum = wave_sum(sum);
+    for (int m = lane; m < R; m += 64) att[n * AP + m] = att[n * AP + m] / sum;
+  }
+  __syncthreads();
+  // out[n][c] = sum_m att[n][m] v[m][c]: wave w owns channel block w (32 channels); v rows from global (rows past the map: weight 0)
+  const int c = 32 * wave + l31;
+  pam_f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  for (int kk = 0; kk < R / 2; ++kk) {
+    const int m = 2 * kk + lh;
+    const float bv = fq[(int64_t)min(m, Np - 1) * 160 + 32 + c];
+    o = __builtin_amdgcn_mfma_f32_32x32x2f32(att[l31 * AP + m], bv, o, 0, 0, 0);
+  }
+  const float* xf = x + (int64_t)f * Np * 128;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    if (n < Np) {
+      const float res = gamma * o[r] + xf[(int64_t)n * 128 + c];
+      if (out_bf16) reinterpret_cast<__bf16*>(y)[(int64_t)f * Np * 128 + (int64_t)n * 128 + c] = (__bf16)res;
+      else y[(int64_t)f * Np * 128 + (int64_t)n * 128 + c] = res;
+    }
+  }
+}
+
 static int pam_launch(const float* x, const float* qkv, float gamma, void* y, int32_t F, int32_t Np, int out_bf16,
                       void* stream);
 extern "C" int cadre_pam(const float* x, const float* qkv, float gamma, float* y, int32_t F, int32_t Np,
@@ -476,7 +551,18 @@ extern "C" int cadre_pam_bf16out(const float* x, const float* qkv, float gamma, 
 }
 static int pam_launch(const float* x, const float* qkv, float gamma, void* y, int32_t F, int32_t Np, int out_bf16,
                       void* stream) {
-  FAIL_IF(!x || !qkv || !y || F < 1 || Np < 1 || Np > PAM_MAXNP, "cadre_pam: bad argument (Np<=128)");
+  FAIL_IF(!x || !qkv || !y || F < 1 || Np < 1 || Np > PAM_BIGNP, "cadre_pam: bad argument (Np<=1024)");
+  if (Np > PAM_MAXNP) {                                    // the map does not fit one CU's LDS: a workgroup per block of 32 query rows
+    const size_t Rb = (size_t)((Np + 31) / 32) * 32;
+    const size_t shm_b = sizeof(float) * (32 * 17 + 32 * (Rb + 1));
+    static bool attr_b = false;
+    if (!attr_b) {
+      (void)hipFuncSetAttribute((const void*)pam_large_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_b = true;
+    }
+    hipLaunchKernelGGL(pam_large_kernel, dim3(F, (Np + 31) / 32), dim3(256), shm_b, ST(stream), qkv, x, gamma, (float*)y, Np, out_bf16);
+    return (int)hipGetLastError();
+  }
   const size_t R = (size_t)((Np + 31) / 32) * 32;
   const size_t shm = sizeof(float) * (R * 34 + R * 128 + R * (R + 1));
   static bool attr_set = false;
@@ -586,6 +672,73 @@ __global__ __launch_bounds__(CAM_THREADS) void cam_kernel(const float* x, float 
     }
 }
 
+
+// ---- CAM for maps above PAM_MAXNP positions: the frame is read from global memory (energy: row pairs, coalesced; product: a row per
+// lane), only the 128 x 128 attention matrix lives in LDS — any Np.  Same fma chains as the small kernel.
+__global__ __launch_bounds__(CAM_THREADS) void cam_large_kernel(const float* x, float gamma, float* y, int Np, int out_bf16) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int NW = CAM_THREADS / 64;
+  float* E = sm;                  // [128][CAM_EP]
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const float* xf = x + (int64_t)f * Np * 128;
+  {
+    const int c0 = 32 * (wave >> 1), d0 = 64 * (wave & 1);
+    pam_f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int nk = (Np + 1) >> 1;
+    for (int kk = 0; kk < nk; ++kk) {
+      const int n = 2 * kk + lh;
+      const float* row = xf + (int64_t)min(n, Np - 1) * 128;
+      const bool ok = n < Np;
+      const float a = ok ? row[c0 + l31] : 0.f;
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, ok ? row[d0 + l31] : 0.f, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, ok ? row[d0 + 32 + l31] : 0.f, acc[1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) E[(c0 + (r & 3) + 8 * (r >> 2) + 4 * lh) * CAM_EP + d0 + 32 * j + l31] = acc[j][r];
+  }
+  __syncthreads();
+  for (int c = wave; c < 128; c += NW) {              // energy_new = rowmax - energy; softmax (:75-76)
+    const float e0 = E[c * CAM_EP + lane], e1 = E[c * CAM_EP + lane + 64];
+    const float rmax = wave_max(fmaxf(e0, e1));
+    const float n0 = rmax - e0, n1 = rmax - e1;
+    const float m2 = wave_max(fmaxf(n0, n1));
+    const float p0 = expf(n0 - m2), p1 = expf(n1 - m2);
+    const float s = wave_sum(p0 + p1);
+    E[c * CAM_EP + lane] = p0 / s;
+    E[c * CAM_EP + lane + 64] = p1 / s;
+  }
+  __syncthreads();
+  // out[n][c] = sum_d x[n][d] att[c][d] (d ascending): wave w owns channel block w & 3 and the position blocks (w >> 2), + 2, + 4, ...
+  const int c = 32 * (wave & 3) + l31;
+  const int RB = (Np + 31) >> 5;
+  const float* er = E + c * CAM_EP + lh;
+  for (int nb = wave >> 2; nb < RB; nb += 2) {
+    const int n_a = 32 * nb + l31;
+    const float* xr = xf + (int64_t)min(n_a, Np - 1) * 128 + lh;
+    pam_f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll 8
+    for (int kk = 0; kk < 64; ++kk) o = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[2 * kk], er[2 * kk], o, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (n < Np) {
+        const float res = gamma * o[r] + xf[(int64_t)n * 128 + c];
+        if (out_bf16) reinterpret_cast<__bf16*>(y)[(int64_t)f * Np * 128 + (int64_t)n * 128 + c] = (__bf16)res;
+        else y[(int64_t)f * Np * 128 + (int64_t)n * 128 + c] = res;
+      }
+    }
+  }
+}
+
 static int cam_launch(const float* x, float gamma, void* y, int32_t F, int32_t Np, int out_bf16, void* stream);
 extern "C" int cadre_cam(const float* x, float gamma, float* y, int32_t F, int32_t Np, void* stream) {
   return cam_launch(x, gamma, y, F, Np, 0, stream);
@@ -594,7 +747,16 @@ extern "C" int cadre_cam_bf16out(const float* x, float gamma, void* y, int32_t F
   return cam_launch(x, gamma, y, F, Np, 1, stream);
 }
 static int cam_launch(const float* x, float gamma, void* y, int32_t F, int32_t Np, int out_bf16, void* stream) {
-  FAIL_IF(!x || !y || F < 1 || Np < 1 || Np > PAM_MAXNP, "cadre_cam: bad argument (Np<=128)");
+  FAIL_IF(!x || !y || F < 1 || Np < 1 || Np > PAM_BIGNP, "cadre_cam: bad argument (Np<=1024)");
+  if (Np > PAM_MAXNP) {
+    static bool attr_b = false;
+    if (!attr_b) {
+      (void)hipFuncSetAttribute((const void*)cam_large_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_b = true;
+    }
+    hipLaunchKernelGGL(cam_large_kernel, dim3(F), dim3(CAM_THREADS), sizeof(float) * 128 * CAM_EP, ST(stream), x, gamma, (float*)y, Np, out_bf16);
+    return (int)hipGetLastError();
+  }
   const size_t shm = sizeof(float) * ((size_t)((Np + 31) / 32) * 32 * CAM_XP + 128 * CAM_EP);
   static bool attr_set = false;
   if (!attr_set) {

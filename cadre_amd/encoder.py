@@ -10,7 +10,7 @@ branch so the 128 M weights (288x288) stream through HBM once per frame batch.
 
 Weights come in the reference's state_dict naming so a real `net_epoch<N>` checkpoint
 (`{'autoencoder': state_dict}`, experiments_builder.py:442-462) drops in.  Any input size
-whose layer-4 map has <= 128 positions is supported (the reference hard-codes 5x8).
+whose layer-4 map has <= 1024 positions is supported (the reference hard-codes 5x8).
 """
 import os
 
@@ -302,8 +302,8 @@ class DANetEncoderHIP:
         self.fh, self.fw, self.Np = fh, fw, fh * fw
         # identity of the loaded checkpoint (CadreAgent.ensemble_act shares one pass between equal encoders)
         self.fingerprint = (dtype, H, W) + tuple(float(sd[k].sum(dtype=torch.float64)) for k in sorted(sd))
-        if self.Np > 128:
-            raise hip.CadreHipError("layer-4 map %dx%d > 128 positions not supported by the PAM/CAM kernels" % (fh, fw))
+        if self.Np > 1024:
+            raise hip.CadreHipError("layer-4 map %dx%d > 1024 positions not supported by the PAM/CAM kernels" % (fh, fw))
         need = 512 * self.Np
         got = sd["inter_task_att.visual_query_layer.1.weight"].shape[1]
         if got != need:

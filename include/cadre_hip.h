@@ -243,8 +243,8 @@ int cadre_maxpool3x3s2_bf16(const void* x, void* y, int32_t F, int32_t H, int32_
 /* PAM_Module.forward da_att.py:32-51 after the three 1x1 convs: qkv [F][Np][160] =
  * (query 16 | key 16 | value 128) comes from ONE cadre_gemm_f32 over the concatenated
  * query/key/value conv weights; this kernel does energy = q.k^T, row softmax,
- * out = att.v, y = gamma*out + x on NHWC x [F][Np][128].  One workgroup per frame, Np <= 128 (the attention
- * matrix of a frame lives in one CU's LDS). */
+ * out = att.v, y = gamma*out + x on NHWC x [F][Np][128].  Np <= 128: one workgroup per frame (the attention matrix of a frame
+ * lives in one CU's LDS); 128 < Np <= 1024: a workgroup per block of 32 query rows, keys / values from global memory. */
 int cadre_pam(const float* x, const float* qkv, float gamma, float* y, int32_t F, int32_t Np,
               void* stream);
 /* CAM_Module.forward da_att.py:63-83 on NHWC x [F][Np][128] */

@@ -39,7 +39,7 @@ def test_encoder_vs_reference_golden(golden, tag):
     assert e[0] < TOL and e[1] < TOL and e[2] < TOL
 
 
-@pytest.mark.parametrize("H,W", [(320, 352), (352, 352)])
+@pytest.mark.parametrize("H,W", [(320, 352), (352, 352), (384, 384), (384, 512)])
 def test_encoder_above_96_positions_vs_oracle(H, W):
     """Layer-4 maps of 10 x 11 = 110 and 11 x 11 = 121 positions (the PAM / CAM kernels hold a frame's attention matrix in one CU's
     LDS up to 128; the reference itself only builds 5 x 8, intertask_att.py:17-18): the whole fp32 encoder against the oracle's
@@ -48,7 +48,7 @@ def test_encoder_above_96_positions_vs_oracle(H, W):
     from oracle import encoder_ref
     from cadre_amd.encoder import DANetEncoderHIP
     fh, fw = synth.feat_hw(H, W)
-    assert 96 < fh * fw <= 128
+    assert 96 < fh * fw <= 1024            # (<= 128: a frame's attention in one CU's LDS; above: the row-block kernels)
     sd = synth.encoder_state(fh, fw, 11)
     enc = DANetEncoderHIP(sd, H, W, "cuda:0")
     r = np.random.RandomState(H + W)

@@ -147,7 +147,7 @@ def test_cabi_rejects_bad_arguments_without_launching():
     assert L.cadre_gemm_bf16(C.byref(d), None) == -1
     assert L.cadre_gae(None, None, None, None, None, None, 1, 8, 0.99, 0.94, 1, None) == -1
     assert b"cadre_gae" in L.cadre_last_error()
-    assert L.cadre_pam(16, 16, 0.5, 16, 1, 200, None) == -1 and b"Np<=128" in L.cadre_last_error()
+    assert L.cadre_pam(16, 16, 0.5, 16, 1, 2000, None) == -1 and b"Np<=1024" in L.cadre_last_error()
     assert L.cadre_sample(16, 64, 16, 64, 1, 65, 16, 16, None) == -1
     assert L.cadre_clip_adam(16, 16, 16, 16, 16, 0, 16, 250.0, 3e-4, 0.9, 0.999, 1e-8, 1, None) == -1
     with pytest.raises(hip.CadreHipError, match="cadre_gemm_f32"):

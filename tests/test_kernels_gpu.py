@@ -198,7 +198,7 @@ def test_maxpool(hip):
     assert torch.equal(out.permute(0, 3, 1, 2).cpu(), want)
 
 
-@pytest.mark.parametrize("h,w", [(3, 3), (5, 8), (9, 9), (10, 11), (11, 11), (8, 16)])
+@pytest.mark.parametrize("h,w", [(3, 3), (5, 8), (9, 9), (10, 11), (11, 11), (8, 16), (12, 12), (11, 13), (16, 16), (20, 25)])
 def test_pam_cam(hip, h, w):
     from oracle import encoder_ref
     g = torch.Generator().manual_seed(h * w)
