@@ -552,7 +552,11 @@ extern "C" int cadre_pam_bf16out(const float* x, const float* qkv, float gamma, 
 static int pam_launch(const float* x, const float* qkv, float gamma, void* y, int32_t F, int32_t Np, int out_bf16,
                       void* stream) {
   FAIL_IF(!x || !qkv || !y || F < 1 || Np < 1 || Np > PAM_BIGNP, "cadre_pam: bad argument (Np<=1024)");
-  if (Np > PAM_MAXNP) {                                    // the map does not fit one CU's LDS: a workgroup per block of 32 query rows
+  // The row-block kernel at EVERY size (round 6): three workgroups of 15 KB per 9 x 9 frame instead of one of 99 KB — several frames per
+  // CU in flight where the one-CU kernel ran its five barrier-separated phases frame after frame: 268 -> 167 us per 2048 frames, 128 ->
+  // 87 per 1024 (tools/dbg/pam_cam_time.py), the same bits.  CADRE_PAM_LARGE=0: the one-CU kernel up to 128 positions.
+  static const int pam_force_large = [] { const char* e = getenv("CADRE_PAM_LARGE"); return e ? atoi(e) : 1; }();
+  if (Np > PAM_MAXNP || pam_force_large) {                 // a workgroup per block of 32 query rows
     const size_t Rb = (size_t)((Np + 31) / 32) * 32;
     const size_t shm_b = sizeof(float) * (32 * 17 + 32 * (Rb + 1));
     static bool attr_b = false;
@@ -748,7 +752,8 @@ extern "C" int cadre_cam_bf16out(const float* x, float gamma, void* y, int32_t F
 }
 static int cam_launch(const float* x, float gamma, void* y, int32_t F, int32_t Np, int out_bf16, void* stream) {
   FAIL_IF(!x || !y || F < 1 || Np < 1 || Np > PAM_BIGNP, "cadre_cam: bad argument (Np<=1024)");
-  if (Np > PAM_MAXNP) {
+  static const int cam_force_large = [] { const char* e = getenv("CADRE_CAM_LARGE"); return e ? atoi(e) : 0; }();
+  if (Np > PAM_MAXNP || cam_force_large) {
     static bool attr_b = false;
     if (!attr_b) {
       (void)hipFuncSetAttribute((const void*)cam_large_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
