@@ -743,6 +743,74 @@ __global__ __launch_bounds__(CAM_THREADS) void cam_large_kernel(const float* x, 
   }
 }
 
+
+// ---- CAM by output-channel halves (round 6): two workgroups per frame, each with the frame's rows (Np + 1 of them) and ITS 64 rows of
+// the channel attention in LDS — 77 KB at Np = 81, two workgroups per CU where cam_kernel's 118 KB ran one frame at a time through its
+// four barrier-separated phases.  The same fma chains (ascending k) as cam_kernel: the same bits.
+__global__ __launch_bounds__(CAM_THREADS) void cam_split_kernel(const float* x, float gamma, float* y, int Np, int out_bf16) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int NW = CAM_THREADS / 64;
+  const int NR = (Np + 2) & ~1;     // rows staged: Np rounded up to even (+ a zero row when Np is odd: the energy's last k pair)
+  float* xs = sm;                   // [NR][CAM_XP]
+  float* E = xs + NR * CAM_XP;      // [64][CAM_EP]: rows 64 hc .. + 63 of the attention
+  const int f = blockIdx.x, hc = blockIdx.y, tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+  const float* xf = x + (int64_t)f * Np * 128;
+  for (int i = tid; i < NR * 32; i += CAM_THREADS) {
+    const int r = i >> 5;
+    const float4 t = r < Np ? reinterpret_cast<const float4*>(xf)[i] : float4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<float4*>(xs + r * CAM_XP + (i & 31) * 4) = t;
+  }
+  __syncthreads();
+  {  // energy[c][d] = sum_n x[n][c] x[n][d], c in this half: wave w owns tile (w >> 2, w & 3)
+    const int cl = 32 * (wave >> 2), c0 = 64 * hc + cl, d0 = 32 * (wave & 3);
+    pam_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nk = (Np + 1) >> 1;
+#pragma unroll 8
+    for (int kk = 0; kk < nk; ++kk) {
+      const float* row = xs + (2 * kk + lh) * CAM_XP;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(row[c0 + l31], row[d0 + l31], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) E[(cl + (r & 3) + 8 * (r >> 2) + 4 * lh) * CAM_EP + d0 + l31] = acc[r];
+  }
+  __syncthreads();
+  for (int c = wave; c < 64; c += NW) {               // energy_new = rowmax - energy; softmax (:75-76)
+    const float e0 = E[c * CAM_EP + lane], e1 = E[c * CAM_EP + lane + 64];
+    const float rmax = wave_max(fmaxf(e0, e1));
+    const float n0 = rmax - e0, n1 = rmax - e1;
+    const float m2 = wave_max(fmaxf(n0, n1));
+    const float p0 = expf(n0 - m2), p1 = expf(n1 - m2);
+    const float s = wave_sum(p0 + p1);
+    E[c * CAM_EP + lane] = p0 / s;
+    E[c * CAM_EP + lane + 64] = p1 / s;
+  }
+  __syncthreads();
+  // out[n][c] = sum_d x[n][d] att[c][d] (d ascending): wave w owns channel block w & 1 of the half and the position blocks (w >> 1), + 4
+  const int RB = (Np + 31) >> 5;
+  const int cl = 32 * (wave & 1) + l31, c = 64 * hc + cl;
+  const float* er = E + cl * CAM_EP + lh;
+  for (int nb = wave >> 1; nb < RB; nb += 4) {
+    const float* x0 = xs + min(32 * nb + l31, Np - 1) * CAM_XP + lh;
+    pam_f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll 8
+    for (int kk = 0; kk < 64; ++kk) o = __builtin_amdgcn_mfma_f32_32x32x2f32(x0[2 * kk], er[2 * kk], o, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = 32 * nb + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (n < Np) {
+        const float res = gamma * o[r] + xs[n * CAM_XP + c];
+        if (out_bf16) reinterpret_cast<__bf16*>(y)[(int64_t)f * Np * 128 + n * 128 + c] = (__bf16)res;
+        else y[(int64_t)f * Np * 128 + n * 128 + c] = res;
+      }
+    }
+  }
+}
+
 static int cam_launch(const float* x, float gamma, void* y, int32_t F, int32_t Np, int out_bf16, void* stream);
 extern "C" int cadre_cam(const float* x, float gamma, float* y, int32_t F, int32_t Np, void* stream) {
   return cam_launch(x, gamma, y, F, Np, 0, stream);
@@ -760,6 +828,18 @@ static int cam_launch(const float* x, float gamma, void* y, int32_t F, int32_t N
       attr_b = true;
     }
     hipLaunchKernelGGL(cam_large_kernel, dim3(F), dim3(CAM_THREADS), sizeof(float) * 128 * CAM_EP, ST(stream), x, gamma, (float*)y, Np, out_bf16);
+    return (int)hipGetLastError();
+  }
+  // (round 6) two workgroups per frame, by output-channel halves: 240 -> see tools/dbg/pam_cam_time.py; CADRE_CAM_SPLIT=0: one per frame
+  static const int cam_split = [] { const char* e = getenv("CADRE_CAM_SPLIT"); return e ? atoi(e) : 1; }();
+  if (cam_split) {
+    const size_t shm_s = sizeof(float) * ((size_t)((Np + 2) & ~1) * CAM_XP + 64 * CAM_EP);
+    static bool attr_s = false;
+    if (!attr_s) {
+      (void)hipFuncSetAttribute((const void*)cam_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_s = true;
+    }
+    hipLaunchKernelGGL(cam_split_kernel, dim3(F, 2), dim3(CAM_THREADS), shm_s, ST(stream), x, gamma, (float*)y, Np, out_bf16);
     return (int)hipGetLastError();
   }
   const size_t shm = sizeof(float) * ((size_t)((Np + 31) / 32) * 32 * CAM_XP + 128 * CAM_EP);

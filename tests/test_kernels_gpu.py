@@ -231,6 +231,16 @@ def test_pam_cam(hip, h, w):
     y2 = torch.empty_like(xd)
     hip.check(hip.lib().cadre_cam(xd.data_ptr(), 0.7, y2.data_ptr(), Fn, Np, hip.stream()), "cam")
     assert rel(y2.permute(0, 3, 1, 2), want_c) < 2e-5
+    if Np <= 128:               # the one-workgroup-per-frame kernel (CADRE_CAM_SPLIT=0) gives the same bits as the default channel-split kernel
+        import subprocess, sys, tempfile, os
+        with tempfile.TemporaryDirectory() as td:
+            torch.save(dict(x=xd.cpu(), y=y2.cpu()), os.path.join(td, "io.pt"))
+            code = ("import torch, sys; sys.path.insert(0, %r); from cadre_amd import hip; d = torch.load(%r); x = d['x'].cuda(); "
+                    "y = torch.empty_like(x); hip.check(hip.lib().cadre_cam(x.data_ptr(), 0.7, y.data_ptr(), %d, %d, hip.stream()), 'cam'); "
+                    "torch.cuda.synchronize(); sys.exit(0 if torch.equal(y.cpu(), d['y']) else 3)"
+                    % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(td, "io.pt"), Fn, Np))
+            r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CADRE_CAM_SPLIT="0"), capture_output=True, text=True)
+            assert r.returncode == 0, (r.returncode, r.stderr[-500:])
 
 
 def test_intertask_tail_and_measurements(hip):
