@@ -218,6 +218,17 @@ __global__ __launch_bounds__(256) void pack_obs4_kernel(const uint8_t* rgb, cons
   const int fo = blockIdx.z, h0 = blockIdx.y * 32, w0 = blockIdx.x * 32;
   const int64_t f = frame_idx ? frame_idx[fo] : fo;
   const uint32_t mx = frame_max[f];                      // (per source frame: a window repeats each frame 8 times)
+  // (round 6) the pixel group's three dwords are requested BEFORE the route tile goes through LDS: one memory round trip of the
+  // workgroup's dependent chain (frame index -> route bytes -> barrier -> pixels -> store) less — the kernel is 83 k small
+  // workgroups per 1024 frames and paced by that chain, not by bytes
+  const int hl = threadIdx.x >> 3, wq = (threadIdx.x & 7) * 4;      // 32 rows x 8 groups of 4 pixels
+  const int h = h0 + hl, w = w0 + wq;
+  const bool live = h < H && w < W;                      // (W % 4 == 0: a group is all in or all out)
+  uint32_t a = 0, b = 0, c = 0;                          // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+  if (live) {
+    const uint32_t* px = reinterpret_cast<const uint32_t*>(rgb + (((int64_t)f * H + h) * W + w) * 3);
+    a = px[0]; b = px[1]; c = px[2];
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {                          // route tile [w][h] -> LDS (stored transposed in memory)
     const int wl = ty + 8 * j, w = w0 + wl, h = h0 + tx;
@@ -231,11 +242,7 @@ __global__ __launch_bounds__(256) void pack_obs4_kernel(const uint8_t* rgb, cons
     s_r[wl][tx] = rn;
   }
   __syncthreads();
-  const int hl = threadIdx.x >> 3, wq = (threadIdx.x & 7) * 4;      // 32 rows x 8 groups of 4 pixels
-  const int h = h0 + hl, w = w0 + wq;
-  if (h < H && w < W) {                                  // (W % 4 == 0: a group is all in or all out)
-    const uint32_t* px = reinterpret_cast<const uint32_t*>(rgb + (((int64_t)f * H + h) * W + w) * 3);
-    const uint32_t a = px[0], b = px[1], c = px[2];      // R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+  if (live) {
     uint4 o;
     o.x = (a & 0x00ffffffu) | (s_r[wq][hl] ? 0xff000000u : 0u);
     o.y = (a >> 24) | ((b & 0x0000ffffu) << 8) | (s_r[wq + 1][hl] ? 0xff000000u : 0u);
