@@ -218,29 +218,39 @@ def test_pam_cam(hip, h, w):
     y = torch.empty_like(xd)
     hip.check(hip.lib().cadre_pam(xd.data_ptr(), qkv.data_ptr(), 0.5, y.data_ptr(), Fn, Np, hip.stream()), "pam")
     assert rel(y.permute(0, 3, 1, 2), want_p) < 2e-5
-    if Np <= 128:               # the one-CU kernel (CADRE_PAM_LARGE=0 in a fresh process) gives the same bits as the default row-block kernel
-        import subprocess, sys, tempfile, os
-        with tempfile.TemporaryDirectory() as td:
-            torch.save(dict(x=xd.cpu(), qkv=qkv.cpu(), y=y.cpu()), os.path.join(td, "io.pt"))
-            code = ("import torch, sys; sys.path.insert(0, %r); from cadre_amd import hip; d = torch.load(%r); x = d['x'].cuda(); q = d['qkv'].cuda(); "
-                    "y = torch.empty_like(x); hip.check(hip.lib().cadre_pam(x.data_ptr(), q.data_ptr(), 0.5, y.data_ptr(), %d, %d, hip.stream()), 'pam'); "
-                    "torch.cuda.synchronize(); sys.exit(0 if torch.equal(y.cpu(), d['y']) else 3)"
-                    % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(td, "io.pt"), Fn, Np))
-            r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CADRE_PAM_LARGE="0"), capture_output=True, text=True)
-            assert r.returncode == 0, (r.returncode, r.stderr[-500:])
     y2 = torch.empty_like(xd)
     hip.check(hip.lib().cadre_cam(xd.data_ptr(), 0.7, y2.data_ptr(), Fn, Np, hip.stream()), "cam")
     assert rel(y2.permute(0, 3, 1, 2), want_c) < 2e-5
-    if Np <= 128:               # the one-workgroup-per-frame kernel (CADRE_CAM_SPLIT=0) gives the same bits as the default channel-split kernel
-        import subprocess, sys, tempfile, os
-        with tempfile.TemporaryDirectory() as td:
-            torch.save(dict(x=xd.cpu(), y=y2.cpu()), os.path.join(td, "io.pt"))
-            code = ("import torch, sys; sys.path.insert(0, %r); from cadre_amd import hip; d = torch.load(%r); x = d['x'].cuda(); "
-                    "y = torch.empty_like(x); hip.check(hip.lib().cadre_cam(x.data_ptr(), 0.7, y.data_ptr(), %d, %d, hip.stream()), 'cam'); "
-                    "torch.cuda.synchronize(); sys.exit(0 if torch.equal(y.cpu(), d['y']) else 3)"
-                    % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(td, "io.pt"), Fn, Np))
-            r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CADRE_CAM_SPLIT="0"), capture_output=True, text=True)
-            assert r.returncode == 0, (r.returncode, r.stderr[-500:])
+
+
+def test_attention_kernel_forms_give_the_same_bits(hip, tmp_path):
+    """The default attention kernels (pam_large_kernel: a workgroup per 32 query rows; cam_split_kernel: two per frame) against the
+    one-workgroup-per-frame kernels they replaced (CADRE_PAM_LARGE=0 / CADRE_CAM_SPLIT=0, read once per process: ONE child process
+    for all sizes): same fma chains, same bits."""
+    import subprocess, sys, os
+    g = torch.Generator().manual_seed(3)
+    cases = {}
+    for (h, w) in ((3, 3), (5, 8), (9, 9), (11, 11), (8, 16)):
+        Fn, Np = 3, h * w
+        x = dev((torch.randn(Fn, Np, 128, generator=g) * 0.4).contiguous())
+        qkv = dev((torch.randn(Fn * Np, 160, generator=g) * 0.3).contiguous())
+        yp, yc = torch.empty_like(x), torch.empty_like(x)
+        hip.check(hip.lib().cadre_pam(x.data_ptr(), qkv.data_ptr(), 0.5, yp.data_ptr(), Fn, Np, hip.stream()), "pam")
+        hip.check(hip.lib().cadre_cam(x.data_ptr(), 0.7, yc.data_ptr(), Fn, Np, hip.stream()), "cam")
+        cases["%dx%d" % (h, w)] = dict(x=x.cpu(), qkv=qkv.cpu(), yp=yp.cpu(), yc=yc.cpu(), Fn=Fn, Np=Np)
+    io = str(tmp_path / "io.pt")
+    torch.save(cases, io)
+    code = ("import torch, sys; sys.path.insert(0, %r); from cadre_amd import hip; L = hip.lib(); cases = torch.load(%r); bad = []\n"
+            "for k, d in cases.items():\n"
+            "    x = d['x'].cuda(); q = d['qkv'].cuda(); yp = torch.empty_like(x); yc = torch.empty_like(x)\n"
+            "    hip.check(L.cadre_pam(x.data_ptr(), q.data_ptr(), 0.5, yp.data_ptr(), d['Fn'], d['Np'], hip.stream()), 'pam')\n"
+            "    hip.check(L.cadre_cam(x.data_ptr(), 0.7, yc.data_ptr(), d['Fn'], d['Np'], hip.stream()), 'cam')\n"
+            "    torch.cuda.synchronize()\n"
+            "    if not torch.equal(yp.cpu(), d['yp']): bad.append('pam ' + k)\n"
+            "    if not torch.equal(yc.cpu(), d['yc']): bad.append('cam ' + k)\n"
+            "print(bad); sys.exit(3 if bad else 0)\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), io))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CADRE_PAM_LARGE="0", CADRE_CAM_SPLIT="0"), capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout[-300:], r.stderr[-500:])
 
 
 def test_intertask_tail_and_measurements(hip):
